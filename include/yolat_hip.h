@@ -1,0 +1,241 @@
+/*
+ * yolat_hip.h — C ABI of libyolat_hip.so: the MI355X (gfx950) kernels of the YOLaT GNN
+ * message-passing hot path (SparseCADGCN forward / backward / Adam).
+ *
+ * The reference (microsoft/YOLaT-VectorGraphicsRecognition) is pure Python and has no FFI layer
+ * of its own: its "operators" for this path are torch / torch_geometric / torch_scatter calls
+ * made from
+ *     cad_recognition/architecture3cc_rpn_gp_iter2.py   (model wiring, :44-71, :106-137, :358-379)
+ *     gcn_lib/sparse/torch_vertex.py                    (AttrRelativeEdgeConvGlobalPool2, :288-341)
+ *     gcn_lib/sparse/torch_nn.py                        (MLP = Linear/BatchNorm1d/ReLU, :50-71)
+ *     cad_recognition/train.py                          (Adam step, :212,283-284)
+ * Each entry point below names the reference call it replaces.  A ctypes binding is in
+ * yolat_vectorgraphicsrecognition_amd/_lib.py; INTEGRATION.md shows the stub a reference
+ * maintainer would add.
+ *
+ * Conventions
+ *  - every pointer is a DEVICE pointer (HBM) unless marked "host"; the library never allocates,
+ *    never frees, never synchronises; all work is enqueued on `stream` (a hipStream_t);
+ *  - float tensors are fp32 row-major with an explicit leading dimension `ld*` (in elements), so
+ *    a column slice of a concat buffer can be passed without a copy;
+ *  - device index arrays are int32 (after yolat_coo_to_csr); raw inputs are int64 as in the
+ *    reference (Datasets/graph_dict3.py:1049-1066);
+ *  - return value: 0 = enqueued; <0 = invalid argument (YOLAT_E_*); >0 = hipError_t from launch.
+ *  - `status` words are device int32 flags OR-ed by kernels that validate data (bit meanings
+ *    YOLAT_STATUS_*); the caller reads them back when it next synchronises.
+ *  - optional pointers may be NULL where the comment says "nullable".
+ */
+#ifndef YOLAT_HIP_H
+#define YOLAT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* yolat_stream_t; /* hipStream_t */
+
+#define YOLAT_E_INVALID   (-1) /* bad size / NULL pointer                    */
+#define YOLAT_E_UNSUPPORTED (-2) /* shape outside what the kernels implement */
+
+#define YOLAT_STATUS_EDGE_RANGE  1 /* an edge endpoint is outside [0,N)      */
+#define YOLAT_STATUS_SEG_UNSORTED 2 /* bbox_idx is not non-decreasing        */
+#define YOLAT_STATUS_SEG_RANGE   4 /* bbox_idx value outside [0,P)           */
+
+/* A-operand "prologue": the consumer applies  a' = a*scale[k] + shift[k]; if (relu) a' = max(a',0)
+ * while loading, so BatchNorm1d+ReLU outputs (gcn_lib/sparse/torch_nn.py:58-66) need not be
+ * materialised.  scale == NULL means identity. */
+
+int yolat_abi_version(void);
+const char* yolat_strerror(int code);
+
+/* ------------------------------------------------------------------------------------------
+ * Graph pre-processing (integer, bit-exact).  Replaces what PyG's MessagePassing.propagate does
+ * implicitly with edge_index (gather by edge_index[0]/[1], scatter by edge_index[1];
+ * gcn_lib/sparse/torch_vertex.py:324) by an explicit destination-sorted CSR.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Stable counting sort of E edges by destination.
+ *   edge: int64, element (e, c) at edge[e*stride_e + c*stride_c]; c=0 source j, c=1 target i
+ *         (data.edge is [E,2]: stride_e=2, stride_c=1; the model's .T view is the same memory:
+ *         architecture3cc_rpn_gp_iter2.py:110)
+ *   row_ptr[N+1], perm[E] (CSR slot -> original edge id, ascending inside a row),
+ *   src_csr[E], dst_csr[E]
+ *   work: int32 scratch of yolat_csr_work_elems(N,E) elements.                                  */
+size_t yolat_csr_work_elems(int64_t N, int64_t E);
+int yolat_coo_to_csr(const int64_t* edge, int64_t stride_e, int64_t stride_c, int64_t E, int64_t N,
+                     int32_t* row_ptr, int32_t* perm, int32_t* src_csr, int32_t* dst_csr,
+                     int32_t* work, int32_t* status, yolat_stream_t stream);
+
+/* CSC by source over the CSR slots (needed only by the backward scatter to x[src]):
+ *   col_ptr[N+1], slots[E] = CSR slots of the edges leaving each node, ascending.               */
+int yolat_csc_by_source(const int32_t* src_csr, int64_t E, int64_t N, int32_t* col_ptr,
+                        int32_t* slots, int32_t* work, yolat_stream_t stream);
+
+/* seg_ptr[P+1] from a non-decreasing int64 bbox_idx[N] (Datasets/graph_dict3.py:732):
+ * seg_ptr[p] = first row r with bbox_idx[r] >= p.  Also writes node_seg[N] (int32 copy).
+ * Replaces the implicit segmentation done by torch_scatter.scatter(index=bbox_idx)
+ * (architecture3cc_rpn_gp_iter2.py:67,122).                                                     */
+int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, int32_t* seg_ptr,
+                      int32_t* node_seg, int32_t* status, yolat_stream_t stream);
+
+/* dst[r, 0:width] = src[idx[r], 0:width]  (e_attr -> CSR order; fp32)                           */
+int yolat_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, int64_t rows,
+                      int64_t width, float* dst, int64_t ld_dst, yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Dense layers: nn.Linear (+ BatchNorm1d + ReLU) of gcn_lib/sparse/torch_nn.py:50-71.
+ * fp32-input MFMA (v_mfma_f32_32x32x2_f32), fp32 accumulate.
+ * ------------------------------------------------------------------------------------------ */
+
+/* Y[M,Nout] = epi( pro(A)[M,K] . W[Nout,K]^T + bias )
+ *   pro: a_scale/a_shift [K] nullable, a_relu
+ *   epi: o_scale/o_shift [Nout] nullable (eval-mode BatchNorm folded), o_relu
+ *   accumulate != 0: Y += (result)   (used for  out += lin_r(x), torch_vertex.py:325)
+ *   stats (nullable): float2 [ceil(M/YOLAT_STATS_ROWS)][Nout] per-row-block (sum, M2) of the
+ *        pre-epilogue values (incl. bias) for training-mode BatchNorm (batch statistics over all
+ *        M rows, torch_nn.py:27); reduce with yolat_bn_finalize.                                 */
+#define YOLAT_STATS_ROWS 64
+int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t K,
+                     const float* a_scale, const float* a_shift, int a_relu,
+                     const float* W, int64_t ldw, const float* bias, int64_t Nout,
+                     const float* o_scale, const float* o_shift, int o_relu,
+                     float* Y, int64_t ldy, int accumulate, float* stats, yolat_stream_t stream);
+
+/* Same, with W used transposed: Y[M,Nout] = pro(A)[M,K] . Wt[K,Nout]   (dX = dY . W)            */
+int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
+                        const float* Wt, int64_t ldw, int64_t Nout,
+                        float* Y, int64_t ldy, int accumulate, yolat_stream_t stream);
+
+/* dW[Nout,K] (+)= dY[M,Nout]^T . pro(A)[M,K];  db[Nout] (+)= colsum(dY)  (db nullable)
+ *   partial: fp32 scratch of yolat_linear_bwd_w_work_elems(M,Nout,K) elements; the split-row
+ *   partial products are reduced in a fixed order (deterministic, no atomics).                  */
+size_t yolat_linear_bwd_w_work_elems(int64_t M, int64_t Nout, int64_t K);
+int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int64_t Nout,
+                       const float* A, int64_t lda, int64_t K,
+                       const float* a_scale, const float* a_shift, int a_relu,
+                       float* dW, int64_t lddw, float* db, int accumulate,
+                       float* partial, yolat_stream_t stream);
+
+/* Training-mode BatchNorm1d statistics from the row-block partials of yolat_linear_fwd /
+ * yolat_edge_lin1_fwd:  mean, biased var -> invstd; scale = gamma*invstd; shift = beta-mean*scale;
+ * running_mean/var updated with `momentum` and the UNBIASED variance (torch defaults,
+ * torch_nn.py:27).  fp64 Chan merge in row-block order (deterministic).
+ * save_mean/save_invstd [C] are kept for the backward.                                           */
+int yolat_bn_finalize(const float* stats, int64_t M, int64_t C, const float* gamma,
+                      const float* beta, float* running_mean, float* running_var,
+                      float momentum, float eps, float* save_mean, float* save_invstd,
+                      float* scale, float* shift, yolat_stream_t stream);
+
+/* Eval-mode coefficients from running stats: scale = gamma/sqrt(var+eps), shift = beta-mean*scale */
+int yolat_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                         const float* running_var, float eps, int64_t C, float* scale,
+                         float* shift, yolat_stream_t stream);
+
+/* Z[M,C] = max(Y*scale + shift, 0)  (relu optional)                                             */
+int yolat_scale_shift_relu(const float* Y, int64_t ldy, int64_t M, int64_t C, const float* scale,
+                           const float* shift, int relu, float* Z, int64_t ldz,
+                           yolat_stream_t stream);
+
+/* Backward of Z = relu(BN_train(Y)) given dZ:  (torch autograd of torch_nn.py:58-66)
+ *   step 1 (reduce): per-column s1 = sum dyh, s2 = sum dyh*xhat with dyh = dZ*[Z>0],
+ *           xhat = (Y-mean)*invstd; writes dgamma(+)=s2, dbeta(+)=s1 and coef[2*C] = (s1/M, s2/M)
+ *   step 2 (apply):  dY = scale*(dyh - coef1 - xhat*coef2)
+ *   work: fp32 scratch of yolat_bn_bwd_work_elems(M,C).
+ *   If relu == 0 the mask is all-ones.                                                           */
+size_t yolat_bn_bwd_work_elems(int64_t M, int64_t C);
+int yolat_bn_relu_bwd(const float* dZ, int64_t lddz, const float* Y, int64_t ldy, int64_t M,
+                      int64_t C, const float* gamma, const float* save_mean,
+                      const float* save_invstd, const float* scale, const float* shift, int relu,
+                      float* dgamma, float* dbeta, int accumulate, float* dY, int64_t lddy,
+                      float* work, yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Edge convolution AttrRelativeEdgeConvGlobalPool2 (gcn_lib/sparse/torch_vertex.py:288-341):
+ *   m_e = nn([x_i, x_j - x_i, a_e]);  out_i = mean_{e->i} m_e + lin_r(x_i)
+ * All [E,*] tensors are in CSR (destination-sorted) order.
+ * ------------------------------------------------------------------------------------------ */
+
+/* H1[E,C] = epi( [x[dst], x[src]-x[dst], attr] . W1[C,2Cin+4]^T + b1 )
+ * (gather = PyG __lift__, cat+Linear = torch_vertex.py:331,335 / nn.0).  epi/stats as in
+ * yolat_linear_fwd.  The 2Cin+4 wide edge-feature matrix is never materialised.                 */
+int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64_t Cin,
+                        const int32_t* src_csr, const int32_t* dst_csr, const float* attr_csr,
+                        int64_t E, const float* W1, int64_t ldw, const float* b1, int64_t C,
+                        const float* o_scale, const float* o_shift, int o_relu,
+                        float* H1, int64_t ldh, float* stats, yolat_stream_t stream);
+
+/* dW1[C,2Cin+4] (+)= dH1^T . [x[dst], x[src]-x[dst], attr];  db1 (+)= colsum(dH1)               */
+int yolat_edge_lin1_bwd_w(const float* dH1, int64_t lddh, int64_t E, int64_t C,
+                          const float* x, int64_t ldx, int64_t N, int64_t Cin,
+                          const int32_t* src_csr, const int32_t* dst_csr, const float* attr_csr,
+                          float* dW1, int64_t lddw, float* db1, int accumulate, float* partial,
+                          yolat_stream_t stream);
+
+/* dG[E,2Cin] = dH1[E,C] . Wc,  Wc[:,0:Cin] = W1[:,0:Cin]-W1[:,Cin:2Cin], Wc[:,Cin:2Cin] = W1[:,Cin:2Cin]
+ * i.e. dG[:,0:Cin] is the gradient that flows to x[dst_e], dG[:,Cin:2Cin] to x[src_e].          */
+int yolat_edge_lin1_bwd_x(const float* dH1, int64_t lddh, int64_t E, int64_t C, const float* W1,
+                          int64_t ldw, int64_t Cin, float* dG, int64_t lddg,
+                          yolat_stream_t stream);
+
+/* dX[n,0:Cin] (+)= sum_{q in CSR row n} dG[q,0:Cin] + sum_{q in CSC col n} dG[q,Cin:2Cin]
+ * (autograd of the two index_selects = two scatter-adds; here an atomic-free gather-reduce).     */
+int yolat_edge_scatter_bwd(const float* dG, int64_t lddg, int64_t Cin, const int32_t* row_ptr,
+                           const int32_t* col_ptr, const int32_t* slots, int64_t N, float* dX,
+                           int64_t lddx, int accumulate, yolat_stream_t stream);
+
+/* out[n,0:C] (+)= (1/max(deg,1)) * sum_{q in CSR row n} pro(H)[q,0:C]
+ * (= torch_scatter.scatter(reduce='mean', dim_size=N) called by propagate, aggr='mean'
+ * torch_vertex.py:308; summation in ascending edge order like the CPU scatter_add).             */
+int yolat_csr_mean_fwd(const float* H, int64_t ldh, int64_t C, const float* h_scale,
+                       const float* h_shift, int h_relu, const int32_t* row_ptr, int64_t N,
+                       float* out, int64_t ldo, int accumulate, yolat_stream_t stream);
+
+/* dM[q,0:C] = dOut[dst_csr[q],0:C] / max(deg(dst),1)    (backward of the mean)                  */
+int yolat_csr_mean_bwd(const float* dOut, int64_t lddo, int64_t C, const int32_t* row_ptr,
+                       const int32_t* dst_csr, int64_t E, float* dM, int64_t lddm,
+                       yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Per-proposal pooling: torch_scatter.scatter(src, bbox_idx, dim=0, reduce='mean'|'max')
+ * (architecture3cc_rpn_gp_iter2.py:67,122).  Rows of a proposal are contiguous (seg_ptr).
+ * Empty segments give 0 (both modes); max ties: lowest row wins; arg = N for empty.
+ * ------------------------------------------------------------------------------------------ */
+int yolat_segment_mean_fwd(const float* X, int64_t ldx, int64_t D, const float* x_scale,
+                           const float* x_shift, int x_relu, const int32_t* seg_ptr, int64_t P,
+                           float* Y, int64_t ldy, yolat_stream_t stream);
+int yolat_segment_max_fwd(const float* X, int64_t ldx, int64_t D, const float* x_scale,
+                          const float* x_shift, int x_relu, const int32_t* seg_ptr, int64_t P,
+                          int64_t N, float* Y, int64_t ldy, int32_t* arg /* nullable [P,D] */,
+                          yolat_stream_t stream);
+/* dX[r,:] = dY[seg(r),:] / max(len(seg),1) */
+int yolat_segment_mean_bwd(const float* dY, int64_t lddy, int64_t D, const int32_t* seg_ptr,
+                           const int32_t* node_seg, int64_t N, float* dX, int64_t lddx,
+                           yolat_stream_t stream);
+/* dX[r,c] = (arg[seg(r),c] == r) ? dY[seg(r),c] : 0 */
+int yolat_segment_max_bwd(const float* dY, int64_t lddy, int64_t D, const int32_t* arg,
+                          const int32_t* node_seg, int64_t N, float* dX, int64_t lddx,
+                          yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Loss and optimiser
+ * ------------------------------------------------------------------------------------------ */
+
+/* nn.CrossEntropyLoss() (mean over P) of architecture3cc_rpn_gp_iter2.py:363,376.
+ * loss[0] = mean_p( logsumexp(z_p) - z_p[label_p] );  dlogits[P,K] = (softmax - onehot)/P
+ * (dlogits nullable).  Deterministic single-workgroup reduction.                                 */
+int yolat_softmax_ce(const float* logits, int64_t ld, const int64_t* labels, int64_t P, int64_t K,
+                     float* loss, float* dlogits, int64_t lddl, yolat_stream_t stream);
+
+/* torch.optim.Adam step (train.py:212: lr, weight_decay as L2-in-grad, betas (0.9,0.999),
+ * eps 1e-8, no amsgrad) over one flat fp32 buffer of n elements; `step` is the 1-based step.     */
+int yolat_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq, int64_t n,
+                    float lr, float beta1, float beta2, float eps, float weight_decay,
+                    int64_t step, float grad_scale, yolat_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* YOLAT_HIP_H */

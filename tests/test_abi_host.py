@@ -1,0 +1,132 @@
+"""CPU tests (-m "not gpu"): the C-ABI library loads and exports everything include/yolat_hip.h
+declares (no compute calls without a GPU), and the host-side mirror of the reference interface."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import yolat_vectorgraphicsrecognition_amd as yv
+from yolat_vectorgraphicsrecognition_amd import _lib
+from oracle import oracle_np as onp
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _header_decls():
+    src = open(os.path.join(REPO, "include", "yolat_hip.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    decls = {}
+    for m in re.finditer(r"\b(?:int|size_t|const char\*)\s+(yolat_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+        args = m.group(2).strip()
+        n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
+        decls[m.group(1)] = n
+    return decls
+
+
+def test_library_exports_every_declared_symbol():
+    decls = _header_decls()
+    assert len(decls) >= 28
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in decls:
+        assert hasattr(lib, name), "libyolat_hip.so does not export %s" % name
+
+
+def test_ctypes_signatures_match_header():
+    decls = _header_decls()
+    assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
+    for name, n in decls.items():
+        assert len(_lib.SIGNATURES[name][1]) == n, name
+
+
+def test_abi_version_and_strerror():
+    assert _lib.lib.yolat_abi_version() == 1
+    assert b"invalid" in _lib.lib.yolat_strerror(-1)
+    assert _lib.lib.yolat_strerror(0) == b"ok"
+
+
+def test_invalid_arguments_are_rejected_without_a_gpu():
+    # argument validation happens before any launch, so this is safe on a CPU-only box
+    rc = _lib.lib.yolat_linear_fwd(None, 4, 8, 0, None, None, 0, None, 4, None, 4, None, None, 0, None, 4, 0,
+                                   None, None)
+    assert rc == -1
+    rc = _lib.lib.yolat_coo_to_csr(None, 2, 1, 5, 0, None, None, None, None, None, None, None)
+    assert rc == -1
+    with pytest.raises(_lib.YolatLibraryError):
+        _lib.check(rc, "yolat_coo_to_csr")
+
+
+def test_ops_refuse_cpu_tensors():
+    a = torch.zeros(4, 8)
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        yv.ops.linear_fwd(a, torch.zeros(3, 8), None, torch.zeros(4, 3))
+
+
+def test_state_dict_keys_match_reference(golden_dir):
+    want = [l.split()[0] for l in open(os.path.join(golden_dir, "state_dict_keys.txt"))]
+    shapes = {l.split()[0]: l.split()[1] if len(l.split()) > 1 else "" for l in open(os.path.join(golden_dir, "state_dict_keys.txt"))}
+    m = yv.SparseCADGCN(yv.Opt())
+    sd = m.state_dict()
+    assert list(sd.keys()) == want
+    for k, v in sd.items():
+        assert "x".join(str(s) for s in v.shape) == shapes[k], k
+    assert sum(p.numel() for p in m.parameters()) == 1613329
+    assert sum(p.numel() for p in yv.SparseCADGCN(yv.Opt(n_classes=22)).parameters()) == 1614614
+    assert sum(p.numel() for p in yv.SparseCADGCN(yv.Opt(n_blocks=4)).parameters()) == 1656081
+
+
+def test_unknown_conv_act_norm_raise_like_reference():
+    with pytest.raises(NotImplementedError, match="conv foo is not implemented"):
+        yv.GraphConv(5, 64, "foo")
+    from yolat_vectorgraphicsrecognition_amd.nn_modules import act_layer, norm_layer
+    with pytest.raises(NotImplementedError, match="is not found"):
+        act_layer("swish")
+    with pytest.raises(NotImplementedError, match="is not found"):
+        norm_layer("group", 4)
+
+
+def test_multiseq_is_indexable_and_splats_tuples():
+    class Two(torch.nn.Module):
+        def forward(self, a, b=None):
+            return (a + 1, a + 2) if b is None else a + b
+    ms = yv.MultiSeq(Two(), Two())
+    assert isinstance(ms[0], Two)
+    assert float(ms(torch.zeros(1))) == 3.0
+
+
+def test_collate_and_fixup_match_fixture(golden_dir):
+    z = np.load(os.path.join(golden_dir, "collate.npz"))
+    items = []
+    for i in range(3):
+        d = yv.Data(x=torch.from_numpy(z["item%d/x" % i]), pos=torch.from_numpy(z["item%d/pos" % i]))
+        for k in ("edge", "e_attr", "bbox_idx", "bbox", "labels"):
+            d[k] = torch.from_numpy(z["item%d/%s" % (i, k)].copy())
+        items.append(d)
+    data, slices = yv.collate(items)
+    yv.fixup_offsets(data, slices)
+    for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "labels"):
+        np.testing.assert_array_equal(data[k].numpy(), z["batch/" + k], err_msg=k)
+        np.testing.assert_array_equal(slices[k].numpy(), z["slices/" + k], err_msg=k)
+
+
+def test_synthetic_graph_invariants():
+    d = yv.synth_graph(num_proposals=50, nodes_lo=4, nodes_hi=40, seed=3)
+    N, E, P = d.x.shape[0], d.edge.shape[0], d.bbox.shape[0]
+    assert d.x.shape[1] == 5 and torch.all(d.x[:, :3] == 0)
+    assert torch.all(d.bbox_idx[1:] >= d.bbox_idx[:-1]) and int(d.bbox_idx[-1]) == P - 1
+    assert torch.all(d.edge[:, 0] != d.edge[:, 1])
+    assert torch.all(d.bbox_idx[d.edge[:, 0]] == d.bbox_idx[d.edge[:, 1]])      # edges stay inside a proposal
+    assert 0.7 < float((d.e_attr.abs().sum(1) == 0).float().mean()) < 0.95
+    seg = onp.segment_ptr(d.bbox_idx.numpy(), P)
+    for p in range(P):
+        pos = d.x[seg[p]:seg[p + 1], 3:5]
+        assert float(pos.min()) == 0.0 and float(pos.max()) == 1.0
+    assert d.labels.shape[0] == P and d.e_attr.shape == (E, 4)
+
+
+def test_named_configs_have_the_stated_sizes():
+    d, s, kw, n = yv.config("2")
+    assert (d.x.shape[0], d.edge.shape[0], d.bbox.shape[0], n) == (10000, 40000, 400, 1)
+    assert kw["n_blocks"] == 2

@@ -1,0 +1,123 @@
+"""CPU tests (-m "not gpu"): the oracle against the golden vectors produced from the reference's own
+module code, the naive-loop oracle against the torch oracle, and the integer fixtures."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import oracle_np as onp
+from oracle import oracle_torch as orc
+from yolat_vectorgraphicsrecognition_amd.data import Data
+
+# fp32 features: 1e-4 relative (BASELINE.json north_star); oracle-vs-reference is in fact bit-exact
+RTOL, ATOL = 1e-4, 1e-6
+
+
+@pytest.mark.parametrize("kind", ["tiny", "small", "medium", "deep"])
+def test_oracle_matches_reference_golden(kind, golden_dir):
+    z = np.load(os.path.join(golden_dir, "model_%s.npz" % kind))
+    arrs, optkw = gu.graph_case(kind)
+    for k, v in optkw.items():
+        assert int(z["opt/" + k]) == v
+    opt = orc.Opt(**optkw)
+    torch.set_num_threads(1)
+    model = gu.fill_state_(orc.SparseCADGCN(opt), int(z["seed"]))
+    assert gu.state_hash(model) == str(z["state_hash"]), "weights differ from the fixture's"
+    out = gu.run_case(model, orc.DetectionLoss(opt), gu.to_data(arrs, Data))
+    names = sorted({k.rsplit("/", 1)[0] for k in z.files if "/" in k and not k.startswith("opt/")})
+    assert len(names) > 50
+    for name in names:
+        gu.compare_summary(name, out[name], gu.unpack(name, z), RTOL, ATOL)
+
+
+def test_naive_scatter_matches_torch_oracle():
+    rng = np.random.default_rng(0)
+    src = rng.standard_normal((57, 9)).astype(np.float32)
+    idx = np.sort(rng.integers(0, 11, size=57)).astype(np.int64)
+    idx[idx == 4] = 5                       # empty row 4
+    m_np = onp.scatter_mean(src, idx, 12)
+    m_t = orc.scatter(torch.from_numpy(src), torch.from_numpy(idx), dim_size=12, reduce="mean").numpy()
+    np.testing.assert_allclose(m_np, m_t, rtol=1e-6, atol=1e-7)
+    assert np.all(m_np[4] == 0) and np.all(m_np[11] == 0)
+    x_np, a_np = onp.scatter_max(src, idx, 12)
+    x_t, a_t = orc._ScatterMax.apply(torch.from_numpy(src), torch.from_numpy(idx), 12)
+    np.testing.assert_array_equal(x_np, x_t.numpy())
+    np.testing.assert_array_equal(a_np, a_t.numpy())
+    assert np.all(x_np[4] == 0) and np.all(a_np[4] == 57)
+
+
+def test_scatter_max_ties_first_wins_and_grad_routes_to_arg():
+    src = torch.tensor([[1.0, 0.0], [1.0, 0.0], [0.5, 0.0]], requires_grad=True)
+    idx = torch.tensor([0, 0, 0])
+    out, arg = orc._ScatterMax.apply(src, idx, 1)
+    assert arg.tolist() == [[0, 0]]
+    out.sum().backward()
+    assert src.grad.tolist() == [[1.0, 1.0], [0.0, 0.0], [0.0, 0.0]]
+
+
+def test_naive_conv_layer_matches_torch_oracle():
+    arrs, _ = gu.graph_case("small")
+    conv = orc.AttrRelativeEdgeConvGlobalPool2(5, 64)
+    gu.fill_state_(conv, 5)
+    conv.eval()
+    x = torch.from_numpy(arrs["x"])
+    ei = torch.from_numpy(arrs["edge"]).T
+    with torch.no_grad():
+        out_t, xn_t = conv(x, x, ei, None, torch.from_numpy(arrs["e_attr"]))
+    p = {k: v.numpy() for k, v in conv.state_dict().items()}
+    out_n, xn_n = onp.conv_gp2_eval(arrs["x"], arrs["x"], arrs["edge"][:, 0], arrs["edge"][:, 1],
+                                    arrs["e_attr"], p)
+    np.testing.assert_allclose(out_n, out_t.numpy(), rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(xn_n, xn_t.numpy(), rtol=1e-4, atol=1e-5)
+
+
+def test_integer_fixtures_match_naive_oracle(golden_dir):
+    z = np.load(os.path.join(golden_dir, "integer_ops.npz"))
+    for tag in "abc":
+        N = int(z["csr_%s/N" % tag])
+        row_ptr, perm, src_csr, dst_csr = onp.coo_to_csr(z["csr_%s/src" % tag], z["csr_%s/dst" % tag], N)
+        col_ptr, slots = onp.csc_by_source(src_csr, N)
+        for name, got in (("row_ptr", row_ptr), ("perm", perm), ("src_csr", src_csr), ("dst_csr", dst_csr),
+                          ("col_ptr", col_ptr), ("slots", slots)):
+            np.testing.assert_array_equal(got, z["csr_%s/%s" % (tag, name)])
+        # structural properties of the contract
+        assert np.all(np.diff(dst_csr) >= 0)
+        assert sorted(perm.tolist()) == list(range(len(perm)))
+        for n in range(N):
+            seg = perm[row_ptr[n]:row_ptr[n + 1]]
+            assert np.all(np.diff(seg) > 0)
+    np.testing.assert_array_equal(onp.segment_ptr(z["seg/bbox_idx"], int(z["seg/P"])), z["seg/seg_ptr"])
+
+
+def test_c_oracle_matches_numpy_oracle(golden_dir):
+    """oracle/oracle_int.c (compiled by __graft_entry__.build) against the numpy loops."""
+    import ctypes
+    so = os.path.join(os.path.dirname(golden_dir), "..", "oracle", "_build", "liboracle_int.so")
+    so = os.path.abspath(so)
+    if not os.path.exists(so):
+        import __graft_entry__ as ge
+        ge.build_oracle()
+    lib = ctypes.CDLL(so)
+    z = np.load(os.path.join(golden_dir, "integer_ops.npz"))
+    for tag in "abc":
+        N = int(z["csr_%s/N" % tag])
+        src = np.ascontiguousarray(z["csr_%s/src" % tag]); dst = np.ascontiguousarray(z["csr_%s/dst" % tag])
+        E = len(src)
+        row_ptr = np.zeros(N + 1, np.int32); perm = np.zeros(E, np.int32)
+        s32 = np.zeros(E, np.int32); d32 = np.zeros(E, np.int32)
+        rc = lib.oracle_coo_to_csr(src.ctypes.data_as(ctypes.c_void_p), dst.ctypes.data_as(ctypes.c_void_p),
+                                   ctypes.c_int64(E), ctypes.c_int64(N), row_ptr.ctypes.data_as(ctypes.c_void_p),
+                                   perm.ctypes.data_as(ctypes.c_void_p), s32.ctypes.data_as(ctypes.c_void_p),
+                                   d32.ctypes.data_as(ctypes.c_void_p))
+        assert rc == 0
+        np.testing.assert_array_equal(row_ptr, z["csr_%s/row_ptr" % tag])
+        np.testing.assert_array_equal(perm, z["csr_%s/perm" % tag])
+        np.testing.assert_array_equal(s32, z["csr_%s/src_csr" % tag])
+        np.testing.assert_array_equal(d32, z["csr_%s/dst_csr" % tag])
+    bb = np.ascontiguousarray(z["seg/bbox_idx"]); P = int(z["seg/P"])
+    seg = np.zeros(P + 1, np.int32)
+    assert lib.oracle_segment_ptr(bb.ctypes.data_as(ctypes.c_void_p), ctypes.c_int64(len(bb)), ctypes.c_int64(P),
+                                  seg.ctypes.data_as(ctypes.c_void_p)) == 0
+    np.testing.assert_array_equal(seg, z["seg/seg_ptr"])

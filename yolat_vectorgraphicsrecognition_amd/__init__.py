@@ -1,0 +1,22 @@
+"""yolat_vectorgraphicsrecognition_amd — MI355X (gfx950) native implementation of the YOLaT GNN
+message-passing hot path (SparseCADGCN forward / train step over Bezier-curve graphs).
+
+Layout
+    csrc/            hand-written HIP kernels + the C ABI (include/yolat_hip.h) -> libyolat_hip.so
+    _lib.py          ctypes binding (fails loudly when the library is missing: no CPU fallback)
+    ops.py           tensor-level wrappers of the C ABI
+    engine.py        hand-scheduled forward / backward of the model blocks
+    nn_modules.py    gcn_lib.sparse mirror: MultiSeq, MLP, GraphConv, ResBlock
+    architecture.py  cad_recognition/architecture3cc_rpn_gp_iter2 mirror: SparseCADGCN, ...
+    trainer.py       flat-buffer Adam + data-parallel step (RCCL all-reduce of one gradient bucket)
+    data.py          Data bag, collate / offset fix-up, synthetic Bezier-graph generators
+    dropin/          import shims so the reference's own scripts resolve gcn_lib / torch_scatter / ...
+"""
+from . import _lib  # noqa: F401  (raises if libyolat_hip.so is missing)
+from . import ops, engine  # noqa: F401
+from .nn_modules import MultiSeq, MLP, GraphConv, ResBlock, scatter  # noqa: F401
+from .architecture import Backbone, SparseCADGCN, DetectionLoss, Opt  # noqa: F401
+from .data import Data, collate, fixup_offsets, synth_graph, synth_batch, config  # noqa: F401
+from .trainer import FlatParams, FlatAdam, Trainer  # noqa: F401
+
+__version__ = "0.1.0"

@@ -1,0 +1,87 @@
+"""ctypes binding of libyolat_hip.so (C ABI declared in include/yolat_hip.h).
+
+The product path has NO CPU fallback: if the shared library is missing or a symbol cannot be
+resolved, importing this module raises.  Build it with ``python __graft_entry__.py`` (or
+``make -C yolat_vectorgraphicsrecognition_amd/csrc``).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libyolat_hip.so")
+
+c_p = ctypes.c_void_p
+c_i64 = ctypes.c_int64
+c_int = ctypes.c_int
+c_f = ctypes.c_float
+c_sz = ctypes.c_size_t
+
+# name -> (restype, argtypes); order mirrors include/yolat_hip.h
+SIGNATURES = {
+    "yolat_abi_version": (c_int, []),
+    "yolat_strerror": (ctypes.c_char_p, [c_int]),
+    "yolat_csr_work_elems": (c_sz, [c_i64, c_i64]),
+    "yolat_coo_to_csr": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_gather_rows": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+    "yolat_linear_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int,
+                                 c_p, c_i64, c_p, c_i64, c_p, c_p, c_int,
+                                 c_p, c_i64, c_int, c_p, c_p]),
+    "yolat_linear_fwd_wt": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p]),
+    "yolat_linear_bwd_w_work_elems": (c_sz, [c_i64, c_i64, c_i64]),
+    "yolat_linear_bwd_w": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_int,
+                                   c_p, c_i64, c_p, c_int, c_p, c_p]),
+    "yolat_bn_finalize": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_bn_eval_coeffs": (c_int, [c_p, c_p, c_p, c_p, c_f, c_i64, c_p, c_p, c_p]),
+    "yolat_scale_shift_relu": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p]),
+    "yolat_bn_bwd_work_elems": (c_sz, [c_i64, c_i64]),
+    "yolat_bn_relu_bwd": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_int,
+                                  c_p, c_p, c_int, c_p, c_i64, c_p, c_p]),
+    "yolat_edge_lin1_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_p,
+                                    c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_p]),
+    "yolat_edge_lin1_bwd_w": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p,
+                                      c_p, c_i64, c_p, c_int, c_p, c_p]),
+    "yolat_edge_lin1_bwd_x": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+    "yolat_edge_scatter_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_i64, c_p, c_i64, c_int, c_p]),
+    "yolat_csr_mean_fwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64, c_int, c_p]),
+    "yolat_csr_mean_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_segment_mean_fwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_segment_max_fwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_i64, c_p, c_i64,
+                                      c_p, c_p]),
+    "yolat_segment_mean_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_segment_max_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_softmax_ce": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+    "yolat_adam_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p]),
+}
+
+
+class YolatLibraryError(RuntimeError):
+    pass
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            "libyolat_hip.so not found at %s — the HIP extension is required (no CPU fallback). "
+            "Run `python -c 'import __graft_entry__ as g; g.build()'` from the repo root." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise ImportError("libyolat_hip.so does not export %s (stale build?)" % name) from e
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+def check(rc, what=""):
+    """Raise on a non-zero return code of a yolat_* entry point."""
+    if rc != 0:
+        msg = lib.yolat_strerror(int(rc))
+        raise YolatLibraryError("%s failed (%d): %s" % (what or "yolat call", rc,
+                                                      msg.decode() if msg else "?"))

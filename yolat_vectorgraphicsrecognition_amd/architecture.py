@@ -1,0 +1,218 @@
+"""MI355X-native ``cad_recognition/architecture3cc_rpn_gp_iter2.py``.
+
+Same classes and signatures as the reference model file:
+
+    Backbone(opt).forward(x, edges, edge_weights, edge_attrs, bbox_idx)       arch:15-71
+    SparseCADGCN(opt).forward(data, slices) -> (pred_cls, pred_bbox)          arch:73-137
+    SparseCADGCN.predict(data, slices) -> 6-tuple                             arch:139-356
+    DetectionLoss(opt)(out, data) -> {'loss', 'loss_cls'}                     arch:358-379
+
+``SparseCADGCN.forward`` moves the CPU batch to the GPU itself (like the reference's ``.cuda()`` calls,
+arch:107-115), derives the CSR / segment structure on the device (ops.build_graph) and runs the
+hand-scheduled HIP sequence of engine.model_fwd; in training mode the result carries a custom
+autograd node whose backward is engine.model_bwd.  Module attribute names reproduce the reference
+state_dict keys so reference checkpoints load.
+"""
+import torch
+from torch import nn
+
+from . import engine, ops
+from .engine import GradSink
+from .nn_modules import MultiSeq, MLP, GraphConv, ResBlock, scatter, graph_for
+from .data import Data
+
+
+class Backbone(nn.Module):
+    def __init__(self, opt, n_edges=3, edge_max_pool=None):
+        super(Backbone, self).__init__()
+        channels = opt.n_filters
+        act, norm, bias = opt.act, opt.norm, opt.bias
+        conv = "attr_edge_gp2"          # hard-coded in the reference too (arch:22); opt.conv is ignored
+        c_growth = channels
+        self.n_edges = 1
+        self.n_blocks = opt.n_blocks
+        self.n_blocks_out = opt.n_blocks_out
+        self.heads = nn.ModuleList()
+        self.n_classes = opt.n_classes
+        self.class_specific = opt.class_specific
+        self.head = GraphConv(opt.in_channels, channels, conv, act, norm, bias)
+        self.backbone = MultiSeq(*[ResBlock(channels, conv, act, norm, bias)
+                                   for _ in range(self.n_blocks - 1)])
+        fusion_dims = int(channels + c_growth * (self.n_blocks_out - 1))
+        self.fusion_block = MLP([fusion_dims, 1024], act, norm, bias)
+        self.fusion_block_super = MLP([fusion_dims, 1024], act, norm, bias)
+        self.fusion_dims = fusion_dims
+
+    def forward(self, x, edges, edge_weights, edge_attrs, bbox_idx):
+        """Module-by-module path (each sub-module launches its own HIP kernels and has its own
+        autograd node).  SparseCADGCN.forward does not go through here: it uses the fused
+        schedule in engine.model_fwd."""
+        f, f_super = self.head(x, edges[0], edge_weights[0], edge_attrs[0], x_node=x)
+        feats, feats_super = [f], [f_super]
+        for i in range(self.n_blocks - 1):
+            f, f_super = self.backbone[i](feats[-1], edges[0], edge_weights[0], edge_attrs[0],
+                                          x_node=feats_super[-1])
+            feats.append(f)
+            feats_super.append(f_super)
+        lo = self.n_blocks - self.n_blocks_out
+        feats = torch.cat(feats[lo:self.n_blocks], dim=1)
+        out_feat = torch.cat((self.fusion_block(feats), feats), dim=1)
+        feats_super = torch.cat(feats_super[lo:self.n_blocks], dim=1)
+        feats_super = scatter(feats_super, bbox_idx, dim=0, reduce="mean")
+        out_feat_super = torch.cat((self.fusion_block_super(feats_super), feats_super), dim=1)
+        return out_feat, out_feat_super
+
+
+class _ModelFn(torch.autograd.Function):
+    """One autograd node for the whole SparseCADGCN forward."""
+
+    @staticmethod
+    def forward(ctx, model, g, x, *params):
+        training = model.training
+        logits, sv = engine.model_fwd(model, g, x, training)
+        ctx.model, ctx.g, ctx.sv, ctx.params = model, g, sv, params
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        if ctx.sv is None:
+            raise RuntimeError("backward through an eval-mode SparseCADGCN is not supported by the HIP path")
+        model = ctx.model
+        flat = getattr(model, "_yolat_flat", None)
+        dl = dlogits.contiguous().clone()
+        if flat is not None and flat.direct_grads:
+            # trainer path: gradients land in the flat buffer, autograd sees no per-tensor grads
+            engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink(flat.grad_views))
+            flat.grads_ready = True
+            return (None, None, None) + tuple(None for _ in ctx.params)
+        sink = engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink())
+        return (None, None, None) + tuple(sink.out.get(id(p)) for p in ctx.params)
+
+
+class SparseCADGCN(nn.Module):
+    def __init__(self, opt, n_edges=3, edge_max_pool=None, expand_ratio=0.25):
+        super(SparseCADGCN, self).__init__()
+        self.expand_ratio = expand_ratio
+        act, norm, bias = opt.act, opt.norm, opt.bias
+        self.n_classes = opt.n_classes
+        self.classifier = opt.classifier
+        self.class_specific = opt.class_specific
+        self.dim_stat = 0
+        self.cls_net = Backbone(opt)
+        d = (self.cls_net.fusion_dims + 1024) * 2 + self.dim_stat
+        self.prediction_cls = MultiSeq(*[MLP([d, 512], act, norm, bias),
+                                         MLP([512, 256], act, norm, bias, drop=opt.dropout),
+                                         MLP([256, opt.n_classes], None, None, bias)])
+        self.model_init()
+
+    def model_init(self):
+        """arch:97-104: kaiming_normal_ on every Linear weight, zero bias."""
+        for m in self.modules():
+            if isinstance(m, nn.Linear):
+                nn.init.kaiming_normal_(m.weight)
+                m.weight.requires_grad = True
+                if m.bias is not None:
+                    m.bias.data.zero_()
+                    m.bias.requires_grad = True
+
+    # -- device staging ---------------------------------------------------------------------
+    @staticmethod
+    def _stage(data):
+        """H2D of the tensors forward reads (arch:107-115) + device-side graph structure, cached on
+        the batch object so a second forward on the same batch (predict, epochs over a cached
+        batch) re-uses it."""
+        cache = getattr(data, "_yolat_stage", None)
+        key = (data.x.data_ptr(), data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
+               data.bbox_idx._version, data.e_attr.data_ptr(), tuple(data.x.shape), tuple(data.edge.shape))
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        x = data.x.cuda(non_blocking=True)
+        edge = data.edge.cuda(non_blocking=True)
+        e_attr = data.e_attr.cuda(non_blocking=True)
+        bbox_idx = data.bbox_idx.cuda(non_blocking=True)
+        pred_bbox = data.bbox.cuda(non_blocking=True)
+        if x.dtype != torch.float32:
+            x = x.float()
+        g = ops.build_graph(edge, e_attr, bbox_idx, x.shape[0], pred_bbox.shape[0])
+        staged = (x, g, pred_bbox)
+        try:
+            data._yolat_stage = (key, staged)
+        except AttributeError:
+            pass
+        return staged
+
+    def forward(self, data, slices=None):
+        x, g, pred_bbox = self._stage(data)
+        pred_cls = _ModelFn.apply(self, g, x, *list(self.parameters()))
+        if self.classifier != "softmax":
+            pred_cls = torch.sigmoid(pred_cls)
+        return pred_cls, pred_bbox
+
+    def forward_modular(self, data, slices=None):
+        """Same result through the module-by-module path (Backbone.forward + scatter + MLPs)."""
+        x, g, pred_bbox = self._stage(data)
+        bbox_idx = data.bbox_idx.cuda()
+        e_attr = data.e_attr.cuda()
+        out_feat, out_super = self.cls_net(x, [g], [None], [e_attr], bbox_idx)
+        out_feat = scatter(out_feat, bbox_idx, dim=0, reduce="max")
+        pred_cls = self.prediction_cls(torch.cat([out_feat, out_super], dim=1))
+        if self.classifier != "softmax":
+            pred_cls = torch.sigmoid(pred_cls)
+        return pred_cls, pred_bbox
+
+
+class _CEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, labels):
+        loss = torch.empty(1, dtype=torch.float32, device=logits.device)
+        dl = torch.empty_like(logits)
+        ops.softmax_ce(logits, labels, loss, dl)
+        ctx.save_for_backward(dl)
+        return loss[0]
+
+    @staticmethod
+    def backward(ctx, gout):
+        (dl,) = ctx.saved_tensors
+        return dl * gout, None
+
+
+class DetectionLoss(nn.Module):
+    """arch:358-379: CrossEntropyLoss (mean over proposals) for classifier='softmax'."""
+
+    def __init__(self, opt):
+        super(DetectionLoss, self).__init__()
+        self.classifier = opt.classifier
+        if opt.classifier != "softmax":
+            self.cls_loss = nn.BCELoss()
+
+    def forward(self, out, data):
+        pred_cls = out[0]
+        gt_cls = data.labels.cuda(non_blocking=True)
+        if self.classifier == "softmax":
+            l0 = _CEFn.apply(pred_cls.contiguous(), gt_cls)
+        else:
+            # non-default branch of the reference (BCE on sigmoid outputs): plain torch ops
+            tgt = torch.zeros(pred_cls.size(), device=pred_cls.device).scatter_(1, gt_cls.unsqueeze(1), 1)
+            l0 = self.cls_loss(pred_cls, tgt)
+        return {"loss": l0, "loss_cls": l0}
+
+
+class Opt(object):
+    """The ``opt`` attributes the model reads (cad_recognition/config.py:26-85, train.py:195-197),
+    defaulting to the README recipe (README.md:33-42)."""
+
+    def __init__(self, **kw):
+        self.n_filters = 64
+        self.act = "relu"
+        self.norm = "batch"
+        self.bias = True
+        self.conv = "attr_edge"
+        self.n_classes = 17
+        self.classifier = "softmax"
+        self.class_specific = False
+        self.in_channels = 5
+        self.n_blocks = 2
+        self.n_blocks_out = 2
+        self.dropout = 0.0
+        for k, v in kw.items():
+            setattr(self, k, v)

@@ -1,0 +1,346 @@
+// dense.hip — nn.Linear / BatchNorm1d / ReLU of gcn_lib/sparse/torch_nn.py:50-71 on gfx950.
+// Entry points: yolat_linear_fwd, yolat_linear_fwd_wt, yolat_linear_bwd_w, yolat_bn_finalize,
+// yolat_bn_eval_coeffs, yolat_scale_shift_relu, yolat_bn_relu_bwd.
+#include "common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// GEMM dispatch
+// ------------------------------------------------------------------------------------------------
+template <class AL, class BL, bool NFAST>
+static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, long N, long K,
+                          hipStream_t st) {
+  if (M <= 0 || N <= 0) return 0;
+  if (ep.stats != nullptr || N <= 64 || M <= 512) {
+    // 64x64 tiles (stats are defined on 64-row groups; also the small-M shapes)
+    dim3 grid(yl_cdiv(M, 64), yl_cdiv(N, 64));
+    if (K <= 16)
+      hipLaunchKernelGGL((k_gemm_nt<64, 64, 16, AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep,
+                         (int)M, (int)N, (int)K);
+    else
+      hipLaunchKernelGGL((k_gemm_nt<64, 64, 32, AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep,
+                         (int)M, (int)N, (int)K);
+  } else {
+    dim3 grid(yl_cdiv(M, 128), yl_cdiv(N, 128));
+    hipLaunchKernelGGL((k_gemm_nt<128, 128, 16, AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep,
+                       (int)M, (int)N, (int)K);
+  }
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+static DenseOp make_dense(const float* p, long ld, long rows, long cols, const float* scale,
+                          const float* shift, int relu) {
+  DenseOp d;
+  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
+  d.scale = scale; d.shift = shift; d.relu = relu;
+  d.vec = (ld % 4 == 0) && yl_aligned16(p);
+  return d;
+}
+
+extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t K,
+                                const float* a_scale, const float* a_shift, int a_relu,
+                                const float* W, int64_t ldw, const float* bias, int64_t Nout,
+                                const float* o_scale, const float* o_shift, int o_relu, float* Y,
+                                int64_t ldy, int accumulate, float* stats, yolat_stream_t stream) {
+  if (M < 0 || K <= 0 || Nout <= 0 || (M > 0 && (!A || !Y)) || !W) return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lda < K || ldw < K || ldy < Nout) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr)) return YOLAT_E_INVALID;
+  if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
+  DenseOp a = make_dense(A, lda, M, K, a_scale, a_shift, a_relu);
+  DenseOp b = make_dense(W, ldw, Nout, K, nullptr, nullptr, 0);
+  Epilogue ep;
+  ep.bias = bias; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;
+  ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = stats;
+  return launch_gemm_nt<DenseOp, DenseOp, false>(a, b, ep, M, Nout, K, (hipStream_t)stream);
+}
+
+extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
+                                   const float* Wt, int64_t ldw, int64_t Nout, float* Y,
+                                   int64_t ldy, int accumulate, yolat_stream_t stream) {
+  if (M < 0 || K <= 0 || Nout <= 0 || (M > 0 && (!A || !Y)) || !Wt) return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lda < K || ldw < Nout || ldy < Nout) return YOLAT_E_INVALID;
+  DenseOp a = make_dense(A, lda, M, K, nullptr, nullptr, 0);
+  TransOp b;
+  b.p = Wt; b.ld = ldw; b.rows = (int)Nout; b.cols = (int)K;
+  Epilogue ep;
+  ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
+  ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = nullptr;
+  return launch_gemm_nt<DenseOp, TransOp, true>(a, b, ep, M, Nout, K, (hipStream_t)stream);
+}
+
+extern "C" size_t yolat_linear_bwd_w_work_elems(int64_t M, int64_t Nout, int64_t K) {
+  TnPlan p = yl_tn_plan(M, Nout, K);
+  return (size_t)p.S * (size_t)(Nout * K + Nout);
+}
+
+extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int64_t Nout,
+                                  const float* A, int64_t lda, int64_t K, const float* a_scale,
+                                  const float* a_shift, int a_relu, float* dW, int64_t lddw,
+                                  float* db, int accumulate, float* partial,
+                                  yolat_stream_t stream) {
+  if (M < 0 || K <= 0 || Nout <= 0 || !dW || !partial || (M > 0 && (!dY || !A)))
+    return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lddy < Nout || lda < K || lddw < K) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  TnPlan p = yl_tn_plan(M, Nout, K);
+  DenseOp y = make_dense(dY, lddy, M, Nout, nullptr, nullptr, 0);
+  DenseOp a = make_dense(A, lda, M, K, a_scale, a_shift, a_relu);
+  float* dbpart = db ? partial + (size_t)p.S * Nout * K : nullptr;
+  dim3 grid(yl_cdiv(Nout, 64), yl_cdiv(K, 64), p.S);
+  hipLaunchKernelGGL((k_gemm_tn<DenseOp, DenseOp>), grid, dim3(256), 0, st, y, a, partial, dbpart,
+                     (int)M, (int)Nout, (int)K, p.rows_per_split);
+  YL_LAUNCH_CHECK();
+  const long elems = Nout * K;
+  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 256)), dim3(256), 0, st, partial, elems,
+                     p.S, dW, (long)lddw, (int)K, accumulate);
+  YL_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(Nout, 256)), dim3(256), 0, st, dbpart,
+                       (long)Nout, p.S, db, (long)Nout, (int)Nout, accumulate);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm1d statistics (training mode): Chan merge of the 64-row (sum, M2) partials in fp64.
+// block = 64 columns x 16 partitions; partition p owns a contiguous range of row blocks; the 16
+// partition results are merged in order by partition 0  => deterministic.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(1024) k_bn_finalize(const float2* stats, long M, int C,
+                                                      const float* gamma, const float* beta,
+                                                      float* running_mean, float* running_var,
+                                                      float momentum, float eps, float* save_mean,
+                                                      float* save_invstd, float* scale,
+                                                      float* shift) {
+  __shared__ double s_n[16][64], s_mean[16][64], s_m2[16][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long nb = (M + 63) / 64;
+  const long per = (nb + 15) / 16;
+  const long b0 = part * per;
+  long b1 = b0 + per;
+  if (b1 > nb) b1 = nb;
+  double n = 0.0, mean = 0.0, m2 = 0.0;
+  if (c < C) {
+    for (long b = b0; b < b1; ++b) {
+      const float2 t = stats[b * C + c];
+      long cnt = M - b * 64;
+      if (cnt > 64) cnt = 64;
+      const double nb_ = (double)cnt;
+      const double mb = (double)t.x / nb_;
+      const double delta = mb - mean;
+      const double tot = n + nb_;
+      mean += delta * (nb_ / tot);
+      m2 += (double)t.y + delta * delta * (n * nb_ / tot);
+      n = tot;
+    }
+  }
+  s_n[part][cl] = n; s_mean[part][cl] = mean; s_m2[part][cl] = m2;
+  __syncthreads();
+  if (part == 0 && c < C) {
+    n = s_n[0][cl]; mean = s_mean[0][cl]; m2 = s_m2[0][cl];
+    for (int p = 1; p < 16; ++p) {
+      const double nb_ = s_n[p][cl];
+      if (nb_ == 0.0) continue;
+      const double delta = s_mean[p][cl] - mean;
+      const double tot = n + nb_;
+      mean += delta * (nb_ / tot);
+      m2 += s_m2[p][cl] + delta * delta * (n * nb_ / tot);
+      n = tot;
+    }
+    const double var_b = n > 0.0 ? m2 / n : 0.0;                 // biased: used to normalise
+    const double var_u = n > 1.0 ? m2 / (n - 1.0) : var_b;       // unbiased: running update
+    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+    const float meanf = (float)mean;
+    save_mean[c] = meanf;
+    save_invstd[c] = invstd;
+    const float sc = gamma[c] * invstd;
+    scale[c] = sc;
+    shift[c] = beta[c] - meanf * sc;
+    if (running_mean != nullptr) {
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+    }
+  }
+}
+
+extern "C" int yolat_bn_finalize(const float* stats, int64_t M, int64_t C, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* save_mean, float* save_invstd,
+                                 float* scale, float* shift, yolat_stream_t stream) {
+  if (!stats || M <= 0 || C <= 0 || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift)
+    return YOLAT_E_INVALID;
+  if ((running_mean == nullptr) != (running_var == nullptr)) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_bn_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream,
+                     reinterpret_cast<const float2*>(stats), (long)M, (int)C, gamma, beta,
+                     running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_bn_eval_coeffs(const float* gamma, const float* beta, const float* rm,
+                                 const float* rv, float eps, int C, float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float invstd = 1.f / sqrtf(rv[c] + eps);
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - rm[c] * sc;
+}
+
+extern "C" int yolat_bn_eval_coeffs(const float* gamma, const float* beta,
+                                    const float* running_mean, const float* running_var, float eps,
+                                    int64_t C, float* scale, float* shift, yolat_stream_t stream) {
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift || C <= 0)
+    return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_bn_eval_coeffs, dim3(yl_cdiv(C, 256)), dim3(256), 0, (hipStream_t)stream,
+                     gamma, beta, running_mean, running_var, eps, (int)C, scale, shift);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Z = relu(Y*scale + shift) — elementwise, grid-stride over rows, threads along columns.
+// ------------------------------------------------------------------------------------------------
+__global__ void k_scale_shift_relu(const float* Y, long ldy, long M, int C, const float* scale,
+                                   const float* shift, int relu, float* Z, long ldz) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= C) return;
+  const float sc = scale ? scale[c] : 1.f, sh = scale ? shift[c] : 0.f;
+  for (long r = (long)blockIdx.y * 4 + (threadIdx.x >> 6); r < M; r += (long)gridDim.y * 4) {
+    float v = fmaf(Y[r * ldy + c], sc, sh);
+    if (relu) v = fmaxf(v, 0.f);
+    Z[r * ldz + c] = v;
+  }
+}
+
+extern "C" int yolat_scale_shift_relu(const float* Y, int64_t ldy, int64_t M, int64_t C,
+                                      const float* scale, const float* shift, int relu, float* Z,
+                                      int64_t ldz, yolat_stream_t stream) {
+  if (M < 0 || C <= 0 || (M > 0 && (!Y || !Z))) return YOLAT_E_INVALID;
+  if (M == 0) return 0;
+  int gy = yl_cdiv(M, 4);
+  if (gy > 2048) gy = 2048;
+  hipLaunchKernelGGL(k_scale_shift_relu, dim3(yl_cdiv(C, 64), gy), dim3(256), 0,
+                     (hipStream_t)stream, Y, (long)ldy, (long)M, (int)C, scale, shift, relu, Z,
+                     (long)ldz);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of Z = relu(BN_train(Y)).
+//  k_bn_bwd_partial: per 256-row block, per column: (sum dyh, sum dyh*xhat)
+//  k_bn_bwd_finalize: fp64 ordered sum over blocks -> dgamma, dbeta, coef = (s1/M, s2/M)
+//  k_bn_bwd_apply:   dY = scale*(dyh - c1 - xhat*c2)
+// ------------------------------------------------------------------------------------------------
+#define BNB_ROWS 256
+__global__ void __launch_bounds__(256) k_bn_bwd_partial(const float* dZ, long lddz, const float* Y,
+                                                        long ldy, long M, int C, const float* mean,
+                                                        const float* invstd, const float* scale,
+                                                        const float* shift, int relu,
+                                                        float2* part) {
+  __shared__ float2 red[4][64];
+  const int cl = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long r0 = (long)blockIdx.y * BNB_ROWS;
+  float s1 = 0.f, s2 = 0.f;
+  if (c < C) {
+    const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+    long r1 = r0 + BNB_ROWS;
+    if (r1 > M) r1 = M;
+    for (long r = r0 + ty; r < r1; r += 4) {
+      const float y = Y[r * ldy + c];
+      float g = dZ[r * lddz + c];
+      if (relu && !(fmaf(y, sc, sh) > 0.f)) g = 0.f;
+      s1 += g;
+      s2 += g * ((y - mu) * is);
+    }
+  }
+  red[ty][cl] = make_float2(s1, s2);
+  __syncthreads();
+  if (ty == 0 && c < C) {
+    float2 a = red[0][cl];
+    for (int t = 1; t < 4; ++t) { a.x += red[t][cl].x; a.y += red[t][cl].y; }
+    part[(long)blockIdx.y * C + c] = a;
+  }
+}
+
+__global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float2* part, long nb, long M,
+                                                          int C, float* dgamma, float* dbeta,
+                                                          int accumulate, float* coef) {
+  __shared__ double s1s[16][64], s2s[16][64];
+  const int cl = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long per = (nb + 15) / 16;
+  long b0 = p * per, b1 = b0 + per;
+  if (b1 > nb) b1 = nb;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (long i = b0; i < b1; ++i) {
+      const float2 t = part[i * C + c];
+      a += (double)t.x; b += (double)t.y;
+    }
+  s1s[p][cl] = a; s2s[p][cl] = b;
+  __syncthreads();
+  if (p == 0 && c < C) {
+    for (int t = 1; t < 16; ++t) { a += s1s[t][cl]; b += s2s[t][cl]; }
+    float dg = (float)b, dbt = (float)a;
+    if (accumulate) { dg += dgamma[c]; dbt += dbeta[c]; }
+    dgamma[c] = dg; dbeta[c] = dbt;
+    coef[c] = (float)(a / (double)M);
+    coef[C + c] = (float)(b / (double)M);
+  }
+}
+
+__global__ void k_bn_bwd_apply(const float* dZ, long lddz, const float* Y, long ldy, long M, int C,
+                               const float* mean, const float* invstd, const float* scale,
+                               const float* shift, int relu, const float* coef, float* dY,
+                               long lddy) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= C) return;
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c];
+  const float c1 = coef[c], c2 = coef[C + c];
+  for (long r = (long)blockIdx.y * 4 + (threadIdx.x >> 6); r < M; r += (long)gridDim.y * 4) {
+    const float y = Y[r * ldy + c];
+    float g = dZ[r * lddz + c];
+    if (relu && !(fmaf(y, sc, sh) > 0.f)) g = 0.f;
+    const float xh = (y - mu) * is;
+    dY[r * lddy + c] = sc * (g - c1 - xh * c2);
+  }
+}
+
+extern "C" size_t yolat_bn_bwd_work_elems(int64_t M, int64_t C) {
+  return (size_t)(2 * yl_cdiv(M, BNB_ROWS) * C + 2 * C);
+}
+
+extern "C" int yolat_bn_relu_bwd(const float* dZ, int64_t lddz, const float* Y, int64_t ldy,
+                                 int64_t M, int64_t C, const float* gamma, const float* save_mean,
+                                 const float* save_invstd, const float* scale, const float* shift,
+                                 int relu, float* dgamma, float* dbeta, int accumulate, float* dY,
+                                 int64_t lddy, float* work, yolat_stream_t stream) {
+  (void)gamma;
+  if (M <= 0 || C <= 0 || !dZ || !Y || !save_mean || !save_invstd || !scale || !shift || !dgamma ||
+      !dbeta || !dY || !work)
+    return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const long nb = yl_cdiv(M, BNB_ROWS);
+  float2* part = reinterpret_cast<float2*>(work);
+  float* coef = work + 2 * nb * C;
+  hipLaunchKernelGGL(k_bn_bwd_partial, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, dZ,
+                     (long)lddz, Y, (long)ldy, (long)M, (int)C, save_mean, save_invstd, scale,
+                     shift, relu, part);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, part, nb, (long)M,
+                     (int)C, dgamma, dbeta, accumulate, coef);
+  YL_LAUNCH_CHECK();
+  int gy = yl_cdiv(M, 4);
+  if (gy > 2048) gy = 2048;
+  hipLaunchKernelGGL(k_bn_bwd_apply, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st, dZ, (long)lddz, Y,
+                     (long)ldy, (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, coef,
+                     dY, (long)lddy);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,201 @@
+// edge.hip — AttrRelativeEdgeConvGlobalPool2 (gcn_lib/sparse/torch_vertex.py:288-341) on gfx950:
+// gathered edge-feature GEMM, CSR mean aggregation and their backward.  All [E,*] tensors are in
+// destination-sorted (CSR) order, so aggregation reads contiguous rows and needs no atomics.
+#include "common.hpp"
+
+static EdgeOp make_edge(const float* x, long ldx, long Cin, const int* src, const int* dst,
+                        const float* attr, long E) {
+  EdgeOp a;
+  a.x = x; a.ldx = ldx; a.Cin = (int)Cin; a.src = src; a.dst = dst; a.attr = attr; a.E = (int)E;
+  a.vec = (Cin % 4 == 0) && (ldx % 4 == 0) && yl_aligned16(x) && yl_aligned16(attr);
+  return a;
+}
+
+static DenseOp make_dense_e(const float* p, long ld, long rows, long cols) {
+  DenseOp d;
+  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
+  d.scale = nullptr; d.shift = nullptr; d.relu = 0;
+  d.vec = (ld % 4 == 0) && yl_aligned16(p);
+  return d;
+}
+
+extern "C" int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64_t Cin,
+                                   const int32_t* src_csr, const int32_t* dst_csr,
+                                   const float* attr_csr, int64_t E, const float* W1, int64_t ldw,
+                                   const float* b1, int64_t C, const float* o_scale,
+                                   const float* o_shift, int o_relu, float* H1, int64_t ldh,
+                                   float* stats, yolat_stream_t stream) {
+  if (E < 0 || N <= 0 || Cin <= 0 || C <= 0 || !x || !W1) return YOLAT_E_INVALID;
+  if (E == 0) return 0;
+  if (!src_csr || !dst_csr || !attr_csr || !H1 || E >= (1LL << 31)) return YOLAT_E_INVALID;
+  const long K = 2 * Cin + 4;
+  if (ldw < K || ldh < C || ldx < Cin) return YOLAT_E_INVALID;
+  if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
+  EdgeOp a = make_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
+  DenseOp b = make_dense_e(W1, ldw, C, K);
+  Epilogue ep;
+  ep.bias = b1; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;
+  ep.Y = H1; ep.ldy = ldh; ep.accumulate = 0; ep.stats = stats;
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(yl_cdiv(E, 64), yl_cdiv(C, 64));
+  if (K <= 16)
+    hipLaunchKernelGGL((k_gemm_nt<64, 64, 16, EdgeOp, DenseOp, false>), grid, dim3(256), 0, st, a,
+                       b, ep, (int)E, (int)C, (int)K);
+  else
+    hipLaunchKernelGGL((k_gemm_nt<64, 64, 32, EdgeOp, DenseOp, false>), grid, dim3(256), 0, st, a,
+                       b, ep, (int)E, (int)C, (int)K);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_edge_lin1_bwd_w(const float* dH1, int64_t lddh, int64_t E, int64_t C,
+                                     const float* x, int64_t ldx, int64_t N, int64_t Cin,
+                                     const int32_t* src_csr, const int32_t* dst_csr,
+                                     const float* attr_csr, float* dW1, int64_t lddw, float* db1,
+                                     int accumulate, float* partial, yolat_stream_t stream) {
+  if (E < 0 || N <= 0 || Cin <= 0 || C <= 0 || !x || !dW1 || !partial) return YOLAT_E_INVALID;
+  if (E > 0 && (!dH1 || !src_csr || !dst_csr || !attr_csr)) return YOLAT_E_INVALID;
+  const long K = 2 * Cin + 4;
+  if (lddw < K || lddh < C || E >= (1LL << 31)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  TnPlan p = yl_tn_plan(E, C, K);
+  DenseOp y = make_dense_e(dH1, lddh, E, C);
+  EdgeOp a = make_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
+  float* dbpart = db1 ? partial + (size_t)p.S * C * K : nullptr;
+  dim3 grid(yl_cdiv(C, 64), yl_cdiv(K, 64), p.S);
+  hipLaunchKernelGGL((k_gemm_tn<DenseOp, EdgeOp>), grid, dim3(256), 0, st, y, a, partial, dbpart,
+                     (int)E, (int)C, (int)K, p.rows_per_split);
+  YL_LAUNCH_CHECK();
+  const long elems = C * K;
+  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 256)), dim3(256), 0, st, partial, elems,
+                     p.S, dW1, (long)lddw, (int)K, accumulate);
+  YL_LAUNCH_CHECK();
+  if (db1) {
+    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(C, 256)), dim3(256), 0, st, dbpart, (long)C,
+                       p.S, db1, (long)C, (int)C, accumulate);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int yolat_edge_lin1_bwd_x(const float* dH1, int64_t lddh, int64_t E, int64_t C,
+                                     const float* W1, int64_t ldw, int64_t Cin, float* dG,
+                                     int64_t lddg, yolat_stream_t stream) {
+  if (E < 0 || C <= 0 || Cin <= 0 || !W1) return YOLAT_E_INVALID;
+  if (E == 0) return 0;
+  if (!dH1 || !dG || lddh < C || lddg < 2 * Cin || ldw < 2 * Cin + 4 || E >= (1LL << 31))
+    return YOLAT_E_INVALID;
+  DenseOp a = make_dense_e(dH1, lddh, E, C);
+  EdgeWcOp b;
+  b.W1 = W1; b.ldw = ldw; b.Cin = (int)Cin; b.C = (int)C;
+  Epilogue ep;
+  ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
+  ep.Y = dG; ep.ldy = lddg; ep.accumulate = 0; ep.stats = nullptr;
+  const long Nn = 2 * Cin;
+  dim3 grid(yl_cdiv(E, 64), yl_cdiv(Nn, 64));
+  hipLaunchKernelGGL((k_gemm_nt<64, 64, 32, DenseOp, EdgeWcOp, true>), grid, dim3(256), 0,
+                     (hipStream_t)stream, a, b, ep, (int)E, (int)Nn, (int)C);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// CSR mean aggregation.  One wave per destination node, lanes across channels (256-B rows are
+// read fully coalesced); rows of a node are consecutive CSR slots, summed in ascending edge order.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_csr_mean_fwd(const float* H, long ldh, int C,
+                                                      const float* hs, const float* hb, int relu,
+                                                      const int* row_ptr, int N, float* out,
+                                                      long ldo, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int q0 = row_ptr[n], q1 = row_ptr[n + 1];
+  const float inv = 1.f / (float)((q1 - q0) > 1 ? (q1 - q0) : 1);
+  for (int c = lane; c < C; c += 64) {
+    const float sc = hs ? hs[c] : 1.f, sh = hs ? hb[c] : 0.f;
+    float s = 0.f;
+    for (int q = q0; q < q1; ++q) {
+      float v = H[(long)q * ldh + c];
+      if (hs) v = fmaf(v, sc, sh);
+      if (relu) v = fmaxf(v, 0.f);
+      s += v;
+    }
+    s *= inv;
+    float* o = out + (long)n * ldo + c;
+    if (accumulate) s += *o;
+    *o = s;
+  }
+}
+
+extern "C" int yolat_csr_mean_fwd(const float* H, int64_t ldh, int64_t C, const float* h_scale,
+                                  const float* h_shift, int h_relu, const int32_t* row_ptr,
+                                  int64_t N, float* out, int64_t ldo, int accumulate,
+                                  yolat_stream_t stream) {
+  if (N <= 0 || C <= 0 || !row_ptr || !out || ldo < C) return YOLAT_E_INVALID;
+  if ((h_scale == nullptr) != (h_shift == nullptr)) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_csr_mean_fwd, dim3(yl_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, H,
+                     (long)ldh, (int)C, h_scale, h_shift, h_relu, row_ptr, (int)N, out, (long)ldo,
+                     accumulate);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void __launch_bounds__(256) k_csr_mean_bwd(const float* dOut, long lddo, int C,
+                                                      const int* row_ptr, const int* dst, int E,
+                                                      float* dM, long lddm) {
+  const int lane = threadIdx.x & 63;
+  const int q = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (q >= E) return;
+  const int n = dst[q];
+  const int deg = row_ptr[n + 1] - row_ptr[n];
+  const float inv = 1.f / (float)(deg > 1 ? deg : 1);
+  for (int c = lane; c < C; c += 64) dM[(long)q * lddm + c] = dOut[(long)n * lddo + c] * inv;
+}
+
+extern "C" int yolat_csr_mean_bwd(const float* dOut, int64_t lddo, int64_t C,
+                                  const int32_t* row_ptr, const int32_t* dst_csr, int64_t E,
+                                  float* dM, int64_t lddm, yolat_stream_t stream) {
+  if (E < 0 || C <= 0 || !dOut || !row_ptr) return YOLAT_E_INVALID;
+  if (E == 0) return 0;
+  if (!dst_csr || !dM || lddm < C) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_csr_mean_bwd, dim3(yl_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, dOut,
+                     (long)lddo, (int)C, row_ptr, dst_csr, (int)E, dM, (long)lddm);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Backward of the two gathers: dX[n] (+)= sum_{q in CSR row n} dG[q, 0:Cin]
+//                                       + sum_{q in CSC col n} dG[q, Cin:2Cin]   (ascending slots)
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_scatter_bwd(const float* dG, long lddg, int Cin,
+                                                          const int* row_ptr, const int* col_ptr,
+                                                          const int* slots, int N, float* dX,
+                                                          long lddx, int accumulate) {
+  const int lane = threadIdx.x & 63;
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const int q0 = row_ptr[n], q1 = row_ptr[n + 1];
+  const int t0 = col_ptr[n], t1 = col_ptr[n + 1];
+  for (int c = lane; c < Cin; c += 64) {
+    float s = 0.f;
+    for (int q = q0; q < q1; ++q) s += dG[(long)q * lddg + c];
+    for (int t = t0; t < t1; ++t) s += dG[(long)slots[t] * lddg + Cin + c];
+    float* o = dX + (long)n * lddx + c;
+    if (accumulate) s += *o;
+    *o = s;
+  }
+}
+
+extern "C" int yolat_edge_scatter_bwd(const float* dG, int64_t lddg, int64_t Cin,
+                                      const int32_t* row_ptr, const int32_t* col_ptr,
+                                      const int32_t* slots, int64_t N, float* dX, int64_t lddx,
+                                      int accumulate, yolat_stream_t stream) {
+  if (N <= 0 || Cin <= 0 || !row_ptr || !col_ptr || !dX || lddx < Cin) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_edge_scatter_bwd, dim3(yl_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream,
+                     dG, (long)lddg, (int)Cin, row_ptr, col_ptr, slots, (int)N, dX, (long)lddx,
+                     accumulate);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

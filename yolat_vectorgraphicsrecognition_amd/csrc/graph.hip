@@ -1,0 +1,214 @@
+// graph.hip — integer pre-processing of one batch (bit-exact contract, see oracle/oracle_np.py):
+//   COO edge list (int64, as the reference hands it to GraphConv: architecture3cc_rpn_gp_iter2.py:110)
+//   -> destination-sorted CSR (stable: ascending edge id inside a row), CSC by source for the
+//   backward, proposal segment pointers from the sorted bbox_idx, row gather for e_attr.
+// Counting sort = histogram (int atomics: order-independent result) -> single-workgroup exclusive
+// scan -> cursor fill (unordered) -> per-row insertion sort by edge id (restores the stable order;
+// rows are short: in-degree of a Bezier end point is a handful).
+#include "common.hpp"
+
+__global__ void k_edge_count(const int64_t* edge, long se, long sc, int E, int N, int* src32,
+                             int* dst32, int* cnt, int* status) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int64_t s = edge[(long)e * se];
+  const int64_t d = edge[(long)e * se + sc];
+  if (s < 0 || s >= N || d < 0 || d >= N) {
+    atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
+    src32[e] = -1; dst32[e] = -1;
+    return;
+  }
+  src32[e] = (int)s; dst32[e] = (int)d;
+  atomicAdd(&cnt[d], 1);
+}
+
+__global__ void k_count32(const int* key, int n, int* cnt) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = key[i];
+  if (k >= 0) atomicAdd(&cnt[k], 1);
+}
+
+// Exclusive scan of cnt[0..N) into ptr[0..N], ptr[N] = total; cnt is zeroed (it becomes the fill
+// cursor).  One 1024-thread workgroup, 4 elements per thread per sweep.
+__global__ void __launch_bounds__(1024) k_scan_excl(int* cnt, int N, int* ptr) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int carry = 0;
+  for (int base = 0; base < N; base += 4096) {
+    const int idx = base + tid * 4;
+    int v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      v[j] = (idx + j < N) ? cnt[idx + j] : 0;
+      if (idx + j < N) cnt[idx + j] = 0;
+    }
+    const int t = v[0] + v[1] + v[2] + v[3];
+    int incl = t;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int nb = __shfl_up(incl, off);
+      if (lane >= off) incl += nb;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int s = wsum[w];
+      if (w < wave) woff += s;
+      total += s;
+    }
+    int excl = carry + woff + incl - t;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (idx + j < N) ptr[idx + j] = excl;
+      excl += v[j];
+    }
+    carry += total;
+    __syncthreads();
+  }
+  if (tid == 0) ptr[N] = carry;
+}
+
+__global__ void k_fill(const int* key, int n, const int* ptr, int* cursor, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int k = key[i];
+  if (k < 0) return;
+  const int pos = ptr[k] + atomicAdd(&cursor[k], 1);
+  out[pos] = i;
+}
+
+__global__ void k_sort_rows(const int* ptr, int* items, int N) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int b = ptr[n], e = ptr[n + 1];
+  for (int i = b + 1; i < e; ++i) {
+    const int v = items[i];
+    int j = i - 1;
+    while (j >= b && items[j] > v) { items[j + 1] = items[j]; --j; }
+    items[j + 1] = v;
+  }
+}
+
+__global__ void k_emit_csr(const int* perm_tmp, const int* src32, const int* dst32, int total,
+                           int* perm, int* src_csr, int* dst_csr) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= total) return;
+  const int e = perm_tmp[q];
+  perm[q] = e;
+  src_csr[q] = src32[e];
+  dst_csr[q] = dst32[e];
+}
+
+extern "C" size_t yolat_csr_work_elems(int64_t N, int64_t E) { return (size_t)(N + 3 * E + 16); }
+
+extern "C" int yolat_coo_to_csr(const int64_t* edge, int64_t stride_e, int64_t stride_c, int64_t E,
+                                int64_t N, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
+                                int32_t* dst_csr, int32_t* work, int32_t* status,
+                                yolat_stream_t stream) {
+  if (N <= 0 || E < 0 || N >= (1LL << 31) - 4096 || E >= (1LL << 31) - 256) return YOLAT_E_INVALID;
+  if (!row_ptr || !work || !status || (E > 0 && (!edge || !perm || !src_csr || !dst_csr)))
+    return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  int* cnt = work;
+  int* src32 = work + N;
+  int* dst32 = src32 + E;
+  int* tmp = dst32 + E;
+  hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)N, st);
+  if (err != hipSuccess) return (int)err;
+  if (E > 0) {
+    hipLaunchKernelGGL(k_edge_count, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, edge, (long)stride_e,
+                       (long)stride_c, (int)E, (int)N, src32, dst32, cnt, status);
+    YL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, cnt, (int)N, row_ptr);
+  YL_LAUNCH_CHECK();
+  if (E > 0) {
+    hipLaunchKernelGGL(k_fill, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, dst32, (int)E, row_ptr, cnt,
+                       tmp);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sort_rows, dim3(yl_cdiv(N, 256)), dim3(256), 0, st, row_ptr, tmp, (int)N);
+    YL_LAUNCH_CHECK();
+    // NOTE: with out-of-range edges (status flagged) the tail of tmp is undefined; the emit
+    // kernel is still bounded by E and the caller must treat the result as invalid.
+    hipLaunchKernelGGL(k_emit_csr, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, tmp, src32, dst32,
+                       (int)E, perm, src_csr, dst_csr);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int yolat_csc_by_source(const int32_t* src_csr, int64_t E, int64_t N, int32_t* col_ptr,
+                                   int32_t* slots, int32_t* work, yolat_stream_t stream) {
+  if (N <= 0 || E < 0 || !col_ptr || !work || (E > 0 && (!src_csr || !slots)))
+    return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  hipError_t err = hipMemsetAsync(work, 0, sizeof(int) * (size_t)N, st);
+  if (err != hipSuccess) return (int)err;
+  if (E > 0) {
+    hipLaunchKernelGGL(k_count32, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, src_csr, (int)E, work);
+    YL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, work, (int)N, col_ptr);
+  YL_LAUNCH_CHECK();
+  if (E > 0) {
+    hipLaunchKernelGGL(k_fill, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, src_csr, (int)E, col_ptr,
+                       work, slots);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_sort_rows, dim3(yl_cdiv(N, 256)), dim3(256), 0, st, col_ptr, slots, (int)N);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// seg_ptr[p] = first row r with bbox_idx[r] >= p.  Thread r in [0, N] owns the boundary between
+// rows r-1 and r and writes seg_ptr for every p in (bbox[r-1], bbox[r]].
+__global__ void k_segment_ptr(const int64_t* bbox, long N, long P, int* seg_ptr, int* node_seg,
+                              int* status) {
+  const long r = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r > N) return;
+  long prev = (r == 0) ? -1 : bbox[r - 1];
+  long cur = (r == N) ? P : bbox[r];
+  if (r < N) {
+    if (cur < 0 || cur >= P) { atomicOr(status, YOLAT_STATUS_SEG_RANGE); cur = cur < 0 ? 0 : P - 1; }
+    node_seg[r] = (int)cur;
+  }
+  if (prev >= P) prev = P - 1;
+  if (prev < -1) prev = -1;
+  if (cur < prev) { atomicOr(status, YOLAT_STATUS_SEG_UNSORTED); return; }
+  for (long p = prev + 1; p <= cur; ++p) seg_ptr[p] = (int)r;
+}
+
+extern "C" int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, int32_t* seg_ptr,
+                                 int32_t* node_seg, int32_t* status, yolat_stream_t stream) {
+  if (N < 0 || P <= 0 || N >= (1LL << 31) - 1 || !seg_ptr || !status || (N > 0 && (!bbox_idx || !node_seg)))
+    return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_segment_ptr, dim3(yl_cdiv(N + 1, 256)), dim3(256), 0, (hipStream_t)stream,
+                     bbox_idx, (long)N, (long)P, seg_ptr, node_seg, status);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_gather_rows(const float* src, long ld_src, const int* idx, long rows, int width,
+                              float* dst, long ld_dst) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long r = i / width;
+  const int c = (int)(i % width);
+  if (r >= rows) return;
+  dst[r * ld_dst + c] = src[(long)idx[r] * ld_src + c];
+}
+
+extern "C" int yolat_gather_rows(const float* src, int64_t ld_src, const int32_t* idx,
+                                 int64_t rows, int64_t width, float* dst, int64_t ld_dst,
+                                 yolat_stream_t stream) {
+  if (rows < 0 || width <= 0) return YOLAT_E_INVALID;
+  if (rows == 0) return 0;
+  if (!src || !idx || !dst) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_gather_rows, dim3(yl_cdiv(rows * width, 256)), dim3(256), 0,
+                     (hipStream_t)stream, src, (long)ld_src, idx, (long)rows, (int)width, dst,
+                     (long)ld_dst);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

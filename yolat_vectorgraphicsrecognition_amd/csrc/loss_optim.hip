@@ -1,0 +1,99 @@
+// loss_optim.hip — nn.CrossEntropyLoss of DetectionLoss (architecture3cc_rpn_gp_iter2.py:363,376)
+// and the torch.optim.Adam step of cad_recognition/train.py:212,284 over one flat buffer.
+#include "common.hpp"
+
+// One 1024-thread workgroup; thread t owns rows t, t+1024, ...; fixed-order tree reduction.
+__global__ void __launch_bounds__(1024) k_softmax_ce(const float* logits, long ld,
+                                                     const int64_t* labels, int P, int K,
+                                                     float* loss, float* dl, long lddl) {
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  const float invP = 1.f / (float)P;
+  float acc = 0.f;
+  for (int p = tid; p < P; p += 1024) {
+    const float* z = logits + (long)p * ld;
+    float m = z[0];
+    for (int k = 1; k < K; ++k) m = fmaxf(m, z[k]);
+    float s = 0.f;
+    for (int k = 0; k < K; ++k) s += expf(z[k] - m);
+    const float lse = m + logf(s);
+    const int y = (int)labels[p];
+    acc += lse - z[y];
+    if (dl != nullptr) {
+      float* d = dl + (long)p * lddl;
+      const float invs = 1.f / s;
+      for (int k = 0; k < K; ++k) {
+        float g = expf(z[k] - m) * invs;
+        if (k == y) g -= 1.f;
+        d[k] = g * invP;
+      }
+    }
+  }
+  red[tid] = acc;
+  __syncthreads();
+  for (int s = 512; s > 0; s >>= 1) {
+    if (tid < s) red[tid] += red[tid + s];
+    __syncthreads();
+  }
+  if (tid == 0) loss[0] = red[0] * invP;
+}
+
+extern "C" int yolat_softmax_ce(const float* logits, int64_t ld, const int64_t* labels, int64_t P,
+                                int64_t K, float* loss, float* dlogits, int64_t lddl,
+                                yolat_stream_t stream) {
+  if (P <= 0 || K <= 0 || !logits || !labels || !loss || ld < K || P >= (1LL << 31))
+    return YOLAT_E_INVALID;
+  if (dlogits && lddl < K) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_softmax_ce, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (long)ld,
+                     labels, (int)P, (int)K, loss, dlogits, (long)lddl);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// torch.optim.Adam (single-tensor formulation): g += wd*p; m.lerp_(g, 1-b1);
+// v = b2*v + (1-b2)*g*g; p -= step_size * m / (sqrt(v)/sqrt(bc2) + eps)
+__global__ void k_adam(float* p, const float* g, float* m, float* v, long n, float step_size,
+                       float beta1, float beta2, float inv_bc2_sqrt, float eps, float wd,
+                       float gscale) {
+  for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+       i += (long)gridDim.x * blockDim.x) {
+    const float pi = p[i];
+    float gi = g[i] * gscale;
+    if (wd != 0.f) gi = fmaf(wd, pi, gi);
+    float mi = m[i];
+    mi = mi + (gi - mi) * (1.f - beta1);
+    const float vi = v[i] * beta2 + (1.f - beta2) * gi * gi;
+    const float denom = sqrtf(vi) * inv_bc2_sqrt + eps;
+    m[i] = mi;
+    v[i] = vi;
+    p[i] = pi - step_size * (mi / denom);
+  }
+}
+
+extern "C" int yolat_adam_step(float* param, const float* grad, float* exp_avg, float* exp_avg_sq,
+                               int64_t n, float lr, float beta1, float beta2, float eps,
+                               float weight_decay, int64_t step, float grad_scale,
+                               yolat_stream_t stream) {
+  if (n <= 0 || step <= 0 || !param || !grad || !exp_avg || !exp_avg_sq) return YOLAT_E_INVALID;
+  const double bc1 = 1.0 - pow((double)beta1, (double)step);
+  const double bc2 = 1.0 - pow((double)beta2, (double)step);
+  const float step_size = (float)((double)lr / bc1);
+  const float inv_bc2_sqrt = (float)(1.0 / sqrt(bc2));
+  int blocks = yl_cdiv(n, 256);
+  if (blocks > 4096) blocks = 4096;
+  hipLaunchKernelGGL(k_adam, dim3(blocks), dim3(256), 0, (hipStream_t)stream, param, grad, exp_avg,
+                     exp_avg_sq, (long)n, step_size, beta1, beta2, inv_bc2_sqrt, eps, weight_decay,
+                     grad_scale);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_abi_version(void) { return 1; }
+
+extern "C" const char* yolat_strerror(int code) {
+  if (code == 0) return "ok";
+  if (code == YOLAT_E_INVALID) return "yolat: invalid argument (size, NULL pointer or leading dimension)";
+  if (code == YOLAT_E_UNSUPPORTED) return "yolat: shape not supported by the gfx950 kernels";
+  if (code > 0) return hipGetErrorString((hipError_t)code);
+  return "yolat: unknown error";
+}

@@ -1,0 +1,139 @@
+// segment.hip — per-proposal pooling = torch_scatter.scatter(src, bbox_idx, dim=0,
+// reduce='mean'|'max') of cad_recognition/architecture3cc_rpn_gp_iter2.py:67,122.
+// bbox_idx is non-decreasing (Datasets/graph_dict3.py:732) so a proposal is a contiguous row range
+// [seg_ptr[p], seg_ptr[p+1]).  One thread per (proposal, column): threads of a workgroup cover 256
+// consecutive columns -> every row read is a coalesced 1 KiB burst; no atomics, fixed row order.
+#include "common.hpp"
+
+__global__ void __launch_bounds__(256) k_segment_mean_fwd(const float* X, long ldx, int D,
+                                                          const float* xs, const float* xb,
+                                                          int relu, const int* seg_ptr, float* Y,
+                                                          long ldy) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (c >= D) return;
+  const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
+  const float sc = xs ? xs[c] : 1.f, sh = xs ? xb[c] : 0.f;
+  float s = 0.f;
+  for (int r = r0; r < r1; ++r) {
+    float v = X[(long)r * ldx + c];
+    if (xs) v = fmaf(v, sc, sh);
+    if (relu) v = fmaxf(v, 0.f);
+    s += v;
+  }
+  const int cnt = r1 - r0;
+  Y[(long)p * ldy + c] = s / (float)(cnt > 1 ? cnt : 1);
+}
+
+__global__ void __launch_bounds__(256) k_segment_max_fwd(const float* X, long ldx, int D,
+                                                         const float* xs, const float* xb,
+                                                         int relu, const int* seg_ptr, int N,
+                                                         float* Y, long ldy, int* arg) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  if (c >= D) return;
+  const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
+  const float sc = xs ? xs[c] : 1.f, sh = xs ? xb[c] : 0.f;
+  float best = 0.f;
+  int a = N;  // empty segment -> 0, arg = N   (torch_scatter semantics)
+  for (int r = r0; r < r1; ++r) {
+    float v = X[(long)r * ldx + c];
+    if (xs) v = fmaf(v, sc, sh);
+    if (relu) v = fmaxf(v, 0.f);
+    if (a == N || v > best) { best = v; a = r; }  // strict '>' : first (lowest) row wins ties
+  }
+  Y[(long)p * ldy + c] = best;
+  if (arg) arg[(long)p * D + c] = a;
+}
+
+static int seg_args_ok(const float* X, int64_t ldx, int64_t D, const float* s, const float* b,
+                       const int32_t* seg_ptr, int64_t P, float* Y, int64_t ldy) {
+  if (P < 0 || D <= 0 || ldx < D || ldy < D) return 0;
+  if (P > 0 && (!X || !seg_ptr || !Y)) return 0;
+  if ((s == nullptr) != (b == nullptr)) return 0;
+  if (P > 65535LL * 1) { /* grid.y limit handled by caller loop */ }
+  return 1;
+}
+
+extern "C" int yolat_segment_mean_fwd(const float* X, int64_t ldx, int64_t D, const float* x_scale,
+                                      const float* x_shift, int x_relu, const int32_t* seg_ptr,
+                                      int64_t P, float* Y, int64_t ldy, yolat_stream_t stream) {
+  if (!seg_args_ok(X, ldx, D, x_scale, x_shift, seg_ptr, P, Y, ldy)) return YOLAT_E_INVALID;
+  for (int64_t p0 = 0; p0 < P; p0 += 65535) {
+    const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
+    hipLaunchKernelGGL(k_segment_mean_fwd, dim3(yl_cdiv(D, 256), (unsigned)np), dim3(256), 0,
+                       (hipStream_t)stream, X, (long)ldx, (int)D, x_scale, x_shift, x_relu,
+                       seg_ptr + p0, Y + p0 * ldy, (long)ldy);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int yolat_segment_max_fwd(const float* X, int64_t ldx, int64_t D, const float* x_scale,
+                                     const float* x_shift, int x_relu, const int32_t* seg_ptr,
+                                     int64_t P, int64_t N, float* Y, int64_t ldy, int32_t* arg,
+                                     yolat_stream_t stream) {
+  if (!seg_args_ok(X, ldx, D, x_scale, x_shift, seg_ptr, P, Y, ldy)) return YOLAT_E_INVALID;
+  for (int64_t p0 = 0; p0 < P; p0 += 65535) {
+    const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
+    hipLaunchKernelGGL(k_segment_max_fwd, dim3(yl_cdiv(D, 256), (unsigned)np), dim3(256), 0,
+                       (hipStream_t)stream, X, (long)ldx, (int)D, x_scale, x_shift, x_relu,
+                       seg_ptr + p0, (int)N, Y + p0 * ldy, (long)ldy, arg ? arg + p0 * D : nullptr);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ---- backward: elementwise over [N, D]; threads along columns, 4 rows per block iteration
+__global__ void __launch_bounds__(256) k_segment_mean_bwd(const float* dY, long lddy, int D,
+                                                          const int* seg_ptr, const int* node_seg,
+                                                          long N, float* dX, long lddx) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= D) return;
+  for (long r = (long)blockIdx.y * 4 + (threadIdx.x >> 6); r < N; r += (long)gridDim.y * 4) {
+    const int p = node_seg[r];
+    const int cnt = seg_ptr[p + 1] - seg_ptr[p];
+    dX[r * lddx + c] = dY[(long)p * lddy + c] / (float)(cnt > 1 ? cnt : 1);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_segment_max_bwd(const float* dY, long lddy, int D,
+                                                         const int* arg, const int* node_seg,
+                                                         long N, float* dX, long lddx) {
+  const int c = blockIdx.x * 64 + (threadIdx.x & 63);
+  if (c >= D) return;
+  for (long r = (long)blockIdx.y * 4 + (threadIdx.x >> 6); r < N; r += (long)gridDim.y * 4) {
+    const int p = node_seg[r];
+    dX[r * lddx + c] = (arg[(long)p * D + c] == (int)r) ? dY[(long)p * lddy + c] : 0.f;
+  }
+}
+
+extern "C" int yolat_segment_mean_bwd(const float* dY, int64_t lddy, int64_t D,
+                                      const int32_t* seg_ptr, const int32_t* node_seg, int64_t N,
+                                      float* dX, int64_t lddx, yolat_stream_t stream) {
+  if (N < 0 || D <= 0 || lddx < D || lddy < D) return YOLAT_E_INVALID;
+  if (N == 0) return 0;
+  if (!dY || !seg_ptr || !node_seg || !dX) return YOLAT_E_INVALID;
+  int gy = yl_cdiv(N, 4);
+  if (gy > 4096) gy = 4096;
+  hipLaunchKernelGGL(k_segment_mean_bwd, dim3(yl_cdiv(D, 64), gy), dim3(256), 0,
+                     (hipStream_t)stream, dY, (long)lddy, (int)D, seg_ptr, node_seg, (long)N, dX,
+                     (long)lddx);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_segment_max_bwd(const float* dY, int64_t lddy, int64_t D, const int32_t* arg,
+                                     const int32_t* node_seg, int64_t N, float* dX, int64_t lddx,
+                                     yolat_stream_t stream) {
+  if (N < 0 || D <= 0 || lddx < D || lddy < D) return YOLAT_E_INVALID;
+  if (N == 0) return 0;
+  if (!dY || !arg || !node_seg || !dX) return YOLAT_E_INVALID;
+  int gy = yl_cdiv(N, 4);
+  if (gy > 4096) gy = 4096;
+  hipLaunchKernelGGL(k_segment_max_bwd, dim3(yl_cdiv(D, 64), gy), dim3(256), 0,
+                     (hipStream_t)stream, dY, (long)lddy, (int)D, arg, node_seg, (long)N, dX,
+                     (long)lddx);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,205 @@
+"""Host-side batch container, block-diagonal batching and synthetic Bézier-graph generators.
+
+Mirrors what the reference's callers hand to ``SparseCADGCN.forward(data, slices)``:
+
+* ``Data`` — attribute bag standing in for ``torch_geometric.data.Data`` (absent from the image),
+  with the tiny surface the reference touches: ``.keys``, ``__cat_dim__``, item get/set
+  (cad_recognition/train.py:126-157, architecture3cc_rpn_gp_iter2.py:180).
+* ``collate`` / ``fixup_offsets`` — cad_recognition/train.py:123-171 and :238-258.
+* ``synth_graph`` — seeded synthetic graphs that honour the structural invariants of
+  ``Datasets/graph_dict3.py`` (SURVEY.md §8 d, App. F): nodes grouped by proposal with sorted
+  ``bbox_idx`` (:732); edges only inside a proposal, stored once, arbitrary direction (:594-600);
+  ``x = [0,0,0,px,py]`` with per-proposal min-max-normalised positions (:714,966-969);
+  ``e_attr`` 4-d control-point offsets, exactly 0 for straight segments
+  (Datasets/bezier_parser.py:62-71).
+"""
+from itertools import product
+
+import numpy as np
+import torch
+
+
+class Data(object):
+    """Minimal ``torch_geometric.data.Data`` look-alike (attribute bag)."""
+
+    def __init__(self, x=None, pos=None, **kwargs):
+        self.x = x
+        self.pos = pos
+        for k, v in kwargs.items():
+            setattr(self, k, v)
+
+    @property
+    def keys(self):
+        return [k for k in self.__dict__.keys() if not k.startswith("_") and self.__dict__[k] is not None]
+
+    def __getitem__(self, key):
+        return getattr(self, key, None)
+
+    def __setitem__(self, key, value):
+        setattr(self, key, value)
+
+    def __contains__(self, key):
+        return key in self.keys
+
+    def __cat_dim__(self, key, value):
+        return 0
+
+    @property
+    def num_nodes(self):
+        return None if self.x is None else self.x.size(0)
+
+    def to_dict(self):
+        return {k: self[k] for k in self.keys}
+
+
+def collate(data_list):
+    """List of per-image ``Data`` -> (batched ``Data``, ``slices``) — train.py:123-171."""
+    keys = data_list[0].keys
+    data = data_list[0].__class__()
+    for key in keys:
+        data[key] = []
+    slices = {key: [0] for key in keys}
+    for item, key in product(data_list, keys):
+        v = item[key]
+        data[key].append(v)
+        if isinstance(v, torch.Tensor) and v.dim() > 0:
+            s = slices[key][-1] + v.size(0)
+        elif isinstance(v, list):
+            s = slices[key][-1] + len(v)
+        else:
+            s = slices[key][-1] + 1
+        slices[key].append(s)
+    for key in keys:
+        item = data_list[0][key]
+        if isinstance(item, torch.Tensor) and len(data_list) > 1:
+            data[key] = torch.cat(data[key], dim=0) if item.dim() > 0 else torch.stack(data[key])
+        elif isinstance(item, torch.Tensor):
+            data[key] = data[key][0]
+        elif isinstance(item, (int, float)):
+            data[key] = torch.tensor(data[key])
+        elif isinstance(item, list):
+            flat = []
+            for it in data[key]:
+                flat += it
+            data[key] = flat
+        slices[key] = torch.tensor(slices[key], dtype=torch.long)
+    return data, slices
+
+
+def fixup_offsets(data, slices):
+    """In-place index fix-up of a collated batch — train.py:238-258: every key containing
+    'edge' += node offset of its image (``slices['pos']``); 'bbox_idx' += proposal offset
+    (``slices['labels']``).  Integer, bit-exact."""
+    pos_slice = slices["pos"]
+    for key in slices:
+        if "edge" in key:
+            s = slices[key]
+            o = getattr(data, key)
+            if not isinstance(o, torch.Tensor):
+                continue
+            for i in range(len(s) - 1):
+                o[int(s[i]):int(s[i + 1])] += pos_slice[i]
+        elif "bbox_idx" in key:
+            s = slices[key]
+            o = getattr(data, key)
+            off = slices["labels"]
+            for i in range(len(s) - 1):
+                o[int(s[i]):int(s[i + 1])] += off[i]
+    return data
+
+
+# --------------------------------------------------------------------------------------
+# synthetic graphs (SURVEY.md §8 d)
+# --------------------------------------------------------------------------------------
+
+def synth_graph(num_proposals, nodes_lo, nodes_hi, edge_factor=1.2, n_classes=17, seed=0,
+                edges_per_proposal=None, augmented=False):
+    """One synthetic "image" (a dataset item) as a ``Data``.
+
+    nodes per proposal ~ U{nodes_lo..nodes_hi}; directed edges per proposal =
+    ``edges_per_proposal`` or ceil(edge_factor * n_p), uniform inside the proposal, src != dst,
+    stored once; 85 % of e_attr rows exactly zero, rest N(0, 0.05^2).
+    """
+    rng = np.random.default_rng(seed)
+    P = int(num_proposals)
+    n_p = rng.integers(nodes_lo, nodes_hi + 1, size=P)
+    N = int(n_p.sum())
+    starts = np.concatenate([[0], np.cumsum(n_p)])[:-1]
+    bbox_idx = np.repeat(np.arange(P), n_p)
+
+    pos = rng.random((N, 2)).astype(np.float32)
+    # per-proposal min-max normalisation touching 0 and 1 on both axes (graph_dict3.py:714)
+    for p in range(P):
+        s, e = starts[p], starts[p] + n_p[p]
+        seg = pos[s:e]
+        lo, hi = seg.min(0), seg.max(0)
+        span = np.where(hi > lo, hi - lo, 1.0)
+        pos[s:e] = (seg - lo) / span
+    if augmented:  # graph_dict3.py:236-258,283-298: positions roam ~[-0.5, 2.1]
+        pos = (pos - 0.5) * rng.uniform(0.4, 1.6) + 0.5 + rng.uniform(-0.1, 0.1, size=(1, 2))
+        pos = pos.astype(np.float32)
+    x = np.zeros((N, 5), dtype=np.float32)
+    x[:, 3:5] = pos
+
+    if edges_per_proposal is None:
+        e_p = np.ceil(edge_factor * n_p).astype(np.int64)
+    else:
+        e_p = np.full(P, int(edges_per_proposal), dtype=np.int64)
+    E = int(e_p.sum())
+    owner = np.repeat(np.arange(P), e_p)
+    n_own = n_p[owner]
+    a = rng.integers(0, 1 << 30, size=E) % n_own
+    b = rng.integers(0, 1 << 30, size=E) % (n_own - 1)
+    b = np.where(b >= a, b + 1, b)              # src != dst
+    edge = np.stack([starts[owner] + a, starts[owner] + b], axis=1).astype(np.int64)
+
+    e_attr = (rng.standard_normal((E, 4)) * 0.05).astype(np.float32)
+    e_attr[rng.random(E) < 0.85] = 0.0
+
+    labels = rng.integers(0, n_classes, size=P).astype(np.int64)
+    bbox = rng.random((P, 4)).astype(np.float32)
+    bbox[:, 2:] = bbox[:, :2] + 0.05 + bbox[:, 2:] * 0.2
+    stat = rng.random((P, 13)).astype(np.float32)
+
+    d = Data(x=torch.from_numpy(x), pos=torch.from_numpy(pos))
+    d.edge = torch.from_numpy(edge)
+    d.e_attr = torch.from_numpy(e_attr)
+    d.bbox_idx = torch.from_numpy(bbox_idx.astype(np.int64))
+    d.bbox = torch.from_numpy(bbox)
+    d.stat_feats = torch.from_numpy(stat)
+    d.labels = torch.from_numpy(labels)
+    d.is_super = torch.zeros(N, dtype=torch.bool)
+    return d
+
+
+def synth_batch(n_graphs, seed, **kw):
+    """``n_graphs`` synthetic items collated + offset-fixed like train.py does."""
+    items = [synth_graph(seed=seed * 1000 + i, **kw) for i in range(n_graphs)]
+    data, slices = collate(items)
+    fixup_offsets(data, slices)
+    return data, slices
+
+
+# Named configurations of BASELINE.md / SURVEY.md §8(d)
+def config(name, rank=0):
+    """Returns (data, slices, opt_kwargs, n_graphs) for cfg '1'..'5' (synthetic, seeded)."""
+    name = str(name)
+    if name == "1":      # Floorplans-sized, batch 1
+        d, s = synth_batch(1, 1, num_proposals=2000, nodes_lo=4, nodes_hi=40, edge_factor=1.2)
+        return d, s, dict(n_classes=17, n_blocks=2, n_blocks_out=2), 1
+    if name == "2":      # N=10k / E=40k / P=400
+        d, s = synth_batch(1, 2, num_proposals=400, nodes_lo=25, nodes_hi=25, edges_per_proposal=100)
+        return d, s, dict(n_classes=17, n_blocks=2, n_blocks_out=2), 1
+    if name == "3":      # 4 cfg-1 graphs collated, train step
+        d, s = synth_batch(4, 3, num_proposals=2000, nodes_lo=4, nodes_hi=40, edge_factor=1.2,
+                           augmented=True)
+        return d, s, dict(n_classes=17, n_blocks=2, n_blocks_out=2), 4
+    if name == "4":      # Diagrams-style, 32 graphs / step / GPU
+        d, s = synth_batch(32, 4 + rank, num_proposals=300, nodes_lo=4, nodes_hi=24,
+                           edge_factor=1.2, n_classes=22, augmented=True)
+        return d, s, dict(n_classes=22, n_blocks=2, n_blocks_out=2), 32
+    if name == "5":      # N=200k / E=1.2M / P=8000, n_blocks=4
+        d, s = synth_batch(1, 5 + rank, num_proposals=8000, nodes_lo=25, nodes_hi=25,
+                           edges_per_proposal=150)
+        return d, s, dict(n_classes=17, n_blocks=4, n_blocks_out=2), 1
+    raise ValueError("unknown config %r" % name)

@@ -1,0 +1,325 @@
+"""Hand-scheduled forward / backward of the YOLaT hot path on top of the C ABI (ops.py).
+
+There is no tracing compiler and no autograd tape inside the model: each block below launches its
+kernels in a fixed order and keeps exactly the tensors its backward needs.
+
+Lazy activations.  A training-mode ``Linear -> BatchNorm1d -> ReLU`` (gcn_lib/sparse/torch_nn.py:58-66)
+needs the statistics of *all* rows before it can normalise, so the GEMM stores the pre-activation
+and a per-column (scale, shift); the consumer applies ``relu(scale*y+shift)`` while it loads its
+operand ("prologue").  ``Lazy`` is that pair.  In eval mode BatchNorm is folded into the GEMM
+epilogue and ``Lazy.scale`` is None (materialised).
+
+Blocks
+    conv_fwd / conv_bwd       AttrRelativeEdgeConvGlobalPool2      torch_vertex.py:288-341
+    lbr_fwd / lbr_bwd         Linear(+BN+ReLU)                      torch_nn.py:50-71
+    model_fwd / model_bwd     SparseCADGCN.forward                  architecture3cc_rpn_gp_iter2.py:44-71,106-137
+"""
+import torch
+
+from . import ops
+
+
+class Lazy(object):
+    __slots__ = ("t", "scale", "shift", "relu")
+
+    def __init__(self, t, scale=None, shift=None, relu=False):
+        self.t, self.scale, self.shift, self.relu = t, scale, shift, relu
+
+    @property
+    def pro(self):
+        return None if self.scale is None else (self.scale, self.shift)
+
+    def materialise(self, out=None):
+        if self.scale is None and not self.relu:
+            return self.t
+        out = torch.empty_like(self.t) if out is None else out
+        ops.scale_shift_relu(self.t, self.scale, self.shift, self.relu, out)
+        return out
+
+
+def _empty(rows, cols, dev):
+    return torch.empty(rows, cols, dtype=torch.float32, device=dev)
+
+
+def _vec(n, dev):
+    return torch.empty(n, dtype=torch.float32, device=dev)
+
+
+class GradSink(object):
+    """Where parameter gradients are written: fresh tensors (autograd path) or views of one flat
+    buffer (trainer / data-parallel path)."""
+
+    def __init__(self, views=None):
+        self.views = views          # dict id(param) -> tensor view, or None
+        self.out = {}
+
+    def get(self, p):
+        if self.views is not None:
+            t = self.views[id(p)]
+        else:
+            t = torch.empty_like(p)
+        self.out[id(p)] = t
+        return t
+
+
+# ---------------------------------------------------------------------------------------------
+# BatchNorm coefficient helpers
+# ---------------------------------------------------------------------------------------------
+
+def _bn_train(stats, M, bn, dev):
+    C = bn.num_features
+    coef = torch.empty(4, C, dtype=torch.float32, device=dev)   # scale, shift, mean, invstd
+    ops.bn_finalize(stats, M, bn, coef[0], coef[1], coef[2], coef[3])
+    if bn.num_batches_tracked is not None:
+        bn.num_batches_tracked += 1
+    return coef
+
+
+def _bn_eval(bn, dev):
+    """Folded eval coefficients, cached on the module until any of its tensors changes."""
+    key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
+           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+    cache = getattr(bn, "_yolat_eval", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    coef = torch.empty(2, bn.num_features, dtype=torch.float32, device=dev)
+    ops.bn_eval_coeffs(bn, coef[0], coef[1])
+    bn._yolat_eval = (key, coef)
+    return coef
+
+
+# ---------------------------------------------------------------------------------------------
+# Linear (+ BatchNorm1d + ReLU)
+# ---------------------------------------------------------------------------------------------
+
+def lbr_fwd(a, lin, bn, relu, training, out=None):
+    """a: Lazy input [M,K].  Returns (Lazy output, saved).  ``out`` optionally names the [M,C]
+    destination (may be a column slice of a wider buffer)."""
+    A = a.t
+    M, dev = A.shape[0], A.device
+    C = lin.out_features
+    y = _empty(M, C, dev) if out is None else out
+    sv = {"a": a, "lin": lin, "bn": bn, "relu": relu, "y": y}
+    if bn is None:
+        ops.linear_fwd(A, lin.weight, lin.bias, y, a_pro=a.pro, a_relu=a.relu, o_relu=relu)
+        return Lazy(y), sv
+    if training:
+        if M == 0:
+            raise ValueError("BatchNorm1d in training mode needs at least one row")
+        stats = ops.stats_buffer(M, C, dev)
+        ops.linear_fwd(A, lin.weight, lin.bias, y, a_pro=a.pro, a_relu=a.relu, stats=stats)
+        coef = _bn_train(stats, M, bn, dev)
+        sv["coef"] = coef
+        return Lazy(y, coef[0], coef[1], relu), sv
+    coef = _bn_eval(bn, dev)
+    ops.linear_fwd(A, lin.weight, lin.bias, y, a_pro=a.pro, a_relu=a.relu, o_pro=(coef[0], coef[1]),
+                   o_relu=relu)
+    return Lazy(y), sv
+
+
+def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inplace=True):
+    """dz: gradient w.r.t. the block's (post-activation) output [M,C].  Writes parameter gradients
+    into ``sink``; returns the gradient w.r.t. the block's *post-prologue* input (i.e. w.r.t. the
+    producer's post-activation output), written to ``dx_out`` if given."""
+    a, lin, bn, relu, y = sv["a"], sv["lin"], sv["bn"], sv["relu"], sv["y"]
+    M, dev = y.shape[0], y.device
+    if bn is not None:
+        coef = sv["coef"]
+        dy = dz if dz_inplace else torch.empty(M, y.shape[1], dtype=torch.float32, device=dev)
+        ops.bn_relu_bwd(dz, y, bn.weight, coef[2], coef[3], coef[0], coef[1], relu,
+                        sink.get(bn.weight), sink.get(bn.bias), dy)
+    else:
+        if relu:
+            raise NotImplementedError("Linear+ReLU without BatchNorm is not on the reference path")
+        dy = dz
+    db = sink.get(lin.bias) if lin.bias is not None else None
+    ops.linear_bwd_w(dy, a.t, sink.get(lin.weight), db, a_pro=a.pro, a_relu=a.relu)
+    if not need_dx:
+        return None
+    dx = _empty(M, lin.in_features, dev) if dx_out is None else dx_out
+    ops.linear_fwd_wt(dy, lin.weight, dx, accumulate=dx_accumulate)
+    return dx
+
+
+# ---------------------------------------------------------------------------------------------
+# AttrRelativeEdgeConvGlobalPool2
+# ---------------------------------------------------------------------------------------------
+
+def conv_fwd(conv, g, x, xn, out_f, out_s, training):
+    """x [N,Cin] materialised; xn Lazy [N,Cin]; out_f / out_s: [N,C] destinations (or None).
+    Returns (f tensor, s Lazy, saved)."""
+    nn0, bn1, nn3, bn4 = conv.nn[0], conv.nn[1], conv.nn[3], conv.nn[4]
+    N, dev = x.shape[0], x.device
+    C = nn0.out_features
+    E = g.E
+    out_f = _empty(N, C, dev) if out_f is None else out_f
+    sv = {"conv": conv, "x": x, "E": E}
+    # root term first, the aggregation accumulates onto it:  out = lin_r(x) + mean_e(m_e)   (:325)
+    ops.linear_fwd(x, conv.lin_r.weight, conv.lin_r.bias, out_f)
+    if E > 0:
+        H1, H2 = _empty(E, C, dev), _empty(E, C, dev)
+        if training:
+            st1 = ops.stats_buffer(E, C, dev)
+            ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, stats=st1)
+            c1 = _bn_train(st1, E, bn1, dev)
+            st2 = ops.stats_buffer(E, C, dev)
+            ops.linear_fwd(H1, nn3.weight, nn3.bias, H2, a_pro=(c1[0], c1[1]), a_relu=True, stats=st2)
+            c2 = _bn_train(st2, E, bn4, dev)
+            ops.csr_mean_fwd(H2, g, out_f, h_pro=(c2[0], c2[1]), h_relu=True, accumulate=True)
+            sv.update(H1=H1, H2=H2, c1=c1, c2=c2)
+        else:
+            c1, c2 = _bn_eval(bn1, dev), _bn_eval(bn4, dev)
+            ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, o_pro=(c1[0], c1[1]), o_relu=True)
+            ops.linear_fwd(H1, nn3.weight, nn3.bias, H2, o_pro=(c2[0], c2[1]), o_relu=True)
+            ops.csr_mean_fwd(H2, g, out_f, accumulate=True)
+    s, sv_n = lbr_fwd(xn, conv.mlp_node[0], conv.mlp_node[1], True, training, out=out_s)
+    sv["node"] = sv_n
+    return out_f, s, sv
+
+
+def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=False, need_dx=True):
+    """d_f [N,C]: grad w.r.t. out;  d_s [N,C]: grad w.r.t. the node-branch post-activation output.
+    If need_dx: accumulates/writes grad w.r.t. x into ``dx`` and w.r.t. the (post-activation) x_node
+    into ``dxn``.  d_s is consumed in place."""
+    conv, x, E = sv["conv"], sv["x"], sv["E"]
+    nn0, bn1, nn3, bn4 = conv.nn[0], conv.nn[1], conv.nn[3], conv.nn[4]
+    N, Cin = x.shape
+    C = nn0.out_features
+    dev = x.device
+    # node branch
+    dxn = lbr_bwd(sv["node"], d_s, sink, dx_out=dxn, dx_accumulate=dxn_acc, need_dx=need_dx)
+    # root term
+    ops.linear_bwd_w(d_f, x, sink.get(conv.lin_r.weight), sink.get(conv.lin_r.bias))
+    if need_dx:
+        dx = _empty(N, Cin, dev) if dx is None else dx
+        ops.linear_fwd_wt(d_f, conv.lin_r.weight, dx, accumulate=dx_acc)
+    if E > 0:
+        H1, H2, c1, c2 = sv["H1"], sv["H2"], sv["c1"], sv["c2"]
+        dM = _empty(E, C, dev)
+        ops.csr_mean_bwd(d_f, g, dM)
+        ops.bn_relu_bwd(dM, H2, bn4.weight, c2[2], c2[3], c2[0], c2[1], True,
+                        sink.get(bn4.weight), sink.get(bn4.bias), dM)            # dM -> dH2 in place
+        ops.linear_bwd_w(dM, H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
+        dA1 = _empty(E, C, dev)
+        ops.linear_fwd_wt(dM, nn3.weight, dA1)
+        ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
+                        sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
+        ops.edge_lin1_bwd_w(dA1, x, g, sink.get(nn0.weight), sink.get(nn0.bias))
+        if need_dx:
+            dG = _empty(E, 2 * Cin, dev)
+            ops.edge_lin1_bwd_x(dA1, nn0.weight, Cin, dG)
+            ops.edge_scatter_bwd(dG, Cin, g, dx, accumulate=True)
+    else:
+        for p in (nn0.weight, nn0.bias, bn1.weight, bn1.bias, nn3.weight, nn3.bias, bn4.weight, bn4.bias):
+            sink.get(p).zero_()
+    return dx, dxn
+
+
+# ---------------------------------------------------------------------------------------------
+# whole model
+# ---------------------------------------------------------------------------------------------
+
+def model_convs(net):
+    """The conv modules of a Backbone in layer order (head, then ResBlock bodies)."""
+    return [net.head.gconv] + [blk.body.gconv for blk in net.backbone]
+
+
+def model_fwd(model, g, x, training):
+    """SparseCADGCN.forward on device tensors.  Returns (logits [P,K], saved-or-None)."""
+    net = model.cls_net
+    convs = model_convs(net)
+    L, n_out = net.n_blocks, net.n_blocks_out
+    lo = L - n_out
+    N, dev = x.shape[0], x.device
+    P = g.P
+    C = convs[0].nn[0].out_features
+    F = net.fusion_block[0].out_features
+    D = C * n_out                       # fusion_dims
+    if training and model.prediction_cls[1][-1].__class__.__name__.startswith("Dropout"):
+        raise NotImplementedError("training with dropout > 0 is not implemented (README recipe uses 0.0)")
+
+    feats = _empty(N, D, dev)           # cat of the last n_out conv outputs          (arch:60)
+    fsup = _empty(N, D, dev)            # cat of the last n_out node-branch outputs   (arch:65)
+    sup_coef = torch.empty(2, D, dtype=torch.float32, device=dev) if training else None
+    sv = {"convs": [], "training": training}
+    f, s = x, Lazy(x)
+    for l, conv in enumerate(convs):
+        slot = l - lo
+        of = feats[:, slot * C:(slot + 1) * C] if slot >= 0 else None
+        os_ = fsup[:, slot * C:(slot + 1) * C] if slot >= 0 else None
+        f, s, sv_c = conv_fwd(conv, g, f, s, of, os_, training)
+        if training and slot >= 0:
+            sup_coef[0, slot * C:(slot + 1) * C].copy_(s.scale)
+            sup_coef[1, slot * C:(slot + 1) * C].copy_(s.shift)
+        sv["convs"].append(sv_c)
+
+    Z = _empty(P, 2 * (F + D), dev)     # [max(fusion) | max(feats) | fusion_super | mean(sup)]  (arch:127)
+    # fusion block over nodes, then per-proposal max                                  (arch:61-63,122)
+    fus, sv_fus = lbr_fwd(Lazy(feats), net.fusion_block[0], net.fusion_block[1], True, training)
+    arg_fus = torch.empty(P, F, dtype=torch.int32, device=dev) if training else None
+    arg_feat = torch.empty(P, D, dtype=torch.int32, device=dev) if training else None
+    ops.segment_max_fwd(fus.t, g, Z[:, 0:F], arg_fus, x_pro=fus.pro, x_relu=fus.relu)
+    ops.segment_max_fwd(feats, g, Z[:, F:F + D], arg_feat)
+    # super branch: per-proposal mean, then fusion_block_super                        (arch:65-69)
+    sup = Z[:, 2 * F + D:2 * F + 2 * D]
+    if training:
+        ops.segment_mean_fwd(fsup, g, sup, x_pro=(sup_coef[0], sup_coef[1]), x_relu=True)
+    else:
+        ops.segment_mean_fwd(fsup, g, sup)
+    fs, sv_fs = lbr_fwd(Lazy(sup), net.fusion_block_super[0], net.fusion_block_super[1], True, training,
+                        out=(None if training else Z[:, F + D:2 * F + D]))
+    if training:
+        ops.scale_shift_relu(fs.t, fs.scale, fs.shift, True, Z[:, F + D:2 * F + D])
+    # classifier                                                                      (arch:91-93,128)
+    m1, m2, m3 = model.prediction_cls[0], model.prediction_cls[1], model.prediction_cls[2]
+    c1, sv1 = lbr_fwd(Lazy(Z), m1[0], m1[1], True, training)
+    c2, sv2 = lbr_fwd(c1, m2[0], m2[1], True, training)
+    logits, sv3 = lbr_fwd(c2, m3[0], None, False, training)
+    if not training:
+        return logits.t, None
+    sv.update(feats=feats, fsup=fsup, Z=Z, fus=sv_fus, fs=sv_fs, arg_fus=arg_fus, arg_feat=arg_feat,
+              cls=(sv1, sv2, sv3), dims=(N, P, C, F, D, L, lo))
+    return logits.t, sv
+
+
+def model_bwd(model, g, sv, dlogits, sink):
+    """Backward of model_fwd (training mode).  dlogits [P,K] is consumed."""
+    net = model.cls_net
+    N, P, C, F, D, L, lo = sv["dims"]
+    dev = dlogits.device
+    sv1, sv2, sv3 = sv["cls"]
+    d2 = lbr_bwd(sv3, dlogits, sink)
+    d1 = lbr_bwd(sv2, d2, sink)
+    dZ = lbr_bwd(sv1, d1, sink)                                      # [P, 2(F+D)]
+    # fusion_block_super: input = sup (Z[:, 2F+D:]), output post-activation = Z[:, F+D:2F+D]
+    d_sup = dZ[:, 2 * F + D:2 * F + 2 * D]
+    lbr_bwd(sv["fs"], dZ[:, F + D:2 * F + D], sink, dx_out=d_sup, dx_accumulate=True)
+    d_fsup = _empty(N, D, dev)                                        # grad w.r.t. post-activation s's
+    ops.segment_mean_bwd(d_sup, g, d_fsup)
+    # fusion_block + max pooling
+    d_fus = _empty(N, F, dev)
+    ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)
+    d_feats = _empty(N, D, dev)
+    ops.segment_max_bwd(dZ[:, F:F + D], sv["arg_feat"], g, d_feats)
+    lbr_bwd(sv["fus"], d_fus, sink, dx_out=d_feats, dx_accumulate=True)
+    # conv layers, last to first
+    d_f_next, d_s_next = None, None      # grads flowing into layer l's outputs from layer l+1
+    for l in range(L - 1, -1, -1):
+        slot = l - lo
+        if slot >= 0:
+            d_f = d_feats[:, slot * C:(slot + 1) * C]
+            d_s = d_fsup[:, slot * C:(slot + 1) * C]
+        else:
+            d_f, d_s = d_f_next, d_s_next
+        need_dx = l > 0
+        dx = dxn = None
+        acc = False
+        if need_dx:
+            pslot = l - 1 - lo
+            if pslot >= 0:
+                dx = d_feats[:, pslot * C:(pslot + 1) * C]
+                dxn = d_fsup[:, pslot * C:(pslot + 1) * C]
+                acc = True
+        d_f_next, d_s_next = conv_bwd(sv["convs"][l], g, d_f, d_s, sink, dx=dx, dx_acc=acc, dxn=dxn,
+                                      dxn_acc=acc, need_dx=need_dx)
+    return sink

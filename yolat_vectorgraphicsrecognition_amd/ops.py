@@ -1,0 +1,323 @@
+"""Tensor-level wrappers of the C ABI (include/yolat_hip.h).
+
+Every function takes torch CUDA tensors, checks dtype / device / inner stride, and enqueues the HIP
+kernel(s) on torch's current stream.  torch is used for device memory and streams only — the
+arithmetic is in libyolat_hip.so.  There is no CPU path: a non-CUDA tensor raises.
+"""
+import torch
+
+from ._lib import lib, check
+
+STATS_ROWS = 64
+STATUS_EDGE_RANGE, STATUS_SEG_UNSORTED, STATUS_SEG_RANGE = 1, 2, 4
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _f(t, name="tensor", allow_none=False):
+    """data_ptr of an fp32 CUDA tensor whose last dim is dense."""
+    if t is None:
+        if allow_none:
+            return None
+        raise ValueError("%s is None" % name)
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (ROCm) tensor — the yolat HIP path has no CPU fallback" % name)
+    if t.dtype != torch.float32:
+        raise TypeError("%s must be float32, got %s" % (name, t.dtype))
+    if t.dim() >= 1 and t.shape[-1] > 1 and t.stride(-1) != 1:
+        raise ValueError("%s must be dense along its last dimension" % name)
+    return t.data_ptr()
+
+
+def _i(t, dtype, name="index"):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("%s must be a CUDA (ROCm) tensor" % name)
+    if t.dtype != dtype:
+        raise TypeError("%s must be %s, got %s" % (name, dtype, t.dtype))
+    if t.dim() == 1 and t.numel() > 1 and t.stride(0) != 1:
+        raise ValueError("%s must be contiguous" % name)
+    return t.data_ptr()
+
+
+def _ld(t):
+    return t.stride(0) if t.shape[0] > 1 else max(t.shape[-1], t.stride(0))
+
+
+# ---------------------------------------------------------------------------------------------
+# graph pre-processing
+# ---------------------------------------------------------------------------------------------
+
+class Graph(object):
+    """Device-resident integer structure of one batch (CSR by destination, optional CSC by source,
+    proposal segments).  Owned by the caller / cached on the batch object."""
+
+    __slots__ = ("N", "E", "P", "row_ptr", "perm", "src", "dst", "attr", "col_ptr", "slots",
+                 "seg_ptr", "node_seg", "status", "_work")
+
+    def ensure_csc(self):
+        if self.col_ptr is None:
+            dev = self.row_ptr.device
+            self.col_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
+            self.slots = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
+            work = torch.empty(self.N, dtype=torch.int32, device=dev)
+            check(lib.yolat_csc_by_source(self.src.data_ptr(), self.E, self.N, self.col_ptr.data_ptr(),
+                                          self.slots.data_ptr(), work.data_ptr(), _stream()),
+                  "yolat_csc_by_source")
+            self._work = work  # keep alive until the stream has consumed it
+        return self
+
+    def check_status(self):
+        """Synchronising validity check of the flags raised by the pre-processing kernels."""
+        s = int(self.status.item())
+        if s & STATUS_EDGE_RANGE:
+            raise IndexError("edge_index contains a node id outside [0, N)")
+        if s & STATUS_SEG_UNSORTED:
+            raise ValueError("bbox_idx is not non-decreasing")
+        if s & STATUS_SEG_RANGE:
+            raise IndexError("bbox_idx contains a proposal id outside [0, P)")
+        return True
+
+
+def build_graph(edge, e_attr, bbox_idx, num_nodes, num_proposals):
+    """edge: int64 CUDA tensor, either [E,2] (data.edge) or its [2,E] transposed view;
+    e_attr: fp32 [E,4]; bbox_idx: int64 [N] or None."""
+    if edge.dim() != 2:
+        raise ValueError("edge must be 2-D")
+    if edge.shape[0] == 2 and edge.shape[1] != 2:
+        E, se, sc = edge.shape[1], edge.stride(1), edge.stride(0)
+    elif edge.shape[1] == 2:
+        if edge.shape[0] == 2 and edge.stride(0) == 1:      # a [2,2] transposed view
+            E, se, sc = 2, edge.stride(1), edge.stride(0)
+        else:
+            E, se, sc = edge.shape[0], edge.stride(0), edge.stride(1)
+    else:
+        raise ValueError("edge must be [E,2] or [2,E]")
+    dev = edge.device
+    N, P = int(num_nodes), int(num_proposals)
+    g = Graph()
+    g.N, g.E, g.P = N, E, P
+    g.col_ptr = g.slots = None
+    g.row_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
+    g.perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
+    g.status = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = torch.empty(int(lib.yolat_csr_work_elems(N, E)), dtype=torch.int32, device=dev)
+    st = _stream()
+    check(lib.yolat_coo_to_csr(_i(edge, torch.int64, "edge"), se, sc, E, N, g.row_ptr.data_ptr(),
+                               g.perm.data_ptr(), g.src.data_ptr(), g.dst.data_ptr(),
+                               work.data_ptr(), g.status.data_ptr(), st), "yolat_coo_to_csr")
+    g._work = work
+    g.attr = torch.empty(max(E, 1), 4, dtype=torch.float32, device=dev)
+    if E > 0:
+        if e_attr.shape[0] != E or e_attr.shape[1] != 4:
+            raise ValueError("e_attr must be [E,4]")
+        check(lib.yolat_gather_rows(_f(e_attr, "e_attr"), _ld(e_attr), g.perm.data_ptr(), E, 4,
+                                    g.attr.data_ptr(), 4, st), "yolat_gather_rows")
+    g.seg_ptr = g.node_seg = None
+    if bbox_idx is not None:
+        g.seg_ptr = torch.empty(P + 1, dtype=torch.int32, device=dev)
+        g.node_seg = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        check(lib.yolat_segment_ptr(_i(bbox_idx, torch.int64, "bbox_idx"), N, P, g.seg_ptr.data_ptr(),
+                                    g.node_seg.data_ptr(), g.status.data_ptr(), st),
+              "yolat_segment_ptr")
+    return g
+
+
+# ---------------------------------------------------------------------------------------------
+# dense
+# ---------------------------------------------------------------------------------------------
+
+def stats_buffer(M, C, device):
+    return torch.empty(((M + STATS_ROWS - 1) // STATS_ROWS) * C * 2 + 2, dtype=torch.float32, device=device)
+
+
+def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False,
+               accumulate=False, stats=None):
+    """Y = epi(pro(A) @ W.T + bias).  a_pro / o_pro: (scale, shift) tensors or None."""
+    M, K = A.shape
+    Nout = W.shape[0]
+    asc, ash = (a_pro if a_pro is not None else (None, None))
+    osc, osh = (o_pro if o_pro is not None else (None, None))
+    check(lib.yolat_linear_fwd(_f(A, "A"), _ld(A), M, K, _f(asc, "a_scale", True), _f(ash, "a_shift", True),
+                               int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias", True), Nout,
+                               _f(osc, "o_scale", True), _f(osh, "o_shift", True), int(o_relu),
+                               _f(Y, "Y"), _ld(Y), int(accumulate), _f(stats, "stats", True),
+                               _stream()), "yolat_linear_fwd")
+    return Y
+
+
+def linear_fwd_wt(A, Wt, Y, accumulate=False):
+    """Y = A @ Wt   (Wt: [K, Nout] row-major, e.g. dX = dY @ W)."""
+    M, K = A.shape
+    Nout = Wt.shape[1]
+    check(lib.yolat_linear_fwd_wt(_f(A, "A"), _ld(A), M, K, _f(Wt, "Wt"), _ld(Wt), Nout, _f(Y, "Y"),
+                                  _ld(Y), int(accumulate), _stream()), "yolat_linear_fwd_wt")
+    return Y
+
+
+def linear_bwd_w(dY, A, dW, db=None, a_pro=None, a_relu=False, accumulate=False):
+    M, Nout = dY.shape
+    K = A.shape[1]
+    asc, ash = (a_pro if a_pro is not None else (None, None))
+    work = torch.empty(int(lib.yolat_linear_bwd_w_work_elems(M, Nout, K)), dtype=torch.float32,
+                       device=dY.device)
+    check(lib.yolat_linear_bwd_w(_f(dY, "dY"), _ld(dY), M, Nout, _f(A, "A"), _ld(A), K,
+                                 _f(asc, "a_scale", True), _f(ash, "a_shift", True), int(a_relu),
+                                 _f(dW, "dW"), _ld(dW), _f(db, "db", True), int(accumulate),
+                                 work.data_ptr(), _stream()), "yolat_linear_bwd_w")
+    return dW
+
+
+def bn_finalize(stats, M, bn, scale, shift, save_mean, save_invstd, update_running=True):
+    C = bn.num_features
+    rm = bn.running_mean if (update_running and bn.track_running_stats) else None
+    rv = bn.running_var if (update_running and bn.track_running_stats) else None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    check(lib.yolat_bn_finalize(_f(stats), M, C, _f(bn.weight), _f(bn.bias), _f(rm, "rm", True),
+                                _f(rv, "rv", True), mom, float(bn.eps), _f(save_mean),
+                                _f(save_invstd), _f(scale), _f(shift), _stream()), "yolat_bn_finalize")
+
+
+def bn_eval_coeffs(bn, scale, shift):
+    check(lib.yolat_bn_eval_coeffs(_f(bn.weight), _f(bn.bias), _f(bn.running_mean), _f(bn.running_var),
+                                   float(bn.eps), bn.num_features, _f(scale), _f(shift), _stream()),
+          "yolat_bn_eval_coeffs")
+
+
+def scale_shift_relu(Y, scale, shift, relu, Z):
+    M, C = Y.shape
+    check(lib.yolat_scale_shift_relu(_f(Y), _ld(Y), M, C, _f(scale, "scale", True), _f(shift, "shift", True),
+                                     int(relu), _f(Z), _ld(Z), _stream()), "yolat_scale_shift_relu")
+    return Z
+
+
+def bn_relu_bwd(dZ, Y, gamma, save_mean, save_invstd, scale, shift, relu, dgamma, dbeta, dY,
+                accumulate=False):
+    M, C = Y.shape
+    work = torch.empty(int(lib.yolat_bn_bwd_work_elems(M, C)), dtype=torch.float32, device=Y.device)
+    check(lib.yolat_bn_relu_bwd(_f(dZ), _ld(dZ), _f(Y), _ld(Y), M, C, _f(gamma), _f(save_mean),
+                                _f(save_invstd), _f(scale), _f(shift), int(relu), _f(dgamma),
+                                _f(dbeta), int(accumulate), _f(dY), _ld(dY), work.data_ptr(),
+                                _stream()), "yolat_bn_relu_bwd")
+    return dY
+
+
+# ---------------------------------------------------------------------------------------------
+# edge convolution
+# ---------------------------------------------------------------------------------------------
+
+def edge_lin1_fwd(x, g, W1, b1, H1, o_pro=None, o_relu=False, stats=None):
+    N, Cin = x.shape
+    C = W1.shape[0]
+    osc, osh = (o_pro if o_pro is not None else (None, None))
+    check(lib.yolat_edge_lin1_fwd(_f(x, "x"), _ld(x), N, Cin, g.src.data_ptr(), g.dst.data_ptr(),
+                                  g.attr.data_ptr(), g.E, _f(W1), _ld(W1), _f(b1, "b1", True), C,
+                                  _f(osc, "o_scale", True), _f(osh, "o_shift", True), int(o_relu),
+                                  _f(H1), _ld(H1), _f(stats, "stats", True), _stream()),
+          "yolat_edge_lin1_fwd")
+    return H1
+
+
+def edge_lin1_bwd_w(dH1, x, g, dW1, db1=None, accumulate=False):
+    E, C = dH1.shape[0], dW1.shape[0]
+    N, Cin = x.shape
+    work = torch.empty(int(lib.yolat_linear_bwd_w_work_elems(g.E, C, 2 * Cin + 4)), dtype=torch.float32,
+                       device=x.device)
+    check(lib.yolat_edge_lin1_bwd_w(_f(dH1), _ld(dH1), g.E, C, _f(x), _ld(x), N, Cin, g.src.data_ptr(),
+                                    g.dst.data_ptr(), g.attr.data_ptr(), _f(dW1), _ld(dW1),
+                                    _f(db1, "db1", True), int(accumulate), work.data_ptr(), _stream()),
+          "yolat_edge_lin1_bwd_w")
+    return dW1
+
+
+def edge_lin1_bwd_x(dH1, W1, Cin, dG):
+    C = W1.shape[0]
+    check(lib.yolat_edge_lin1_bwd_x(_f(dH1), _ld(dH1), dH1.shape[0], C, _f(W1), _ld(W1), Cin, _f(dG),
+                                    _ld(dG), _stream()), "yolat_edge_lin1_bwd_x")
+    return dG
+
+
+def edge_scatter_bwd(dG, Cin, g, dX, accumulate=False):
+    g.ensure_csc()
+    check(lib.yolat_edge_scatter_bwd(_f(dG), _ld(dG), Cin, g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
+                                     g.slots.data_ptr(), g.N, _f(dX), _ld(dX), int(accumulate),
+                                     _stream()), "yolat_edge_scatter_bwd")
+    return dX
+
+
+def csr_mean_fwd(H, g, out, h_pro=None, h_relu=False, accumulate=False):
+    C = out.shape[1]
+    hs, hb = (h_pro if h_pro is not None else (None, None))
+    check(lib.yolat_csr_mean_fwd(_f(H, "H", g.E == 0), _ld(H) if H is not None else C, C,
+                                 _f(hs, "h_scale", True), _f(hb, "h_shift", True), int(h_relu),
+                                 g.row_ptr.data_ptr(), g.N, _f(out), _ld(out), int(accumulate),
+                                 _stream()), "yolat_csr_mean_fwd")
+    return out
+
+
+def csr_mean_bwd(dOut, g, dM):
+    C = dOut.shape[1]
+    check(lib.yolat_csr_mean_bwd(_f(dOut), _ld(dOut), C, g.row_ptr.data_ptr(), g.dst.data_ptr(), g.E,
+                                 _f(dM), _ld(dM), _stream()), "yolat_csr_mean_bwd")
+    return dM
+
+
+# ---------------------------------------------------------------------------------------------
+# proposal pooling
+# ---------------------------------------------------------------------------------------------
+
+def segment_mean_fwd(X, g, Y, x_pro=None, x_relu=False):
+    D = X.shape[1]
+    xs, xb = (x_pro if x_pro is not None else (None, None))
+    check(lib.yolat_segment_mean_fwd(_f(X), _ld(X), D, _f(xs, "x_scale", True), _f(xb, "x_shift", True),
+                                     int(x_relu), g.seg_ptr.data_ptr(), g.P, _f(Y), _ld(Y), _stream()),
+          "yolat_segment_mean_fwd")
+    return Y
+
+
+def segment_max_fwd(X, g, Y, arg=None, x_pro=None, x_relu=False):
+    D = X.shape[1]
+    xs, xb = (x_pro if x_pro is not None else (None, None))
+    check(lib.yolat_segment_max_fwd(_f(X), _ld(X), D, _f(xs, "x_scale", True), _f(xb, "x_shift", True),
+                                    int(x_relu), g.seg_ptr.data_ptr(), g.P, g.N, _f(Y), _ld(Y),
+                                    _i(arg, torch.int32, "arg"), _stream()), "yolat_segment_max_fwd")
+    return Y
+
+
+def segment_mean_bwd(dY, g, dX):
+    D = dX.shape[1]
+    check(lib.yolat_segment_mean_bwd(_f(dY), _ld(dY), D, g.seg_ptr.data_ptr(), g.node_seg.data_ptr(),
+                                     g.N, _f(dX), _ld(dX), _stream()), "yolat_segment_mean_bwd")
+    return dX
+
+
+def segment_max_bwd(dY, arg, g, dX):
+    D = dX.shape[1]
+    check(lib.yolat_segment_max_bwd(_f(dY), _ld(dY), D, _i(arg, torch.int32, "arg"),
+                                    g.node_seg.data_ptr(), g.N, _f(dX), _ld(dX), _stream()),
+          "yolat_segment_max_bwd")
+    return dX
+
+
+# ---------------------------------------------------------------------------------------------
+# loss / optimiser
+# ---------------------------------------------------------------------------------------------
+
+def softmax_ce(logits, labels, loss, dlogits=None):
+    P, K = logits.shape
+    check(lib.yolat_softmax_ce(_f(logits), _ld(logits), _i(labels, torch.int64, "labels"), P, K,
+                               _f(loss), _f(dlogits, "dlogits", True),
+                               _ld(dlogits) if dlogits is not None else K, _stream()), "yolat_softmax_ce")
+    return loss
+
+
+def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
+              grad_scale=1.0):
+    check(lib.yolat_adam_step(_f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(),
+                              float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
+                              int(step), float(grad_scale), _stream()), "yolat_adam_step")
