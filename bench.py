@@ -1,0 +1,296 @@
+#!/usr/bin/env python
+"""bench.py — throughput of the YOLaT GNN hot path on MI355X.
+
+    python bench.py --gpus 1 --steps K --warmup W            # default: BASELINE.json configs[1]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+           --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one batch of synthetic input already resident in HBM:
+  --mode fwd   (default)  SparseCADGCN eval forward of ONE synthetic Bezier graph per rank
+                          (cfg 2: N=10 000 nodes / E=40 000 edges / P=400 proposals, in_channels=5,
+                          n_blocks=2), including the device-side CSR / segment build from the raw COO
+                          edge list.  Ranks are independent replicas on different graphs (seed+rank):
+                          no data-path collective, weak scaling.
+  --mode train            one training step (forward + CE + backward + Adam) of cfg 3/4 with ONE RCCL
+                          all-reduce of the flat 6.45 MB gradient bucket per step when N > 1.
+Rank 0 prints ONE JSON line.  `value` = graphs processed by all ranks / max-over-ranks wall time.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+PEAK_MFMA_F32_TFLOPS = 157.3     # MI355X fp32-input MFMA dense peak (MI355X_MICROARCH.md)
+PEAK_HBM_GBS = 8000.0            # HBM3E spec peak
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mode", default="fwd", choices=["fwd", "train"])
+    ap.add_argument("--config", default=None, help="cfg id 1..5 (default: 2 for fwd, 3 for train)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--keep-csr", action="store_true", help="re-use the CSR across steps (fwd mode)")
+    return ap.parse_args()
+
+
+def to_device(data):
+    for k in ("x", "edge", "e_attr", "bbox_idx", "bbox", "labels"):
+        data[k] = data[k].cuda()
+    return data
+
+
+# ---------------------------------------------------------------------------------------------
+# per-op HIP-event timing (roofline of the dominant kernel)
+# ---------------------------------------------------------------------------------------------
+class OpTimer(object):
+    """Wraps the ops.* entry points with HIP events recorded on torch's current stream — the stream
+    the kernels are launched on — and accumulates per-(op, shape) time and algorithmic work."""
+
+    def __init__(self, ops_mod):
+        self.ops = ops_mod
+        self.records = []
+        self.orig = {}
+
+    def _work(self, name, args, kwargs):
+        o = self.ops
+        if name == "linear_fwd":
+            A, W = args[0], args[1]
+            M, K, N = A.shape[0], A.shape[1], W.shape[0]
+            return 2.0 * M * K * N, 4.0 * (M * K + N * K + M * N), "linear_fwd[%dx%d->%d]" % (M, K, N)
+        if name == "edge_lin1_fwd":
+            x, g, W1 = args[0], args[1], args[2]
+            Cin, C, E, Nn = x.shape[1], W1.shape[0], g.E, x.shape[0]
+            K = 2 * Cin + 4
+            # algorithmic bytes (SURVEY.md §8 d B_agg): gathered features + indices + output
+            return 2.0 * E * K * C, E * (K * 4.0 + 8) + E * C * 4.0, "edge_lin1_fwd[E=%d,K=%d]" % (E, K)
+        if name == "csr_mean_fwd":
+            H, g, out = args[0], args[1], args[2]
+            C = out.shape[1]
+            return 1.0 * g.E * C, 4.0 * (g.E * C + 2 * g.N * C) + 4.0 * g.N, "csr_mean_fwd[E=%d]" % g.E
+        if name in ("segment_max_fwd", "segment_mean_fwd"):
+            X, g = args[0], args[1]
+            D = X.shape[1]
+            return 1.0 * g.N * D, 4.0 * (g.N * D + g.P * D), "%s[D=%d]" % (name, D)
+        if name == "build_graph":
+            edge = args[0]
+            E = max(edge.shape)
+            return 0.0, 16.0 * E + 16.0 * E + 12.0 * E, "build_graph[E=%d]" % E
+        return 0.0, 0.0, name
+
+    def __enter__(self):
+        for name in ("linear_fwd", "edge_lin1_fwd", "csr_mean_fwd", "segment_max_fwd", "segment_mean_fwd",
+                     "build_graph", "scale_shift_relu", "bn_eval_coeffs"):
+            fn = getattr(self.ops, name)
+            self.orig[name] = fn
+
+            def wrapped(*a, _fn=fn, _name=name, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _fn(*a, **k)
+                e.record()
+                fl, by, label = self._work(_name, a, k)
+                self.records.append((label, s, e, fl, by))
+                return r
+            setattr(self.ops, name, wrapped)
+        return self
+
+    def __exit__(self, *exc):
+        for name, fn in self.orig.items():
+            setattr(self.ops, name, fn)
+
+    def summary(self):
+        torch.cuda.synchronize()
+        agg = {}
+        for label, s, e, fl, by in self.records:
+            a = agg.setdefault(label, [0.0, 0, fl, by])
+            a[0] += s.elapsed_time(e)
+            a[1] += 1
+        return {k: {"ms_total": v[0], "calls": v[1], "ms_avg": v[0] / v[1], "flops": v[2], "bytes": v[3]}
+                for k, v in agg.items()}
+
+
+def roofline_entry(summary):
+    label, rec = max(summary.items(), key=lambda kv: kv[1]["ms_total"])
+    t = rec["ms_avg"] * 1e-3
+    intensity = rec["flops"] / max(rec["bytes"], 1.0)
+    ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    if intensity >= ridge:
+        ach = rec["flops"] / t / 1e12
+        return {"kernel": label, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
+                "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+                "avg_launch_us": rec["ms_avg"] * 1e3}
+    ach = rec["bytes"] / t / 1e9
+    return {"kernel": label, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+            "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": rec["ms_avg"] * 1e3}
+
+
+# ---------------------------------------------------------------------------------------------
+# CPU baseline: the op-for-op torch oracle on the host cores (bounded sample)
+# ---------------------------------------------------------------------------------------------
+def cpu_baseline(cfg_name, optkw, mode):
+    from oracle import oracle_torch as orc
+    import yolat_vectorgraphicsrecognition_amd as yv
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import golden_util as gu
+    data, slices, _, n_graphs = yv.config(cfg_name)
+    opt = orc.Opt(**optkw)
+    model = gu.fill_state_(orc.SparseCADGCN(opt), 0)
+    crit = orc.DetectionLoss(opt)
+    ncpu = os.cpu_count() or 1
+    best = None
+    budget_t0 = time.time()
+    for threads in [t for t in (8, 16, 32, 64) if t <= ncpu] or [ncpu]:
+        torch.set_num_threads(threads)
+        if mode == "fwd":
+            model.eval()
+
+            def run():
+                with torch.no_grad():
+                    model(data, None)
+        else:
+            model.train()
+            optim = torch.optim.Adam(model.parameters(), lr=2.5e-4, weight_decay=1e-5)
+
+            def run():
+                orc.train_step(model, crit, optim, data)
+        reps = 10 if mode == "fwd" else 3
+        for _ in range(2):
+            run()
+        ts = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            run()
+            ts.append(time.perf_counter() - t0)
+        ts.sort()
+        med = ts[len(ts) // 2]
+        if best is None or med < best[0]:
+            best = (med, threads, reps)
+        if time.time() - budget_t0 > 25:
+            break
+    med, threads, reps = best
+    return {"value": n_graphs / med, "unit": "graphs/s", "cores": threads, "kind": "port",
+            "ms_per_step": med * 1e3, "host_cpus": ncpu,
+            "sample": "cfg %s, %s, median of %d steps of the op-for-op torch oracle (fp32), best of "
+                      "thread counts {8,16,32,64}<=cpu_count" % (cfg_name, mode, reps)}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    torch.cuda.set_device(local)
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+
+    import yolat_vectorgraphicsrecognition_amd as yv
+    sys.path.insert(0, os.path.join(REPO, "tests"))
+    import golden_util as gu
+
+    cfg = args.config or ("2" if args.mode == "fwd" else "3")
+    data, slices, optkw, n_graphs = yv.config(cfg, rank=rank)
+    N, E, P = data.x.shape[0], data.edge.shape[0], data.bbox.shape[0]
+    opt = yv.Opt(**optkw)
+    model = gu.fill_state_(yv.SparseCADGCN(opt), 0).cuda()
+    to_device(data)
+
+    if args.mode == "fwd":
+        model.eval()
+
+        def step():
+            if not args.keep_csr:
+                data._yolat_stage = None          # rebuild CSR / segments from the raw COO list
+            with torch.no_grad():
+                return model(data, slices)[0]
+    else:
+        trainer = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5)
+
+        def step():
+            data._yolat_stage = None
+            return trainer.step(data, slices)
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    roof = None
+    op_table = None
+    if rank == 0 and not args.no_roofline:
+        with OpTimer(yv.ops) as timer:
+            for _ in range(min(args.steps, 50)):
+                step()
+            op_table = timer.summary()
+        roof = roofline_entry(op_table)
+        roof["note"] = ("dominant op by HIP-event time inside this run; algorithmic flops/bytes per launch in "
+                        "DESIGN.md; traffic: PMC pass not collected in-process")
+
+    cpu = None
+    if rank == 0 and not args.no_cpu_baseline:
+        cpu = cpu_baseline(cfg, optkw, args.mode)
+
+    if world > 1:
+        torch.distributed.barrier()
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        line = {
+            "metric": "graphs_per_sec" if args.mode == "fwd" else "train_graphs_per_sec",
+            "value": n_graphs * world * args.steps / elapsed,
+            "unit": "graphs/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": ms,
+            "ms_per_forward": ms if args.mode == "fwd" else None,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "f32",
+            "data": "synthetic",
+            "config": {"workload": "cfg%s %s: synthetic Bezier graph(s), in_channels=5, n_blocks=%d, "
+                                   "%d graph(s)/rank/step" % (cfg, "eval forward" if args.mode == "fwd"
+                                                              else "train step (fwd+CE+bwd+Adam)",
+                                                              optkw["n_blocks"], n_graphs),
+                       "nodes": N, "edges": E, "proposals": P, "n_classes": optkw["n_classes"],
+                       "csr_rebuilt_each_step": not args.keep_csr,
+                       "parallelism": "replicas (graph-id sharding)" if args.mode == "fwd" else "dp%d" % world},
+            "roofline": roof,
+            "cpu_baseline": cpu,
+        }
+        if op_table is not None:
+            top = sorted(op_table.items(), key=lambda kv: -kv[1]["ms_total"])[:6]
+            line["op_breakdown_us"] = {k: round(v["ms_total"] / max(min(args.steps, 50), 1) * 1e3, 2) for k, v in top}
+        print(json.dumps(line))
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -112,10 +112,10 @@ def graph_case(kind):
                 stat_feats=np.zeros((P, 13), np.float32)), opt
 
 
-def to_data(arrs, data_cls):
-    d = data_cls(x=torch.from_numpy(arrs["x"].copy()), pos=torch.from_numpy(arrs["x"][:, 3:5].copy()))
+def to_data(arrs, data_cls, dtype=torch.float32):
+    d = data_cls(x=torch.from_numpy(arrs["x"].copy()).to(dtype), pos=torch.from_numpy(arrs["x"][:, 3:5].copy()))
     d.edge = torch.from_numpy(arrs["edge"].copy())
-    d.e_attr = torch.from_numpy(arrs["e_attr"].copy())
+    d.e_attr = torch.from_numpy(arrs["e_attr"].copy()).to(dtype)
     d.bbox_idx = torch.from_numpy(arrs["bbox_idx"].copy())
     d.bbox = torch.from_numpy(arrs["bbox"].copy())
     d.stat_feats = torch.from_numpy(arrs["stat_feats"].copy())

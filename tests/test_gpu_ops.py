@@ -1,0 +1,426 @@
+"""GPU parity tests (-m gpu): every C-ABI entry point against the CPU oracle on seeded inputs.
+Integer / index results must be bit-exact; fp32 features within 1e-4 relative (north_star)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import oracle_np as onp
+from oracle import oracle_torch as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL = 1e-4
+
+
+def _yv():
+    import yolat_vectorgraphicsrecognition_amd as yv
+    return yv
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def close(got, want, rtol=RTOL, atol=None, msg=""):
+    got = got.detach().cpu().double().numpy() if torch.is_tensor(got) else np.asarray(got, np.float64)
+    want = want.detach().cpu().double().numpy() if torch.is_tensor(want) else np.asarray(want, np.float64)
+    assert got.shape == want.shape, (msg, got.shape, want.shape)
+    scale = np.abs(want).max() if want.size else 1.0
+    atol = rtol * max(scale, 1e-30) if atol is None else atol
+    err = np.abs(got - want)
+    bad = err > atol + rtol * np.abs(want)
+    if bad.any():
+        idx = np.unravel_index(np.argmax(err), err.shape)
+        raise AssertionError("%s: %d/%d mismatches, max err %.3e at %s (got %.6g want %.6g), scale %.3g"
+                             % (msg, bad.sum(), bad.size, err.max(), idx, got[idx], want[idx], scale))
+
+
+# ---------------------------------------------------------------------------------------------
+# graph pre-processing: bit-exact
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("transposed", [False, True])
+def test_coo_to_csr_and_csc_match_fixture(golden_dir, transposed):
+    yv = _yv()
+    z = np.load(os.path.join(golden_dir, "integer_ops.npz"))
+    for tag in "abc":
+        N = int(z["csr_%s/N" % tag])
+        edge = np.stack([z["csr_%s/src" % tag], z["csr_%s/dst" % tag]], axis=1)
+        E = len(edge)
+        e = dev(edge)
+        if transposed:
+            e = e.T                                        # the model passes data.edge.T (arch:110)
+        attr = torch.arange(E * 4, dtype=torch.float32).view(E, 4).cuda()
+        g = yv.ops.build_graph(e, attr, None, N, 1)
+        g.ensure_csc()
+        g.check_status()
+        for name, got in (("row_ptr", g.row_ptr), ("perm", g.perm[:E]), ("src_csr", g.src[:E]),
+                          ("dst_csr", g.dst[:E]), ("col_ptr", g.col_ptr), ("slots", g.slots[:E])):
+            np.testing.assert_array_equal(got.cpu().numpy(), z["csr_%s/%s" % (tag, name)],
+                                          err_msg="%s %s" % (tag, name))
+        np.testing.assert_array_equal(g.attr[:E].cpu().numpy(), attr.cpu().numpy()[z["csr_%s/perm" % tag]])
+
+
+def test_csr_large_random_matches_numpy_and_properties():
+    yv = _yv()
+    rng = np.random.default_rng(5)
+    N, E = 20000, 90001
+    src = rng.integers(0, N, size=E).astype(np.int64)
+    dst = (rng.integers(0, N, size=E) ** 2 // N).astype(np.int64)        # skewed in-degrees
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), torch.zeros(E, 4).cuda(), None, N, 1)
+    g.ensure_csc()
+    g.check_status()
+    order = np.argsort(dst, kind="stable")
+    np.testing.assert_array_equal(g.perm.cpu().numpy(), order.astype(np.int32))
+    np.testing.assert_array_equal(g.dst.cpu().numpy(), dst[order].astype(np.int32))
+    np.testing.assert_array_equal(g.src.cpu().numpy(), src[order].astype(np.int32))
+    rp = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))]).astype(np.int32)
+    np.testing.assert_array_equal(g.row_ptr.cpu().numpy(), rp)
+    src_csr = src[order]
+    order2 = np.argsort(src_csr, kind="stable")
+    np.testing.assert_array_equal(g.slots.cpu().numpy(), order2.astype(np.int32))
+
+
+def test_edge_range_violation_is_flagged():
+    yv = _yv()
+    edge = dev(np.array([[0, 1], [2, 7]], dtype=np.int64))
+    g = yv.ops.build_graph(edge, torch.zeros(2, 4).cuda(), None, 5, 1)
+    with pytest.raises(IndexError):
+        g.check_status()
+
+
+def test_segment_ptr_fixture_and_unsorted_flag(golden_dir):
+    yv = _yv()
+    z = np.load(os.path.join(golden_dir, "integer_ops.npz"))
+    bb, P = z["seg/bbox_idx"], int(z["seg/P"])
+    g = yv.ops.build_graph(torch.zeros(0, 2, dtype=torch.int64).cuda(), torch.zeros(0, 4).cuda(), dev(bb),
+                           len(bb), P)
+    g.check_status()
+    np.testing.assert_array_equal(g.seg_ptr.cpu().numpy(), z["seg/seg_ptr"])
+    np.testing.assert_array_equal(g.node_seg.cpu().numpy(), bb.astype(np.int32))
+    bad = bb.copy()
+    bad[3], bad[20] = bad[20], bad[3]
+    g = yv.ops.build_graph(torch.zeros(0, 2, dtype=torch.int64).cuda(), torch.zeros(0, 4).cuda(), dev(bad),
+                           len(bad), P)
+    with pytest.raises(ValueError):
+        g.check_status()
+
+
+# ---------------------------------------------------------------------------------------------
+# dense layers
+# ---------------------------------------------------------------------------------------------
+
+LIN_SHAPES = [(1, 5, 64), (37, 5, 64), (64, 64, 64), (200, 14, 64), (301, 132, 64), (130, 128, 1024),
+              (700, 128, 1024), (45, 2304, 512), (45, 512, 256), (45, 256, 17), (45, 256, 22), (1000, 64, 64)]
+
+
+@pytest.mark.parametrize("M,K,N", LIN_SHAPES)
+def test_linear_fwd_plain(M, K, N):
+    yv = _yv()
+    g = torch.Generator().manual_seed(M * 7 + K)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g) / K ** 0.5
+    b = torch.randn(N, generator=g)
+    Y = torch.full((M, N), float("nan")).cuda()
+    yv.ops.linear_fwd(A.cuda(), W.cuda(), b.cuda(), Y)
+    close(Y, A.double() @ W.double().T + b.double(), msg="linear %s" % ((M, K, N),))
+
+
+def test_linear_fwd_prologue_epilogue_accumulate_and_strides():
+    yv = _yv()
+    g = torch.Generator().manual_seed(3)
+    M, K, N = 333, 64, 64
+    buf = torch.randn(M, 200, generator=g)
+    A = buf[:, 40:40 + K]                                   # column slice of a wider buffer (ld=200)
+    W = torch.randn(N, K, generator=g) / 8
+    b = torch.randn(N, generator=g)
+    asc, ash = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    osc, osh = torch.rand(N, generator=g) - 0.5, torch.randn(N, generator=g)
+    ybuf = torch.randn(M, 128, generator=g)
+    Yd = ybuf.cuda()
+    Y = Yd[:, 64:128]
+    yv.ops.linear_fwd(buf.cuda()[:, 40:40 + K], W.cuda(), b.cuda(), Y, a_pro=(asc.cuda(), ash.cuda()), a_relu=True,
+                      o_pro=(osc.cuda(), osh.cuda()), o_relu=True, accumulate=True)
+    a2 = torch.relu(A.double() * asc.double() + ash.double())
+    want = torch.relu((a2 @ W.double().T + b.double()) * osc.double() + osh.double()) + ybuf[:, 64:128].double()
+    close(Y, want, msg="pro/epi/acc")
+    np.testing.assert_array_equal(Yd[:, :64].cpu().numpy(), ybuf[:, :64].numpy())   # untouched columns
+
+
+@pytest.mark.parametrize("M,C,K", [(64, 64, 14), (65, 64, 64), (1000, 64, 132), (4097, 64, 64), (300, 1024, 128),
+                                   (45, 512, 2304), (7, 256, 512)])
+def test_linear_stats_and_bn_finalize(M, C, K):
+    yv = _yv()
+    g = torch.Generator().manual_seed(M + C)
+    A = torch.randn(M, K, generator=g) + 0.3
+    lin = torch.nn.Linear(K, C)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g))
+        bn.running_mean.copy_(torch.randn(C, generator=g))
+        bn.running_var.copy_(torch.rand(C, generator=g) + 0.5)
+    ref_bn = torch.nn.BatchNorm1d(C)
+    ref_bn.load_state_dict(bn.state_dict())
+    ref_bn.train()
+    with torch.no_grad():
+        y = lin(A)
+        z = ref_bn(y)
+    lin_d, bn_d = lin.cuda(), bn.cuda()
+    Y = torch.empty(M, C).cuda()
+    stats = yv.ops.stats_buffer(M, C, "cuda")
+    yv.ops.linear_fwd(A.cuda(), lin_d.weight, lin_d.bias, Y, stats=stats)
+    coef = torch.empty(4, C).cuda()
+    yv.ops.bn_finalize(stats, M, bn_d, coef[0], coef[1], coef[2], coef[3])
+    close(Y, y, msg="pre-activation")
+    close(coef[2], y.double().mean(0), msg="batch mean")
+    close(coef[3], 1 / torch.sqrt(y.double().var(0, unbiased=False) + 1e-5), msg="invstd")
+    Z = torch.empty(M, C).cuda()
+    yv.ops.scale_shift_relu(Y, coef[0], coef[1], False, Z)
+    close(Z, z, rtol=2e-4, msg="normalised")
+    close(bn_d.running_mean, ref_bn.running_mean, msg="running_mean")
+    close(bn_d.running_var, ref_bn.running_var, msg="running_var")
+
+
+def test_bn_eval_coeffs():
+    yv = _yv()
+    bn = torch.nn.BatchNorm1d(70)
+    gu.fill_state_(bn, 9)
+    x = torch.randn(33, 70)
+    bn.eval()
+    want = bn(x)
+    bnd = torch.nn.BatchNorm1d(70)
+    bnd.load_state_dict(bn.state_dict())
+    bnd = bnd.cuda()
+    coef = torch.empty(2, 70).cuda()
+    yv.ops.bn_eval_coeffs(bnd, coef[0], coef[1])
+    Z = torch.empty(33, 70).cuda()
+    yv.ops.scale_shift_relu(x.cuda(), coef[0], coef[1], False, Z)
+    close(Z, want, msg="bn eval")
+
+
+@pytest.mark.parametrize("M,K,N", [(100, 64, 64), (777, 64, 132), (64, 1024, 128), (45, 512, 2304), (45, 17, 256),
+                                   (5000, 64, 64)])
+def test_linear_backward_ops(M, K, N):
+    """dX = dY @ W  (linear_fwd_wt) and dW = dY^T @ A, db = colsum(dY) (linear_bwd_w); here the Linear
+    is [K -> N], so W is [N, K], dY is [M, N]."""
+    yv = _yv()
+    g = torch.Generator().manual_seed(K + N)
+    A = torch.randn(M, K, generator=g)
+    W = torch.randn(N, K, generator=g)
+    dY = torch.randn(M, N, generator=g)
+    dX = torch.empty(M, K).cuda()
+    yv.ops.linear_fwd_wt(dY.cuda(), W.cuda(), dX)
+    close(dX, dY.double() @ W.double(), msg="dX")
+    dW, db = torch.empty(N, K).cuda(), torch.empty(N).cuda()
+    yv.ops.linear_bwd_w(dY.cuda(), A.cuda(), dW, db)
+    close(dW, dY.double().T @ A.double(), msg="dW")
+    close(db, dY.double().sum(0), msg="db")
+    # with an A prologue (BN+ReLU of the producer) and accumulation
+    sc, sh = torch.rand(K, generator=g) + 0.5, torch.randn(K, generator=g)
+    dW2 = dW.clone()
+    yv.ops.linear_bwd_w(dY.cuda(), A.cuda(), dW2, None, a_pro=(sc.cuda(), sh.cuda()), a_relu=True, accumulate=True)
+    a2 = torch.relu(A.double() * sc.double() + sh.double())
+    close(dW2, dY.double().T @ a2 + dY.double().T @ A.double(), msg="dW prologue+acc")
+
+
+@pytest.mark.parametrize("M,C,relu", [(50, 64, True), (1000, 64, True), (300, 1024, True), (45, 512, False)])
+def test_bn_relu_backward(M, C, relu):
+    yv = _yv()
+    g = torch.Generator().manual_seed(C + M)
+    y = (torch.randn(M, C, generator=g) * 1.5 + 0.2).requires_grad_(True)
+    bn = torch.nn.BatchNorm1d(C)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(C, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(C, generator=g) * 0.3)
+    bn.train()
+    z = bn(y)
+    if relu:
+        z = torch.relu(z)
+    dz = torch.randn(M, C, generator=g)
+    z.backward(dz)
+    yd = y.detach().cuda()
+    mean = yd.double().mean(0)
+    invstd = 1 / torch.sqrt(yd.double().var(0, unbiased=False) + 1e-5)
+    scale = (bn.weight.detach().cuda().double() * invstd).float()
+    shift = (bn.bias.detach().cuda().double() - mean * scale.double()).float()
+    dgamma, dbeta = torch.empty(C).cuda(), torch.empty(C).cuda()
+    dY = torch.empty(M, C).cuda()
+    yv.ops.bn_relu_bwd(dz.cuda(), yd, bn.weight.detach().cuda(), mean.float(), invstd.float(), scale, shift, relu,
+                       dgamma, dbeta, dY)
+    close(dY, y.grad, rtol=3e-4, msg="dY")
+    close(dgamma, bn.weight.grad, rtol=3e-4, msg="dgamma")
+    close(dbeta, bn.bias.grad, rtol=3e-4, msg="dbeta")
+
+
+# ---------------------------------------------------------------------------------------------
+# edge convolution pieces
+# ---------------------------------------------------------------------------------------------
+
+def _edge_case(N, E, Cin, seed, ldx=None):
+    rng = np.random.default_rng(seed)
+    src = rng.integers(0, N, size=E).astype(np.int64)
+    dst = rng.integers(0, N, size=E).astype(np.int64)
+    x = rng.standard_normal((N, ldx or Cin)).astype(np.float32)
+    attr = rng.standard_normal((E, 4)).astype(np.float32)
+    return src, dst, x, attr
+
+
+@pytest.mark.parametrize("N,E,Cin", [(10, 33, 5), (300, 1000, 5), (300, 1000, 64), (50, 0, 64), (2000, 9001, 64)])
+def test_edge_lin1_forward_and_backward(N, E, Cin):
+    yv = _yv()
+    C = 64
+    src, dst, xfull, attr = _edge_case(N, E, Cin, N + E, ldx=Cin + (64 if Cin == 64 else 0))
+    x = xfull[:, :Cin]
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)) if E else torch.zeros(0, 2, dtype=torch.int64).cuda(),
+                           dev(attr) if E else torch.zeros(0, 4).cuda(), None, N, 1)
+    order = np.argsort(dst, kind="stable")
+    tg = torch.Generator().manual_seed(1)
+    W1 = torch.randn(C, 2 * Cin + 4, generator=tg) / (2 * Cin + 4) ** 0.5
+    b1 = torch.randn(C, generator=tg)
+    xt = torch.from_numpy(x.copy())
+    s_c, d_c = torch.from_numpy(src[order]), torch.from_numpy(dst[order])
+    F = torch.cat([xt[d_c], xt[s_c] - xt[d_c], torch.from_numpy(attr[order])], 1).double()
+    xd = dev(xfull)[:, :Cin]
+    H1 = torch.empty(max(E, 1), C).cuda()[:E]
+    stats = yv.ops.stats_buffer(max(E, 1), C, "cuda")
+    yv.ops.edge_lin1_fwd(xd, g, W1.cuda(), b1.cuda(), H1, stats=stats if E else None)
+    if E == 0:
+        return
+    want = F @ W1.double().T + b1.double()
+    close(H1, want, msg="H1")
+    # statistics partials reduce to the batch statistics
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    coef = torch.empty(4, C).cuda()
+    yv.ops.bn_finalize(stats, E, bn, coef[0], coef[1], coef[2], coef[3])
+    close(coef[2], want.mean(0), msg="edge batch mean")
+    close(coef[3], 1 / torch.sqrt(want.var(0, unbiased=False) + 1e-5), msg="edge invstd")
+    # weight gradient
+    dH = torch.randn(E, C, generator=tg)
+    dW, db = torch.empty(C, 2 * Cin + 4).cuda(), torch.empty(C).cuda()
+    yv.ops.edge_lin1_bwd_w(dH.cuda(), xd, g, dW, db)
+    close(dW, dH.double().T @ F, msg="dW1")
+    close(db, dH.double().sum(0), msg="db1")
+    # input gradient: dG then the atomic-free scatter
+    dG = torch.empty(E, 2 * Cin).cuda()
+    yv.ops.edge_lin1_bwd_x(dH.cuda(), W1.cuda(), Cin, dG)
+    dF = dH.double() @ W1.double()
+    wantG = torch.cat([dF[:, :Cin] - dF[:, Cin:2 * Cin], dF[:, Cin:2 * Cin]], 1)
+    close(dG, wantG, msg="dG")
+    dX = torch.randn(N, Cin).cuda()
+    base = dX.clone()
+    yv.ops.edge_scatter_bwd(dG, Cin, g, dX, accumulate=True)
+    wantX = base.cpu().double()
+    wantX.index_add_(0, d_c, wantG[:, :Cin])
+    wantX.index_add_(0, s_c, wantG[:, Cin:])
+    close(dX, wantX, msg="dX scatter")
+
+
+@pytest.mark.parametrize("N,E,C", [(7, 20, 64), (500, 1500, 64), (100, 30, 64), (64, 640, 128)])
+def test_csr_mean_forward_backward(N, E, C):
+    yv = _yv()
+    src, dst, _, attr = _edge_case(N, E, 4, N * 3 + E)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    order = np.argsort(dst, kind="stable")
+    tg = torch.Generator().manual_seed(2)
+    H = torch.randn(E, C, generator=tg)
+    sc, sh = torch.rand(C, generator=tg) + 0.5, torch.randn(C, generator=tg) * 0.3
+    base = torch.randn(N, C, generator=tg)
+    out = base.clone().cuda()
+    yv.ops.csr_mean_fwd(H.cuda(), g, out, h_pro=(sc.cuda(), sh.cuda()), h_relu=True, accumulate=True)
+    m = torch.relu(H * sc + sh)
+    want = orc.scatter(m, torch.from_numpy(dst[order]), dim_size=N, reduce="mean") + base
+    close(out, want, msg="csr mean")
+    # naive-loop oracle too (summation order = edge order)
+    close(out, onp.scatter_mean(m.numpy(), dst[order], N) + base.numpy(), msg="csr mean (naive)")
+    dOut = torch.randn(N, C, generator=tg)
+    dM = torch.empty(E, C).cuda()
+    yv.ops.csr_mean_bwd(dOut.cuda(), g, dM)
+    deg = np.maximum(np.bincount(dst, minlength=N), 1)
+    wantM = dOut[torch.from_numpy(dst[order])] / torch.from_numpy(deg[dst[order]]).float().view(-1, 1)
+    close(dM, wantM, msg="csr mean bwd")
+
+
+# ---------------------------------------------------------------------------------------------
+# proposal pooling
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("P,D", [(13, 128), (13, 1152), (40, 1024), (3, 5)])
+def test_segment_mean_max_forward_backward(P, D):
+    yv = _yv()
+    rng = np.random.default_rng(P * D)
+    n_p = rng.integers(0, 9, size=P)
+    n_p[0] = 3
+    n_p[-1] = 2                                                  # last segment non-empty
+    N = int(n_p.sum())
+    bb = np.repeat(np.arange(P), n_p).astype(np.int64)
+    X = torch.from_numpy(rng.standard_normal((N, D)).astype(np.float32))
+    X[1] = X[0]                                                  # force ties inside segment 0
+    g = yv.ops.build_graph(torch.zeros(0, 2, dtype=torch.int64).cuda(), torch.zeros(0, 4).cuda(), dev(bb), N, P)
+    g.check_status()
+    Ym = torch.empty(P, D).cuda()
+    yv.ops.segment_mean_fwd(X.cuda(), g, Ym)
+    close(Ym, orc.scatter(X, torch.from_numpy(bb), dim_size=P, reduce="mean"), msg="seg mean")
+    Yx = torch.empty(P, D).cuda()
+    arg = torch.empty(P, D, dtype=torch.int32).cuda()
+    yv.ops.segment_max_fwd(X.cuda(), g, Yx, arg)
+    wx, wa = onp.scatter_max(X.numpy(), bb, P)
+    np.testing.assert_array_equal(Yx.cpu().numpy(), wx)          # max is exact
+    np.testing.assert_array_equal(arg.cpu().numpy(), wa.astype(np.int32))
+    # prologue variant
+    sc, sh = torch.rand(D) - 0.3, torch.randn(D)
+    yv.ops.segment_max_fwd(X.cuda(), g, Yx, arg, x_pro=(sc.cuda(), sh.cuda()), x_relu=True)
+    Xp = torch.relu(X * sc + sh)
+    wx, wa = onp.scatter_max(Xp.numpy(), bb, P)
+    close(Yx, wx, msg="seg max prologue")
+    # backward
+    dY = torch.randn(P, D)
+    dX = torch.empty(N, D).cuda()
+    yv.ops.segment_mean_bwd(dY.cuda(), g, dX)
+    cnt = np.maximum(n_p, 1)
+    close(dX, dY[torch.from_numpy(bb)] / torch.from_numpy(cnt[bb]).float().view(-1, 1), msg="seg mean bwd")
+    yv.ops.segment_max_fwd(X.cuda(), g, Yx, arg)
+    yv.ops.segment_max_bwd(dY.cuda(), arg, g, dX)
+    Xr = X.clone().requires_grad_(True)
+    orc.scatter(Xr, torch.from_numpy(bb), dim_size=P, reduce="max").backward(dY)
+    np.testing.assert_array_equal(dX.cpu().numpy(), Xr.grad.numpy())
+
+
+# ---------------------------------------------------------------------------------------------
+# loss / optimiser
+# ---------------------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("P,K", [(1, 17), (40, 17), (3000, 22)])
+def test_softmax_ce(P, K):
+    yv = _yv()
+    g = torch.Generator().manual_seed(P)
+    z = (torch.randn(P, K, generator=g) * 3).requires_grad_(True)
+    y = torch.randint(0, K, (P,), generator=g)
+    want = torch.nn.functional.cross_entropy(z, y)
+    want.backward()
+    loss = torch.empty(1).cuda()
+    dl = torch.empty(P, K).cuda()
+    yv.ops.softmax_ce(z.detach().cuda(), y.cuda(), loss, dl)
+    close(loss, want.detach().reshape(1), msg="loss")
+    close(dl, z.grad, msg="dlogits")
+
+
+def test_adam_matches_torch_over_several_steps():
+    yv = _yv()
+    g = torch.Generator().manual_seed(0)
+    n = 100003
+    p0 = torch.randn(n, generator=g)
+    p = torch.nn.Parameter(p0.clone())
+    opt = torch.optim.Adam([p], lr=2.5e-4, weight_decay=1e-5)
+    pd, m, v = p0.clone().cuda(), torch.zeros(n).cuda(), torch.zeros(n).cuda()
+    for step in range(1, 6):
+        grad = torch.randn(n, generator=g) * (0.1 if step % 2 else 10.0)
+        p.grad = grad.clone()
+        opt.step()
+        yv.ops.adam_step(pd, grad.cuda(), m, v, 2.5e-4, 0.9, 0.999, 1e-8, 1e-5, step)
+    close(pd, p.detach(), rtol=1e-6, atol=1e-7, msg="adam params")
+    close(m, opt.state[p]["exp_avg"], rtol=1e-5, msg="exp_avg")
+    close(v, opt.state[p]["exp_avg_sq"], rtol=1e-5, msg="exp_avg_sq")

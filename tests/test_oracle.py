@@ -17,19 +17,44 @@ RTOL, ATOL = 1e-4, 1e-6
 
 @pytest.mark.parametrize("kind", ["tiny", "small", "medium", "deep"])
 def test_oracle_matches_reference_golden(kind, golden_dir):
+    """The golden values are the reference's own modules evaluated in float64 (make_golden.py).
+    The oracle in float64 must reproduce them to storage precision; the oracle in float32 (what the
+    GPU path is compared with elsewhere, and the CPU baseline) must be within the fp32 tolerances."""
     z = np.load(os.path.join(golden_dir, "model_%s.npz" % kind))
     arrs, optkw = gu.graph_case(kind)
     for k, v in optkw.items():
         assert int(z["opt/" + k]) == v
     opt = orc.Opt(**optkw)
-    torch.set_num_threads(1)
     model = gu.fill_state_(orc.SparseCADGCN(opt), int(z["seed"]))
     assert gu.state_hash(model) == str(z["state_hash"]), "weights differ from the fixture's"
-    out = gu.run_case(model, orc.DetectionLoss(opt), gu.to_data(arrs, Data))
     names = sorted({k.rsplit("/", 1)[0] for k in z.files if "/" in k and not k.startswith("opt/")})
     assert len(names) > 50
+    # float64 oracle: everything, to the precision the fixture is stored with (fp32 rounding of fp64)
+    out64 = gu.run_case(model.double(), orc.DetectionLoss(opt), gu.to_data(arrs, Data, torch.float64))
     for name in names:
-        gu.compare_summary(name, out[name], gu.unpack(name, z), RTOL, ATOL)
+        ref = gu.unpack(name, z)
+        a = out64[name].detach().double().numpy().reshape(-1)
+        want = ref["full"] if "full" in ref else ref["sample"]
+        sel = a if "full" in ref else a[::int(ref["stride"])]
+        scale = max(np.abs(want).max(), 1e-30)
+        assert np.abs(sel - want).max() <= 2e-7 * scale + 1e-12, name
+    # float32 oracle: forward within 1e-4 (north_star); gradients loosely — torch's fp32 CPU
+    # BatchNorm-backward sums move by up to 7e-3 with the intra-op thread count (see make_golden.py)
+    model32 = gu.fill_state_(orc.SparseCADGCN(opt), int(z["seed"]))
+    out32 = gu.run_case(model32, orc.DetectionLoss(opt), gu.to_data(arrs, Data))
+    fwd_tol = 1e-4 if kind != "tiny" else 1e-3      # tiny: BatchNorm over P=2 rows, ill-conditioned
+    for name in ("eval_logits", "train_logits", "loss"):
+        ref = gu.unpack(name, z)
+        a = out32[name].double().numpy().reshape(-1)
+        assert np.abs(a - ref["full"]).max() <= fwd_tol * np.abs(ref["full"]).max(), name
+    for name in names:
+        if not name.startswith("grad/") or kind == "tiny":
+            continue
+        ref = gu.unpack(name, z)
+        a = out32[name].double().numpy().reshape(-1)
+        want = ref["full"] if "full" in ref else ref["sample"]
+        sel = a if "full" in ref else a[::int(ref["stride"])]
+        assert np.abs(sel - want).max() <= 5e-2 * np.abs(want).max() + 5e-6, name
 
 
 def test_naive_scatter_matches_torch_oracle():

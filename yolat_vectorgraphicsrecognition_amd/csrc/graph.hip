@@ -11,12 +11,14 @@ __global__ void k_edge_count(const int64_t* edge, long se, long sc, int E, int N
                              int* dst32, int* cnt, int* status) {
   const int e = blockIdx.x * blockDim.x + threadIdx.x;
   if (e >= E) return;
-  const int64_t s = edge[(long)e * se];
-  const int64_t d = edge[(long)e * se + sc];
+  int64_t s = edge[(long)e * se];
+  int64_t d = edge[(long)e * se + sc];
   if (s < 0 || s >= N || d < 0 || d >= N) {
+    // flag it and clamp, so that every downstream kernel stays memory-safe; the caller must treat
+    // the results as invalid once it has read the status word
     atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
-    src32[e] = -1; dst32[e] = -1;
-    return;
+    s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+    d = d < 0 ? 0 : (d >= N ? N - 1 : d);
   }
   src32[e] = (int)s; dst32[e] = (int)d;
   atomicAdd(&cnt[d], 1);
@@ -131,8 +133,6 @@ extern "C" int yolat_coo_to_csr(const int64_t* edge, int64_t stride_e, int64_t s
     YL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sort_rows, dim3(yl_cdiv(N, 256)), dim3(256), 0, st, row_ptr, tmp, (int)N);
     YL_LAUNCH_CHECK();
-    // NOTE: with out-of-range edges (status flagged) the tail of tmp is undefined; the emit
-    // kernel is still bounded by E and the caller must treat the result as invalid.
     hipLaunchKernelGGL(k_emit_csr, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, tmp, src32, dst32,
                        (int)E, perm, src_csr, dst_csr);
     YL_LAUNCH_CHECK();
