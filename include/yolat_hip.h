@@ -94,10 +94,12 @@ int yolat_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, int6
  *   pro: a_scale/a_shift [K] nullable, a_relu
  *   epi: o_scale/o_shift [Nout] nullable (eval-mode BatchNorm folded), o_relu
  *   accumulate != 0: Y += (result)   (used for  out += lin_r(x), torch_vertex.py:325)
- *   stats (nullable): float2 [ceil(M/YOLAT_STATS_ROWS)][Nout] per-row-block (sum, M2) of the
- *        pre-epilogue values (incl. bias) for training-mode BatchNorm (batch statistics over all
- *        M rows, torch_nn.py:27); reduce with yolat_bn_finalize.                                 */
-#define YOLAT_STATS_ROWS 64
+ *   stats (nullable): fp32 scratch of yolat_bn_stats_elems(M,Nout) elements; receives per
+ *        32-row-group (sum, M2) partials of the pre-epilogue values (incl. bias) for training-mode
+ *        BatchNorm (batch statistics over all M rows, torch_nn.py:27); reduce with
+ *        yolat_bn_finalize (which also uses the tail of the buffer as fp64 scratch).              */
+#define YOLAT_STATS_ROWS 32
+size_t yolat_bn_stats_elems(int64_t M, int64_t C);
 int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t K,
                      const float* a_scale, const float* a_shift, int a_relu,
                      const float* W, int64_t ldw, const float* bias, int64_t Nout,

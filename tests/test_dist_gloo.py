@@ -1,0 +1,74 @@
+"""CPU tests of the multi-GPU path (-m "not gpu"): world_size-2 `gloo` processes exercise exactly the
+collective code the RCCL run uses (trainer.broadcast_parameters / allreduce_mean_ on the flat
+buffers) and the graph-id sharding."""
+import os
+import socket
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _Flat(object):
+    def __init__(self, rank):
+        g = torch.Generator().manual_seed(100 + rank)
+        self.param = torch.randn(1000, generator=g)
+        self.grad = torch.randn(1000, generator=g)
+
+
+class _Model(torch.nn.Module):
+    def __init__(self, rank):
+        super().__init__()
+        self.bn = torch.nn.BatchNorm1d(8)
+        with torch.no_grad():
+            self.bn.running_mean.fill_(float(rank + 1))
+
+
+def _worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from yolat_vectorgraphicsrecognition_amd import trainer
+    flat, model = _Flat(rank), _Model(rank)
+    g_local = flat.grad.clone()
+    trainer.broadcast_parameters(flat, model, src=0)
+    scale = trainer.allreduce_mean_(flat.grad)
+    gathered = [torch.zeros(1000) for _ in range(world)]
+    dist.all_gather(gathered, g_local)
+    ok = True
+    ok &= abs(scale - 1.0 / world) < 1e-12
+    ok &= torch.allclose(flat.grad, sum(gathered))
+    ok &= torch.equal(flat.param, _Flat(0).param)                     # everyone holds rank 0's parameters
+    ok &= float(model.bn.running_mean[0]) == 1.0                      # and rank 0's BatchNorm buffers
+    ids = trainer.shard_graph_ids(11, rank, world)
+    all_ids = [None] * world
+    dist.all_gather_object(all_ids, ids)
+    flat_ids = sorted(i for part in all_ids for i in part)
+    ok &= flat_ids == list(range(11))
+    out[rank] = bool(ok)
+    dist.destroy_process_group()
+
+
+def test_flat_gradient_allreduce_and_broadcast_world2():
+    world = 2
+    port = _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_worker, args=(world, port, out), nprocs=world, join=True)
+    assert dict(out) == {0: True, 1: True}
+
+
+def test_single_process_allreduce_is_identity():
+    from yolat_vectorgraphicsrecognition_amd import trainer
+    g = torch.arange(5.0)
+    assert trainer.allreduce_mean_(g) == 1.0
+    assert torch.equal(g, torch.arange(5.0))
+    assert trainer.shard_graph_ids(5, 0, 1) == [0, 1, 2, 3, 4]

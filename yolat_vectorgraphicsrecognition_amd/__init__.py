@@ -17,6 +17,6 @@ from . import ops, engine  # noqa: F401
 from .nn_modules import MultiSeq, MLP, GraphConv, ResBlock, scatter  # noqa: F401
 from .architecture import Backbone, SparseCADGCN, DetectionLoss, Opt  # noqa: F401
 from .data import Data, collate, fixup_offsets, synth_graph, synth_batch, config  # noqa: F401
-from .trainer import FlatParams, FlatAdam, Trainer  # noqa: F401
+from .trainer import FlatParams, FlatAdam, Trainer, shard_graph_ids, allreduce_mean_, broadcast_parameters  # noqa: F401
 
 __version__ = "0.1.0"

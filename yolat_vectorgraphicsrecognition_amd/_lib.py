@@ -25,6 +25,7 @@ SIGNATURES = {
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_gather_rows": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+    "yolat_bn_stats_elems": (c_sz, [c_i64, c_i64]),
     "yolat_linear_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int,
                                  c_p, c_i64, c_p, c_i64, c_p, c_p, c_int,
                                  c_p, c_i64, c_int, c_p, c_p]),

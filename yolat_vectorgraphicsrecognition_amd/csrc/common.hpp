@@ -4,6 +4,13 @@
 // one wave per SIMD, fp32-input MFMA v_mfma_f32_32x32x2_f32 (exact fp32 fma chain, 64 cycles per
 // instruction per SIMD), LDS tiles padded by one dword so that the per-lane column reads of the
 // MFMA A/B fragments (ds_read_b32, 2 x 32-lane groups) are bank-conflict free.
+//
+// Loader rule (learned from the ISA): every global load in a staging routine must be UNCONDITIONAL.
+// A per-lane "load or zero" branch makes hipcc wrap each load in its own exec-mask region followed
+// by s_waitcnt vmcnt(0), i.e. one dependent L2 round trip per element.  So out-of-range rows /
+// columns are handled by clamping the address (the loaded value is then discarded by a select, or
+// lands in output rows/columns that the epilogue masks) and the aligned interior case is a
+// compile-time FAST path with plain 16-byte loads.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -21,60 +28,77 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 static inline int yl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool yl_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
+__device__ __forceinline__ int yl_min(int a, int b) { return a < b ? a : b; }
+
 // ------------------------------------------------------------------------------------------------
-// Operand loaders.  load4(r, k, v) returns 4 consecutive k-elements of logical row r, zero beyond
-// the matrix.  k is always a multiple of 4.
+// Operand loaders.  load4<FAST>(r, k, v): 4 consecutive k-elements of logical row r (k % 4 == 0).
+//   FAST  : caller guarantees `vec` (16-byte loads legal) and k + 3 < cols.
+//   !FAST : any alignment / K tail; columns >= cols read as exactly 0.
+// Rows >= rows return the (finite or not) contents of the last valid row: every consumer masks
+// them (NT GEMM: epilogue row/column masks; TN GEMM: explicit select).
 // ------------------------------------------------------------------------------------------------
 
-// Row-major dense operand with optional per-column affine + ReLU prologue (BatchNorm1d+ReLU of the
-// producer applied on the fly).
-struct DenseOp {
+// Row-major dense operand; PRO adds the per-column affine + ReLU prologue (BatchNorm1d+ReLU of the
+// producer applied on the fly):  v = max(v*scale[k] + shift[k], floor),  floor = 0 or -inf.
+template <bool PRO>
+struct DenseOpT {
   const float* p;
   long ld;
   int rows, cols;
-  const float* scale;  // nullable
+  const float* scale;
   const float* shift;
-  int relu;
-  int vec;  // 16-byte loads legal (ld % 4 == 0 and base aligned)
+  float floor;
+  int vec;  // ld % 4 == 0, base (and scale/shift) 16-byte aligned
 
+  template <bool FAST>
   __device__ __forceinline__ void load4(int r, int k, float v[4]) const {
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (r >= rows || k >= cols) return;
-    const float* q = p + (long)r * ld + k;
-    if (vec && k + 3 < cols) {
-      const float4 t = *reinterpret_cast<const float4*>(q);
+    const float* q = p + (long)yl_min(r, rows - 1) * ld;
+    if (FAST) {
+      const float4 t = *reinterpret_cast<const float4*>(q + k);
       v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      if (PRO) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + k);
+        const float4 h = *reinterpret_cast<const float4*>(shift + k);
+        v[0] = fmaxf(fmaf(v[0], s.x, h.x), floor);
+        v[1] = fmaxf(fmaf(v[1], s.y, h.y), floor);
+        v[2] = fmaxf(fmaf(v[2], s.z, h.z), floor);
+        v[3] = fmaxf(fmaf(v[3], s.w, h.w), floor);
+      }
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (k + j < cols) v[j] = q[j];
-    }
-    if (scale != nullptr) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j)
-        if (k + j < cols) v[j] = fmaf(v[j], scale[k + j], shift[k + j]);
-    }
-    if (relu) {
-#pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = fmaxf(v[j], 0.f);
+      for (int j = 0; j < 4; ++j) {
+        const int kc = yl_min(k + j, cols - 1);
+        float t = q[kc];
+        if (PRO) t = fmaxf(fmaf(t, scale[kc], shift[kc]), floor);
+        v[j] = (k + j < cols) ? t : 0.f;
+      }
     }
   }
 };
+typedef DenseOpT<false> DenseOp;
+typedef DenseOpT<true> DenseProOp;
 
-// Dense operand used transposed: logical element (r, k) = p[k*ld + r].
+// Dense operand used transposed: logical element (r, k) = p[k*ld + r]  (r fast in memory).
 struct TransOp {
   const float* p;
   long ld;
-  int rows, cols;  // logical rows (fast in memory), logical cols
+  int rows, cols;
+  int vec;  // 1: the element path is already coalesced along r; FAST only skips the K-tail select
+  template <bool FAST>
   __device__ __forceinline__ void load4(int r, int k, float v[4]) const {
+    const int rc = yl_min(r, rows - 1);
 #pragma unroll
-    for (int j = 0; j < 4; ++j)
-      v[j] = (r < rows && k + j < cols) ? p[(long)(k + j) * ld + r] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const int kc = yl_min(k + j, cols - 1);
+      const float t = p[(long)kc * ld + rc];
+      v[j] = (FAST || k + j < cols) ? t : 0.f;
+    }
   }
 };
 
 // Edge feature rows of AttrRelativeEdgeConvGlobalPool2.message (torch_vertex.py:331), gathered on
 // the fly:  row q (CSR slot) = [ x[dst_q] | x[src_q] - x[dst_q] | attr_q ],  K = 2*Cin + 4.
+// Branch-free: two unconditional loads (pa, pb) and a select per segment.
 struct EdgeOp {
   const float* x;
   long ldx;
@@ -82,34 +106,39 @@ struct EdgeOp {
   const int* src;
   const int* dst;
   const float* attr;  // [E,4] contiguous
-  int E;
-  int vec;  // Cin % 4 == 0, ldx % 4 == 0, x 16-byte aligned
+  int rows;           // E
+  int cols;           // 2*Cin + 4
+  int vec;            // Cin % 4 == 0, ldx % 4 == 0, x and attr 16-byte aligned
 
-  __device__ __forceinline__ float elem(int s, int d, int q, int k) const {
-    if (k < Cin) return x[(long)d * ldx + k];
-    if (k < 2 * Cin) return x[(long)s * ldx + (k - Cin)] - x[(long)d * ldx + (k - Cin)];
-    if (k < 2 * Cin + 4) return attr[(long)q * 4 + (k - 2 * Cin)];
-    return 0.f;
-  }
+  template <bool FAST>
   __device__ __forceinline__ void load4(int q, int k, float v[4]) const {
-    v[0] = v[1] = v[2] = v[3] = 0.f;
-    if (q >= E || k >= 2 * Cin + 4) return;
-    const int s = src[q], d = dst[q];
-    if (vec) {
-      if (k < Cin) {
-        const float4 t = *reinterpret_cast<const float4*>(x + (long)d * ldx + k);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      } else if (k < 2 * Cin) {
-        const float4 a = *reinterpret_cast<const float4*>(x + (long)s * ldx + (k - Cin));
-        const float4 b = *reinterpret_cast<const float4*>(x + (long)d * ldx + (k - Cin));
-        v[0] = a.x - b.x; v[1] = a.y - b.y; v[2] = a.z - b.z; v[3] = a.w - b.w;
-      } else {
-        const float4 t = *reinterpret_cast<const float4*>(attr + (long)q * 4);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-      }
+    const int qc = yl_min(q, rows - 1);
+    const long s = src[qc], d = dst[qc];
+    if (FAST) {
+      // a float4 never straddles a segment because Cin % 4 == 0
+      const bool seg0 = k < Cin, seg1 = !seg0 && (k < 2 * Cin);
+      const int kx = seg0 ? k : (seg1 ? k - Cin : 0);
+      const float* pa = seg0 ? x + d * ldx + kx : (seg1 ? x + s * ldx + kx : attr + (long)qc * 4);
+      const float* pb = x + d * ldx + kx;
+      const float4 a = *reinterpret_cast<const float4*>(pa);
+      const float4 b = *reinterpret_cast<const float4*>(pb);
+      v[0] = seg1 ? a.x - b.x : a.x;
+      v[1] = seg1 ? a.y - b.y : a.y;
+      v[2] = seg1 ? a.z - b.z : a.z;
+      v[3] = seg1 ? a.w - b.w : a.w;
     } else {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v[j] = elem(s, d, q, k + j);
+      for (int j = 0; j < 4; ++j) {
+        const int kk = k + j;
+        const bool seg0 = kk < Cin, seg1 = !seg0 && (kk < 2 * Cin);
+        const bool seg2 = !seg0 && !seg1 && (kk < cols);
+        const int kx = seg0 ? kk : (seg1 ? kk - Cin : 0);
+        const int ka = seg2 ? kk - 2 * Cin : 0;
+        const float xd = x[d * ldx + kx];
+        const float xs = x[s * ldx + kx];
+        const float at = attr[(long)qc * 4 + ka];
+        v[j] = seg0 ? xd : (seg1 ? xs - xd : (seg2 ? at : 0.f));
+      }
     }
   }
 };
@@ -122,15 +151,19 @@ struct EdgeWcOp {
   const float* W1;
   long ldw;
   int Cin, C;
+  int vec;
+  template <bool FAST>
   __device__ __forceinline__ void load4(int n, int k, float v[4]) const {
+    const int nc = yl_min(n, 2 * Cin - 1);
+    const bool lo = nc < Cin;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      float t = 0.f;
-      if (n < 2 * Cin && k + j < C) {
-        const float* row = W1 + (long)(k + j) * ldw;
-        t = (n < Cin) ? row[n] - row[Cin + n] : row[n];
-      }
-      v[j] = t;
+      const int kc = yl_min(k + j, C - 1);
+      const float* row = W1 + (long)kc * ldw;
+      const float a = row[nc];
+      const float b = row[lo ? Cin + nc : nc];
+      const float t = lo ? a - b : a;
+      v[j] = (FAST || k + j < C) ? t : 0.f;
     }
   }
 };
@@ -146,14 +179,76 @@ struct Epilogue {
   float* Y;
   long ldy;
   int accumulate;
-  float* stats;  // nullable: float2 [ceil(M/64)][N]  (sum, M2) of (acc + bias)
+  float* stats;  // nullable: float2 [ceil(M/32)][N]  (sum, M2) of (acc + bias) per 32-row group
 };
+
+// Epilogue of one 32x32 MFMA sub-tile held by one wave (C/D layout: col = lane&31,
+// row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  Everything is wave-local: the training-mode BatchNorm
+// partial statistics of the 32-row group (sum, M2 around the group mean) need one cross-half
+// shuffle and no LDS, and are written once per (32-row group, column) => deterministic.
+__device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col, int lhi,
+                                              const Epilogue& ep, int M, int N) {
+  const bool col_ok = col < N;
+  const int cc = col_ok ? col : N - 1;
+  if (ep.bias != nullptr) {
+    const float bv = ep.bias[cc];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += bv;
+  }
+  if (ep.stats != nullptr) {
+    int cnt = M - row_base;
+    cnt = cnt > 32 ? 32 : cnt;
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      s += (row < M) ? acc[r] : 0.f;
+    }
+    s += __shfl_xor(s, 32);
+    const float mu = cnt > 0 ? s / (float)cnt : 0.f;
+    float m2 = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float d = acc[r] - mu;
+      m2 += (row < M) ? d * d : 0.f;
+    }
+    m2 += __shfl_xor(m2, 32);
+    if (lhi == 0 && col_ok && cnt > 0) {
+      float2* dst = reinterpret_cast<float2*>(ep.stats) + (long)(row_base >> 5) * N + col;
+      *dst = make_float2(s, m2);
+    }
+  }
+  float sc = 1.f, sh = 0.f;
+  if (ep.scale != nullptr) { sc = ep.scale[cc]; sh = ep.shift[cc]; }
+  const float floor = ep.relu ? 0.f : -INFINITY;
+  float old[16];
+  if (ep.accumulate) {   // all 16 reads issued back to back (clamped rows), one wait
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = yl_min(row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi, M - 1);
+      old[r] = ep.Y[(long)row * ep.ldy + cc];
+    }
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) old[r] = 0.f;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    const float v = fmaxf(fmaf(acc[r], sc, sh), floor) + old[r];
+    if (col_ok && row < M) ep.Y[(long)row * ep.ldy + col] = v;
+  }
+}
 
 // ------------------------------------------------------------------------------------------------
 // NT GEMM:  Y[M,N] = epi( A[M,K] . B[N,K]^T )   — 256 threads, 2x2 waves, wave tile (BM/2)x(BN/2)
-// built from 32x32x2 fp32 MFMAs.  LDS tiles As[BM][BK+1], Bs[BN][BK+1].
+// built from 32x32x2 fp32 MFMAs.  LDS tiles As[BM][BK+1], Bs[BN][BK+1] (the +1 dword pad makes the
+// per-lane column reads of the fragments conflict-free).  The global loads of the next K-tile are
+// issued into registers before the MFMAs of the current one (software pipeline), so HBM/L2 latency
+// hides under the 64-cycle fp32 MFMAs.
 //   MFMA operand layout (cdna_hip_programming.md §3): A: lane l holds A[i=l&31][k=l>>5];
-//   B: lane l holds B[k=l>>5][j=l&31]; C/D: col = l&31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
+//   B: lane l holds B[k=l>>5][j=l&31].
 // B_NFAST: the B loader is contiguous along n (transposed operands) -> map consecutive threads to
 // consecutive n when staging.
 // ------------------------------------------------------------------------------------------------
@@ -162,9 +257,9 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int LD = BK + 1;
   constexpr int KQ = BK / 4;
-  constexpr int STAT_FLOATS = (BM / 32) * BN + (BM / 64) * BN;
-  constexpr int TILE_FLOATS = (BM + BN) * LD;
-  __shared__ float smem[TILE_FLOATS > STAT_FLOATS ? TILE_FLOATS : STAT_FLOATS];
+  constexpr int NA = (BM * KQ) / 256, NB = (BN * KQ) / 256;   // float4 loads per thread per tile
+  static_assert((BM * KQ) % 256 == 0 && (BN * KQ) % 256 == 0, "tile/thread mismatch");
+  __shared__ float smem[(BM + BN) * LD];
   float* As = smem;
   float* Bs = smem + BM * LD;
 
@@ -172,6 +267,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
   const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  const bool fastA = A.vec != 0, fastB = B.vec != 0;
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -181,25 +277,62 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  for (int k0 = 0; k0 < K; k0 += BK) {
-    // ---- stage A tile
-    for (int i = tid; i < BM * KQ; i += 256) {
-      const int r = i / KQ, kq = i % KQ;
-      float v[4];
-      A.load4(row0 + r, k0 + 4 * kq, v);
-      float* d = As + r * LD + 4 * kq;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+  float ra[NA][4], rb[NB][4];
+  auto fetch = [&](int k0) {
+    const bool full = (k0 + BK <= K);           // wave-uniform
+    if (full && fastA) {
+#pragma unroll
+      for (int t = 0; t < NA; ++t) {
+        const int i = tid + t * 256;
+        A.template load4<true>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NA; ++t) {
+        const int i = tid + t * 256;
+        A.template load4<false>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+      }
     }
-    // ---- stage B tile
-    for (int i = tid; i < BN * KQ; i += 256) {
-      int n, kq;
-      if (B_NFAST) { n = i % BN; kq = i / BN; } else { n = i / KQ; kq = i % KQ; }
-      float v[4];
-      B.load4(col0 + n, k0 + 4 * kq, v);
+    if (full && fastB) {
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int i = tid + t * 256;
+        const int n = B_NFAST ? (i % BN) : (i / KQ);
+        const int kq = B_NFAST ? (i / BN) : (i % KQ);
+        B.template load4<true>(col0 + n, k0 + 4 * kq, rb[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NB; ++t) {
+        const int i = tid + t * 256;
+        const int n = B_NFAST ? (i % BN) : (i / KQ);
+        const int kq = B_NFAST ? (i / BN) : (i % KQ);
+        B.template load4<false>(col0 + n, k0 + 4 * kq, rb[t]);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int t = 0; t < NA; ++t) {
+      const int i = tid + t * 256;
+      float* d = As + (i / KQ) * LD + 4 * (i % KQ);
+      d[0] = ra[t][0]; d[1] = ra[t][1]; d[2] = ra[t][2]; d[3] = ra[t][3];
+    }
+#pragma unroll
+    for (int t = 0; t < NB; ++t) {
+      const int i = tid + t * 256;
+      const int n = B_NFAST ? (i % BN) : (i / KQ);
+      const int kq = B_NFAST ? (i / BN) : (i % KQ);
       float* d = Bs + n * LD + 4 * kq;
-      d[0] = v[0]; d[1] = v[1]; d[2] = v[2]; d[3] = v[3];
+      d[0] = rb[t][0]; d[1] = rb[t][1]; d[2] = rb[t][2]; d[3] = rb[t][3];
     }
+  };
+
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    stage();
     __syncthreads();
+    if (k0 + BK < K) fetch(k0 + BK);      // in flight while the MFMAs below run
 #pragma unroll
     for (int kk = 0; kk < BK; kk += 2) {
       float a[TM], b[TN];
@@ -216,106 +349,105 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
     __syncthreads();
   }
 
-  // ---- bias
-  if (ep.bias != nullptr) {
 #pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      const int c = col0 + wn * WN + j * 32 + l31;
-      const float bv = (c < N) ? ep.bias[c] : 0.f;
+  for (int i = 0; i < TM; ++i)
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[i][j][r] += bv;
-    }
-  }
+    for (int j = 0; j < TN; ++j)
+      wave_epilogue(acc[i][j], row0 + wm * WM + i * 32, col0 + wn * WN + j * 32 + l31, lhi, ep, M, N);
+}
 
-  // ---- training-mode BatchNorm partial statistics over 64-row groups (deterministic)
-  if (ep.stats != nullptr) {
-    float* red = smem;                      // [BM/32][BN]
-    float* meanS = smem + (BM / 32) * BN;   // [BM/64][BN]
-    // pass 1: sums
+// ------------------------------------------------------------------------------------------------
+// Skinny NT GEMM with split-K inside the workgroup, for few rows x long K (the per-proposal
+// classifier layers: P x 2304 -> 512 ...).  One workgroup = one 32x32 output tile; its 4 waves each
+// own a quarter of every 128-deep K chunk, so a P=400 problem becomes ~200 workgroups instead of
+// 56.  The four partial accumulators are summed through LDS in a fixed order by wave 0, which then
+// runs the same epilogue (bias / BatchNorm statistics / scale-shift-ReLU / store).
+// ------------------------------------------------------------------------------------------------
+template <class AL, class BL, bool B_NFAST>
+__global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int M, int N, int K) {
+  constexpr int BT = 32, BK = 128, LD = BK + 1, KQ = BK / 4;
+  __shared__ float smem[2 * BT * LD];
+  float* As = smem;
+  float* Bs = smem + BT * LD;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = blockIdx.x * BT, col0 = blockIdx.y * BT;
+  const bool fastA = A.vec != 0, fastB = B.vec != 0;
+
+  f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+  float ra[4][4], rb[4][4];
+  auto fetch = [&](int k0) {
+    const bool full = (k0 + BK <= K);
+    if (full && fastA) {
 #pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          s += (row < M) ? acc[i][j][r] : 0.f;
-        }
-        s += __shfl_xor(s, 32);
-        if (lhi == 0) red[(wm * TM + i) * BN + wn * WN + j * 32 + l31] = s;
+      for (int t = 0; t < 4; ++t) {
+        const int i = tid + t * 256;
+        A.template load4<true>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
       }
-    __syncthreads();
-    for (int i = tid; i < (BM / 64) * BN; i += 256) {
-      const int g = i / BN, c = i % BN;
-      int cnt = M - (row0 + 64 * g);
-      cnt = cnt < 0 ? 0 : (cnt > 64 ? 64 : cnt);
-      const float s = red[(2 * g) * BN + c] + red[(2 * g + 1) * BN + c];
-      meanS[i] = cnt > 0 ? s / (float)cnt : 0.f;
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = tid + t * 256;
+        A.template load4<false>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+      }
+    }
+    if (full && fastB) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = tid + t * 256;
+        const int n = B_NFAST ? (i % BT) : (i / KQ);
+        const int kq = B_NFAST ? (i / BT) : (i % KQ);
+        B.template load4<true>(col0 + n, k0 + 4 * kq, rb[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int i = tid + t * 256;
+        const int n = B_NFAST ? (i % BT) : (i / KQ);
+        const int kq = B_NFAST ? (i / BT) : (i % KQ);
+        B.template load4<false>(col0 + n, k0 + 4 * kq, rb[t]);
+      }
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tid + t * 256;
+      float* d = As + (i / KQ) * LD + 4 * (i % KQ);
+      d[0] = ra[t][0]; d[1] = ra[t][1]; d[2] = ra[t][2]; d[3] = ra[t][3];
+      const int n = B_NFAST ? (i % BT) : (i / KQ);
+      const int kq = B_NFAST ? (i / BT) : (i % KQ);
+      float* e = Bs + n * LD + 4 * kq;
+      e[0] = rb[t][0]; e[1] = rb[t][1]; e[2] = rb[t][2]; e[3] = rb[t][3];
     }
     __syncthreads();
-    // pass 2: M2 around the 64-row group mean
+    if (k0 + BK < K) fetch(k0 + BK);
+    const int kb = wave * 32;
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int g = (wm * WM + i * 32) / 64;
-        const float mu = meanS[g * BN + wn * WN + j * 32 + l31];
-        float s = 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-          const float d = acc[i][j][r] - mu;
-          s += (row < M) ? d * d : 0.f;
-        }
-        s += __shfl_xor(s, 32);
-        if (lhi == 0) red[(wm * TM + i) * BN + wn * WN + j * 32 + l31] = s;
-      }
+    for (int kk = 0; kk < 32; kk += 2) {
+      const float a = As[l31 * LD + kb + kk + lhi];
+      const float b = Bs[l31 * LD + kb + kk + lhi];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
     __syncthreads();
-    // red now holds M2 per 32-row group.  One writer per (64-row group, column): the wave owning
-    // the even 32-row group; the group sum is mean*cnt.
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        const int g32 = wm * TM + i;
-        const int cl = wn * WN + j * 32 + l31;
-        const int c = col0 + cl;
-        const int rb = (row0 / 64) + (g32 >> 1);
-        if ((g32 & 1) == 0 && lhi == 0 && c < N && (long)rb * 64 < M) {
-          int cnt = M - rb * 64;
-          cnt = cnt > 64 ? 64 : cnt;
-          const float m2 = red[g32 * BN + cl] + red[(g32 + 1) * BN + cl];
-          const float sum = meanS[(g32 >> 1) * BN + cl] * (float)cnt;
-          float2* dst = reinterpret_cast<float2*>(ep.stats) + (long)rb * N + c;
-          *dst = make_float2(sum, m2);
-        }
-      }
   }
-
-  // ---- scale/shift/relu + store
+  // fixed-order reduction of the 4 K-partials: waves 1..3 park theirs in LDS, wave 0 adds 1,2,3
+  float* red = smem;   // [3][16][64]
+  if (wave > 0) {
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    const int c = col0 + wn * WN + j * 32 + l31;
-    if (c >= N) continue;
-    const float sc = ep.scale != nullptr ? ep.scale[c] : 1.f;
-    const float sh = ep.scale != nullptr ? ep.shift[c] : 0.f;
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
+    for (int w = 0; w < 3; ++w)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int row = row0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row < M) {
-          float v = acc[i][j][r];
-          if (ep.scale != nullptr) v = fmaf(v, sc, sh);
-          if (ep.relu) v = fmaxf(v, 0.f);
-          float* y = ep.Y + (long)row * ep.ldy + c;
-          if (ep.accumulate) v += *y;
-          *y = v;
-        }
-      }
+      for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
+    wave_epilogue(acc, row0, col0 + l31, lhi, ep, M, N);
   }
 }
 
@@ -336,6 +468,8 @@ __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial,
   const int r_begin = s * rows_per_split;
   int r_end = r_begin + rows_per_split;
   if (r_end > M) r_end = M;
+  const bool fastY = (Yop.vec != 0) && (n0 + BT <= Nout);
+  const bool fastA = (Aop.vec != 0) && (k0 + BT <= K);
 
   f32x16 acc;
 #pragma unroll
@@ -343,17 +477,50 @@ __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial,
   float dbacc = 0.f;
   const bool do_db = (dbpart != nullptr) && (blockIdx.y == 0);
 
+  float ry[2][4], rx[2][4];
+  auto fetch = [&](int r0) {
+    if (fastY) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + t * 256;
+        Yop.template load4<true>(r0 + i / 16, n0 + 4 * (i % 16), ry[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + t * 256;
+        Yop.template load4<false>(r0 + i / 16, n0 + 4 * (i % 16), ry[t]);
+      }
+    }
+    if (fastA) {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + t * 256;
+        Aop.template load4<true>(r0 + i / 16, k0 + 4 * (i % 16), rx[t]);
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + t * 256;
+        Aop.template load4<false>(r0 + i / 16, k0 + 4 * (i % 16), rx[t]);
+      }
+    }
+  };
+
+  if (r_begin < r_end) fetch(r_begin);
   for (int r0 = r_begin; r0 < r_end; r0 += BR) {
-    for (int i = tid; i < BR * (BT / 4); i += 256) {
-      const int r = i / (BT / 4), q = i % (BT / 4);
-      float v[4];
-      const int rr = r0 + r;
-      if (rr < r_end) Yop.load4(rr, n0 + 4 * q, v); else v[0] = v[1] = v[2] = v[3] = 0.f;
-      *reinterpret_cast<float4*>(&Ys[r][4 * q]) = make_float4(v[0], v[1], v[2], v[3]);
-      if (rr < r_end) Aop.load4(rr, k0 + 4 * q, v); else v[0] = v[1] = v[2] = v[3] = 0.f;
-      *reinterpret_cast<float4*>(&As[r][4 * q]) = make_float4(v[0], v[1], v[2], v[3]);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + t * 256;
+      const int r = i / 16, q = i % 16;
+      const bool ok = (r0 + r) < r_end;          // rows are the reduction dimension: mask them
+      *reinterpret_cast<float4*>(&Ys[r][4 * q]) =
+          make_float4(ok ? ry[t][0] : 0.f, ok ? ry[t][1] : 0.f, ok ? ry[t][2] : 0.f, ok ? ry[t][3] : 0.f);
+      *reinterpret_cast<float4*>(&As[r][4 * q]) =
+          make_float4(ok ? rx[t][0] : 0.f, ok ? rx[t][1] : 0.f, ok ? rx[t][2] : 0.f, ok ? rx[t][3] : 0.f);
     }
     __syncthreads();
+    if (r0 + BR < r_end) fetch(r0 + BR);
 #pragma unroll
     for (int rr = 0; rr < BR; rr += 2) {
       const float a = Ys[rr + lhi][wm * 32 + l31];
@@ -377,8 +544,8 @@ __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial,
 }
 
 // dst[i] (+)= sum_s partial[s][i]   (fixed order)
-static __global__ void k_reduce_splits(const float* partial, long elems, int S, float* dst, long ld_dst,
-                                int cols, int accumulate) {
+static __global__ void k_reduce_splits(const float* partial, long elems, int S, float* dst,
+                                       long ld_dst, int cols, int accumulate) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= elems) return;
   float s = 0.f;
@@ -401,4 +568,29 @@ static inline TnPlan yl_tn_plan(long M, long Nout, long K) {
   if (S < 1) S = 1;
   TnPlan p; p.S = (int)S; p.rows_per_split = (int)rps;
   return p;
+}
+
+// ---- host-side operand constructors --------------------------------------------------------------
+static inline DenseOp yl_dense(const float* p, long ld, long rows, long cols) {
+  DenseOp d;
+  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
+  d.scale = nullptr; d.shift = nullptr; d.floor = -INFINITY;
+  d.vec = (ld % 4 == 0) && yl_aligned16(p);
+  return d;
+}
+static inline DenseProOp yl_dense_pro(const float* p, long ld, long rows, long cols,
+                                      const float* scale, const float* shift, int relu) {
+  DenseProOp d;
+  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
+  d.scale = scale; d.shift = shift; d.floor = relu ? 0.f : -INFINITY;
+  d.vec = (ld % 4 == 0) && yl_aligned16(p) && yl_aligned16(scale) && yl_aligned16(shift);
+  return d;
+}
+static inline EdgeOp yl_edge(const float* x, long ldx, long Cin, const int* src, const int* dst,
+                             const float* attr, long E) {
+  EdgeOp a;
+  a.x = x; a.ldx = ldx; a.Cin = (int)Cin; a.src = src; a.dst = dst; a.attr = attr;
+  a.rows = (int)E; a.cols = (int)(2 * Cin + 4);
+  a.vec = (Cin % 4 == 0) && (ldx % 4 == 0) && yl_aligned16(x) && yl_aligned16(attr);
+  return a;
 }

@@ -10,8 +10,16 @@ template <class AL, class BL, bool NFAST>
 static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, long N, long K,
                           hipStream_t st) {
   if (M <= 0 || N <= 0) return 0;
-  if (ep.stats != nullptr || N <= 64 || M <= 512) {
-    // 64x64 tiles (stats are defined on 64-row groups; also the small-M shapes)
+  const long tiles64 = (long)yl_cdiv(M, 64) * yl_cdiv(N, 64);
+  const long tiles128 = (long)yl_cdiv(M, 128) * yl_cdiv(N, 128);
+  // measured on MI355X (tools/exp/gemm_bench.hip): 4096^3 136.7 TF/s with 128x128x32; for the
+  // K=128 fusion GEMM 64x64x32 wins below ~2k 128-tiles (tail quantisation over 256 CUs).
+  if (K >= 256 && tiles64 < 160) {
+    // few rows, long K: split K across the 4 waves of a 32x32-tile workgroup
+    dim3 grid(yl_cdiv(M, 32), yl_cdiv(N, 32));
+    hipLaunchKernelGGL((k_gemm_nt_sk<AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep, (int)M,
+                       (int)N, (int)K);
+  } else if (N <= 64 || tiles128 < 2048) {
     dim3 grid(yl_cdiv(M, 64), yl_cdiv(N, 64));
     if (K <= 16)
       hipLaunchKernelGGL((k_gemm_nt<64, 64, 16, AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep,
@@ -21,20 +29,11 @@ static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, 
                          (int)M, (int)N, (int)K);
   } else {
     dim3 grid(yl_cdiv(M, 128), yl_cdiv(N, 128));
-    hipLaunchKernelGGL((k_gemm_nt<128, 128, 16, AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep,
+    hipLaunchKernelGGL((k_gemm_nt<128, 128, 32, AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep,
                        (int)M, (int)N, (int)K);
   }
   YL_LAUNCH_CHECK();
   return 0;
-}
-
-static DenseOp make_dense(const float* p, long ld, long rows, long cols, const float* scale,
-                          const float* shift, int relu) {
-  DenseOp d;
-  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
-  d.scale = scale; d.shift = shift; d.relu = relu;
-  d.vec = (ld % 4 == 0) && yl_aligned16(p);
-  return d;
 }
 
 extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t K,
@@ -46,11 +45,16 @@ extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t 
   if (M >= (1LL << 31) || lda < K || ldw < K || ldy < Nout) return YOLAT_E_INVALID;
   if ((a_scale == nullptr) != (a_shift == nullptr)) return YOLAT_E_INVALID;
   if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
-  DenseOp a = make_dense(A, lda, M, K, a_scale, a_shift, a_relu);
-  DenseOp b = make_dense(W, ldw, Nout, K, nullptr, nullptr, 0);
+  if (a_relu && !a_scale) return YOLAT_E_INVALID;
+  DenseOp b = yl_dense(W, ldw, Nout, K);
   Epilogue ep;
   ep.bias = bias; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;
   ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = stats;
+  if (a_scale != nullptr) {
+    DenseProOp a = yl_dense_pro(A, lda, M, K, a_scale, a_shift, a_relu);
+    return launch_gemm_nt<DenseProOp, DenseOp, false>(a, b, ep, M, Nout, K, (hipStream_t)stream);
+  }
+  DenseOp a = yl_dense(A, lda, M, K);
   return launch_gemm_nt<DenseOp, DenseOp, false>(a, b, ep, M, Nout, K, (hipStream_t)stream);
 }
 
@@ -59,9 +63,9 @@ extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64
                                    int64_t ldy, int accumulate, yolat_stream_t stream) {
   if (M < 0 || K <= 0 || Nout <= 0 || (M > 0 && (!A || !Y)) || !Wt) return YOLAT_E_INVALID;
   if (M >= (1LL << 31) || lda < K || ldw < Nout || ldy < Nout) return YOLAT_E_INVALID;
-  DenseOp a = make_dense(A, lda, M, K, nullptr, nullptr, 0);
+  DenseOp a = yl_dense(A, lda, M, K);
   TransOp b;
-  b.p = Wt; b.ld = ldw; b.rows = (int)Nout; b.cols = (int)K;
+  b.p = Wt; b.ld = ldw; b.rows = (int)Nout; b.cols = (int)K; b.vec = 1;
   Epilogue ep;
   ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
   ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = nullptr;
@@ -82,14 +86,21 @@ extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int6
     return YOLAT_E_INVALID;
   if (M >= (1LL << 31) || lddy < Nout || lda < K || lddw < K) return YOLAT_E_INVALID;
   if ((a_scale == nullptr) != (a_shift == nullptr)) return YOLAT_E_INVALID;
+  if (a_relu && !a_scale) return YOLAT_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   TnPlan p = yl_tn_plan(M, Nout, K);
-  DenseOp y = make_dense(dY, lddy, M, Nout, nullptr, nullptr, 0);
-  DenseOp a = make_dense(A, lda, M, K, a_scale, a_shift, a_relu);
+  DenseOp y = yl_dense(dY, lddy, M, Nout);
   float* dbpart = db ? partial + (size_t)p.S * Nout * K : nullptr;
   dim3 grid(yl_cdiv(Nout, 64), yl_cdiv(K, 64), p.S);
-  hipLaunchKernelGGL((k_gemm_tn<DenseOp, DenseOp>), grid, dim3(256), 0, st, y, a, partial, dbpart,
-                     (int)M, (int)Nout, (int)K, p.rows_per_split);
+  if (a_scale != nullptr) {
+    DenseProOp a = yl_dense_pro(A, lda, M, K, a_scale, a_shift, a_relu);
+    hipLaunchKernelGGL((k_gemm_tn<DenseOp, DenseProOp>), grid, dim3(256), 0, st, y, a, partial,
+                       dbpart, (int)M, (int)Nout, (int)K, p.rows_per_split);
+  } else {
+    DenseOp a = yl_dense(A, lda, M, K);
+    hipLaunchKernelGGL((k_gemm_tn<DenseOp, DenseOp>), grid, dim3(256), 0, st, y, a, partial, dbpart,
+                       (int)M, (int)Nout, (int)K, p.rows_per_split);
+  }
   YL_LAUNCH_CHECK();
   const long elems = Nout * K;
   hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 256)), dim3(256), 0, st, partial, elems,
@@ -104,66 +115,92 @@ extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int6
 }
 
 // ------------------------------------------------------------------------------------------------
-// BatchNorm1d statistics (training mode): Chan merge of the 64-row (sum, M2) partials in fp64.
-// block = 64 columns x 16 partitions; partition p owns a contiguous range of row blocks; the 16
-// partition results are merged in order by partition 0  => deterministic.
+// BatchNorm1d statistics (training mode): Chan merge of the 32-row (sum, M2) partials in fp64.
+// Level 1: workgroup g merges a contiguous range of row groups (64 columns x 16 partitions per
+// workgroup) into one (n, mean, M2) triple per column.  Level 2: one workgroup merges the level-1
+// triples in order and emits mean / invstd / scale / shift and the running-stat update.
+// Every merge order is fixed => deterministic.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(1024) k_bn_finalize(const float2* stats, long M, int C,
-                                                      const float* gamma, const float* beta,
-                                                      float* running_mean, float* running_var,
-                                                      float momentum, float eps, float* save_mean,
-                                                      float* save_invstd, float* scale,
-                                                      float* shift) {
+#define BN_L1_MAX 128
+struct Chan { double n, mean, m2; };
+__device__ __forceinline__ void chan_merge(Chan& a, double nb, double mb, double m2b) {
+  if (nb == 0.0) return;
+  const double delta = mb - a.mean;
+  const double tot = a.n + nb;
+  a.mean += delta * (nb / tot);
+  a.m2 += m2b + delta * delta * (a.n * nb / tot);
+  a.n = tot;
+}
+
+__global__ void __launch_bounds__(1024) k_bn_merge_l1(const float2* stats, long M, int C, long nb,
+                                                      long per_wg, double* l1) {
   __shared__ double s_n[16][64], s_mean[16][64], s_m2[16][64];
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
-  const long nb = (M + 63) / 64;
-  const long per = (nb + 15) / 16;
-  const long b0 = part * per;
-  long b1 = b0 + per;
-  if (b1 > nb) b1 = nb;
-  double n = 0.0, mean = 0.0, m2 = 0.0;
+  const long g0 = (long)blockIdx.y * per_wg;
+  long g1 = g0 + per_wg;
+  if (g1 > nb) g1 = nb;
+  const long per = (g1 - g0 + 15) / 16;
+  long b0 = g0 + part * per, b1 = b0 + per;
+  if (b1 > g1) b1 = g1;
+  Chan a; a.n = 0.0; a.mean = 0.0; a.m2 = 0.0;
   if (c < C) {
     for (long b = b0; b < b1; ++b) {
       const float2 t = stats[b * C + c];
-      long cnt = M - b * 64;
-      if (cnt > 64) cnt = 64;
-      const double nb_ = (double)cnt;
-      const double mb = (double)t.x / nb_;
-      const double delta = mb - mean;
-      const double tot = n + nb_;
-      mean += delta * (nb_ / tot);
-      m2 += (double)t.y + delta * delta * (n * nb_ / tot);
-      n = tot;
+      long cnt = M - b * 32;
+      if (cnt > 32) cnt = 32;
+      chan_merge(a, (double)cnt, (double)t.x / (double)cnt, (double)t.y);
     }
   }
-  s_n[part][cl] = n; s_mean[part][cl] = mean; s_m2[part][cl] = m2;
+  s_n[part][cl] = a.n; s_mean[part][cl] = a.mean; s_m2[part][cl] = a.m2;
   __syncthreads();
   if (part == 0 && c < C) {
-    n = s_n[0][cl]; mean = s_mean[0][cl]; m2 = s_m2[0][cl];
-    for (int p = 1; p < 16; ++p) {
-      const double nb_ = s_n[p][cl];
-      if (nb_ == 0.0) continue;
-      const double delta = s_mean[p][cl] - mean;
-      const double tot = n + nb_;
-      mean += delta * (nb_ / tot);
-      m2 += s_m2[p][cl] + delta * delta * (n * nb_ / tot);
-      n = tot;
-    }
-    const double var_b = n > 0.0 ? m2 / n : 0.0;                 // biased: used to normalise
-    const double var_u = n > 1.0 ? m2 / (n - 1.0) : var_b;       // unbiased: running update
-    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
-    const float meanf = (float)mean;
-    save_mean[c] = meanf;
-    save_invstd[c] = invstd;
-    const float sc = gamma[c] * invstd;
-    scale[c] = sc;
-    shift[c] = beta[c] - meanf * sc;
-    if (running_mean != nullptr) {
-      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
-      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
-    }
+    for (int p = 1; p < 16; ++p) chan_merge(a, s_n[p][cl], s_mean[p][cl], s_m2[p][cl]);
+    double* o = l1 + ((long)blockIdx.y * C + c) * 3;
+    o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
   }
+}
+
+__global__ void k_bn_finalize_l2(const double* l1, int G, int C, const float* gamma,
+                                 const float* beta, float* running_mean, float* running_var,
+                                 float momentum, float eps, float* save_mean, float* save_invstd,
+                                 float* scale, float* shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  Chan a; a.n = 0.0; a.mean = 0.0; a.m2 = 0.0;
+  for (int g = 0; g < G; ++g) {
+    const double* o = l1 + ((long)g * C + c) * 3;
+    chan_merge(a, o[0], o[1], o[2]);
+  }
+  const double var_b = a.n > 0.0 ? a.m2 / a.n : 0.0;                 // biased: used to normalise
+  const double var_u = a.n > 1.0 ? a.m2 / (a.n - 1.0) : var_b;       // unbiased: running update
+  const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+  const float meanf = (float)a.mean;
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  if (running_mean != nullptr) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+  }
+}
+
+static inline void bn_l1_plan(long M, long* nb, long* G, long* per_wg) {
+  *nb = (M + 31) / 32;
+  long g = (*nb + 255) / 256;          // >= 256 row groups (8192 rows) per level-1 workgroup
+  if (g > BN_L1_MAX) g = BN_L1_MAX;
+  if (g < 1) g = 1;
+  *per_wg = (*nb + g - 1) / g;
+  *G = (*nb + *per_wg - 1) / *per_wg;
+}
+
+extern "C" size_t yolat_bn_stats_elems(int64_t M, int64_t C) {
+  // fp32 elements: float2 partials per 32-row group + (8-byte aligned) level-1 triples in fp64
+  long nb, G, per;
+  bn_l1_plan(M, &nb, &G, &per);
+  return (size_t)(2 * nb * C + 2 + 2 * 3 * BN_L1_MAX * C);
 }
 
 extern "C" int yolat_bn_finalize(const float* stats, int64_t M, int64_t C, const float* gamma,
@@ -173,9 +210,18 @@ extern "C" int yolat_bn_finalize(const float* stats, int64_t M, int64_t C, const
   if (!stats || M <= 0 || C <= 0 || !gamma || !beta || !save_mean || !save_invstd || !scale || !shift)
     return YOLAT_E_INVALID;
   if ((running_mean == nullptr) != (running_var == nullptr)) return YOLAT_E_INVALID;
-  hipLaunchKernelGGL(k_bn_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, (hipStream_t)stream,
-                     reinterpret_cast<const float2*>(stats), (long)M, (int)C, gamma, beta,
-                     running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+  long nb, G, per;
+  bn_l1_plan(M, &nb, &G, &per);
+  size_t off = (size_t)(2 * nb * C);
+  off = (off + 1) & ~(size_t)1;                       // 8-byte alignment for the fp64 triples
+  double* l1 = reinterpret_cast<double*>(const_cast<float*>(stats) + off);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_bn_merge_l1, dim3(yl_cdiv(C, 64), (unsigned)G), dim3(1024), 0, st,
+                     reinterpret_cast<const float2*>(stats), (long)M, (int)C, nb, per, l1);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_finalize_l2, dim3(yl_cdiv(C, 64)), dim3(64), 0, st, l1, (int)G, (int)C,
+                     gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
+                     scale, shift);
   YL_LAUNCH_CHECK();
   return 0;
 }

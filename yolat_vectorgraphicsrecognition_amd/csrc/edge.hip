@@ -3,22 +3,6 @@
 // destination-sorted (CSR) order, so aggregation reads contiguous rows and needs no atomics.
 #include "common.hpp"
 
-static EdgeOp make_edge(const float* x, long ldx, long Cin, const int* src, const int* dst,
-                        const float* attr, long E) {
-  EdgeOp a;
-  a.x = x; a.ldx = ldx; a.Cin = (int)Cin; a.src = src; a.dst = dst; a.attr = attr; a.E = (int)E;
-  a.vec = (Cin % 4 == 0) && (ldx % 4 == 0) && yl_aligned16(x) && yl_aligned16(attr);
-  return a;
-}
-
-static DenseOp make_dense_e(const float* p, long ld, long rows, long cols) {
-  DenseOp d;
-  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
-  d.scale = nullptr; d.shift = nullptr; d.relu = 0;
-  d.vec = (ld % 4 == 0) && yl_aligned16(p);
-  return d;
-}
-
 extern "C" int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64_t Cin,
                                    const int32_t* src_csr, const int32_t* dst_csr,
                                    const float* attr_csr, int64_t E, const float* W1, int64_t ldw,
@@ -31,8 +15,8 @@ extern "C" int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64
   const long K = 2 * Cin + 4;
   if (ldw < K || ldh < C || ldx < Cin) return YOLAT_E_INVALID;
   if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
-  EdgeOp a = make_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
-  DenseOp b = make_dense_e(W1, ldw, C, K);
+  EdgeOp a = yl_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
+  DenseOp b = yl_dense(W1, ldw, C, K);
   Epilogue ep;
   ep.bias = b1; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;
   ep.Y = H1; ep.ldy = ldh; ep.accumulate = 0; ep.stats = stats;
@@ -59,8 +43,8 @@ extern "C" int yolat_edge_lin1_bwd_w(const float* dH1, int64_t lddh, int64_t E, 
   if (lddw < K || lddh < C || E >= (1LL << 31)) return YOLAT_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
   TnPlan p = yl_tn_plan(E, C, K);
-  DenseOp y = make_dense_e(dH1, lddh, E, C);
-  EdgeOp a = make_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
+  DenseOp y = yl_dense(dH1, lddh, E, C);
+  EdgeOp a = yl_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
   float* dbpart = db1 ? partial + (size_t)p.S * C * K : nullptr;
   dim3 grid(yl_cdiv(C, 64), yl_cdiv(K, 64), p.S);
   hipLaunchKernelGGL((k_gemm_tn<DenseOp, EdgeOp>), grid, dim3(256), 0, st, y, a, partial, dbpart,
@@ -85,9 +69,9 @@ extern "C" int yolat_edge_lin1_bwd_x(const float* dH1, int64_t lddh, int64_t E, 
   if (E == 0) return 0;
   if (!dH1 || !dG || lddh < C || lddg < 2 * Cin || ldw < 2 * Cin + 4 || E >= (1LL << 31))
     return YOLAT_E_INVALID;
-  DenseOp a = make_dense_e(dH1, lddh, E, C);
+  DenseOp a = yl_dense(dH1, lddh, E, C);
   EdgeWcOp b;
-  b.W1 = W1; b.ldw = ldw; b.Cin = (int)Cin; b.C = (int)C;
+  b.W1 = W1; b.ldw = ldw; b.Cin = (int)Cin; b.C = (int)C; b.vec = 1;
   Epilogue ep;
   ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
   ep.Y = dG; ep.ldy = lddg; ep.accumulate = 0; ep.stats = nullptr;

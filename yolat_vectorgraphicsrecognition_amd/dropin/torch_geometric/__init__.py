@@ -1,0 +1,2 @@
+"""Minimal torch_geometric surface used by the YOLaT model file and collate (Data only)."""
+from . import data  # noqa: F401

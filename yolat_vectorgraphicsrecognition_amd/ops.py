@@ -8,7 +8,7 @@ import torch
 
 from ._lib import lib, check
 
-STATS_ROWS = 64
+STATS_ROWS = 32
 STATUS_EDGE_RANGE, STATUS_SEG_UNSORTED, STATUS_SEG_RANGE = 1, 2, 4
 
 
@@ -133,7 +133,7 @@ def build_graph(edge, e_attr, bbox_idx, num_nodes, num_proposals):
 # ---------------------------------------------------------------------------------------------
 
 def stats_buffer(M, C, device):
-    return torch.empty(((M + STATS_ROWS - 1) // STATS_ROWS) * C * 2 + 2, dtype=torch.float32, device=device)
+    return torch.empty(int(lib.yolat_bn_stats_elems(M, C)), dtype=torch.float32, device=device)
 
 
 def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False,

@@ -74,6 +74,13 @@ class FlatAdam(object):
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
 
 
+def shard_graph_ids(num_graphs, rank, world_size):
+    """Round-robin partition of dataset items (graph ids) over ranks — DistributedSampler-style.
+    Every edge joins two nodes of the same image (Datasets/graph_dict3.py:594-600), so a shard never
+    needs data from another rank."""
+    return list(range(rank, num_graphs, world_size))
+
+
 def broadcast_parameters(flat, model, src=0):
     """Make every replica start from rank ``src``'s parameters and BatchNorm buffers."""
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
