@@ -90,6 +90,8 @@ class OpTimer(object):
     def __enter__(self):
         for name in ("linear_fwd", "edge_lin1_fwd", "csr_mean_fwd", "segment_max_fwd", "segment_mean_fwd",
                      "build_graph", "scale_shift_relu", "bn_eval_coeffs"):
+            if not hasattr(self.ops, name):
+                continue
             fn = getattr(self.ops, name)
             self.orig[name] = fn
 
@@ -117,6 +119,29 @@ class OpTimer(object):
             a[1] += 1
         return {k: {"ms_total": v[0], "calls": v[1], "ms_avg": v[0] / v[1], "flops": v[2], "bytes": v[3]}
                 for k, v in agg.items()}
+
+
+def plan_profile(step, n):
+    """Per-stage HIP-event times of the C-side eval plan (yolat_profile_*): the events are recorded on
+    the launch stream around every stage of yolat_forward_eval while `step` runs n times."""
+    import ctypes
+    from yolat_vectorgraphicsrecognition_amd._lib import lib
+    lib.yolat_profile_reset()
+    lib.yolat_profile_enable(1)
+    for _ in range(n):
+        step()
+    torch.cuda.synchronize()
+    lib.yolat_profile_enable(0)
+    out = {}
+    name = ctypes.create_string_buffer(128)
+    ms, calls = ctypes.c_float(), ctypes.c_int()
+    fl, by = ctypes.c_double(), ctypes.c_double()
+    for i in range(lib.yolat_profile_count()):
+        lib.yolat_profile_get(i, name, 128, ctypes.byref(ms), ctypes.byref(calls), ctypes.byref(fl), ctypes.byref(by))
+        out[name.value.decode()] = {"ms_total": ms.value, "calls": calls.value, "ms_avg": ms.value / max(calls.value, 1),
+                                    "flops": fl.value, "bytes": by.value}
+    lib.yolat_profile_reset()
+    return out
 
 
 def roofline_entry(summary):
@@ -244,10 +269,14 @@ def main():
     roof = None
     op_table = None
     if rank == 0 and not args.no_roofline:
-        with OpTimer(yv.ops) as timer:
-            for _ in range(min(args.steps, 50)):
-                step()
-            op_table = timer.summary()
+        nprof = min(args.steps, 50)
+        if args.mode == "fwd":
+            op_table = plan_profile(step, nprof)
+        else:
+            with OpTimer(yv.ops) as timer:
+                for _ in range(nprof):
+                    step()
+                op_table = timer.summary()
         roof = roofline_entry(op_table)
         roof["note"] = ("dominant op by HIP-event time inside this run; algorithmic flops/bytes per launch in "
                         "DESIGN.md; traffic: PMC pass not collected in-process")
@@ -287,6 +316,8 @@ def main():
         if op_table is not None:
             top = sorted(op_table.items(), key=lambda kv: -kv[1]["ms_total"])[:6]
             line["op_breakdown_us"] = {k: round(v["ms_total"] / max(min(args.steps, 50), 1) * 1e3, 2) for k, v in top}
+            line["gpu_us_per_step_sum_of_stages"] = round(sum(v["ms_total"] for v in op_table.values()) /
+                                                          max(min(args.steps, 50), 1) * 1e3, 1)
         print(json.dumps(line))
     if world > 1:
         torch.distributed.destroy_process_group()

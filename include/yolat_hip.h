@@ -237,6 +237,57 @@ int yolat_adam_step(float* param, const float* grad, float* exp_avg, float* exp_
                     float lr, float beta1, float beta2, float eps, float weight_decay,
                     int64_t step, float grad_scale, yolat_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Whole-model eval forward: SparseCADGCN.forward in eval mode
+ * (architecture3cc_rpn_gp_iter2.py:44-71,106-137) as ONE host call that enqueues the complete kernel
+ * sequence (graph pre-processing included) on `stream`.  BatchNorm1d is folded: every (s*, t*) pair is
+ * the per-channel scale/shift of yolat_bn_eval_coeffs.  All pointers are device pointers; the structs
+ * themselves are host memory.
+ * ------------------------------------------------------------------------------------------ */
+#define YOLAT_MAX_LAYERS 8
+
+typedef struct {
+  int64_t Cin;                                /* input channels of this layer                    */
+  const float *W1, *b1, *s1, *t1;             /* gconv.nn.0 [C,2Cin+4], gconv.nn.1 folded        */
+  const float *W2, *b2, *s2, *t2;             /* gconv.nn.3 [C,C],     gconv.nn.4 folded        */
+  const float *Wr, *br;                       /* gconv.lin_r [C,Cin]                             */
+  const float *Wn, *bn, *sn, *tn;             /* gconv.mlp_node.0 [C,Cin], mlp_node.1 folded     */
+} yolat_conv_eval;
+
+typedef struct {
+  int32_t n_blocks, n_blocks_out, n_classes, reserved;
+  int64_t C;                                  /* n_filters (64)                                  */
+  int64_t F;                                  /* fusion width (1024)                             */
+  int64_t H1, H2;                             /* classifier hidden widths (512, 256)             */
+  yolat_conv_eval conv[YOLAT_MAX_LAYERS];     /* head, then backbone[i].body                     */
+  const float *Wf, *bf, *sf, *tf;             /* cls_net.fusion_block                            */
+  const float *Wfs, *bfs, *sfs, *tfs;         /* cls_net.fusion_block_super                      */
+  const float *Wc1, *bc1, *sc1, *tc1;         /* prediction_cls.0                                */
+  const float *Wc2, *bc2, *sc2, *tc2;         /* prediction_cls.1                                */
+  const float *Wc3, *bc3;                     /* prediction_cls.2 (bare Linear)                  */
+} yolat_model_eval;
+
+/* workspace (bytes) needed by yolat_forward_eval for a batch of N nodes / E edges / P proposals */
+size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, int64_t N, int64_t E, int64_t P);
+
+/* x [N,Cin0] fp32 (ld = ldx); edge int64 with element strides like yolat_coo_to_csr; e_attr [E,4];
+ * bbox_idx int64 [N] non-decreasing; logits [P,n_classes] (ld = ld_logits).  `status` as above.   */
+int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx, const int64_t* edge,
+                       int64_t stride_e, int64_t stride_c, const float* e_attr,
+                       const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, float* logits,
+                       int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
+                       yolat_stream_t stream);
+
+/* Stage profiler of yolat_forward_eval: when enabled, a hipEvent pair is recorded on `stream` around
+ * every stage (each stage = the launch(es) of one kernel family); totals accumulate across calls until
+ * reset.  yolat_profile_get must be called after the stream has been synchronised.  `flops` / `bytes`
+ * are the ALGORITHMIC work of one call of the stage.                                */
+int yolat_profile_enable(int on);
+int yolat_profile_reset(void);
+int yolat_profile_count(void);
+int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms, int* calls,
+                      double* flops, double* bytes);
+
 #ifdef __cplusplus
 }
 #endif

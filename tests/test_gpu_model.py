@@ -80,10 +80,13 @@ def test_eval_forward_matches_reference_golden(kind, golden_dir):
     assert pred.shape == (arrs["bbox"].shape[0], optkw["n_classes"])
     np.testing.assert_array_equal(bbox.cpu().numpy(), arrs["bbox"])         # pred_bbox is a passthrough
     _cmp("eval_logits", pred, gu.unpack("eval_logits", z), RTOL_FWD)
-    # module-by-module path gives the same answer as the fused schedule
+    # module-by-module path and the Python-scheduled sequence give the same answer as the eval plan
     with torch.no_grad():
         pred2, _ = model.forward_modular(gu.to_data(arrs, yv.Data), None)
+        pred3, _ = model.forward_scheduled(gu.to_data(arrs, yv.Data), None)
     _cmp("eval_logits(modular)", pred2, gu.unpack("eval_logits", z), RTOL_FWD)
+    _cmp("eval_logits(scheduled)", pred3, gu.unpack("eval_logits", z), RTOL_FWD)
+    model._yolat_plan.check_status()
 
 
 @pytest.mark.parametrize("kind", ["tiny", "small", "medium", "deep"])
@@ -230,4 +233,8 @@ def test_bad_inputs_raise():
     with torch.no_grad():
         model(data, None)
     with pytest.raises(IndexError):
-        data._yolat_stage[1][1].check_status()
+        model._yolat_plan.check_status()
+    model.train()
+    model(data, None)
+    with pytest.raises(IndexError):
+        data._yolat_stage[1]["g"].check_status()

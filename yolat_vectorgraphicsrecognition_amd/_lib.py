@@ -16,6 +16,24 @@ c_int = ctypes.c_int
 c_f = ctypes.c_float
 c_sz = ctypes.c_size_t
 
+YOLAT_MAX_LAYERS = 8
+
+
+class ConvEval(ctypes.Structure):
+    """yolat_conv_eval (include/yolat_hip.h)"""
+    _fields_ = [("Cin", c_i64)] + [(n, c_p) for n in
+                                   ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn")]
+
+
+class ModelEval(ctypes.Structure):
+    """yolat_model_eval (include/yolat_hip.h)"""
+    _fields_ = ([("n_blocks", ctypes.c_int32), ("n_blocks_out", ctypes.c_int32), ("n_classes", ctypes.c_int32),
+                 ("reserved", ctypes.c_int32), ("C", c_i64), ("F", c_i64), ("H1", c_i64), ("H2", c_i64),
+                 ("conv", ConvEval * YOLAT_MAX_LAYERS)] +
+                [(n, c_p) for n in ("Wf", "bf", "sf", "tf", "Wfs", "bfs", "sfs", "tfs", "Wc1", "bc1", "sc1", "tc1",
+                                    "Wc2", "bc2", "sc2", "tc2", "Wc3", "bc3")])
+
+
 # name -> (restype, argtypes); order mirrors include/yolat_hip.h
 SIGNATURES = {
     "yolat_abi_version": (c_int, []),
@@ -54,6 +72,14 @@ SIGNATURES = {
     "yolat_segment_max_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_softmax_ce": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
     "yolat_adam_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p]),
+    "yolat_profile_enable": (c_int, [c_int]),
+    "yolat_profile_reset": (c_int, []),
+    "yolat_profile_count": (c_int, []),
+    "yolat_profile_get": (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_f), ctypes.POINTER(c_int),
+                                  ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "yolat_forward_eval_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEval), c_i64, c_i64, c_i64]),
+    "yolat_forward_eval": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64,
+                                   c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
 }
 
 

@@ -117,42 +117,61 @@ class SparseCADGCN(nn.Module):
 
     # -- device staging ---------------------------------------------------------------------
     @staticmethod
-    def _stage(data):
-        """H2D of the tensors forward reads (arch:107-115) + device-side graph structure, cached on
-        the batch object so a second forward on the same batch (predict, epochs over a cached
-        batch) re-uses it."""
+    def _stage(data, need_graph=True):
+        """H2D of the tensors forward reads (arch:107-115), cached on the batch object so a second
+        forward on the same batch (predict, epochs over a cached batch) re-uses them; the device-side
+        CSR / segment structure is added lazily for the training path (the eval plan builds its own)."""
         cache = getattr(data, "_yolat_stage", None)
         key = (data.x.data_ptr(), data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
                data.bbox_idx._version, data.e_attr.data_ptr(), tuple(data.x.shape), tuple(data.edge.shape))
-        if cache is not None and cache[0] == key:
-            return cache[1]
-        x = data.x.cuda(non_blocking=True)
-        edge = data.edge.cuda(non_blocking=True)
-        e_attr = data.e_attr.cuda(non_blocking=True)
-        bbox_idx = data.bbox_idx.cuda(non_blocking=True)
-        pred_bbox = data.bbox.cuda(non_blocking=True)
-        if x.dtype != torch.float32:
-            x = x.float()
-        g = ops.build_graph(edge, e_attr, bbox_idx, x.shape[0], pred_bbox.shape[0])
-        staged = (x, g, pred_bbox)
-        try:
-            data._yolat_stage = (key, staged)
-        except AttributeError:
-            pass
-        return staged
+        if cache is None or cache[0] != key:
+            x = data.x.cuda(non_blocking=True)
+            if x.dtype != torch.float32:
+                x = x.float()
+            st = {"x": x, "edge": data.edge.cuda(non_blocking=True), "e_attr": data.e_attr.cuda(non_blocking=True),
+                  "bbox_idx": data.bbox_idx.cuda(non_blocking=True), "bbox": data.bbox.cuda(non_blocking=True),
+                  "g": None}
+            cache = (key, st)
+            try:
+                data._yolat_stage = cache
+            except AttributeError:
+                pass
+        st = cache[1]
+        if need_graph and st["g"] is None:
+            st["g"] = ops.build_graph(st["edge"], st["e_attr"], st["bbox_idx"], st["x"].shape[0],
+                                      st["bbox"].shape[0])
+        return st
 
     def forward(self, data, slices=None):
-        x, g, pred_bbox = self._stage(data)
-        pred_cls = _ModelFn.apply(self, g, x, *list(self.parameters()))
+        if not self.training and not torch.is_grad_enabled():
+            # eval fast path: one call into libyolat_hip.so (plan.EvalPlan / yolat_forward_eval)
+            st = self._stage(data, need_graph=False)
+            plan = getattr(self, "_yolat_plan", None)
+            if plan is None:
+                from .plan import EvalPlan
+                plan = self._yolat_plan = EvalPlan(self)
+            pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])
+            st["plan_status"] = plan
+        else:
+            st = self._stage(data)
+            pred_cls = _ModelFn.apply(self, st["g"], st["x"], *list(self.parameters()))
         if self.classifier != "softmax":
             pred_cls = torch.sigmoid(pred_cls)
-        return pred_cls, pred_bbox
+        return pred_cls, st["bbox"]
+
+    def forward_scheduled(self, data, slices=None):
+        """The Python-scheduled kernel sequence (engine.model_fwd) regardless of mode — the training
+        path; in eval mode it must agree with the eval plan."""
+        st = self._stage(data)
+        pred_cls = _ModelFn.apply(self, st["g"], st["x"], *list(self.parameters()))
+        if self.classifier != "softmax":
+            pred_cls = torch.sigmoid(pred_cls)
+        return pred_cls, st["bbox"]
 
     def forward_modular(self, data, slices=None):
         """Same result through the module-by-module path (Backbone.forward + scatter + MLPs)."""
-        x, g, pred_bbox = self._stage(data)
-        bbox_idx = data.bbox_idx.cuda()
-        e_attr = data.e_attr.cuda()
+        st = self._stage(data)
+        x, g, pred_bbox, bbox_idx, e_attr = st["x"], st["g"], st["bbox"], st["bbox_idx"], st["e_attr"]
         out_feat, out_super = self.cls_net(x, [g], [None], [e_attr], bbox_idx)
         out_feat = scatter(out_feat, bbox_idx, dim=0, reduce="max")
         pred_cls = self.prediction_cls(torch.cat([out_feat, out_super], dim=1))

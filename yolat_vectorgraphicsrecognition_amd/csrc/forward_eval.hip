@@ -1,0 +1,205 @@
+// forward_eval.hip — SparseCADGCN.forward (eval mode) as one host call: the complete kernel sequence
+// of cad_recognition/architecture3cc_rpn_gp_iter2.py:44-71,106-137 is enqueued from C++ with no
+// Python between launches (the cfg-2 forward is ~100-300 us of GPU time, i.e. launch-latency
+// territory: the host side has to be a tight loop of hipLaunchKernel calls).
+#include "common.hpp"
+
+namespace {
+struct Carver {
+  char* base; size_t off, cap;
+  template <class T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+
+struct Plan {
+  int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
+  float* H1; float* H2; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
+  float* feats; float* fsup; float* fus; float* Z; float* c1; float* c2;
+  size_t bytes;
+};
+
+Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
+  Carver c; c.base = reinterpret_cast<char*>(ws); c.off = 0; c.cap = 0;
+  Plan p;
+  const long C = m->C, F = m->F, D = C * m->n_blocks_out, Ee = E > 0 ? E : 1;
+  p.row_ptr = c.take<int>(N + 1); p.perm = c.take<int>(Ee); p.src = c.take<int>(Ee); p.dst = c.take<int>(Ee);
+  p.attr = c.take<float>(Ee * 4); p.work = c.take<int>(yolat_csr_work_elems(N, E));
+  p.seg_ptr = c.take<int>(P + 1); p.node_seg = c.take<int>(N);
+  p.H1 = c.take<float>(Ee * C); p.H2 = c.take<float>(Ee * C);
+  const int lo = m->n_blocks - m->n_blocks_out;
+  for (int l = 0; l < m->n_blocks; ++l) {
+    p.f_tmp[l] = (l < lo) ? c.take<float>(N * C) : nullptr;
+    p.s_tmp[l] = (l < lo) ? c.take<float>(N * C) : nullptr;
+  }
+  p.feats = c.take<float>(N * D); p.fsup = c.take<float>(N * D); p.fus = c.take<float>(N * F);
+  p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
+  p.bytes = c.off + 256;
+  return p;
+}
+}  // namespace
+
+#define YL_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+
+// ---- stage profiler (hipEvent pairs on the launch stream) ------------------------------------------
+#include <string>
+#include <vector>
+namespace {
+struct StageRec { std::string name; double flops, bytes; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
+std::vector<StageRec> g_stages;
+std::vector<hipEvent_t> g_pool;
+bool g_profile = false;
+
+hipEvent_t new_event() {
+  if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
+  hipEvent_t e; (void)hipEventCreate(&e); return e;
+}
+StageRec& stage_rec(const char* name, double flops, double bytes) {
+  for (auto& s : g_stages) if (s.name == name) return s;
+  g_stages.push_back(StageRec{name, flops, bytes, {}});
+  return g_stages.back();
+}
+}  // namespace
+
+#define YL_STAGE(name, flops, bytes, call)                                  \
+  do {                                                                      \
+    if (g_profile) {                                                        \
+      StageRec& sr__ = stage_rec(name, (double)(flops), (double)(bytes));   \
+      hipEvent_t a__ = new_event(), b__ = new_event();                      \
+      (void)hipEventRecord(a__, (hipStream_t)stream);                             \
+      int rc__ = (call);                                                    \
+      (void)hipEventRecord(b__, (hipStream_t)stream);                             \
+      sr__.ev.push_back({a__, b__});                                        \
+      if (rc__ != 0) return rc__;                                           \
+    } else {                                                                \
+      YL_TRY(call);                                                         \
+    }                                                                       \
+  } while (0)
+
+extern "C" int yolat_profile_enable(int on) { g_profile = on != 0; return 0; }
+extern "C" int yolat_profile_reset(void) {
+  for (auto& s : g_stages) for (auto& e : s.ev) { g_pool.push_back(e.first); g_pool.push_back(e.second); }
+  g_stages.clear();
+  return 0;
+}
+extern "C" int yolat_profile_count(void) { return (int)g_stages.size(); }
+extern "C" int yolat_profile_get(int index, char* name, int cap, float* total_ms, int* calls, double* flops,
+                                 double* bytes) {
+  if (index < 0 || index >= (int)g_stages.size() || !name || cap <= 0) return YOLAT_E_INVALID;
+  StageRec& s = g_stages[index];
+  snprintf(name, cap, "%s", s.name.c_str());
+  float tot = 0.f;
+  for (auto& e : s.ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) tot += ms; }
+  if (total_ms) *total_ms = tot;
+  if (calls) *calls = (int)s.ev.size();
+  if (flops) *flops = s.flops;
+  if (bytes) *bytes = s.bytes;
+  return 0;
+}
+
+extern "C" size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, int64_t N, int64_t E,
+                                                     int64_t P) {
+  if (!m || N <= 0 || E < 0 || P <= 0) return 0;
+  return carve(m, N, E, P, nullptr).bytes;
+}
+
+extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx,
+                                  const int64_t* edge, int64_t stride_e, int64_t stride_c,
+                                  const float* e_attr, const int64_t* bbox_idx, int64_t N, int64_t E,
+                                  int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                  size_t workspace_bytes, int32_t* status, yolat_stream_t stream) {
+  if (!m || !x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0)
+    return YOLAT_E_INVALID;
+  if (m->n_blocks < 1 || m->n_blocks > YOLAT_MAX_LAYERS || m->n_blocks_out < 1 ||
+      m->n_blocks_out > m->n_blocks)
+    return YOLAT_E_INVALID;
+  Plan p = carve(m, N, E, P, workspace);
+  if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
+  const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
+  const int lo = m->n_blocks - m->n_blocks_out;
+
+  // ---- graph structure (CSR by destination, e_attr in CSR order, proposal segments)
+  char nm[96];
+  YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N, [&]() -> int {
+    YL_TRY(yolat_coo_to_csr(edge, stride_e, stride_c, E, N, p.row_ptr, p.perm, p.src, p.dst, p.work, status,
+                            stream));
+    if (E > 0) YL_TRY(yolat_gather_rows(e_attr, 4, p.perm, E, 4, p.attr, 4, stream));
+    YL_TRY(yolat_segment_ptr(bbox_idx, N, P, p.seg_ptr, p.node_seg, status, stream));
+    return 0;
+  }());
+
+  // ---- conv layers (torch_vertex.py:319-337), outputs written into their concat slots
+  const float* f_in = x; long ld_f = ldx;
+  const float* s_in = x; long ld_s = ldx;
+  for (int l = 0; l < m->n_blocks; ++l) {
+    const yolat_conv_eval& cv = m->conv[l];
+    const int slot = l - lo;
+    float* f_out = slot >= 0 ? p.feats + slot * C : p.f_tmp[l];
+    float* s_out = slot >= 0 ? p.fsup + slot * C : p.s_tmp[l];
+    const long ld_out = slot >= 0 ? D : C;
+    const double K1 = 2.0 * cv.Cin + 4;
+    // out = lin_r(x)
+    snprintf(nm, sizeof nm, "lin_r[N x %ld -> %ld]", (long)cv.Cin, C);
+    YL_STAGE(nm, 2.0 * N * cv.Cin * C, 4.0 * (N * cv.Cin + N * C + C * cv.Cin),
+             yolat_linear_fwd(f_in, ld_f, N, cv.Cin, nullptr, nullptr, 0, cv.Wr, cv.Cin, cv.br, C, nullptr,
+                              nullptr, 0, f_out, ld_out, 0, nullptr, stream));
+    if (E > 0) {
+      snprintf(nm, sizeof nm, "edge_lin1[E x %ld -> %ld, gathered]", (long)K1, C);
+      YL_STAGE(nm, 2.0 * E * K1 * C, E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
+               yolat_edge_lin1_fwd(f_in, ld_f, N, cv.Cin, p.src, p.dst, p.attr, E, cv.W1, 2 * cv.Cin + 4,
+                                   cv.b1, C, cv.s1, cv.t1, 1, p.H1, C, nullptr, stream));
+      snprintf(nm, sizeof nm, "edge_lin2[E x %ld -> %ld]", C, C);
+      YL_STAGE(nm, 2.0 * E * C * C, 8.0 * E * C,
+               yolat_linear_fwd(p.H1, C, E, C, nullptr, nullptr, 0, cv.W2, C, cv.b2, C, cv.s2, cv.t2, 1, p.H2,
+                                C, 0, nullptr, stream));
+      YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
+               yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
+    }
+    // node branch
+    snprintf(nm, sizeof nm, "mlp_node[N x %ld -> %ld]", (long)cv.Cin, C);
+    YL_STAGE(nm, 2.0 * N * cv.Cin * C, 4.0 * (N * cv.Cin + N * C + C * cv.Cin),
+             yolat_linear_fwd(s_in, ld_s, N, cv.Cin, nullptr, nullptr, 0, cv.Wn, cv.Cin, cv.bn, C, cv.sn, cv.tn, 1,
+                              s_out, ld_out, 0, nullptr, stream));
+    f_in = f_out; ld_f = ld_out; s_in = s_out; ld_s = ld_out;
+  }
+
+  // ---- fusion over nodes + per-proposal max (arch:61-63,122)
+  snprintf(nm, sizeof nm, "fusion_gemm[N x %ld -> %ld]", D, F);
+  YL_STAGE(nm, 2.0 * N * D * F, 4.0 * (N * D + D * F + N * F),
+           yolat_linear_fwd(p.feats, D, N, D, nullptr, nullptr, 0, m->Wf, D, m->bf, F, m->sf, m->tf, 1, p.fus, F,
+                            0, nullptr, stream));
+  YL_STAGE("segment_max[N x F -> P x F]", 1.0 * N * F, 4.0 * (N * F + P * F),
+           yolat_segment_max_fwd(p.fus, F, F, nullptr, nullptr, 0, p.seg_ptr, P, N, p.Z, ZW, nullptr, stream));
+  YL_STAGE("segment_max[N x D -> P x D]", 1.0 * N * D, 4.0 * (N * D + P * D),
+           yolat_segment_max_fwd(p.feats, D, D, nullptr, nullptr, 0, p.seg_ptr, P, N, p.Z + F, ZW, nullptr,
+                                 stream));
+  // ---- super branch: per-proposal mean + fusion_block_super (arch:65-69)
+  float* sup = p.Z + 2 * F + D;
+  YL_STAGE("segment_mean[N x D -> P x D]", 1.0 * N * D, 4.0 * (N * D + P * D),
+           yolat_segment_mean_fwd(p.fsup, D, D, nullptr, nullptr, 0, p.seg_ptr, P, sup, ZW, stream));
+  snprintf(nm, sizeof nm, "fusion_super_gemm[P x %ld -> %ld]", D, F);
+  YL_STAGE(nm, 2.0 * P * D * F, 4.0 * (P * D + D * F + P * F),
+           yolat_linear_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->Wfs, D, m->bfs, F, m->sfs, m->tfs, 1,
+                            p.Z + F + D, ZW, 0, nullptr, stream));
+  // ---- classifier (arch:91-93,127-128)
+  snprintf(nm, sizeof nm, "cls1[P x %ld -> %ld]", ZW, (long)m->H1);
+  YL_STAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + ZW * m->H1 + P * m->H1),
+           yolat_linear_fwd(p.Z, ZW, P, ZW, nullptr, nullptr, 0, m->Wc1, ZW, m->bc1, m->H1, m->sc1, m->tc1, 1,
+                            p.c1, m->H1, 0, nullptr, stream));
+  snprintf(nm, sizeof nm, "cls2[P x %ld -> %ld]", (long)m->H1, (long)m->H2);
+  YL_STAGE(nm, 2.0 * P * m->H1 * m->H2, 4.0 * (P * m->H1 + m->H1 * m->H2 + P * m->H2),
+           yolat_linear_fwd(p.c1, m->H1, P, m->H1, nullptr, nullptr, 0, m->Wc2, m->H1, m->bc2, m->H2, m->sc2,
+                            m->tc2, 1, p.c2, m->H2, 0, nullptr, stream));
+  snprintf(nm, sizeof nm, "cls3[P x %ld -> %d]", (long)m->H2, (int)m->n_classes);
+  YL_STAGE(nm, 2.0 * P * m->H2 * m->n_classes, 4.0 * (P * m->H2 + m->H2 * m->n_classes + P * m->n_classes),
+           yolat_linear_fwd(p.c2, m->H2, P, m->H2, nullptr, nullptr, 0, m->Wc3, m->H2, m->bc3, m->n_classes,
+                            nullptr, nullptr, 0, logits, ld_logits, 0, nullptr, stream));
+  return 0;
+}

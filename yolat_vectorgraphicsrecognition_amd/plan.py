@@ -1,0 +1,110 @@
+"""Eval-mode fast path: SparseCADGCN.forward as ONE call into libyolat_hip.so (yolat_forward_eval).
+
+``EvalPlan`` folds every BatchNorm1d into per-channel (scale, shift) once per weight version, fills
+the ``yolat_model_eval`` descriptor with device pointers and owns a grow-only workspace.  Each forward
+is then a single ctypes call; the C++ side enqueues graph pre-processing and all layers back to back.
+"""
+import ctypes
+
+import torch
+
+from . import ops
+from ._lib import lib, check, ModelEval, YOLAT_MAX_LAYERS
+
+
+def _fold(bn, dev):
+    coef = torch.empty(2, bn.num_features, dtype=torch.float32, device=dev)
+    ops.bn_eval_coeffs(bn, coef[0], coef[1])
+    return coef
+
+
+class EvalPlan(object):
+    def __init__(self, model):
+        self.model = model
+        self._tensors = [t for t in model.parameters()] + [b for b in model.buffers()]
+        self._key = None
+        self._desc = None
+        self._keep = None
+        self._ws = None
+        self._status = None
+
+    def _version_key(self):
+        return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(),)
+
+    def _build(self):
+        from .engine import model_convs
+        m = self.model
+        dev = self._tensors[0].device
+        net = m.cls_net
+        convs = model_convs(net)
+        if len(convs) > YOLAT_MAX_LAYERS:
+            raise ValueError("n_blocks > %d is not supported by the eval plan" % YOLAT_MAX_LAYERS)
+        d = ModelEval()
+        keep = []
+
+        def ptr(t):
+            if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+                raise ValueError("model tensors must be contiguous fp32 CUDA tensors")
+            return t.data_ptr()
+
+        def folded(bn):
+            c = _fold(bn, dev)
+            keep.append(c)
+            return c[0].data_ptr(), c[1].data_ptr()
+
+        d.n_blocks, d.n_blocks_out, d.n_classes = net.n_blocks, net.n_blocks_out, m.n_classes
+        d.C = convs[0].nn[0].out_features
+        d.F = net.fusion_block[0].out_features
+        for l, cv in enumerate(convs):
+            c = d.conv[l]
+            c.Cin = cv.in_channels
+            c.W1, c.b1 = ptr(cv.nn[0].weight), ptr(cv.nn[0].bias)
+            c.s1, c.t1 = folded(cv.nn[1])
+            c.W2, c.b2 = ptr(cv.nn[3].weight), ptr(cv.nn[3].bias)
+            c.s2, c.t2 = folded(cv.nn[4])
+            c.Wr, c.br = ptr(cv.lin_r.weight), ptr(cv.lin_r.bias)
+            c.Wn, c.bn = ptr(cv.mlp_node[0].weight), ptr(cv.mlp_node[0].bias)
+            c.sn, c.tn = folded(cv.mlp_node[1])
+        fb, fs = net.fusion_block, net.fusion_block_super
+        d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
+        d.sf, d.tf = folded(fb[1])
+        d.Wfs, d.bfs = ptr(fs[0].weight), ptr(fs[0].bias)
+        d.sfs, d.tfs = folded(fs[1])
+        m1, m2, m3 = m.prediction_cls[0], m.prediction_cls[1], m.prediction_cls[2]
+        d.H1, d.H2 = m1[0].out_features, m2[0].out_features
+        d.Wc1, d.bc1 = ptr(m1[0].weight), ptr(m1[0].bias)
+        d.sc1, d.tc1 = folded(m1[1])
+        d.Wc2, d.bc2 = ptr(m2[0].weight), ptr(m2[0].bias)
+        d.sc2, d.tc2 = folded(m2[1])
+        d.Wc3, d.bc3 = ptr(m3[0].weight), ptr(m3[0].bias)
+        self._desc, self._keep = d, keep
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=dev)
+
+    def run(self, x, edge, e_attr, bbox_idx, num_proposals):
+        key = self._version_key()
+        if key != self._key:
+            self._build()
+            self._key = key
+        N, P = x.shape[0], int(num_proposals)
+        if edge.dim() != 2 or (edge.shape[1] != 2 and edge.shape[0] != 2):
+            raise ValueError("edge must be [E,2] or [2,E]")
+        if edge.shape[1] == 2 and not (edge.shape[0] == 2 and edge.stride(0) == 1):
+            E, se, sc = edge.shape[0], edge.stride(0), edge.stride(1)
+        else:
+            E, se, sc = edge.shape[1], edge.stride(1), edge.stride(0)
+        need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=x.device)
+        logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
+        check(lib.yolat_forward_eval(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x),
+                                     ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
+                                     ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
+                                     logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
+                                     self._status.data_ptr(), ops._stream()), "yolat_forward_eval")
+        return logits
+
+    def check_status(self):
+        g = ops.Graph()
+        g.status = self._status
+        return ops.Graph.check_status(g)
