@@ -81,6 +81,16 @@ int yolat_csc_by_source(const int32_t* src_csr, int64_t E, int64_t N, int32_t* c
 int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, int32_t* seg_ptr,
                       int32_t* node_seg, int32_t* status, yolat_stream_t stream);
 
+/* All of the above in one call (4 kernel launches + 1 memset): CSR by destination (stable), e_attr
+ * permuted to CSR order, and — when bbox_idx is not NULL — the proposal segment pointers.
+ *   e_attr [E,4] contiguous, 16-byte aligned;  work: int32 scratch of yolat_graph_work_elems(N,E).   */
+size_t yolat_graph_work_elems(int64_t N, int64_t E);
+int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                        const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr,
+                        int32_t* perm, int32_t* src_csr, int32_t* dst_csr, float* attr_csr,
+                        int32_t* seg_ptr, int32_t* node_seg, int32_t* work, int32_t* status,
+                        yolat_stream_t stream);
+
 /* dst[r, 0:width] = src[idx[r], 0:width]  (e_attr -> CSR order; fp32)                           */
 int yolat_gather_rows(const float* src, int64_t ld_src, const int32_t* idx, int64_t rows,
                       int64_t width, float* dst, int64_t ld_dst, yolat_stream_t stream);
@@ -105,6 +115,15 @@ int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t K,
                      const float* W, int64_t ldw, const float* bias, int64_t Nout,
                      const float* o_scale, const float* o_shift, int o_relu,
                      float* Y, int64_t ldy, int accumulate, float* stats, yolat_stream_t stream);
+
+/* Eval-mode fusion_block + per-proposal max pooling fused (arch:61-63 + arch:122):
+ *   pool[p, 0:Nout] = max_{rows r of proposal p} relu((A[r].W^T + bias)*o_scale + o_shift)
+ * node_seg[M] = proposal id of each row (non-decreasing).  `pool` MUST be zero-filled first
+ * (yolat_pool_prepare does it); the [M,Nout] activation is never materialised.                    */
+int yolat_linear_segmax_fwd(const float* A, int64_t lda, int64_t M, int64_t K, const float* W,
+                            int64_t ldw, const float* bias, int64_t Nout, const float* o_scale,
+                            const float* o_shift, const int32_t* node_seg, float* pool, int64_t ldpool,
+                            yolat_stream_t stream);
 
 /* Same, with W used transposed: Y[M,Nout] = pro(A)[M,K] . Wt[K,Nout]   (dX = dY . W)            */
 int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
@@ -212,6 +231,11 @@ int yolat_segment_max_fwd(const float* X, int64_t ldx, int64_t D, const float* x
                           const float* x_shift, int x_relu, const int32_t* seg_ptr, int64_t P,
                           int64_t N, float* Y, int64_t ldy, int32_t* arg /* nullable [P,D] */,
                           yolat_stream_t stream);
+/* Pooling prologue of the eval forward in one launch, Z = [P, 2(F+D)] (arch:127 layout):
+ *   Z[:,0:F] = 0;  Z[:,F:F+D] = segment-max of feats[N,D];  Z[:,2F+D:2F+2D] = segment-mean of fsup[N,D] */
+int yolat_pool_prepare(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F,
+                       const int32_t* seg_ptr, int64_t P, float* Z, int64_t ldz, yolat_stream_t stream);
+
 /* dX[r,:] = dY[seg(r),:] / max(len(seg),1) */
 int yolat_segment_mean_bwd(const float* dY, int64_t lddy, int64_t D, const int32_t* seg_ptr,
                            const int32_t* node_seg, int64_t N, float* dX, int64_t lddx,

@@ -389,6 +389,42 @@ def test_segment_mean_max_forward_backward(P, D):
     np.testing.assert_array_equal(dX.cpu().numpy(), Xr.grad.numpy())
 
 
+def test_fused_linear_segmax_and_pool_prepare_match_unfused():
+    """Eval-plan kernels: fusion GEMM + BN + ReLU + per-proposal max in one launch, and the pooling
+    prologue, against the oracle's scatter on the materialised activations."""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    rng = np.random.default_rng(3)
+    P, D, F = 37, 128, 1024
+    n_p = rng.integers(1, 40, size=P)
+    n_p[5] = 0                                   # an empty proposal -> zeros
+    N = int(n_p.sum())
+    bb = np.repeat(np.arange(P), n_p).astype(np.int64)
+    tg = torch.Generator().manual_seed(4)
+    feats = torch.randn(N, D, generator=tg)
+    fsup = torch.randn(N, D, generator=tg)
+    W = torch.randn(F, D, generator=tg) / D ** 0.5
+    b = torch.randn(F, generator=tg) * 0.1
+    sc, sh = torch.rand(F, generator=tg) - 0.3, torch.randn(F, generator=tg) * 0.2
+    g = yv.ops.build_graph(torch.zeros(0, 2, dtype=torch.int64).cuda(), torch.zeros(0, 4).cuda(), dev(bb), N, P)
+    ZW = 2 * (F + D)
+    Z = torch.full((P, ZW), float("nan")).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    fd, sd = feats.cuda(), fsup.cuda()
+    check(lib.yolat_pool_prepare(fd.data_ptr(), sd.data_ptr(), D, D, F, g.seg_ptr.data_ptr(), P, Z.data_ptr(), ZW, st))
+    Wd, bd, scd, shd = W.cuda(), b.cuda(), sc.cuda(), sh.cuda()
+    check(lib.yolat_linear_segmax_fwd(fd.data_ptr(), D, N, D, Wd.data_ptr(), D, bd.data_ptr(), F, scd.data_ptr(),
+                                      shd.data_ptr(), g.node_seg.data_ptr(), Z.data_ptr(), ZW, st))
+    act = torch.relu((feats.double() @ W.double().T + b.double()) * sc.double() + sh.double())
+    idx = torch.from_numpy(bb)
+    close(Z[:, :F], orc.scatter(act.float(), idx, dim_size=P, reduce="max"), msg="fused max")
+    np.testing.assert_array_equal(Z[:, F:F + D].cpu().numpy(),
+                                  orc.scatter(feats, idx, dim_size=P, reduce="max").numpy())
+    close(Z[:, 2 * F + D:], orc.scatter(fsup, idx, dim_size=P, reduce="mean"), msg="mean(fsup)")
+    assert torch.isnan(Z[:, F + D:2 * F + D]).all()       # untouched slot (fusion_super writes it later)
+    assert float(Z[5, :F].abs().max()) == 0.0
+
+
 # ---------------------------------------------------------------------------------------------
 # loss / optimiser
 # ---------------------------------------------------------------------------------------------

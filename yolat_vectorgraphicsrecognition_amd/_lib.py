@@ -42,11 +42,16 @@ SIGNATURES = {
     "yolat_coo_to_csr": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_graph_work_elems": (c_sz, [c_i64, c_i64]),
+    "yolat_graph_prepare": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
+                                    c_p, c_p, c_p, c_p, c_p]),
     "yolat_gather_rows": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_bn_stats_elems": (c_sz, [c_i64, c_i64]),
     "yolat_linear_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int,
                                  c_p, c_i64, c_p, c_i64, c_p, c_p, c_int,
                                  c_p, c_i64, c_int, c_p, c_p]),
+    "yolat_linear_segmax_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64,
+                                        c_p]),
     "yolat_linear_fwd_wt": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p]),
     "yolat_linear_bwd_w_work_elems": (c_sz, [c_i64, c_i64, c_i64]),
     "yolat_linear_bwd_w": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_int,
@@ -68,6 +73,7 @@ SIGNATURES = {
     "yolat_segment_mean_fwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_segment_max_fwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_i64, c_p, c_i64,
                                       c_p, c_p]),
+    "yolat_pool_prepare": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_segment_mean_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_segment_max_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_softmax_ce": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),

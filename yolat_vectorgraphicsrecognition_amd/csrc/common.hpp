@@ -180,6 +180,12 @@ struct Epilogue {
   long ldy;
   int accumulate;
   float* stats;  // nullable: float2 [ceil(M/32)][N]  (sum, M2) of (acc + bias) per 32-row group
+  // fused per-proposal max pooling (eval): when seg != nullptr the tile is NOT stored; instead
+  // pool[seg[row]][col] = max(pool, value) with integer atomicMax on the float bits (values are
+  // post-ReLU, i.e. >= 0, so int order == float order and max is exact and order-independent).
+  const int* seg;  // nullable [M]
+  float* pool;
+  long ldpool;
 };
 
 // Epilogue of one 32x32 MFMA sub-tile held by one wave (C/D layout: col = lane&31,
@@ -222,6 +228,28 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
   float sc = 1.f, sh = 0.f;
   if (ep.scale != nullptr) { sc = ep.scale[cc]; sh = ep.shift[cc]; }
   const float floor = ep.relu ? 0.f : -INFINITY;
+  if (ep.seg != nullptr) {
+    // rows of a proposal are consecutive: run-length max over this lane's 16 rows, one atomic per run
+    int cur_seg = -1;
+    float cur = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int sg = (row < M) ? ep.seg[yl_min(row, M - 1)] : -1;
+      const float v = fmaxf(fmaf(acc[r], sc, sh), 0.f);
+      if (sg != cur_seg) {
+        if (cur_seg >= 0 && col_ok && cur > 0.f)
+          atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
+        cur_seg = sg;
+        cur = v;
+      } else {
+        cur = fmaxf(cur, v);
+      }
+    }
+    if (cur_seg >= 0 && col_ok && cur > 0.f)
+      atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
+    return;
+  }
   float old[16];
   if (ep.accumulate) {   // all 16 reads issued back to back (clamped rows), one wait
 #pragma unroll
@@ -373,59 +401,66 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
   const int l31 = lane & 31, lhi = lane >> 5;
   const int row0 = blockIdx.x * BT, col0 = blockIdx.y * BT;
   const bool fastA = A.vec != 0, fastB = B.vec != 0;
+  // Staging map: float4 slot i (0..1023) -> (row, kq).  32 consecutive lanes cover a 4-row x 8-kq patch:
+  // each row gets a full 128-B line from global, and with LD = 129 the ds_write_b32 banks
+  // (row + 4*kq + j) mod 32 of a 32-lane group are all distinct.  (The naive row = i/32, kq = i%32 map
+  // is a 4-way bank conflict on every write and made this kernel LDS-write-bound.)
+  auto map_r = [](int i) { return 4 * ((i >> 5) & 7) + ((i & 31) >> 3); };
+  auto map_q = [](int i) { return 8 * (i >> 8) + (i & 7); };
 
   f32x16 acc;
 #pragma unroll
   for (int r = 0; r < 16; ++r) acc[r] = 0.f;
 
-  float ra[4][4], rb[4][4];
-  auto fetch = [&](int k0) {
+  // Two register sets = two K-chunks in flight: with ~1 workgroup per CU (P is a few hundred rows)
+  // there is no other wave to hide the L2/MALL latency of the 4.7 MB classifier weight behind.
+  float ra0[4][4], rb0[4][4], ra1[4][4], rb1[4][4];
+  auto fetch = [&](int k0, float (&ra)[4][4], float (&rb)[4][4]) {
     const bool full = (k0 + BK <= K);
     if (full && fastA) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = tid + t * 256;
-        A.template load4<true>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+        A.template load4<true>(row0 + map_r(i), k0 + 4 * map_q(i), ra[t]);
       }
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = tid + t * 256;
-        A.template load4<false>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+        A.template load4<false>(row0 + map_r(i), k0 + 4 * map_q(i), ra[t]);
       }
     }
     if (full && fastB) {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = tid + t * 256;
-        const int n = B_NFAST ? (i % BT) : (i / KQ);
-        const int kq = B_NFAST ? (i / BT) : (i % KQ);
+        const int n = B_NFAST ? (i % BT) : map_r(i);
+        const int kq = B_NFAST ? (i / BT) : map_q(i);
         B.template load4<true>(col0 + n, k0 + 4 * kq, rb[t]);
       }
     } else {
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         const int i = tid + t * 256;
-        const int n = B_NFAST ? (i % BT) : (i / KQ);
-        const int kq = B_NFAST ? (i / BT) : (i % KQ);
+        const int n = B_NFAST ? (i % BT) : map_r(i);
+        const int kq = B_NFAST ? (i / BT) : map_q(i);
         B.template load4<false>(col0 + n, k0 + 4 * kq, rb[t]);
       }
     }
   };
-  fetch(0);
-  for (int k0 = 0; k0 < K; k0 += BK) {
+  auto stage = [&](float (&ra)[4][4], float (&rb)[4][4]) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int i = tid + t * 256;
-      float* d = As + (i / KQ) * LD + 4 * (i % KQ);
+      float* d = As + map_r(i) * LD + 4 * map_q(i);
       d[0] = ra[t][0]; d[1] = ra[t][1]; d[2] = ra[t][2]; d[3] = ra[t][3];
-      const int n = B_NFAST ? (i % BT) : (i / KQ);
-      const int kq = B_NFAST ? (i / BT) : (i % KQ);
+      const int n = B_NFAST ? (i % BT) : map_r(i);
+      const int kq = B_NFAST ? (i / BT) : map_q(i);
       float* e = Bs + n * LD + 4 * kq;
       e[0] = rb[t][0]; e[1] = rb[t][1]; e[2] = rb[t][2]; e[3] = rb[t][3];
     }
-    __syncthreads();
-    if (k0 + BK < K) fetch(k0 + BK);
+  };
+  auto compute = [&]() {
     const int kb = wave * 32;
 #pragma unroll
     for (int kk = 0; kk < 32; kk += 2) {
@@ -433,6 +468,21 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
       const float b = Bs[l31 * LD + kb + kk + lhi];
       acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
     }
+  };
+
+  fetch(0, ra0, rb0);
+  if (BK < K) fetch(BK, ra1, rb1);
+  for (int k0 = 0; k0 < K; k0 += 2 * BK) {
+    stage(ra0, rb0);
+    __syncthreads();
+    if (k0 + 2 * BK < K) fetch(k0 + 2 * BK, ra0, rb0);
+    compute();
+    __syncthreads();
+    if (k0 + BK >= K) break;
+    stage(ra1, rb1);
+    __syncthreads();
+    if (k0 + 3 * BK < K) fetch(k0 + 3 * BK, ra1, rb1);
+    compute();
     __syncthreads();
   }
   // fixed-order reduction of the 4 K-partials: waves 1..3 park theirs in LDS, wave 0 adds 1,2,3

@@ -49,13 +49,35 @@ extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t 
   DenseOp b = yl_dense(W, ldw, Nout, K);
   Epilogue ep;
   ep.bias = bias; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;
-  ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = stats;
+  ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = stats; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
   if (a_scale != nullptr) {
     DenseProOp a = yl_dense_pro(A, lda, M, K, a_scale, a_shift, a_relu);
     return launch_gemm_nt<DenseProOp, DenseOp, false>(a, b, ep, M, Nout, K, (hipStream_t)stream);
   }
   DenseOp a = yl_dense(A, lda, M, K);
   return launch_gemm_nt<DenseOp, DenseOp, false>(a, b, ep, M, Nout, K, (hipStream_t)stream);
+}
+
+// Eval-mode fusion block + per-proposal max pooling in one kernel (arch:61-63 + arch:122):
+//   pool[p, 0:Nout] = max over rows r of proposal p of relu((A[r] . W^T + bias)*scale + shift)
+// The [M,Nout] activation is never written to HBM.  `pool` must be zero-filled beforehand.
+extern "C" int yolat_linear_segmax_fwd(const float* A, int64_t lda, int64_t M, int64_t K, const float* W,
+                                       int64_t ldw, const float* bias, int64_t Nout, const float* o_scale,
+                                       const float* o_shift, const int32_t* node_seg, float* pool,
+                                       int64_t ldpool, yolat_stream_t stream) {
+  if (M <= 0 || K <= 0 || Nout <= 0 || !A || !W || !node_seg || !pool) return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lda < K || ldw < K || ldpool < Nout) return YOLAT_E_INVALID;
+  if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
+  DenseOp a = yl_dense(A, lda, M, K), b = yl_dense(W, ldw, Nout, K);
+  Epilogue ep;
+  ep.bias = bias; ep.scale = o_scale; ep.shift = o_shift; ep.relu = 1;
+  ep.Y = nullptr; ep.ldy = 0; ep.accumulate = 0; ep.stats = nullptr;
+  ep.seg = node_seg; ep.pool = pool; ep.ldpool = ldpool;
+  dim3 grid(yl_cdiv(M, 64), yl_cdiv(Nout, 64));
+  hipLaunchKernelGGL((k_gemm_nt<64, 64, 32, DenseOp, DenseOp, false>), grid, dim3(256), 0, (hipStream_t)stream,
+                     a, b, ep, (int)M, (int)Nout, (int)K);
+  YL_LAUNCH_CHECK();
+  return 0;
 }
 
 extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
@@ -68,7 +90,7 @@ extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64
   b.p = Wt; b.ld = ldw; b.rows = (int)Nout; b.cols = (int)K; b.vec = 1;
   Epilogue ep;
   ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
-  ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = nullptr;
+  ep.Y = Y; ep.ldy = ldy; ep.accumulate = accumulate; ep.stats = nullptr; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
   return launch_gemm_nt<DenseOp, TransOp, true>(a, b, ep, M, Nout, K, (hipStream_t)stream);
 }
 

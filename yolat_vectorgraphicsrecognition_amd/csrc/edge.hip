@@ -19,7 +19,7 @@ extern "C" int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64
   DenseOp b = yl_dense(W1, ldw, C, K);
   Epilogue ep;
   ep.bias = b1; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;
-  ep.Y = H1; ep.ldy = ldh; ep.accumulate = 0; ep.stats = stats;
+  ep.Y = H1; ep.ldy = ldh; ep.accumulate = 0; ep.stats = stats; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(yl_cdiv(E, 64), yl_cdiv(C, 64));
   if (K <= 16)
@@ -74,7 +74,7 @@ extern "C" int yolat_edge_lin1_bwd_x(const float* dH1, int64_t lddh, int64_t E, 
   b.W1 = W1; b.ldw = ldw; b.Cin = (int)Cin; b.C = (int)C; b.vec = 1;
   Epilogue ep;
   ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
-  ep.Y = dG; ep.ldy = lddg; ep.accumulate = 0; ep.stats = nullptr;
+  ep.Y = dG; ep.ldy = lddg; ep.accumulate = 0; ep.stats = nullptr; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
   const long Nn = 2 * Cin;
   dim3 grid(yl_cdiv(E, 64), yl_cdiv(Nn, 64));
   hipLaunchKernelGGL((k_gemm_nt<64, 64, 32, DenseOp, EdgeWcOp, true>), grid, dim3(256), 0,

@@ -18,7 +18,7 @@ struct Carver {
 struct Plan {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
   float* H1; float* H2; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
-  float* feats; float* fsup; float* fus; float* Z; float* c1; float* c2;
+  float* feats; float* fsup; float* Z; float* c1; float* c2;
   size_t bytes;
 };
 
@@ -27,7 +27,7 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   Plan p;
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, Ee = E > 0 ? E : 1;
   p.row_ptr = c.take<int>(N + 1); p.perm = c.take<int>(Ee); p.src = c.take<int>(Ee); p.dst = c.take<int>(Ee);
-  p.attr = c.take<float>(Ee * 4); p.work = c.take<int>(yolat_csr_work_elems(N, E));
+  p.attr = c.take<float>(Ee * 4); p.work = c.take<int>(yolat_graph_work_elems(N, E));
   p.seg_ptr = c.take<int>(P + 1); p.node_seg = c.take<int>(N);
   p.H1 = c.take<float>(Ee * C); p.H2 = c.take<float>(Ee * C);
   const int lo = m->n_blocks - m->n_blocks_out;
@@ -35,7 +35,7 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
     p.f_tmp[l] = (l < lo) ? c.take<float>(N * C) : nullptr;
     p.s_tmp[l] = (l < lo) ? c.take<float>(N * C) : nullptr;
   }
-  p.feats = c.take<float>(N * D); p.fsup = c.take<float>(N * D); p.fus = c.take<float>(N * F);
+  p.feats = c.take<float>(N * D); p.fsup = c.take<float>(N * D);
   p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
   p.bytes = c.off + 256;
   return p;
@@ -127,13 +127,9 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
 
   // ---- graph structure (CSR by destination, e_attr in CSR order, proposal segments)
   char nm[96];
-  YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N, [&]() -> int {
-    YL_TRY(yolat_coo_to_csr(edge, stride_e, stride_c, E, N, p.row_ptr, p.perm, p.src, p.dst, p.work, status,
-                            stream));
-    if (E > 0) YL_TRY(yolat_gather_rows(e_attr, 4, p.perm, E, 4, p.attr, 4, stream));
-    YL_TRY(yolat_segment_ptr(bbox_idx, N, P, p.seg_ptr, p.node_seg, status, stream));
-    return 0;
-  }());
+  YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N,
+           yolat_graph_prepare(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
+                               p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, stream));
 
   // ---- conv layers (torch_vertex.py:319-337), outputs written into their concat slots
   const float* f_in = x; long ld_f = ldx;
@@ -171,19 +167,14 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   }
 
   // ---- fusion over nodes + per-proposal max (arch:61-63,122)
-  snprintf(nm, sizeof nm, "fusion_gemm[N x %ld -> %ld]", D, F);
-  YL_STAGE(nm, 2.0 * N * D * F, 4.0 * (N * D + D * F + N * F),
-           yolat_linear_fwd(p.feats, D, N, D, nullptr, nullptr, 0, m->Wf, D, m->bf, F, m->sf, m->tf, 1, p.fus, F,
-                            0, nullptr, stream));
-  YL_STAGE("segment_max[N x F -> P x F]", 1.0 * N * F, 4.0 * (N * F + P * F),
-           yolat_segment_max_fwd(p.fus, F, F, nullptr, nullptr, 0, p.seg_ptr, P, N, p.Z, ZW, nullptr, stream));
-  YL_STAGE("segment_max[N x D -> P x D]", 1.0 * N * D, 4.0 * (N * D + P * D),
-           yolat_segment_max_fwd(p.feats, D, D, nullptr, nullptr, 0, p.seg_ptr, P, N, p.Z + F, ZW, nullptr,
-                                 stream));
-  // ---- super branch: per-proposal mean + fusion_block_super (arch:65-69)
   float* sup = p.Z + 2 * F + D;
-  YL_STAGE("segment_mean[N x D -> P x D]", 1.0 * N * D, 4.0 * (N * D + P * D),
-           yolat_segment_mean_fwd(p.fsup, D, D, nullptr, nullptr, 0, p.seg_ptr, P, sup, ZW, stream));
+  YL_STAGE("pool_prepare[max(feats), mean(fsup), zero]", 2.0 * N * D, 8.0 * N * D + 4.0 * P * (F + 2 * D),
+           yolat_pool_prepare(p.feats, p.fsup, D, D, F, p.seg_ptr, P, p.Z, ZW, stream));
+  snprintf(nm, sizeof nm, "fusion_gemm+segmax[N x %ld -> %ld -> P]", D, F);
+  YL_STAGE(nm, 2.0 * N * D * F, 4.0 * (N * D + D * F + P * F),
+           yolat_linear_segmax_fwd(p.feats, D, N, D, m->Wf, D, m->bf, F, m->sf, m->tf, p.node_seg, p.Z, ZW,
+                                   stream));
+  // ---- super branch: fusion_block_super on the per-proposal means (arch:65-69)
   snprintf(nm, sizeof nm, "fusion_super_gemm[P x %ld -> %ld]", D, F);
   YL_STAGE(nm, 2.0 * P * D * F, 4.0 * (P * D + D * F + P * F),
            yolat_linear_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->Wfs, D, m->bfs, F, m->sfs, m->tfs, 1,

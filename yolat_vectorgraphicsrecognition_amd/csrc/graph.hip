@@ -191,6 +191,206 @@ extern "C" int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// yolat_graph_prepare: the whole per-batch structure in 4 launches + 1 memset.
+//   1. k_prep_count   edge e: int64 -> int32, range check, rank[e] = atomicAdd(cnt[dst]) (arrival order,
+//                     only used to place e somewhere inside its row); row r: segment pointers
+//   2. k_prep_scan    per-4096-element-block exclusive scan of cnt (multi-workgroup) + block totals
+//   3. k_prep_fill    items[local[dst] + blockprefix + rank[e]] = e
+//   4. k_prep_rows    node n: insertion-sort its row by edge id (restores the stable order), emit
+//                     perm / src / dst / attr in CSR order, write the final row_ptr
+// ------------------------------------------------------------------------------------------------
+#define PREP_BLK 4096
+__global__ void k_prep_count(const int64_t* edge, long se, long sc, int E, int N, int* src32, int* dst32,
+                             int* rank, int* cnt, const int64_t* bbox, long P, int* seg_ptr, int* node_seg,
+                             int* status) {
+  const int t = blockIdx.x * blockDim.x + threadIdx.x;
+  if (t < E) {
+    int64_t s = edge[(long)t * se];
+    int64_t d = edge[(long)t * se + sc];
+    if (s < 0 || s >= N || d < 0 || d >= N) {
+      atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
+      s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+      d = d < 0 ? 0 : (d >= N ? N - 1 : d);
+    }
+    src32[t] = (int)s; dst32[t] = (int)d;
+    rank[t] = atomicAdd(&cnt[d], 1);
+  }
+  if (bbox != nullptr && t <= N) {
+    long prev = (t == 0) ? -1 : bbox[t - 1];
+    long cur = (t == N) ? P : bbox[t];
+    if (t < N) {
+      if (cur < 0 || cur >= P) { atomicOr(status, YOLAT_STATUS_SEG_RANGE); cur = cur < 0 ? 0 : P - 1; }
+      node_seg[t] = (int)cur;
+    }
+    if (prev >= P) prev = P - 1;
+    if (prev < -1) prev = -1;
+    if (cur < prev) atomicOr(status, YOLAT_STATUS_SEG_UNSORTED);
+    else for (long p = prev + 1; p <= cur; ++p) seg_ptr[p] = t;
+  }
+}
+
+// local[i] = exclusive scan of cnt inside its PREP_BLK block; btot[b] = block total.  n = N + 1.
+__global__ void __launch_bounds__(1024) k_prep_scan(const int* cnt, int n, int* local, int* btot) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int idx = blockIdx.x * PREP_BLK + tid * 4;
+  int v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (idx + j < n) ? cnt[idx + j] : 0;
+  const int t = v[0] + v[1] + v[2] + v[3];
+  int incl = t;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int nb = __shfl_up(incl, off);
+    if (lane >= off) incl += nb;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int s = wsum[w];
+    if (w < wave) woff += s;
+    total += s;
+  }
+  int excl = woff + incl - t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (idx + j < n) local[idx + j] = excl;
+    excl += v[j];
+  }
+  if (tid == 0) btot[blockIdx.x] = total;
+}
+
+__device__ __forceinline__ int prep_prefix(const int* btot, int b) {
+  int s = 0;
+  for (int i = 0; i < b; ++i) s += btot[i];
+  return s;
+}
+
+__global__ void k_prep_fill(const int* dst32, const int* rank, int E, const int* local, const int* btot,
+                            int* items) {
+  const int e = blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= E) return;
+  const int d = dst32[e];
+  items[local[d] + prep_prefix(btot, d / PREP_BLK) + rank[e]] = e;
+}
+
+__global__ void k_prep_rows(const int* local, const int* btot, int N, int* items, const int* src32,
+                            const float4* attr, int* row_ptr, int* perm, int* src_csr, int* dst_csr,
+                            float4* attr_csr) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n > N) return;
+  const int b = local[n] + prep_prefix(btot, n / PREP_BLK);
+  row_ptr[n] = b;
+  if (n == N) return;
+  const int e = local[n + 1] + prep_prefix(btot, (n + 1) / PREP_BLK);
+  const int deg = e - b;
+  if (deg <= 0) return;
+  constexpr int RMAX = 16;
+  if (deg <= RMAX) {
+    // the whole row in registers: RMAX independent (clamped) loads, an odd-even transposition
+    // network, then independent gathers + stores  => one memory latency per phase instead of one
+    // dependent global round trip per insertion-sort step
+    int it[RMAX];
+#pragma unroll
+    for (int j = 0; j < RMAX; ++j) {
+      const int v = items[b + (j < deg ? j : deg - 1)];
+      it[j] = j < deg ? v : 0x7fffffff;
+    }
+#pragma unroll
+    for (int round = 0; round < RMAX; ++round) {
+#pragma unroll
+      for (int j = (round & 1); j + 1 < RMAX; j += 2) {
+        const int lo = it[j] < it[j + 1] ? it[j] : it[j + 1];
+        const int hi = it[j] < it[j + 1] ? it[j + 1] : it[j];
+        it[j] = lo; it[j + 1] = hi;
+      }
+    }
+#pragma unroll
+    for (int j0 = 0; j0 < RMAX; j0 += 8) {
+      int sv[8];
+      float4 av[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int ed = it[(j0 + j) < deg ? (j0 + j) : 0];
+        sv[j] = src32[ed];
+        av[j] = attr[ed];
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (j0 + j < deg) {
+          perm[b + j0 + j] = it[j0 + j];
+          src_csr[b + j0 + j] = sv[j];
+          dst_csr[b + j0 + j] = n;
+          attr_csr[b + j0 + j] = av[j];
+        }
+      }
+    }
+    return;
+  }
+  for (int i = b + 1; i < e; ++i) {
+    const int v = items[i];
+    int j = i - 1;
+    while (j >= b && items[j] > v) { items[j + 1] = items[j]; --j; }
+    items[j + 1] = v;
+  }
+  for (int q = b; q < e; ++q) {
+    const int ed = items[q];
+    perm[q] = ed;
+    src_csr[q] = src32[ed];
+    dst_csr[q] = n;
+    attr_csr[q] = attr[ed];
+  }
+}
+
+extern "C" size_t yolat_graph_work_elems(int64_t N, int64_t E) {
+  return (size_t)(2 * (((N + 1) + 63) / 64 * 64) + 4 * E + (N + 1) / PREP_BLK + 16);
+}
+
+extern "C" int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_t stride_c,
+                                   const float* e_attr, const int64_t* bbox_idx, int64_t E, int64_t N,
+                                   int64_t P, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
+                                   int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
+                                   int32_t* work, int32_t* status, yolat_stream_t stream) {
+  if (N <= 0 || E < 0 || N >= (1LL << 31) - 8192 || E >= (1LL << 31) - 256) return YOLAT_E_INVALID;
+  if (!row_ptr || !work || !status) return YOLAT_E_INVALID;
+  if (E > 0 && (!edge || !e_attr || !perm || !src_csr || !dst_csr || !attr_csr)) return YOLAT_E_INVALID;
+  if (bbox_idx && (P <= 0 || !seg_ptr || !node_seg)) return YOLAT_E_INVALID;
+  if (E > 0 && !yl_aligned16(e_attr)) return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int n1 = (int)N + 1;
+  const int nblk = yl_cdiv(n1, PREP_BLK);
+  const int n1p = (n1 + 63) / 64 * 64;   // memset a multiple of 256 B: one fill kernel, not two
+  int* cnt = work;                 // [N+1] (padded)
+  int* local = cnt + n1p;          // [N+1] (padded)
+  int* btot = local + n1p;         // [nblk]
+  int* src32 = btot + nblk + 1;
+  int* dst32 = src32 + E;
+  int* rank = dst32 + E;
+  int* items = rank + E;
+  hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n1p, st);
+  if (err != hipSuccess) return (int)err;
+  const long nthreads = (E > N + 1) ? E : N + 1;
+  hipLaunchKernelGGL(k_prep_count, dim3(yl_cdiv(nthreads, 256)), dim3(256), 0, st, edge, (long)stride_e,
+                     (long)stride_c, (int)E, (int)N, src32, dst32, rank, cnt, bbox_idx, (long)P, seg_ptr,
+                     node_seg, status);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_prep_scan, dim3(nblk), dim3(1024), 0, st, cnt, n1, local, btot);
+  YL_LAUNCH_CHECK();
+  if (E > 0) {
+    hipLaunchKernelGGL(k_prep_fill, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, dst32, rank, (int)E, local, btot,
+                       items);
+    YL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_prep_rows, dim3(yl_cdiv(n1, 256)), dim3(256), 0, st, local, btot, (int)N, items, src32,
+                     reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
+                     reinterpret_cast<float4*>(attr_csr));
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void k_gather_rows(const float* src, long ld_src, const int* idx, long rows, int width,
                               float* dst, long ld_dst) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;

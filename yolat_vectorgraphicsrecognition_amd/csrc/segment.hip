@@ -46,6 +46,50 @@ __global__ void __launch_bounds__(256) k_segment_max_fwd(const float* X, long ld
   if (arg) arg[(long)p * D + c] = a;
 }
 
+// Pooling prologue of the eval plan, one launch: for proposal p
+//   Z[p, 0:F]              = 0                       (target of the fused GEMM+max kernel)
+//   Z[p, F:F+D]            = max over rows of feats  (pass-through half of out_feat, arch:63,122)
+//   Z[p, 2F+D:2F+2D]       = mean over rows of fsup  (arch:67)
+__global__ void __launch_bounds__(256) k_pool_prepare(const float* feats, const float* fsup, long ld, int D,
+                                                      int F, const int* seg_ptr, float* Z, long ldz) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  float* z = Z + (long)p * ldz;
+  if (c < F) { z[c] = 0.f; return; }
+  const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
+  if (c < F + D) {
+    const int k = c - F;
+    float best = 0.f;
+    bool any = false;
+    for (int r = r0; r < r1; ++r) {
+      const float v = feats[(long)r * ld + k];
+      if (!any || v > best) { best = v; any = true; }
+    }
+    z[F + k] = best;
+  } else if (c < F + 2 * D) {
+    const int k = c - F - D;
+    float s = 0.f;
+    for (int r = r0; r < r1; ++r) s += fsup[(long)r * ld + k];
+    const int cnt = r1 - r0;
+    z[2 * F + D + k] = s / (float)(cnt > 1 ? cnt : 1);
+  }
+}
+
+extern "C" int yolat_pool_prepare(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F,
+                                  const int32_t* seg_ptr, int64_t P, float* Z, int64_t ldz,
+                                  yolat_stream_t stream) {
+  if (P <= 0 || D <= 0 || F <= 0 || !feats || !fsup || !seg_ptr || !Z || ld < D || ldz < 2 * (F + D))
+    return YOLAT_E_INVALID;
+  for (int64_t p0 = 0; p0 < P; p0 += 65535) {
+    const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
+    hipLaunchKernelGGL(k_pool_prepare, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)np), dim3(256), 0,
+                       (hipStream_t)stream, feats, fsup, (long)ld, (int)D, (int)F, seg_ptr + p0, Z + p0 * ldz,
+                       (long)ldz);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
 static int seg_args_ok(const float* X, int64_t ldx, int64_t D, const float* s, const float* b,
                        const int32_t* seg_ptr, int64_t P, float* Y, int64_t ldy) {
   if (P < 0 || D <= 0 || ldx < D || ldy < D) return 0;

@@ -106,25 +106,24 @@ def build_graph(edge, e_attr, bbox_idx, num_nodes, num_proposals):
     g.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     g.dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     g.status = torch.zeros(1, dtype=torch.int32, device=dev)
-    work = torch.empty(int(lib.yolat_csr_work_elems(N, E)), dtype=torch.int32, device=dev)
-    st = _stream()
-    check(lib.yolat_coo_to_csr(_i(edge, torch.int64, "edge"), se, sc, E, N, g.row_ptr.data_ptr(),
-                               g.perm.data_ptr(), g.src.data_ptr(), g.dst.data_ptr(),
-                               work.data_ptr(), g.status.data_ptr(), st), "yolat_coo_to_csr")
-    g._work = work
     g.attr = torch.empty(max(E, 1), 4, dtype=torch.float32, device=dev)
-    if E > 0:
-        if e_attr.shape[0] != E or e_attr.shape[1] != 4:
-            raise ValueError("e_attr must be [E,4]")
-        check(lib.yolat_gather_rows(_f(e_attr, "e_attr"), _ld(e_attr), g.perm.data_ptr(), E, 4,
-                                    g.attr.data_ptr(), 4, st), "yolat_gather_rows")
     g.seg_ptr = g.node_seg = None
     if bbox_idx is not None:
         g.seg_ptr = torch.empty(P + 1, dtype=torch.int32, device=dev)
         g.node_seg = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
-        check(lib.yolat_segment_ptr(_i(bbox_idx, torch.int64, "bbox_idx"), N, P, g.seg_ptr.data_ptr(),
-                                    g.node_seg.data_ptr(), g.status.data_ptr(), st),
-              "yolat_segment_ptr")
+    if E > 0:
+        if e_attr.shape[0] != E or e_attr.shape[1] != 4:
+            raise ValueError("e_attr must be [E,4]")
+        if not e_attr.is_contiguous():
+            e_attr = e_attr.contiguous()
+    work = torch.empty(int(lib.yolat_graph_work_elems(N, E)), dtype=torch.int32, device=dev)
+    check(lib.yolat_graph_prepare(_i(edge, torch.int64, "edge"), se, sc, _f(e_attr, "e_attr") if E > 0 else None,
+                                  _i(bbox_idx, torch.int64, "bbox_idx"), E, N, P, g.row_ptr.data_ptr(),
+                                  g.perm.data_ptr(), g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(),
+                                  g.seg_ptr.data_ptr() if g.seg_ptr is not None else None,
+                                  g.node_seg.data_ptr() if g.node_seg is not None else None,
+                                  work.data_ptr(), g.status.data_ptr(), _stream()), "yolat_graph_prepare")
+    g._work = work
     return g
 
 
