@@ -276,6 +276,7 @@ typedef struct {
   const float *W2, *b2, *s2, *t2;             /* gconv.nn.3 [C,C],     gconv.nn.4 folded        */
   const float *Wr, *br;                       /* gconv.lin_r [C,Cin]                             */
   const float *Wn, *bn, *sn, *tn;             /* gconv.mlp_node.0 [C,Cin], mlp_node.1 folded     */
+  const float *packed;                        /* nullable: yolat_conv_pack_weights(W1, W2) output  */
 } yolat_conv_eval;
 
 typedef struct {
@@ -290,6 +291,30 @@ typedef struct {
   const float *Wc2, *bc2, *sc2, *tc2;         /* prediction_cls.1                                */
   const float *Wc3, *bc3;                     /* prediction_cls.2 (bare Linear)                  */
 } yolat_model_eval;
+
+/* One AttrRelativeEdgeConvGlobalPool2 layer in eval mode (torch_vertex.py:319-337, BatchNorm folded)
+ * as ONE persistent kernel: gather -> edge MLP (2 MFMA GEMMs) -> mean aggregation -> + lin_r(x), and
+ * the node branch mlp_node(xn).  No [E,*] intermediate is written to HBM.  C must be 64, Cin <= 64.
+ * f_out / s_out: [N,C] destinations (ld = ldf / lds), e.g. column slots of the concat buffers.     */
+int yolat_conv_eval_fused(const float* x, int64_t ldx, const float* xn, int64_t ldxn, int64_t N,
+                          int64_t Cin, const int32_t* row_ptr, const int32_t* src_csr,
+                          const int32_t* dst_csr, const float* attr_csr, int64_t E,
+                          const yolat_conv_eval* w, int64_t C, float* f_out, int64_t ldf, float* s_out,
+                          int64_t lds, yolat_stream_t stream);
+
+/* Same contract, second implementation (conv_chain.hip): every wave owns 32 edges end to end, its features
+ * stream from global memory straight into the MFMA B operand, the two edge-MLP GEMMs are chained through
+ * the accumulator registers, and there is no workgroup barrier in the edge loop.  Cin in {5, 6, 64}.
+ * `packed`: W1 / W2 re-ordered into MFMA fragment order by yolat_conv_pack_weights (once per weight
+ * version; yolat_conv_pack_elems(Cin) floats, 16-byte aligned).                                      */
+size_t yolat_conv_pack_elems(int64_t Cin);
+int yolat_conv_pack_weights(const float* W1, const float* W2, int64_t Cin, float* packed,
+                            yolat_stream_t stream);
+int yolat_conv_eval_chain(const float* x, int64_t ldx, const float* xn, int64_t ldxn, int64_t N,
+                          int64_t Cin, const int32_t* row_ptr, const int32_t* src_csr,
+                          const int32_t* dst_csr, const float* attr_csr, int64_t E,
+                          const yolat_conv_eval* w, const float* packed, int64_t C, float* f_out,
+                          int64_t ldf, float* s_out, int64_t lds, yolat_stream_t stream);
 
 /* workspace (bytes) needed by yolat_forward_eval for a batch of N nodes / E edges / P proposals */
 size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, int64_t N, int64_t E, int64_t P);

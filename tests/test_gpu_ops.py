@@ -389,6 +389,67 @@ def test_segment_mean_max_forward_backward(P, D):
     np.testing.assert_array_equal(dX.cpu().numpy(), Xr.grad.numpy())
 
 
+@pytest.mark.parametrize("impl", ["yolat_conv_eval_fused", "yolat_conv_eval_chain"])
+@pytest.mark.parametrize("N,E,Cin", [(6, 7, 5), (70, 300, 5), (70, 300, 64), (1000, 4000, 64), (33, 0, 64),
+                                     (500, 9000, 64), (2500, 3000, 5), (300, 700, 6), (9000, 30000, 64)])
+def test_fused_conv_layer_eval_matches_oracle(N, E, Cin, impl):
+    """yolat_conv_eval_fused (gather -> MLP -> mean -> + root, node branch in one persistent kernel) against
+    the oracle's AttrRelativeEdgeConvGlobalPool2 in eval mode; outputs land in column slots of wider
+    buffers (ld = 128) like in the model."""
+    import ctypes
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check, ConvEval
+    src, dst, xfull, attr = _edge_case(N, max(E, 1), Cin, 7 * N + E, ldx=Cin)
+    src, dst, attr = src[:E], dst[:E], attr[:E]
+    if E > 20:
+        dst[:15] = 3                                  # one high-degree node spanning chunks
+    conv = orc.AttrRelativeEdgeConvGlobalPool2(Cin, 64)
+    gu.fill_state_(conv, 11)
+    conv.eval()
+    x = torch.from_numpy(xfull.copy())
+    xn = torch.relu(torch.from_numpy(np.random.default_rng(1).standard_normal((N, Cin)).astype(np.float32)))
+    ei = torch.from_numpy(np.stack([src, dst], 0)) if E else torch.zeros(2, 0, dtype=torch.long)
+    with torch.no_grad():
+        want_f, want_s = conv(x, xn, ei, None, torch.from_numpy(attr) if E else torch.zeros(0, 4))
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)) if E else torch.zeros(0, 2, dtype=torch.int64).cuda(),
+                           dev(attr) if E else torch.zeros(0, 4).cuda(), None, N, 1)
+    cd = conv.cuda()
+    keep = []
+
+    def fold(bn):
+        c = torch.empty(2, 64).cuda()
+        yv.ops.bn_eval_coeffs(bn, c[0], c[1])
+        keep.append(c)
+        return c[0].data_ptr(), c[1].data_ptr()
+
+    w = ConvEval()
+    w.Cin = Cin
+    w.W1, w.b1 = cd.nn[0].weight.data_ptr(), cd.nn[0].bias.data_ptr()
+    w.s1, w.t1 = fold(cd.nn[1])
+    w.W2, w.b2 = cd.nn[3].weight.data_ptr(), cd.nn[3].bias.data_ptr()
+    w.s2, w.t2 = fold(cd.nn[4])
+    w.Wr, w.br = cd.lin_r.weight.data_ptr(), cd.lin_r.bias.data_ptr()
+    w.Wn, w.bn = cd.mlp_node[0].weight.data_ptr(), cd.mlp_node[0].bias.data_ptr()
+    w.sn, w.tn = fold(cd.mlp_node[1])
+    fbuf = torch.full((N, 128), float("nan")).cuda()
+    sbuf = torch.full((N, 128), float("nan")).cuda()
+    xd, xnd = x.cuda(), xn.cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    if impl == "yolat_conv_eval_chain":
+        pk = torch.empty(int(lib.yolat_conv_pack_elems(Cin))).cuda()
+        check(lib.yolat_conv_pack_weights(w.W1, w.W2, Cin, pk.data_ptr(), st))
+        check(lib.yolat_conv_eval_chain(xd.data_ptr(), Cin, xnd.data_ptr(), Cin, N, Cin, g.row_ptr.data_ptr(),
+                                        g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E, ctypes.byref(w),
+                                        pk.data_ptr(), 64, fbuf[:, 64:].data_ptr(), 128, sbuf[:, :64].data_ptr(), 128, st))
+    else:
+        check(lib.yolat_conv_eval_fused(xd.data_ptr(), Cin, xnd.data_ptr(), Cin, N, Cin, g.row_ptr.data_ptr(),
+                                        g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E, ctypes.byref(w), 64,
+                                        fbuf[:, 64:].data_ptr(), 128, sbuf[:, :64].data_ptr(), 128, st))
+    close(fbuf[:, 64:], want_f, msg="fused conv out")
+    close(sbuf[:, :64], want_s, msg="fused conv node branch")
+    assert torch.isnan(fbuf[:, :64]).all() and torch.isnan(sbuf[:, 64:]).all()
+
+
 def test_fused_linear_segmax_and_pool_prepare_match_unfused():
     """Eval-plan kernels: fusion GEMM + BN + ReLU + per-proposal max in one launch, and the pooling
     prologue, against the oracle's scatter on the materialised activations."""

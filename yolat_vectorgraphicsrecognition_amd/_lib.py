@@ -22,7 +22,8 @@ YOLAT_MAX_LAYERS = 8
 class ConvEval(ctypes.Structure):
     """yolat_conv_eval (include/yolat_hip.h)"""
     _fields_ = [("Cin", c_i64)] + [(n, c_p) for n in
-                                   ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn")]
+                                   ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn",
+                                    "packed")]
 
 
 class ModelEval(ctypes.Structure):
@@ -83,6 +84,12 @@ SIGNATURES = {
     "yolat_profile_count": (c_int, []),
     "yolat_profile_get": (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_f), ctypes.POINTER(c_int),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
+    "yolat_conv_eval_fused": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64,
+                                      ctypes.POINTER(ConvEval), c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_conv_pack_elems": (c_sz, [c_i64]),
+    "yolat_conv_pack_weights": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
+    "yolat_conv_eval_chain": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64,
+                                      ctypes.POINTER(ConvEval), c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_forward_eval_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEval), c_i64, c_i64, c_i64]),
     "yolat_forward_eval": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64,
                                    c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),

@@ -393,7 +393,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
 // ------------------------------------------------------------------------------------------------
 template <class AL, class BL, bool B_NFAST>
 __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int M, int N, int K) {
-  constexpr int BT = 32, BK = 128, LD = BK + 1, KQ = BK / 4;
+  constexpr int BT = 32, BK = 128, LD = BK + 1;
   __shared__ float smem[2 * BT * LD];
   float* As = smem;
   float* Bs = smem + BT * LD;

@@ -49,6 +49,7 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   } while (0)
 
 // ---- stage profiler (hipEvent pairs on the launch stream) ------------------------------------------
+#include <stdlib.h>
 #include <string>
 #include <vector>
 namespace {
@@ -56,6 +57,10 @@ struct StageRec { std::string name; double flops, bytes; std::vector<std::pair<h
 std::vector<StageRec> g_stages;
 std::vector<hipEvent_t> g_pool;
 bool g_profile = false;
+int g_conv_mode = -1;   // conv layer implementation: 0 per-op kernels, 1 conv_fused.hip, 2 conv_chain.hip,
+                        // 3 (default) = by size: measured on MI355X the per-op path wins below ~200k edges
+                        // (cfg 2: 85 vs 92 us for both layers) and conv_chain above (cfg 5: 742 vs 800 us
+                        // per block layer).  env YOLAT_CONV_MODE overrides (A/B testing).
 
 hipEvent_t new_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -122,6 +127,11 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     return YOLAT_E_INVALID;
   Plan p = carve(m, N, E, P, workspace);
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
+  if (g_conv_mode < 0) {
+    const char* e = getenv("YOLAT_CONV_MODE");
+    g_conv_mode = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : 3;
+  }
+  const int conv_mode = (g_conv_mode == 3) ? (E >= 200000 ? 2 : 0) : g_conv_mode;
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
   const int lo = m->n_blocks - m->n_blocks_out;
 
@@ -141,6 +151,23 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     float* s_out = slot >= 0 ? p.fsup + slot * C : p.s_tmp[l];
     const long ld_out = slot >= 0 ? D : C;
     const double K1 = 2.0 * cv.Cin + 4;
+    const bool chain_ok = C == 64 && cv.packed != nullptr && (cv.Cin == 64 || cv.Cin == 5 || cv.Cin == 6) &&
+                          (cv.Cin != 64 || ld_f % 4 == 0);
+    if (conv_mode == 2 && chain_ok) {
+      // register-chained persistent kernel (conv_chain.hip)
+      snprintf(nm, sizeof nm, "conv_chain[Cin=%ld: gather+MLP+mean+root+node]", (long)cv.Cin);
+      YL_STAGE(nm, 2.0 * E * (K1 * C + C * C) + 4.0 * N * cv.Cin * C,
+               E * (K1 * 4.0 + 8.0) + 4.0 * N * (2.0 * cv.Cin + 2.0 * C),
+               yolat_conv_eval_chain(f_in, ld_f, s_in, ld_s, N, cv.Cin, p.row_ptr, p.src, p.dst, p.attr, E, &cv,
+                                     cv.packed, C, f_out, ld_out, s_out, ld_out, stream));
+    } else if (conv_mode == 1 && C == 64 && (cv.Cin == 64 || cv.Cin <= 8)) {
+      // LDS-staged persistent kernel (conv_fused.hip)
+      snprintf(nm, sizeof nm, "conv_fused[Cin=%ld: gather+MLP+mean+root+node]", (long)cv.Cin);
+      YL_STAGE(nm, 2.0 * E * (K1 * C + C * C) + 4.0 * N * cv.Cin * C,
+               E * (K1 * 4.0 + 8.0) + 4.0 * N * (2.0 * cv.Cin + 2.0 * C),
+               yolat_conv_eval_fused(f_in, ld_f, s_in, ld_s, N, cv.Cin, p.row_ptr, p.src, p.dst, p.attr, E, &cv, C,
+                                     f_out, ld_out, s_out, ld_out, stream));
+    } else {
     // out = lin_r(x)
     snprintf(nm, sizeof nm, "lin_r[N x %ld -> %ld]", (long)cv.Cin, C);
     YL_STAGE(nm, 2.0 * N * cv.Cin * C, 4.0 * (N * cv.Cin + N * C + C * cv.Cin),
@@ -163,6 +190,7 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     YL_STAGE(nm, 2.0 * N * cv.Cin * C, 4.0 * (N * cv.Cin + N * C + C * cv.Cin),
              yolat_linear_fwd(s_in, ld_s, N, cv.Cin, nullptr, nullptr, 0, cv.Wn, cv.Cin, cv.bn, C, cv.sn, cv.tn, 1,
                               s_out, ld_out, 0, nullptr, stream));
+    }
     f_in = f_out; ld_f = ld_out; s_in = s_out; ld_s = ld_out;
   }
 

@@ -65,6 +65,12 @@ class EvalPlan(object):
             c.Wr, c.br = ptr(cv.lin_r.weight), ptr(cv.lin_r.bias)
             c.Wn, c.bn = ptr(cv.mlp_node[0].weight), ptr(cv.mlp_node[0].bias)
             c.sn, c.tn = folded(cv.mlp_node[1])
+            # W1 / W2 in MFMA fragment order for the register-chained conv kernel (conv_chain.hip)
+            pk = torch.empty(int(lib.yolat_conv_pack_elems(cv.in_channels)), dtype=torch.float32, device=dev)
+            check(lib.yolat_conv_pack_weights(c.W1, c.W2, cv.in_channels, pk.data_ptr(), ops._stream()),
+                  "yolat_conv_pack_weights")
+            keep.append(pk)
+            c.packed = pk.data_ptr()
         fb, fs = net.fusion_block, net.fusion_block_super
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
