@@ -98,13 +98,17 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd(const float* H, long ldh, 
   const float inv = 1.f / (float)((q1 - q0) > 1 ? (q1 - q0) : 1);
   for (int c = lane; c < C; c += 64) {
     const float sc = hs ? hs[c] : 1.f, sh = hs ? hb[c] : 0.f;
+    const float floor = relu ? 0.f : -INFINITY;
     float s = 0.f;
-    for (int q = q0; q < q1; ++q) {
-      float v = H[(long)q * ldh + c];
-      if (hs) v = fmaf(v, sc, sh);
-      if (relu) v = fmaxf(v, 0.f);
-      s += v;
+    int q = q0;
+    for (; q + 4 <= q1; q += 4) {      // 4 independent row loads in flight; summation stays in edge order
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v[j] = H[(long)(q + j) * ldh + c];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) s += fmaxf(fmaf(v[j], sc, sh), floor);
     }
+    for (; q < q1; ++q) s += fmaxf(fmaf(H[(long)q * ldh + c], sc, sh), floor);
     s *= inv;
     float* o = out + (long)n * ldo + c;
     if (accumulate) s += *o;

@@ -56,20 +56,34 @@ __global__ void __launch_bounds__(256) k_pool_prepare(const float* feats, const 
   const int p = blockIdx.y;
   float* z = Z + (long)p * ldz;
   if (c < F) { z[c] = 0.f; return; }
+  if (c >= F + 2 * D) return;
   const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
-  if (c < F + D) {
-    const int k = c - F;
-    float best = 0.f;
-    bool any = false;
-    for (int r = r0; r < r1; ++r) {
-      const float v = feats[(long)r * ld + k];
-      if (!any || v > best) { best = v; any = true; }
+  const bool is_max = c < F + D;
+  const int k = is_max ? c - F : c - F - D;
+  const float* src = (is_max ? feats : fsup) + k;
+  // rows are read 8 at a time (independent loads in flight) — a one-row-per-iteration loop is a chain of
+  // dependent L2 round trips; the reduction itself still runs in row order
+  float best = 0.f, s = 0.f;
+  bool any = false;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = src[(long)(r + j) * ld];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!any || v[j] > best) { best = v[j]; any = true; }
+      s += v[j];
     }
+  }
+  for (; r < r1; ++r) {
+    const float v = src[(long)r * ld];
+    if (!any || v > best) { best = v; any = true; }
+    s += v;
+  }
+  if (is_max) {
     z[F + k] = best;
-  } else if (c < F + 2 * D) {
-    const int k = c - F - D;
-    float s = 0.f;
-    for (int r = r0; r < r1; ++r) s += fsup[(long)r * ld + k];
+  } else {
     const int cnt = r1 - r0;
     z[2 * F + D + k] = s / (float)(cnt > 1 ? cnt : 1);
   }
