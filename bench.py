@@ -159,6 +159,35 @@ def roofline_entry(summary):
             "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": rec["ms_avg"] * 1e3}
 
 
+def aggregation_roofline(cfg_name="5", C=64, reps=20):
+    """HBM roofline of the sparse aggregation kernel (csr_mean: per-node mean over the CSR edge range,
+    torch_vertex.py:333-335 'mean' aggr) on a cfg-5-sized graph, where the E x C message matrix (307 MB)
+    does not fit in L2/MALL.  Algorithmic bytes per launch = E*C*4 (messages) + N*C*4 (output) +
+    (N+1)*4 (row_ptr); timed with HIP events on the launch stream."""
+    import yolat_vectorgraphicsrecognition_amd as yv
+    data, _, _, _ = yv.config(cfg_name)
+    g = yv.ops.build_graph(data.edge.cuda(), data.e_attr.cuda(), data.bbox_idx.cuda(), int(data.x.shape[0]),
+                           int(data.bbox.shape[0]))
+    E, N = g.E, g.N
+    H = torch.randn(E, C, device="cuda")
+    sc, sh = torch.rand(C, device="cuda") + 0.5, torch.randn(C, device="cuda")
+    out = torch.empty(N, C, device="cuda")
+    for _ in range(3):
+        yv.ops.csr_mean_fwd(H, g, out, h_pro=(sc, sh), h_relu=True)
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        yv.ops.csr_mean_fwd(H, g, out, h_pro=(sc, sh), h_relu=True)
+    e.record()
+    torch.cuda.synchronize()
+    t = s.elapsed_time(e) * 1e-3 / reps
+    by = 4.0 * (E * C + N * C + N + 1)
+    ach = by / t / 1e9
+    return {"kernel": "csr_mean_fwd[E=%d x C=%d -> N=%d] (BN+ReLU prologue fused)" % (E, C, N), "bound": "hbm",
+            "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": ach / PEAK_HBM_GBS, "traffic": None,
+            "avg_launch_us": t * 1e6, "bytes_per_launch": by}
+
+
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the op-for-op torch oracle on the host cores (bounded sample)
 # ---------------------------------------------------------------------------------------------
@@ -281,6 +310,10 @@ def main():
         roof["note"] = ("dominant op by HIP-event time inside this run; algorithmic flops/bytes per launch in "
                         "DESIGN.md; traffic: PMC pass not collected in-process")
 
+    agg = None
+    if rank == 0 and not args.no_roofline:
+        agg = aggregation_roofline()
+
     cpu = None
     if rank == 0 and not args.no_cpu_baseline:
         cpu = cpu_baseline(cfg, optkw, args.mode)
@@ -311,6 +344,7 @@ def main():
                        "csr_rebuilt_each_step": not args.keep_csr,
                        "parallelism": "replicas (graph-id sharding)" if args.mode == "fwd" else "dp%d" % world},
             "roofline": roof,
+            "roofline_aggregation": agg,
             "cpu_baseline": cpu,
         }
         if op_table is not None:

@@ -116,12 +116,69 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd(const float* H, long ldh, 
   }
 }
 
+// C == 4*LPN, 16-byte aligned rows: LPN lanes own one node (one float4 of columns each), 64/LPN nodes per
+// wave, up to 8 rows (8 x 16 B per lane) in flight per lane.  Per-column summation order is unchanged
+// (ascending CSR slot), so results are bit-identical to the scalar kernel above.
+template <int LPN>
+__global__ void __launch_bounds__(256) k_csr_mean_fwd_v4(const float* __restrict__ H, long ldh,
+                                                         const float* hs, const float* hb, int relu,
+                                                         const int* __restrict__ row_ptr, int N,
+                                                         float* out, long ldo, int accumulate) {
+  const int sub = threadIdx.x % LPN;
+  const int n = blockIdx.x * (256 / LPN) + threadIdx.x / LPN;
+  if (n >= N) return;
+  const int q0 = row_ptr[n], q1 = row_ptr[n + 1];
+  const float inv = 1.f / (float)((q1 - q0) > 1 ? (q1 - q0) : 1);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (hs) {
+    sc = *reinterpret_cast<const float4*>(hs + 4 * sub);
+    sh = *reinterpret_cast<const float4*>(hb + 4 * sub);
+  }
+  const float floor = relu ? 0.f : -INFINITY;
+  const float* hp = H + 4 * sub;
+  float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto add = [&](const float4& v) {
+    s.x += fmaxf(fmaf(v.x, sc.x, sh.x), floor);
+    s.y += fmaxf(fmaf(v.y, sc.y, sh.y), floor);
+    s.z += fmaxf(fmaf(v.z, sc.z, sh.z), floor);
+    s.w += fmaxf(fmaf(v.w, sc.w, sh.w), floor);
+  };
+  int q = q0;
+  for (; q + 8 <= q1; q += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)(q + j) * ldh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) add(v[j]);
+  }
+  if (q < q1) {   // 1..7 remaining rows: clamped (re-read) addresses keep the loads unconditional
+    float4 v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)yl_min(q + j, q1 - 1) * ldh);
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (q + j < q1) add(v[j]);
+  }
+  s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+  float4* o = reinterpret_cast<float4*>(out + (long)n * ldo + 4 * sub);
+  if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+  *o = s;
+}
+
 extern "C" int yolat_csr_mean_fwd(const float* H, int64_t ldh, int64_t C, const float* h_scale,
                                   const float* h_shift, int h_relu, const int32_t* row_ptr,
                                   int64_t N, float* out, int64_t ldo, int accumulate,
                                   yolat_stream_t stream) {
   if (N <= 0 || C <= 0 || !row_ptr || !out || ldo < C) return YOLAT_E_INVALID;
   if ((h_scale == nullptr) != (h_shift == nullptr)) return YOLAT_E_INVALID;
+  const bool al16 = ((uintptr_t)H % 16 == 0) && ((uintptr_t)out % 16 == 0) && ldh % 4 == 0 && ldo % 4 == 0 &&
+                    (!h_scale || ((uintptr_t)h_scale % 16 == 0 && (uintptr_t)h_shift % 16 == 0));
+  if (C == 64 && al16) {
+    hipLaunchKernelGGL(k_csr_mean_fwd_v4<16>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, H,
+                       (long)ldh, h_scale, h_shift, h_relu, row_ptr, (int)N, out, (long)ldo, accumulate);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_csr_mean_fwd, dim3(yl_cdiv(N, 4)), dim3(256), 0, (hipStream_t)stream, H,
                      (long)ldh, (int)C, h_scale, h_shift, h_relu, row_ptr, (int)N, out, (long)ldo,
                      accumulate);
