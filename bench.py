@@ -144,7 +144,24 @@ def plan_profile(step, n):
     return out
 
 
-def roofline_entry(summary):
+# HBM/fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
+# runs of this same command: profiles/r01_fwd_cfg2_pmc_{fetch,write}_v3.txt; FETCH_SIZE doubled per the gfx950
+# note in MI355X_MICROARCH.md §HBM, KiB -> bytes).  Only valid for the default cfg-2 workload.
+PMC_TRAFFIC_CFG2 = {
+    "fusion_gemm+segmax[N x 128 -> 1024 -> P]": 2 * 4783.4 * 1024 + 6380.3 * 1024,
+}
+
+
+def roofline_entry(summary, cfg=None):
+    r = _roofline_entry(summary)
+    if cfg == "2" and r["kernel"] in PMC_TRAFFIC_CFG2:
+        r["traffic"] = PMC_TRAFFIC_CFG2[r["kernel"]]
+        r["traffic_source"] = "profiles/r01_fwd_cfg2_pmc_fetch_v3.txt (x2, gfx950) + r01_fwd_cfg2_pmc_write_v3.txt"
+        r["algorithmic_bytes"] = summary[r["kernel"]]["bytes"]
+    return r
+
+
+def _roofline_entry(summary):
     label, rec = max(summary.items(), key=lambda kv: kv[1]["ms_total"])
     t = rec["ms_avg"] * 1e-3
     intensity = rec["flops"] / max(rec["bytes"], 1.0)
@@ -306,9 +323,10 @@ def main():
                 for _ in range(nprof):
                     step()
                 op_table = timer.summary()
-        roof = roofline_entry(op_table)
+        roof = roofline_entry(op_table, str(cfg) if args.mode == "fwd" else None)
         roof["note"] = ("dominant op by HIP-event time inside this run; algorithmic flops/bytes per launch in "
-                        "DESIGN.md; traffic: PMC pass not collected in-process")
+                        "DESIGN.md; traffic: from the committed separate --pmc passes (null when none exists for "
+                        "this workload)")
 
     agg = None
     if rank == 0 and not args.no_roofline:

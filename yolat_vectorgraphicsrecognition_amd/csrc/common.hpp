@@ -168,6 +168,22 @@ struct EdgeWcOp {
   }
 };
 
+// XCD-aware workgroup -> tile map.  The dispatcher places linear workgroup id b on XCD b % 8 (observed,
+// MI355X_MICROARCH.md "Workgroup dispatch"); each XCD has a private 4 MiB L2.  With the plain (x, y) map
+// the gridDim.y workgroups that share one A row-tile land on 8 different XCDs, and every one of them
+// pulls the tile over the fabric (PMC: 79 MB fetched for the 5.6 MB fusion GEMM at cfg 2).  Here XCD x
+// owns a contiguous range of row-major (row-tile, col-tile) pairs, column tile fastest, so the sharers of
+// an A tile run back-to-back on one XCD and hit its L2.  A speed choice only: any placement is correct.
+__device__ __forceinline__ void yl_xcd_tile(int& rt, int& ct) {
+  const int tm = gridDim.x, tn = gridDim.y;
+  const int total = tm * tn, id = blockIdx.x + tm * blockIdx.y;
+  const int chunk = total >> 3, rem = total & 7;
+  const int xcd = id & 7, slot = id >> 3;
+  const int logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
+  rt = logical / tn;
+  ct = logical - rt * tn;
+}
+
 // ------------------------------------------------------------------------------------------------
 // Epilogue of the NT GEMM
 // ------------------------------------------------------------------------------------------------
@@ -294,7 +310,9 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int row0 = blockIdx.x * BM, col0 = blockIdx.y * BN;
+  int rt_, ct_;
+  yl_xcd_tile(rt_, ct_);
+  const int row0 = rt_ * BM, col0 = ct_ * BN;
   const bool fastA = A.vec != 0, fastB = B.vec != 0;
 
   f32x16 acc[TM][TN];
@@ -399,7 +417,9 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
   float* Bs = smem + BT * LD;
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int l31 = lane & 31, lhi = lane >> 5;
-  const int row0 = blockIdx.x * BT, col0 = blockIdx.y * BT;
+  int rt_, ct_;
+  yl_xcd_tile(rt_, ct_);
+  const int row0 = rt_ * BT, col0 = ct_ * BT;
   const bool fastA = A.vec != 0, fastB = B.vec != 0;
   // Staging map: float4 slot i (0..1023) -> (row, kq).  32 consecutive lanes cover a 4-row x 8-kq patch:
   // each row gets a full 128-B line from global, and with LD = 129 the ds_write_b32 banks
