@@ -70,7 +70,9 @@ int yolat_coo_to_csr(const int64_t* edge, int64_t stride_e, int64_t stride_c, in
                      int32_t* work, int32_t* status, yolat_stream_t stream);
 
 /* CSC by source over the CSR slots (needed only by the backward scatter to x[src]):
- *   col_ptr[N+1], slots[E] = CSR slots of the edges leaving each node, ascending.               */
+ *   col_ptr[N+1], slots[E] = CSR slots of the edges leaving each node, ascending.
+ *   work: int32 scratch of yolat_csc_work_elems(N) elements.                                    */
+size_t yolat_csc_work_elems(int64_t N);
 int yolat_csc_by_source(const int32_t* src_csr, int64_t E, int64_t N, int32_t* col_ptr,
                         int32_t* slots, int32_t* work, yolat_stream_t stream);
 
@@ -251,9 +253,11 @@ int yolat_segment_max_bwd(const float* dY, int64_t lddy, int64_t D, const int32_
 
 /* nn.CrossEntropyLoss() (mean over P) of architecture3cc_rpn_gp_iter2.py:363,376.
  * loss[0] = mean_p( logsumexp(z_p) - z_p[label_p] );  dlogits[P,K] = (softmax - onehot)/P
- * (dlogits nullable).  Deterministic single-workgroup reduction.                                 */
+ * (dlogits nullable).  work: fp32 scratch of yolat_softmax_ce_work_elems(P) elements (per-workgroup
+ * partial sums, added in a fixed order -> deterministic); NULL selects a single-workgroup kernel.   */
+size_t yolat_softmax_ce_work_elems(int64_t P);
 int yolat_softmax_ce(const float* logits, int64_t ld, const int64_t* labels, int64_t P, int64_t K,
-                     float* loss, float* dlogits, int64_t lddl, yolat_stream_t stream);
+                     float* loss, float* dlogits, int64_t lddl, float* work, yolat_stream_t stream);
 
 /* torch.optim.Adam step (train.py:212: lr, weight_decay as L2-in-grad, betas (0.9,0.999),
  * eps 1e-8, no amsgrad) over one flat fp32 buffer of n elements; `step` is the 1-based step.     */

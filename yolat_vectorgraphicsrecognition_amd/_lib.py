@@ -41,6 +41,7 @@ SIGNATURES = {
     "yolat_strerror": (ctypes.c_char_p, [c_int]),
     "yolat_csr_work_elems": (c_sz, [c_i64, c_i64]),
     "yolat_coo_to_csr": (c_int, [c_p, c_i64, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_graph_work_elems": (c_sz, [c_i64, c_i64]),
@@ -77,7 +78,8 @@ SIGNATURES = {
     "yolat_pool_prepare": (c_int, [c_p, c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_segment_mean_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_segment_max_bwd": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
-    "yolat_softmax_ce": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p]),
+    "yolat_softmax_ce_work_elems": (c_sz, [c_i64]),
+    "yolat_softmax_ce": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p]),
     "yolat_adam_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p]),
     "yolat_profile_enable": (c_int, [c_int]),
     "yolat_profile_reset": (c_int, []),

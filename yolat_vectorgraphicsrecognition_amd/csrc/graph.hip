@@ -140,22 +140,35 @@ extern "C" int yolat_coo_to_csr(const int64_t* edge, int64_t stride_e, int64_t s
   return 0;
 }
 
+// col_ptr[i] = block-local exclusive scan + prefix of the block totals; the counters are zeroed so they
+// can serve as the fill cursors.  n = N + 1 (the last element is the grand total).
+__global__ void k_csc_ptr(int* local, const int* btot, int n, int* ptr);
+__global__ void __launch_bounds__(1024) k_prep_scan(const int* cnt, int n, int* local, int* btot);
+
+extern "C" size_t yolat_csc_work_elems(int64_t N) { return (size_t)(N + 1 + (N + 1 + 4095) / 4096 + 16); }
+
 extern "C" int yolat_csc_by_source(const int32_t* src_csr, int64_t E, int64_t N, int32_t* col_ptr,
                                    int32_t* slots, int32_t* work, yolat_stream_t stream) {
   if (N <= 0 || E < 0 || !col_ptr || !work || (E > 0 && (!src_csr || !slots)))
     return YOLAT_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
-  hipError_t err = hipMemsetAsync(work, 0, sizeof(int) * (size_t)N, st);
+  const int n1 = (int)N + 1;
+  int* cnt = work;             // [N+1] counters -> block-local scan (in place) -> fill cursors
+  int* btot = work + n1;       // [ceil((N+1)/4096)]
+  hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n1, st);
   if (err != hipSuccess) return (int)err;
   if (E > 0) {
-    hipLaunchKernelGGL(k_count32, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, src_csr, (int)E, work);
+    hipLaunchKernelGGL(k_count32, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, src_csr, (int)E, cnt);
     YL_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_scan_excl, dim3(1), dim3(1024), 0, st, work, (int)N, col_ptr);
+  // multi-workgroup scan (a single-workgroup sweep over N = 174k took 121 us)
+  hipLaunchKernelGGL(k_prep_scan, dim3(yl_cdiv(n1, 4096)), dim3(1024), 0, st, cnt, n1, cnt, btot);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_csc_ptr, dim3(yl_cdiv(n1, 256)), dim3(256), 0, st, cnt, btot, n1, col_ptr);
   YL_LAUNCH_CHECK();
   if (E > 0) {
     hipLaunchKernelGGL(k_fill, dim3(yl_cdiv(E, 256)), dim3(256), 0, st, src_csr, (int)E, col_ptr,
-                       work, slots);
+                       cnt, slots);
     YL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_sort_rows, dim3(yl_cdiv(N, 256)), dim3(256), 0, st, col_ptr, slots, (int)N);
     YL_LAUNCH_CHECK();
@@ -267,6 +280,13 @@ __device__ __forceinline__ int prep_prefix(const int* btot, int b) {
   int s = 0;
   for (int i = 0; i < b; ++i) s += btot[i];
   return s;
+}
+
+__global__ void k_csc_ptr(int* local, const int* btot, int n, int* ptr) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  ptr[i] = local[i] + prep_prefix(btot, i / PREP_BLK);
+  local[i] = 0;
 }
 
 __global__ void k_prep_fill(const int* dst32, const int* rank, int E, const int* local, const int* btot,

@@ -38,12 +38,80 @@ __global__ void __launch_bounds__(1024) k_softmax_ce(const float* logits, long l
   if (tid == 0) loss[0] = red[0] * invP;
 }
 
+// Multi-workgroup variant: one row per thread, 256 rows per workgroup; the row is held in registers
+// (K <= 32: all loads independent, one expf per element), the workgroup's loss sum goes to work[wg] via a
+// fixed-order tree, and k_ce_final adds the per-workgroup sums in a fixed order -> run-to-run deterministic.
+template <int KMAX>
+__global__ void __launch_bounds__(256) k_softmax_ce_rows(const float* logits, long ld, const int64_t* labels,
+                                                         int P, int K, float* work, float* dl, long lddl) {
+  __shared__ float red[256];
+  const int tid = threadIdx.x;
+  const int p = blockIdx.x * 256 + tid;
+  float row_loss = 0.f;
+  if (p < P) {
+    const float* z = logits + (long)p * ld;
+    float v[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) v[k] = z[k < K ? k : K - 1];
+    float m = v[0];
+#pragma unroll
+    for (int k = 1; k < KMAX; ++k) m = fmaxf(m, v[k]);
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+      v[k] = expf(v[k] - m);
+      s += (k < K) ? v[k] : 0.f;
+    }
+    const int y = (int)labels[p];
+    row_loss = m + logf(s) - z[y];
+    if (dl != nullptr) {
+      const float invs = 1.f / s, invP = 1.f / (float)P;
+      float* d = dl + (long)p * lddl;
+#pragma unroll
+      for (int k = 0; k < KMAX; ++k)
+        if (k < K) d[k] = (v[k] * invs - (k == y ? 1.f : 0.f)) * invP;
+    }
+  }
+  red[tid] = row_loss;
+  __syncthreads();
+  for (int st = 128; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) work[blockIdx.x] = red[0];
+}
+
+__global__ void __launch_bounds__(1024) k_ce_final(const float* work, int n, int P, float* loss) {
+  __shared__ float red[1024];
+  const int tid = threadIdx.x;
+  float a = 0.f;
+  for (int i = tid; i < n; i += 1024) a += work[i];
+  red[tid] = a;
+  __syncthreads();
+  for (int st = 512; st > 0; st >>= 1) {
+    if (tid < st) red[tid] += red[tid + st];
+    __syncthreads();
+  }
+  if (tid == 0) loss[0] = red[0] / (float)P;
+}
+
+extern "C" size_t yolat_softmax_ce_work_elems(int64_t P) { return (size_t)((P + 255) / 256 + 1); }
+
 extern "C" int yolat_softmax_ce(const float* logits, int64_t ld, const int64_t* labels, int64_t P,
-                                int64_t K, float* loss, float* dlogits, int64_t lddl,
+                                int64_t K, float* loss, float* dlogits, int64_t lddl, float* work,
                                 yolat_stream_t stream) {
   if (P <= 0 || K <= 0 || !logits || !labels || !loss || ld < K || P >= (1LL << 31))
     return YOLAT_E_INVALID;
   if (dlogits && lddl < K) return YOLAT_E_INVALID;
+  if (work != nullptr && K <= 32) {
+    const int nwg = yl_cdiv(P, 256);
+    hipLaunchKernelGGL(k_softmax_ce_rows<32>, dim3(nwg), dim3(256), 0, (hipStream_t)stream, logits, (long)ld,
+                       labels, (int)P, (int)K, work, dlogits, (long)lddl);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_ce_final, dim3(1), dim3(1024), 0, (hipStream_t)stream, work, nwg, (int)P, loss);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_softmax_ce, dim3(1), dim3(1024), 0, (hipStream_t)stream, logits, (long)ld,
                      labels, (int)P, (int)K, loss, dlogits, (long)lddl);
   YL_LAUNCH_CHECK();

@@ -63,7 +63,7 @@ class Graph(object):
             dev = self.row_ptr.device
             self.col_ptr = torch.empty(self.N + 1, dtype=torch.int32, device=dev)
             self.slots = torch.empty(max(self.E, 1), dtype=torch.int32, device=dev)
-            work = torch.empty(self.N, dtype=torch.int32, device=dev)
+            work = torch.empty(int(lib.yolat_csc_work_elems(self.N)), dtype=torch.int32, device=dev)
             check(lib.yolat_csc_by_source(self.src.data_ptr(), self.E, self.N, self.col_ptr.data_ptr(),
                                           self.slots.data_ptr(), work.data_ptr(), _stream()),
                   "yolat_csc_by_source")
@@ -309,9 +309,11 @@ def segment_max_bwd(dY, arg, g, dX):
 
 def softmax_ce(logits, labels, loss, dlogits=None):
     P, K = logits.shape
+    work = torch.empty(int(lib.yolat_softmax_ce_work_elems(P)), dtype=torch.float32, device=logits.device)
     check(lib.yolat_softmax_ce(_f(logits), _ld(logits), _i(labels, torch.int64, "labels"), P, K,
                                _f(loss), _f(dlogits, "dlogits", True),
-                               _ld(dlogits) if dlogits is not None else K, _stream()), "yolat_softmax_ce")
+                               _ld(dlogits) if dlogits is not None else K, work.data_ptr(), _stream()),
+          "yolat_softmax_ce")
     return loss
 
 
