@@ -266,6 +266,47 @@ class Backbone(nn.Module):
         return out_feat, out_feat_super
 
 
+def predict_gather(data, slices, has_object):                                                            # :153-164, :277-296
+    roots, slice_root = data.roots, slices["roots"]
+    slice_pos, slice_edge, slice_bbox, image_off = [], [], [], [0]
+    count = 0
+    for i in range(0, len(slice_root) - 1):
+        for root in roots[int(slice_root[i]):int(slice_root[i + 1])]:
+            if has_object is None:
+                nodes = [root]
+            else:
+                nodes = root.children if bool(has_object[count]) else []
+                count += 1
+            for nd in nodes:
+                slice_pos += list(range(nd.value["idx_pos"][0] + int(slices["pos"][i]),
+                                        nd.value["idx_pos"][1] + int(slices["pos"][i])))
+                slice_edge += list(range(nd.value["idx_edge"][0] + int(slices["edge"][i]),
+                                         nd.value["idx_edge"][1] + int(slices["edge"][i])))
+                _ = slices["edge_super"][i]
+                slice_bbox.append(int(nd.value["idx_bbox"] + int(slices["bbox"][i])))
+        image_off.append(len(slice_bbox))
+    return slice_pos, slice_edge, slice_bbox, image_off
+
+def predict_build_data(data, slice_pos, slice_edge, slice_bbox):                                 # :166-242
+    o2n = {}
+    for new_i, old_i in enumerate(slice_pos):
+        o2n[old_i] = new_i
+    nd = data.__class__(x=data.x[slice_pos], pos=data.pos[slice_pos])
+    old_idx = data.bbox_idx[slice_pos]
+    edge = [[o2n[int(e[0])], o2n[int(e[1])]] for e in data.edge[slice_edge].numpy()]
+    nd.edge = torch.tensor(edge, dtype=torch.long).reshape(-1, 2)
+    nd.e_attr = data.e_attr[slice_edge]
+    nd.bbox = data.bbox[slice_bbox]
+    nd.stat_feats = data.stat_feats[slice_bbox]
+    new_idx, count = [0], 0
+    for i in range(1, old_idx.size(0)):
+        if old_idx[i] != old_idx[i - 1]:
+            count += 1
+        new_idx.append(count)
+    nd.bbox_idx = torch.tensor(new_idx, dtype=torch.long)
+    return nd
+
+
 class SparseCADGCN(nn.Module):
     """cad_recognition/architecture3cc_rpn_gp_iter2.py:73-137 (forward only; CPU, no .cuda())."""
 
@@ -301,6 +342,38 @@ class SparseCADGCN(nn.Module):
         if self.classifier != "softmax":
             pred_cls = torch.sigmoid(pred_cls)
         return pred_cls, pred_bbox
+
+
+    def predict(self, data, slices):                                                       # :139-356
+        """Two-pass root/children inference, restated loop for loop (the element-wise Python loops of
+        the reference are kept on purpose: this is the checker for the product's vectorised slicing)."""
+        sp, se, sb_root, img_root = predict_gather(data, slices, None)
+        pred_cls, pred_bbox = self.forward(predict_build_data(data, sp, se, sb_root), slices)
+        _, is_object = pred_cls.max(1)
+        has_object = is_object == self.n_classes - 1
+        sp, se, sb_child, img_child = predict_gather(data, slices, has_object)
+        if len(sp) == 0:
+            slice_image_bbox, slice_bbox = img_root, sb_root
+        else:
+            pred_cls2, pred_bbox2 = self.forward(predict_build_data(data, sp, se, sb_child), slices)
+
+            def interleaf(out_p, out_c):                                                   # :317-328
+                out, s = [], [0]
+                for i in range(len(img_child) - 1):
+                    out.append(out_p[img_root[i]:img_root[i + 1]])
+                    out.append(out_c[img_child[i]:img_child[i + 1]])
+                    s.append(s[-1] + img_root[i + 1] - img_root[i] + img_child[i + 1] - img_child[i])
+                return torch.cat(out, dim=0), s
+            pred_cls, slice_image_bbox = interleaf(pred_cls, pred_cls2)
+            pred_bbox, _ = interleaf(pred_bbox, pred_bbox2)
+            slice_bbox, _ = interleaf(torch.tensor(sb_root), torch.tensor(sb_child))
+        w = (pred_bbox[:, 2] - pred_bbox[:, 0]) * 1.05                                     # :338-351
+        h = (pred_bbox[:, 3] - pred_bbox[:, 1]) * 1.05
+        cx = (pred_bbox[:, 2] + pred_bbox[:, 0]) / 2
+        cy = (pred_bbox[:, 3] + pred_bbox[:, 1]) / 2
+        pred_bbox = torch.cat([(cx - w / 2).unsqueeze(1), (cy - h / 2).unsqueeze(1),
+                               (cx + w / 2).unsqueeze(1), (cy + h / 2).unsqueeze(1)], dim=1)
+        return pred_cls, pred_bbox, None, slice_bbox, slice_image_bbox, None
 
 
 class DetectionLoss(nn.Module):

@@ -151,3 +151,21 @@ def run_case(model, loss_mod, data, lr=2.5e-4, wd=1e-5):
         if not n.endswith("num_batches_tracked"):
             out["buffer_after/" + n] = b.detach().clone()
     return out
+
+
+PREDICT_CASE = dict(n_graphs=2, seed=77, num_proposals=14, nodes_lo=4, nodes_hi=9, edge_factor=1.5,
+                    n_classes=3, with_roots=True)
+PREDICT_OPT = dict(n_classes=3, n_blocks=2, n_blocks_out=2)
+
+
+def predict_case(synth_batch, dtype=torch.float32):
+    """The two-pass inference fixture's inputs: 2 collated synthetic items with proposal trees."""
+    data, slices = synth_batch(**PREDICT_CASE)
+    data.x = data.x.to(dtype)
+    data.e_attr = data.e_attr.to(dtype)
+    return data, slices
+
+
+def input_checksum(data):
+    return np.array([float(data.x.double().sum()), float(data.edge.sum()), float(data.e_attr.double().abs().sum()),
+                     float(data.bbox_idx.sum()), float(len(data.roots))], dtype=np.float64)

@@ -238,3 +238,30 @@ def test_bad_inputs_raise():
     model(data, None)
     with pytest.raises(IndexError):
         data._yolat_stage[1]["g"].check_status()
+
+
+def test_predict_two_pass_matches_reference_golden(golden_dir):
+    """SparseCADGCN.predict (arch:139-356): both forwards on the HIP path, slicing on the host."""
+    yv = _yv()
+    z = np.load(os.path.join(golden_dir, "predict.npz"))
+    data, slices = gu.predict_case(yv.synth_batch)
+    np.testing.assert_array_equal(gu.input_checksum(data), z["input_checksum"])
+    model = _model(yv, gu.PREDICT_OPT, int(z["seed"]))
+    assert gu.state_hash(model) == str(z["state_hash"])
+    model.eval()
+    with torch.no_grad():
+        cls, bbox, n1, slice_bbox, slice_image_bbox, n2 = model.predict(data, slices)
+    assert n1 is None and n2 is None and cls.is_cuda
+    np.testing.assert_array_equal(np.array([int(v) for v in slice_bbox]), z["slice_bbox"])       # bit-exact
+    np.testing.assert_array_equal(np.array(slice_image_bbox), z["slice_image_bbox"])
+    ref = z["pred_cls"]
+    np.testing.assert_allclose(cls.cpu().numpy(), ref, rtol=RTOL_FWD, atol=RTOL_FWD * np.abs(ref).max())
+    np.testing.assert_allclose(bbox.cpu().numpy(), z["pred_bbox"], rtol=1e-6, atol=1e-7)
+    # first-pass-only branch: no proposal is classified as "has object" when that class is impossible
+    with torch.no_grad():
+        last = model.prediction_cls[2][0].bias if hasattr(model.prediction_cls[2], "__getitem__") else None
+    if last is not None:
+        with torch.no_grad():
+            last[model.n_classes - 1] = -1e4
+            out = model.predict(data, slices)
+        assert len(out[3]) == len(data.roots) and out[4][-1] == len(data.roots)

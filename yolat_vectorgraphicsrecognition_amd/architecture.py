@@ -159,6 +159,39 @@ class SparseCADGCN(nn.Module):
             pred_cls = torch.sigmoid(pred_cls)
         return pred_cls, st["bbox"]
 
+    def predict(self, data, slices):
+        """Two-pass root/children inference, arch:139-356: forward on the sub-batch of all root
+        proposals; proposals classified as class ``n_classes-1`` get their children evaluated in a
+        second forward; per image the root rows are followed by the child rows; boxes are enlarged by
+        5 %.  Returns the reference's 6-tuple ``(pred_cls, pred_bbox, None, slice_bbox,
+        slice_image_bbox, None)``.  The slicing is host work (numpy, `data.select_tree_nodes` /
+        `data.build_subset`); both forwards run through the HIP path."""
+        from .data import select_tree_nodes, build_subset, interleave_root_child
+        sp, se, slice_bbox_root, image_root = select_tree_nodes(data, slices)
+        sub = build_subset(data, sp, se, slice_bbox_root)
+        pred_cls, pred_bbox = self.forward(sub, slices)
+        is_object = pred_cls.max(1)[1]
+        has_object = (is_object == self.n_classes - 1).cpu().numpy()     # D2H sync, as in the reference
+        sp, se, slice_bbox_child, image_child = select_tree_nodes(data, slices, has_object)
+        if len(sp) == 0:
+            slice_image_bbox, slice_bbox = image_root, slice_bbox_root
+        else:
+            sub2 = build_subset(data, sp, se, slice_bbox_child)
+            pred_cls2, pred_bbox2 = self.forward(sub2, slices)
+            parts, slice_image_bbox = interleave_root_child(image_root, image_child, pred_cls, pred_cls2)
+            pred_cls = torch.cat(parts, dim=0)
+            parts, _ = interleave_root_child(image_root, image_child, pred_bbox, pred_bbox2)
+            pred_bbox = torch.cat(parts, dim=0)
+            parts, _ = interleave_root_child(image_root, image_child, torch.tensor(slice_bbox_root),
+                                             torch.tensor(slice_bbox_child))
+            slice_bbox = torch.cat(parts, dim=0)
+        w = (pred_bbox[:, 2] - pred_bbox[:, 0]) * 1.05
+        h = (pred_bbox[:, 3] - pred_bbox[:, 1]) * 1.05
+        cx = (pred_bbox[:, 2] + pred_bbox[:, 0]) / 2
+        cy = (pred_bbox[:, 3] + pred_bbox[:, 1]) / 2
+        pred_bbox = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], dim=1)
+        return pred_cls, pred_bbox, None, slice_bbox, slice_image_bbox, None
+
     def forward_scheduled(self, data, slices=None):
         """The Python-scheduled kernel sequence (engine.model_fwd) regardless of mode — the training
         path; in eval mode it must agree with the eval plan."""

@@ -109,11 +109,138 @@ def fixup_offsets(data, slices):
 
 
 # --------------------------------------------------------------------------------------
+# two-pass inference support: root / children proposal tree and sub-batch extraction
+# (architecture3cc_rpn_gp_iter2.py:139-242; tree nodes: Datasets/graph_dict3.py:24-27,745-767)
+# --------------------------------------------------------------------------------------
+
+class idxTree(object):
+    """Node of the proposal tree a dataset item carries in ``data.roots``: ``value`` holds the
+    item-local ranges ``idx_pos``, ``idx_edge``, ``idx_edge_super`` (start, end) and ``idx_bbox``."""
+
+    def __init__(self):
+        self.children = []
+        self.value = {}
+
+
+def _expand_ranges(starts, ends):
+    """Concatenation of ``range(s, e)`` for every (s, e) pair, as one int64 array."""
+    starts = np.asarray(starts, dtype=np.int64)
+    lens = np.asarray(ends, dtype=np.int64) - starts
+    if np.any(lens < 0):
+        raise ValueError("idx range with end < start")
+    total = int(lens.sum())
+    if total == 0:
+        return np.zeros(0, dtype=np.int64)
+    first = np.cumsum(lens) - lens
+    return np.repeat(starts - first, lens) + np.arange(total, dtype=np.int64)
+
+
+def select_tree_nodes(data, slices, has_object=None):
+    """First (``has_object is None``) or second pass selection of arch:153-164 / :277-296.
+    Returns (slice_pos, slice_edge, slice_bbox, slice_image_bbox): global node ids, global edge rows,
+    global proposal rows (python list) and per-image offsets into slice_bbox."""
+    roots = data.roots
+    slice_root = [int(v) for v in slices["roots"]]
+    pos_s, pos_e, edge_s, edge_e, slice_bbox, image_off = [], [], [], [], [], [0]
+    count = 0
+    for i in range(len(slice_root) - 1):
+        off_pos, off_edge, off_bbox = int(slices["pos"][i]), int(slices["edge"][i]), int(slices["bbox"][i])
+        int(slices["edge_super"][i])               # the reference reads it (KeyError if absent)
+        for root in roots[slice_root[i]:slice_root[i + 1]]:
+            if has_object is None:
+                nodes = (root,)
+            else:
+                nodes = root.children if has_object[count] else ()
+                count += 1
+            for nd in nodes:
+                v = nd.value
+                pos_s.append(v["idx_pos"][0] + off_pos)
+                pos_e.append(v["idx_pos"][1] + off_pos)
+                edge_s.append(v["idx_edge"][0] + off_edge)
+                edge_e.append(v["idx_edge"][1] + off_edge)
+                slice_bbox.append(int(v["idx_bbox"] + off_bbox))
+        image_off.append(len(slice_bbox))
+    return _expand_ranges(pos_s, pos_e), _expand_ranges(edge_s, edge_e), slice_bbox, image_off
+
+
+def build_subset(data, slice_pos, slice_edge, slice_bbox):
+    """``build_data`` of arch:166-242 without the per-element Python loops: node re-numbering through
+    a lookup table, run-length renumbering of ``bbox_idx``.  Integer results identical to the loops."""
+    N = data.x.shape[0]
+    sp = torch.from_numpy(slice_pos)
+    se = torch.from_numpy(slice_edge)
+    o2n = np.full(N, -1, dtype=np.int64)
+    o2n[slice_pos] = np.arange(len(slice_pos), dtype=np.int64)    # later duplicates win, like the dict
+    new = data.__class__(x=data.x[sp], pos=data.pos[sp])
+    old_edge = data.edge[se].numpy()
+    new_edge = o2n[old_edge] if len(old_edge) else np.zeros((0, 2), dtype=np.int64)
+    if (new_edge < 0).any():
+        bad = old_edge[(new_edge < 0)][0]
+        raise KeyError(int(bad))                                    # the reference's o2n[...] KeyError
+    new.edge = torch.from_numpy(new_edge.reshape(-1, 2))
+    new.e_attr = data.e_attr[se]
+    sb = torch.tensor(slice_bbox, dtype=torch.long)
+    new.bbox = data.bbox[sb]
+    new.stat_feats = data.stat_feats[sb]
+    old_idx = data.bbox_idx[sp].numpy()
+    if len(old_idx):
+        change = np.concatenate([[0], (old_idx[1:] != old_idx[:-1]).astype(np.int64)])
+        new.bbox_idx = torch.from_numpy(np.cumsum(change))
+    else:
+        new.bbox_idx = torch.zeros(0, dtype=torch.long)
+    return new
+
+
+def interleave_root_child(slice_p, slice_c, out_p, out_c):
+    """``interleaf_pc`` of arch:317-328: per image, the root rows followed by the child rows."""
+    out, s = [], [0]
+    for i in range(len(slice_c) - 1):
+        out.append(out_p[slice_p[i]:slice_p[i + 1]])
+        out.append(out_c[slice_c[i]:slice_c[i + 1]])
+        s.append(s[-1] + slice_p[i + 1] - slice_p[i] + slice_c[i + 1] - slice_c[i])
+    return out, s
+
+
+def synth_roots(item, seed, cluster_lo=1, cluster_hi=4):
+    """Proposal tree for a ``synth_graph`` item (needs its edges grouped by proposal, which
+    synth_graph guarantees): consecutive proposals form clusters of U{lo..hi}; the member with the
+    largest box area is the root, the others its children (graph_dict3.py:740-767)."""
+    rng = np.random.default_rng(seed)
+    bbox_idx = item.bbox_idx.numpy()
+    P = int(item.bbox.shape[0])
+    node_ptr = np.searchsorted(bbox_idx, np.arange(P + 1))
+    owner = bbox_idx[item.edge[:, 0].numpy()] if item.edge.shape[0] else np.zeros(0, dtype=np.int64)
+    if len(owner) and np.any(owner[1:] < owner[:-1]):
+        raise ValueError("edges are not grouped by proposal")
+    edge_ptr = np.searchsorted(owner, np.arange(P + 1))
+    box = item.bbox.numpy()
+    area = (box[:, 2] - box[:, 0]) * (box[:, 3] - box[:, 1])
+    roots, p = [], 0
+    while p < P:
+        k = min(int(rng.integers(cluster_lo, cluster_hi + 1)), P - p)
+        members = list(range(p, p + k))
+        top = p + int(np.argmax(area[p:p + k]))
+        nodes = {}
+        for m in members:
+            t = idxTree()
+            t.value["idx_pos"] = (int(node_ptr[m]), int(node_ptr[m + 1]))
+            t.value["idx_edge"] = (int(edge_ptr[m]), int(edge_ptr[m + 1]))
+            t.value["idx_edge_super"] = (0, 0)
+            t.value["idx_bbox"] = m
+            nodes[m] = t
+        root = nodes[top]
+        root.children = [nodes[m] for m in members if m != top]
+        roots.append(root)
+        p += k
+    return roots
+
+
+# --------------------------------------------------------------------------------------
 # synthetic graphs (SURVEY.md §8 d)
 # --------------------------------------------------------------------------------------
 
 def synth_graph(num_proposals, nodes_lo, nodes_hi, edge_factor=1.2, n_classes=17, seed=0,
-                edges_per_proposal=None, augmented=False):
+                edges_per_proposal=None, augmented=False, with_roots=False):
     """One synthetic "image" (a dataset item) as a ``Data``.
 
     nodes per proposal ~ U{nodes_lo..nodes_hi}; directed edges per proposal =
@@ -169,6 +296,10 @@ def synth_graph(num_proposals, nodes_lo, nodes_hi, edge_factor=1.2, n_classes=17
     d.stat_feats = torch.from_numpy(stat)
     d.labels = torch.from_numpy(labels)
     d.is_super = torch.zeros(N, dtype=torch.bool)
+    if with_roots:      # what predict() needs on top of forward(): the proposal tree + (empty) super edges
+        d.edge_super = torch.zeros((0, 2), dtype=torch.long)
+        d.e_attr_super = torch.zeros((0, 4), dtype=torch.float32)
+        d.roots = synth_roots(d, seed + 7919)
     return d
 
 
