@@ -1,0 +1,113 @@
+// Dev experiment: which resource saturates the K=128 64x64x32 NT GEMM?  MODE bits remove one
+// component at a time (results are then wrong on purpose; only the time is of interest).
+//  1: no global loads after the first k-step   2: no LDS fragment reads (MFMA on fixed registers)
+//  4: no epilogue stores                        8: no LDS staging writes
+//  16: no MFMA
+#include "../../yolat_vectorgraphicsrecognition_amd/csrc/common.hpp"
+#include <stdio.h>
+#include <stdlib.h>
+#include <vector>
+
+template <int MODE>
+__global__ void __launch_bounds__(256) k_exp(const float* __restrict__ A, const float* __restrict__ W, float* Y,
+                                             int M, int N, int K) {
+  constexpr int BM = 64, BN = 64, BK = 32, LD = BK + 1, KQ = BK / 4;
+  __shared__ float As[BM * LD];
+  __shared__ float Bs[BN * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  int rt_, ct_;
+  yl_xcd_tile(rt_, ct_);
+  const int row0 = rt_ * BM, col0 = ct_ * BN;
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float4 ra[2], rb[2];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + t * 256;
+      const int r = min(row0 + i / KQ, M - 1);
+      ra[t] = *reinterpret_cast<const float4*>(A + (long)r * K + k0 + 4 * (i % KQ));
+      rb[t] = *reinterpret_cast<const float4*>(W + (long)(col0 + i / KQ) * K + k0 + 4 * (i % KQ));
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + t * 256;
+      float* d = As + (i / KQ) * LD + 4 * (i % KQ);
+      d[0] = ra[t].x; d[1] = ra[t].y; d[2] = ra[t].z; d[3] = ra[t].w;
+      float* e = Bs + (i / KQ) * LD + 4 * (i % KQ);
+      e[0] = rb[t].x; e[1] = rb[t].y; e[2] = rb[t].z; e[3] = rb[t].w;
+    }
+  };
+  fetch(0);
+  for (int k0 = 0; k0 < K; k0 += BK) {
+    if (!(MODE & 8) || k0 == 0) stage();
+    __syncthreads();
+    if (k0 + BK < K && !(MODE & 1)) fetch(k0 + BK);
+    float fa = ra[0].x, fb = rb[0].y;
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      float a, b;
+      if (MODE & 2) { a = fa; b = fb; fa += 1.f; }
+      else { a = As[(wm * 32 + l31) * LD + kk + lhi]; b = Bs[(wn * 32 + l31) * LD + kk + lhi]; }
+      if (MODE & 16) acc[kk & 15] += a * b;
+      else acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  const int col = col0 + wn * 32 + l31;
+  if (MODE & 4) {
+    float s = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) s += acc[r];
+    if (s == 1234.5678f) Y[tid] = s;
+  } else {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row < M) Y[(long)row * N + col] = acc[r];
+    }
+  }
+}
+
+template <int MODE>
+static void run(int M, int N, int K, int iters, float* A, float* W, float* Y) {
+  dim3 grid((M + 63) / 64, N / 64);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(k_exp<MODE>, grid, dim3(256), 0, 0, A, W, Y, M, N, K);
+  hipEventRecord(e0);
+  for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(k_exp<MODE>, grid, dim3(256), 0, 0, A, W, Y, M, N, K);
+  hipEventRecord(e1); hipEventSynchronize(e1);
+  float ms; hipEventElapsedTime(&ms, e0, e1);
+  float us = ms * 1e3f / iters;
+  printf("M=%6d mode %2d [%s%s%s%s%s]  %8.2f us  %7.2f TF/s-equivalent\n", M, MODE, (MODE & 1) ? "noglobal " : "",
+         (MODE & 2) ? "noldsread " : "", (MODE & 4) ? "nostore " : "", (MODE & 8) ? "noldswrite " : "",
+         (MODE & 16) ? "nomfma " : "", us, 2.0 * M * N * K / us * 1e-6);
+}
+
+int main() {
+  const int MAXM = 1 << 18;
+  float *A, *W, *Y;
+  hipMalloc(&A, (size_t)MAXM * 128 * 4); hipMalloc(&W, (size_t)1024 * 128 * 4); hipMalloc(&Y, (size_t)MAXM * 1024 * 4);
+  std::vector<float> h((size_t)MAXM * 128);
+  for (auto& v : h) v = (rand() % 2001 - 1000) * 1e-3f;
+  hipMemcpy(A, h.data(), h.size() * 4, hipMemcpyHostToDevice);
+  hipMemcpy(W, h.data(), (size_t)1024 * 128 * 4, hipMemcpyHostToDevice);
+  for (int M : {10000, 200000}) {
+    const int it = M > 50000 ? 5 : 30;
+    run<0>(M, 1024, 128, it, A, W, Y);
+    run<1>(M, 1024, 128, it, A, W, Y);
+    run<2>(M, 1024, 128, it, A, W, Y);
+    run<4>(M, 1024, 128, it, A, W, Y);
+    run<8>(M, 1024, 128, it, A, W, Y);
+    run<16>(M, 1024, 128, it, A, W, Y);
+    run<1 | 4>(M, 1024, 128, it, A, W, Y);
+    run<1 | 2 | 4 | 8>(M, 1024, 128, it, A, W, Y);
+    run<2 | 8>(M, 1024, 128, it, A, W, Y);
+    run<1 | 2 | 8>(M, 1024, 128, it, A, W, Y);
+  }
+  return 0;
+}

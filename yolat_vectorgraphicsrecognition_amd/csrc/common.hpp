@@ -174,6 +174,8 @@ struct EdgeWcOp {
 // pulls the tile over the fabric (PMC: 79 MB fetched for the 5.6 MB fusion GEMM at cfg 2).  Here XCD x
 // owns a contiguous range of row-major (row-tile, col-tile) pairs, column tile fastest, so the sharers of
 // an A tile run back-to-back on one XCD and hit its L2.  A speed choice only: any placement is correct.
+__device__ __forceinline__ int l31_of_lane() { return (int)(threadIdx.x & 31); }
+
 __device__ __forceinline__ void yl_xcd_tile(int& rt, int& ct) {
   const int tm = gridDim.x, tn = gridDim.y;
   const int total = tm * tn, id = blockIdx.x + tm * blockIdx.y;
@@ -245,13 +247,19 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
   if (ep.scale != nullptr) { sc = ep.scale[cc]; sh = ep.shift[cc]; }
   const float floor = ep.relu ? 0.f : -INFINITY;
   if (ep.seg != nullptr) {
-    // rows of a proposal are consecutive: run-length max over this lane's 16 rows, one atomic per run
+    // rows of a proposal are consecutive: run-length max over this lane's 16 rows, one atomic per run.
+    // The 32 segment ids of the tile are fetched by ONE coalesced load (lane l31 <- row row_base+l31) and
+    // distributed by cross-lane reads; 16 dependent per-row loads cost more than the tile's 64 MFMAs.
+    const int my_row = row_base + l31_of_lane();
+    const int segv = (my_row < M) ? ep.seg[my_row] : -1;
+    int sgs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);   // all lanes active here
     int cur_seg = -1;
     float cur = 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      const int sg = (row < M) ? ep.seg[yl_min(row, M - 1)] : -1;
+      const int sg = sgs[r];
       const float v = fmaxf(fmaf(acc[r], sc, sh), 0.f);
       if (sg != cur_seg) {
         if (cur_seg >= 0 && col_ok && cur > 0.f)
