@@ -210,12 +210,26 @@ struct Epilogue {
 // row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)).  Everything is wave-local: the training-mode BatchNorm
 // partial statistics of the 32-row group (sum, M2 around the group mean) need one cross-half
 // shuffle and no LDS, and are written once per (32-row group, column) => deterministic.
+// Per-column epilogue constants and the tile's segment ids, loaded at kernel START so their latency hides
+// under the K loop (a dependent load after the last MFMA costs ~1-2k cycles of a 4k-cycle K=128 tile).
+struct EpiPre { float bias, sc, sh; int segv; };
+__device__ __forceinline__ EpiPre epi_prefetch(const Epilogue& ep, int row_base, int col, int M, int N) {
+  EpiPre p;
+  const int cc = col < N ? col : N - 1;
+  p.bias = ep.bias != nullptr ? ep.bias[cc] : 0.f;
+  p.sc = ep.scale != nullptr ? ep.scale[cc] : 1.f;
+  p.sh = ep.scale != nullptr ? ep.shift[cc] : 0.f;
+  const int my_row = row_base + l31_of_lane();
+  p.segv = (ep.seg != nullptr && my_row < M) ? ep.seg[my_row] : -1;
+  return p;
+}
+
 __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col, int lhi,
-                                              const Epilogue& ep, int M, int N) {
+                                              const Epilogue& ep, int M, int N, const EpiPre& pre) {
   const bool col_ok = col < N;
   const int cc = col_ok ? col : N - 1;
   if (ep.bias != nullptr) {
-    const float bv = ep.bias[cc];
+    const float bv = pre.bias;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += bv;
   }
@@ -243,15 +257,13 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
       *dst = make_float2(s, m2);
     }
   }
-  float sc = 1.f, sh = 0.f;
-  if (ep.scale != nullptr) { sc = ep.scale[cc]; sh = ep.shift[cc]; }
+  const float sc = pre.sc, sh = pre.sh;
   const float floor = ep.relu ? 0.f : -INFINITY;
   if (ep.seg != nullptr) {
     // rows of a proposal are consecutive: run-length max over this lane's 16 rows, one atomic per run.
     // The 32 segment ids of the tile are fetched by ONE coalesced load (lane l31 <- row row_base+l31) and
     // distributed by cross-lane reads; 16 dependent per-row loads cost more than the tile's 64 MFMAs.
-    const int my_row = row_base + l31_of_lane();
-    const int segv = (my_row < M) ? ep.seg[my_row] : -1;
+    const int segv = pre.segv;
     int sgs[16];
 #pragma unroll
     for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);   // all lanes active here
@@ -382,6 +394,12 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
     }
   };
 
+  EpiPre pre[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      pre[i][j] = epi_prefetch(ep, row0 + wm * WM + i * 32, col0 + wn * WN + j * 32 + l31, M, N);
   fetch(0);
   for (int k0 = 0; k0 < K; k0 += BK) {
     stage();
@@ -407,7 +425,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
   for (int i = 0; i < TM; ++i)
 #pragma unroll
     for (int j = 0; j < TN; ++j)
-      wave_epilogue(acc[i][j], row0 + wm * WM + i * 32, col0 + wn * WN + j * 32 + l31, lhi, ep, M, N);
+      wave_epilogue(acc[i][j], row0 + wm * WM + i * 32, col0 + wn * WN + j * 32 + l31, lhi, ep, M, N, pre[i][j]);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -435,6 +453,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
   // is a 4-way bank conflict on every write and made this kernel LDS-write-bound.)
   auto map_r = [](int i) { return 4 * ((i >> 5) & 7) + ((i & 31) >> 3); };
   auto map_q = [](int i) { return 8 * (i >> 8) + (i & 7); };
+  const EpiPre pre = epi_prefetch(ep, row0, col0 + l31, M, N);
 
   f32x16 acc;
 #pragma unroll
@@ -525,7 +544,7 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
     for (int w = 0; w < 3; ++w)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
-    wave_epilogue(acc, row0, col0 + l31, lhi, ep, M, N);
+    wave_epilogue(acc, row0, col0 + l31, lhi, ep, M, N, pre);
   }
 }
 
