@@ -234,7 +234,8 @@ int yolat_segment_max_fwd(const float* X, int64_t ldx, int64_t D, const float* x
                           int64_t N, float* Y, int64_t ldy, int32_t* arg /* nullable [P,D] */,
                           yolat_stream_t stream);
 /* Pooling prologue of the eval forward in one launch, Z = [P, 2(F+D)] (arch:127 layout):
- *   Z[:,0:F] = 0;  Z[:,F:F+D] = segment-max of feats[N,D];  Z[:,2F+D:2F+2D] = segment-mean of fsup[N,D] */
+ *   Z[:,0:F] = 0;  Z[:,F:F+D] = segment-max of feats[N,D];  Z[:,2F+D:2F+2D] = segment-mean of fsup[N,D]
+ * (fsup may be NULL: the mean part is skipped, e.g. when it is computed on another stream).              */
 int yolat_pool_prepare(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F,
                        const int32_t* seg_ptr, int64_t P, float* Z, int64_t ldz, yolat_stream_t stream);
 

@@ -56,7 +56,7 @@ __global__ void __launch_bounds__(256) k_pool_prepare(const float* feats, const 
   const int p = blockIdx.y;
   float* z = Z + (long)p * ldz;
   if (c < F) { z[c] = 0.f; return; }
-  if (c >= F + 2 * D) return;
+  if (c >= F + 2 * D || (fsup == nullptr && c >= F + D)) return;
   const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
   const bool is_max = c < F + D;
   const int k = is_max ? c - F : c - F - D;
@@ -92,11 +92,11 @@ __global__ void __launch_bounds__(256) k_pool_prepare(const float* feats, const 
 extern "C" int yolat_pool_prepare(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F,
                                   const int32_t* seg_ptr, int64_t P, float* Z, int64_t ldz,
                                   yolat_stream_t stream) {
-  if (P <= 0 || D <= 0 || F <= 0 || !feats || !fsup || !seg_ptr || !Z || ld < D || ldz < 2 * (F + D))
+  if (P <= 0 || D <= 0 || F <= 0 || !feats || !seg_ptr || !Z || ld < D || ldz < 2 * (F + D))
     return YOLAT_E_INVALID;
   for (int64_t p0 = 0; p0 < P; p0 += 65535) {
     const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
-    hipLaunchKernelGGL(k_pool_prepare, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)np), dim3(256), 0,
+    hipLaunchKernelGGL(k_pool_prepare, dim3(yl_cdiv(F + (fsup ? 2 : 1) * D, 256), (unsigned)np), dim3(256), 0,
                        (hipStream_t)stream, feats, fsup, (long)ld, (int)D, (int)F, seg_ptr + p0, Z + p0 * ldz,
                        (long)ldz);
     YL_LAUNCH_CHECK();
