@@ -209,6 +209,17 @@ int yolat_edge_scatter_bwd(const float* dG, int64_t lddg, int64_t Cin, const int
                            const int32_t* col_ptr, const int32_t* slots, int64_t N, float* dX,
                            int64_t lddx, int accumulate, yolat_stream_t stream);
 
+/* Eval-mode edge MLP `self.nn` of AttrRelativeEdgeConvGlobalPool2 (torch_vertex.py:311,331-335), both
+ * Linear+BN+ReLU layers in one kernel, BatchNorm folded into (s, t):
+ *   H2[q] = relu(s2*(W2.relu(s1*(W1.[x[dst] | x[src]-x[dst] | attr](q) + b1) + t1) + b2) + t2)
+ * W1 [C, 2Cin+4] and W2 [C, C] row-major contiguous, C must be 64.  Bit-identical to
+ * yolat_edge_lin1_fwd followed by yolat_linear_fwd; the [E,C] hidden activation stays in LDS.        */
+int yolat_edge_mlp2_eval(const float* x, int64_t ldx, int64_t N, int64_t Cin, const int32_t* src_csr,
+                         const int32_t* dst_csr, const float* attr_csr, int64_t E, const float* W1,
+                         const float* b1, const float* s1, const float* t1, const float* W2,
+                         const float* b2, const float* s2, const float* t2, int64_t C, float* H2,
+                         int64_t ldh, yolat_stream_t stream);
+
 /* out[n,0:C] (+)= (1/max(deg,1)) * sum_{q in CSR row n} pro(H)[q,0:C]
  * (= torch_scatter.scatter(reduce='mean', dim_size=N) called by propagate, aggr='mean'
  * torch_vertex.py:308; summation in ascending edge order like the CPU scatter_add).             */

@@ -450,6 +450,32 @@ def test_fused_conv_layer_eval_matches_oracle(N, E, Cin, impl):
     assert torch.isnan(fbuf[:, :64]).all() and torch.isnan(sbuf[:, 64:]).all()
 
 
+@pytest.mark.parametrize("N,E,Cin", [(6, 7, 5), (70, 300, 5), (70, 300, 64), (1000, 4000, 64), (500, 9001, 64),
+                                     (300, 700, 6), (2000, 33, 32), (9000, 30000, 64)])
+def test_edge_mlp2_eval_is_bit_identical_to_two_kernel_path(N, E, Cin):
+    """yolat_edge_mlp2_eval (both edge-MLP layers in one kernel, hidden activation in LDS) must reproduce
+    yolat_edge_lin1_fwd + yolat_linear_fwd bit for bit (same k order, same epilogue arithmetic)."""
+    yv = _yv()
+    src, dst, xfull, attr = _edge_case(N, E, Cin, 3 * N + E, ldx=Cin)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    tg = torch.Generator().manual_seed(N + E)
+    K1 = 2 * Cin + 4
+    W1 = (torch.randn(64, K1, generator=tg) / K1 ** 0.5).cuda()
+    W2 = (torch.randn(64, 64, generator=tg) / 8).cuda()
+    b1, b2 = (torch.randn(64, generator=tg) * 0.1).cuda(), (torch.randn(64, generator=tg) * 0.1).cuda()
+    p1 = ((torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda())
+    p2 = ((torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda())
+    x = dev(xfull)
+    H1 = torch.empty(E, 64).cuda()
+    H2a = torch.empty(E, 64).cuda()
+    yv.ops.edge_lin1_fwd(x, g, W1, b1, H1, o_pro=p1, o_relu=True)
+    yv.ops.linear_fwd(H1, W2, b2, H2a, o_pro=p2, o_relu=True)
+    H2b = torch.full((E, 96), float("nan")).cuda()
+    yv.ops.edge_mlp2_eval(x, g, W1, b1, p1, W2, b2, p2, H2b[:, :64])
+    assert torch.equal(H2a, H2b[:, :64])
+    assert torch.isnan(H2b[:, 64:]).all()
+
+
 def test_fused_linear_segmax_and_pool_prepare_match_unfused():
     """Eval-plan kernels: fusion GEMM + BN + ReLU + per-proposal max in one launch, and the pooling
     prologue, against the oracle's scatter on the materialised activations."""

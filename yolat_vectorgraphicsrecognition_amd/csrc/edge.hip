@@ -32,6 +32,154 @@ extern "C" int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Eval-mode edge MLP, both layers in one kernel (torch_vertex.py:311,331-335 `self.nn`, BN folded):
+//   H2[q] = relu(s2*(W2 . relu(s1*(W1 . [x[dst] | x[src]-x[dst] | attr](q) + b1) + t1) + b2) + t2)
+// One 64-edge tile per workgroup.  GEMM1 is the k_gemm_nt<64,64,*> loop on the gathered operand; its
+// activated accumulators go to LDS (never to HBM: saves the E x 64 write + read and one launch), GEMM2
+// reads them back as MFMA A-fragments with W2 staged in LDS during GEMM1.  Same k order and the same
+// epilogue arithmetic as the two-kernel path -> bit-identical H2.
+//   BLOCK = true : Cin % 32 == 0, vector loads; the 4 attr columns are a final 2-MFMA step instead of a
+//                  mostly-zero 32-wide k-step (K = 132 costs 66 MFMAs per wave, not 80)
+//   BLOCK = false: any Cin (the Cin = 5 head layer), 16-wide generic k-steps
+// ------------------------------------------------------------------------------------------------
+template <bool BLOCK>
+__global__ void __launch_bounds__(256) k_edge_mlp2(EdgeOp A, DenseOp W1, const float* __restrict__ b1,
+                                                   const float* __restrict__ s1, const float* __restrict__ t1,
+                                                   DenseOp W2, Epilogue ep2, int E) {
+  constexpr int BK = BLOCK ? 32 : 16, LD = BK + 1, KQ = BK / 4, NL = (64 * KQ) / 256, LDH = 65;
+  __shared__ float As[64 * LD];
+  __shared__ float Bs[64 * LD];
+  __shared__ float Hs[64 * LDH];
+  __shared__ float W2s[64 * LDH];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = blockIdx.x * 64;
+  const int col = wn * 32 + l31;
+  const int K1 = A.cols, KX = BLOCK ? 2 * A.Cin : K1;     // KX: extent covered by the BK-wide steps
+
+  // epilogue constants + W2 (64x64) prefetched now, consumed after GEMM1
+  const float bias1 = b1[col], sc1 = s1 ? s1[col] : 1.f, sh1 = s1 ? t1[col] : 0.f;
+  const EpiPre pre2 = epi_prefetch(ep2, row0 + wm * 32, col, E, 64);
+  float rw2[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = tid + t * 256;
+    W2.template load4<false>(i >> 4, 4 * (i & 15), rw2[t]);
+  }
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  float ra[NL][4], rb[NL][4];
+  auto fetch = [&](int k0) {
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+      const int i = tid + t * 256;
+      if (BLOCK) {
+        A.template load4<true>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+        W1.template load4<true>(i / KQ, k0 + 4 * (i % KQ), rb[t]);
+      } else {
+        A.template load4<false>(row0 + i / KQ, k0 + 4 * (i % KQ), ra[t]);
+        W1.template load4<false>(i / KQ, k0 + 4 * (i % KQ), rb[t]);
+      }
+    }
+  };
+  auto stage = [&]() {
+#pragma unroll
+    for (int t = 0; t < NL; ++t) {
+      const int i = tid + t * 256;
+      float* d = As + (i / KQ) * LD + 4 * (i % KQ);
+      d[0] = ra[t][0]; d[1] = ra[t][1]; d[2] = ra[t][2]; d[3] = ra[t][3];
+      float* e = Bs + (i / KQ) * LD + 4 * (i % KQ);
+      e[0] = rb[t][0]; e[1] = rb[t][1]; e[2] = rb[t][2]; e[3] = rb[t][3];
+    }
+  };
+  // the attr columns (BLOCK): 64 rows x one float4 of A (threads 0..63) and of W1 (threads 64..127)
+  float rattr[4] = {0.f, 0.f, 0.f, 0.f};
+  if (BLOCK) {
+    if (tid < 64) A.template load4<true>(row0 + tid, KX, rattr);
+    else if (tid < 128) W1.template load4<true>(tid - 64, KX, rattr);
+  }
+  fetch(0);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {       // W2 -> LDS (first barrier below publishes it)
+    const int i = tid + t * 256;
+    float* d = W2s + (i >> 4) * LDH + 4 * (i & 15);
+    d[0] = rw2[t][0]; d[1] = rw2[t][1]; d[2] = rw2[t][2]; d[3] = rw2[t][3];
+  }
+  for (int k0 = 0; k0 < KX; k0 += BK) {
+    stage();
+    __syncthreads();
+    if (k0 + BK < KX) fetch(k0 + BK);
+#pragma unroll
+    for (int kk = 0; kk < BK; kk += 2) {
+      const float a = As[(wm * 32 + l31) * LD + kk + lhi];
+      const float b = Bs[(wn * 32 + l31) * LD + kk + lhi];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  if (BLOCK) {
+    if (tid < 128) {
+      float* d = (tid < 64 ? As + tid * LD : Bs + (tid - 64) * LD);
+      d[0] = rattr[0]; d[1] = rattr[1]; d[2] = rattr[2]; d[3] = rattr[3];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 4; kk += 2) {
+      const float a = As[(wm * 32 + l31) * LD + kk + lhi];
+      const float b = Bs[(wn * 32 + l31) * LD + kk + lhi];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+    }
+  }
+  // layer-1 epilogue -> LDS (same arithmetic as wave_epilogue: +bias, fma(scale, shift), relu)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    Hs[row * LDH + col] = fmaxf(fmaf(acc[r] + bias1, sc1, sh1), 0.f);
+  }
+  __syncthreads();
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < 64; kk += 2) {
+    const float a = Hs[(wm * 32 + l31) * LDH + kk + lhi];
+    const float b = W2s[(wn * 32 + l31) * LDH + kk + lhi];
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc2, 0, 0, 0);
+  }
+  wave_epilogue(acc2, row0 + wm * 32, col, lhi, ep2, E, 64, pre2);
+}
+
+extern "C" int yolat_edge_mlp2_eval(const float* x, int64_t ldx, int64_t N, int64_t Cin,
+                                    const int32_t* src_csr, const int32_t* dst_csr, const float* attr_csr,
+                                    int64_t E, const float* W1, const float* b1, const float* s1,
+                                    const float* t1, const float* W2, const float* b2, const float* s2,
+                                    const float* t2, int64_t C, float* H2, int64_t ldh,
+                                    yolat_stream_t stream) {
+  if (E < 0 || N <= 0 || Cin <= 0 || !x || !W1 || !W2 || !b1) return YOLAT_E_INVALID;
+  if (C != 64) return YOLAT_E_UNSUPPORTED;
+  if (E == 0) return 0;
+  if (!src_csr || !dst_csr || !attr_csr || !H2 || E >= (1LL << 31) || ldh < C || ldx < Cin)
+    return YOLAT_E_INVALID;
+  if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return YOLAT_E_INVALID;
+  const long K1 = 2 * Cin + 4;
+  EdgeOp a = yl_edge(x, ldx, Cin, src_csr, dst_csr, attr_csr, E);
+  DenseOp w1 = yl_dense(W1, K1, C, K1), w2 = yl_dense(W2, C, C, C);
+  Epilogue ep;
+  ep.bias = b2; ep.scale = s2; ep.shift = t2; ep.relu = 1;
+  ep.Y = H2; ep.ldy = ldh; ep.accumulate = 0; ep.stats = nullptr; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid(yl_cdiv(E, 64));
+  if (Cin % 32 == 0 && a.vec && w1.vec)
+    hipLaunchKernelGGL(k_edge_mlp2<true>, grid, dim3(256), 0, st, a, w1, b1, s1, t1, w2, ep, (int)E);
+  else
+    hipLaunchKernelGGL(k_edge_mlp2<false>, grid, dim3(256), 0, st, a, w1, b1, s1, t1, w2, ep, (int)E);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_edge_lin1_bwd_w(const float* dH1, int64_t lddh, int64_t E, int64_t C,
                                      const float* x, int64_t ldx, int64_t N, int64_t Cin,
                                      const int32_t* src_csr, const int32_t* dst_csr,

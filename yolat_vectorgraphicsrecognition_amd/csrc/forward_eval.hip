@@ -209,6 +209,13 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
              yolat_linear_fwd(f_in, ld_f, N, cv.Cin, nullptr, nullptr, 0, cv.Wr, cv.Cin, cv.br, C, nullptr,
                               nullptr, 0, f_out, ld_out, 0, nullptr, stream));
     if (E > 0) {
+      if (C == 64) {
+        // both edge-MLP layers in one kernel, hidden activation in LDS (edge.hip k_edge_mlp2)
+        snprintf(nm, sizeof nm, "edge_mlp2[E x %ld -> %ld -> %ld, gathered]", (long)K1, C, C);
+        YL_STAGE(nm, 2.0 * E * (K1 * C + C * C), E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
+                 yolat_edge_mlp2_eval(f_in, ld_f, N, cv.Cin, p.src, p.dst, p.attr, E, cv.W1, cv.b1, cv.s1, cv.t1,
+                                      cv.W2, cv.b2, cv.s2, cv.t2, C, p.H2, C, stream));
+      } else {
       snprintf(nm, sizeof nm, "edge_lin1[E x %ld -> %ld, gathered]", (long)K1, C);
       YL_STAGE(nm, 2.0 * E * K1 * C, E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
                yolat_edge_lin1_fwd(f_in, ld_f, N, cv.Cin, p.src, p.dst, p.attr, E, cv.W1, 2 * cv.Cin + 4,
@@ -217,6 +224,7 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
       YL_STAGE(nm, 2.0 * E * C * C, 8.0 * E * C,
                yolat_linear_fwd(p.H1, C, E, C, nullptr, nullptr, 0, cv.W2, C, cv.b2, C, cv.s2, cv.t2, 1, p.H2,
                                 C, 0, nullptr, stream));
+      }
       YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
                yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
     }

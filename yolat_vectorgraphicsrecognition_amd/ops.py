@@ -222,6 +222,18 @@ def edge_lin1_fwd(x, g, W1, b1, H1, o_pro=None, o_relu=False, stats=None):
     return H1
 
 
+def edge_mlp2_eval(x, g, W1, b1, pro1, W2, b2, pro2, H2):
+    """Eval-mode two-layer edge MLP in one kernel (BN folded into pro1/pro2 = (scale, shift))."""
+    N, Cin = x.shape
+    C = W1.shape[0]
+    if not (W1.is_contiguous() and W2.is_contiguous()):
+        raise ValueError("W1 / W2 must be contiguous")
+    check(lib.yolat_edge_mlp2_eval(_f(x, "x"), _ld(x), N, Cin, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(),
+                                   g.E, _f(W1), _f(b1), _f(pro1[0]), _f(pro1[1]), _f(W2), _f(b2), _f(pro2[0]),
+                                   _f(pro2[1]), C, _f(H2), _ld(H2), _stream()), "yolat_edge_mlp2_eval")
+    return H2
+
+
 def edge_lin1_bwd_w(dH1, x, g, dW1, db1=None, accumulate=False):
     E, C = dH1.shape[0], dW1.shape[0]
     N, Cin = x.shape
