@@ -220,6 +220,17 @@ int yolat_edge_mlp2_eval(const float* x, int64_t ldx, int64_t N, int64_t Cin, co
                          const float* b2, const float* s2, const float* t2, int64_t C, float* H2,
                          int64_t ldh, yolat_stream_t stream);
 
+/* Node side of an eval-mode conv layer in one launch (torch_vertex.py:324-327), BatchNorm folded:
+ *   f_out[n] = mean_{q in [row_ptr[n], row_ptr[n+1])} H2[q]  +  Wr.f_in[n] + br
+ *   s_out[n] = relu(sn*(Wn.s_in[n] + bn) + tn)
+ * Wr, Wn: [C, Cin] row-major contiguous, C <= 64.  H2 NULL (or E == 0) drops the aggregation term.
+ * Same values as yolat_linear_fwd + yolat_csr_mean_fwd(accumulate) + yolat_linear_fwd.                  */
+int yolat_node_side_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
+                         int64_t Cin, const float* Wr, const float* br, const float* Wn, const float* bn,
+                         const float* sn, const float* tn, const float* H2, int64_t ldh,
+                         const int32_t* row_ptr, int64_t E, int64_t C, float* f_out, int64_t ld_fo,
+                         float* s_out, int64_t ld_so, yolat_stream_t stream);
+
 /* out[n,0:C] (+)= (1/max(deg,1)) * sum_{q in CSR row n} pro(H)[q,0:C]
  * (= torch_scatter.scatter(reduce='mean', dim_size=N) called by propagate, aggr='mean'
  * torch_vertex.py:308; summation in ascending edge order like the CPU scatter_add).             */

@@ -476,6 +476,43 @@ def test_edge_mlp2_eval_is_bit_identical_to_two_kernel_path(N, E, Cin):
     assert torch.isnan(H2b[:, 64:]).all()
 
 
+@pytest.mark.parametrize("N,E,Cin", [(6, 7, 5), (70, 300, 64), (1000, 4000, 64), (130, 0, 64), (2500, 3000, 5),
+                                     (64, 3000, 64), (9000, 30000, 64)])
+def test_node_side_eval_is_bit_identical_to_three_kernel_path(N, E, Cin):
+    """yolat_node_side_eval (root Linear with the CSR mean fused into its epilogue + node-branch
+    Linear+BN+ReLU, one launch) against yolat_linear_fwd + yolat_csr_mean_fwd(accumulate) + yolat_linear_fwd."""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    src, dst, xfull, attr = _edge_case(N, max(E, 1), Cin, 5 * N + E, ldx=Cin)
+    src, dst, attr = src[:E], dst[:E], attr[:E]
+    if E > 40:
+        dst[:23] = N // 2                             # a node with more than 4 in-edges (tail loop)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)) if E else torch.zeros(0, 2, dtype=torch.int64).cuda(),
+                           dev(attr) if E else torch.zeros(0, 4).cuda(), None, N, 1)
+    tg = torch.Generator().manual_seed(N + E + 1)
+    Wr = (torch.randn(64, Cin, generator=tg) / Cin ** 0.5).cuda()
+    Wn = (torch.randn(64, Cin, generator=tg) / Cin ** 0.5).cuda()
+    br, bn = (torch.randn(64, generator=tg) * 0.1).cuda(), (torch.randn(64, generator=tg) * 0.1).cuda()
+    pn = ((torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda())
+    f_in = dev(xfull)
+    s_in = torch.randn(N, Cin, generator=tg).cuda()
+    H2 = torch.randn(max(E, 1), 64, generator=tg).cuda()
+    fa, sa = torch.empty(N, 64).cuda(), torch.empty(N, 64).cuda()
+    yv.ops.linear_fwd(f_in, Wr, br, fa)
+    if E:
+        yv.ops.csr_mean_fwd(H2, g, fa, accumulate=True)
+    yv.ops.linear_fwd(s_in, Wn, bn, sa, o_pro=pn, o_relu=True)
+    fb = torch.full((N, 128), float("nan")).cuda()
+    sb = torch.full((N, 128), float("nan")).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.yolat_node_side_eval(f_in.data_ptr(), Cin, s_in.data_ptr(), Cin, N, Cin, Wr.data_ptr(), br.data_ptr(),
+                                   Wn.data_ptr(), bn.data_ptr(), pn[0].data_ptr(), pn[1].data_ptr(),
+                                   H2.data_ptr() if E else None, 64, g.row_ptr.data_ptr(), E, 64,
+                                   fb[:, 64:].data_ptr(), 128, sb[:, :64].data_ptr(), 128, st))
+    assert torch.equal(fa, fb[:, 64:]) and torch.equal(sa, sb[:, :64])
+    assert torch.isnan(fb[:, :64]).all() and torch.isnan(sb[:, 64:]).all()
+
+
 def test_fused_linear_segmax_and_pool_prepare_match_unfused():
     """Eval-plan kernels: fusion GEMM + BN + ReLU + per-proposal max in one launch, and the pooling
     prologue, against the oracle's scatter on the materialised activations."""

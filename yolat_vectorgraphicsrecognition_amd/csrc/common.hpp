@@ -204,6 +204,12 @@ struct Epilogue {
   const int* seg;  // nullable [M]
   float* pool;
   long ldpool;
+  // fused CSR mean aggregation (eval node-side kernel): when agg != nullptr the value stored for row n is
+  //   epi(acc)[n] + mean_{q in [agg_ptr[n], agg_ptr[n+1])} agg[q, col]      (ascending q, like k_csr_mean_fwd)
+  const float* agg = nullptr;
+  long ldagg = 0;
+  const int* agg_ptr = nullptr;
+  int agg_rows = 0;     // number of rows of agg (E), for address clamping
 };
 
 // Epilogue of one 32x32 MFMA sub-tile held by one wave (C/D layout: col = lane&31,
@@ -287,7 +293,38 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
     return;
   }
   float old[16];
-  if (ep.accumulate) {   // all 16 reads issued back to back (clamped rows), one wait
+  if (ep.agg != nullptr) {
+    // CSR range boundaries of the tile's 32 rows: two coalesced loads + cross-lane reads
+    const int n_l = yl_min(row_base + l31_of_lane(), M);
+    const int rp_lo = ep.agg_ptr[n_l], rp_hi = ep.agg_ptr[yl_min(n_l + 1, M)];
+    int q0s[16], q1s[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int off = (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      q0s[r] = __shfl(rp_lo, off);
+      q1s[r] = __shfl(rp_hi, off);
+    }
+    const float* hp = ep.agg + cc;
+    const int qmax = ep.agg_rows - 1;
+#pragma unroll
+    for (int r0 = 0; r0 < 16; r0 += 4) {      // 4 rows x 4 edges = 16 independent (clamped) loads in flight
+      float v[4][4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          v[j][e] = hp[(long)yl_min(q0s[r0 + j] + e, qmax) * ep.ldagg];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int q0 = q0s[r0 + j], q1 = q1s[r0 + j], deg = q1 - q0;
+        float sacc = 0.f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) sacc += (e < deg) ? v[j][e] : 0.f;
+        for (int q = q0 + 4; q < q1; ++q) sacc += hp[(long)q * ep.ldagg];
+        old[r0 + j] = sacc * (1.f / (float)(deg > 1 ? deg : 1));
+      }
+    }
+  } else if (ep.accumulate) {   // all 16 reads issued back to back (clamped rows), one wait
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = yl_min(row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi, M - 1);
@@ -317,7 +354,8 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
 // consecutive n when staging.
 // ------------------------------------------------------------------------------------------------
 template <int BM, int BN, int BK, class AL, class BL, bool B_NFAST>
-__global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M, int N, int K) {
+__device__ __forceinline__ void gemm_nt_tile(const AL& A, const BL& B, const Epilogue& ep, int M, int N, int K,
+                                             int rt_, int ct_) {
   constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
   constexpr int LD = BK + 1;
   constexpr int KQ = BK / 4;
@@ -330,8 +368,6 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1;
   const int l31 = lane & 31, lhi = lane >> 5;
-  int rt_, ct_;
-  yl_xcd_tile(rt_, ct_);
   const int row0 = rt_ * BM, col0 = ct_ * BN;
   const bool fastA = A.vec != 0, fastB = B.vec != 0;
 
@@ -426,6 +462,23 @@ __global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M,
 #pragma unroll
     for (int j = 0; j < TN; ++j)
       wave_epilogue(acc[i][j], row0 + wm * WM + i * 32, col0 + wn * WN + j * 32 + l31, lhi, ep, M, N, pre[i][j]);
+}
+
+template <int BM, int BN, int BK, class AL, class BL, bool B_NFAST>
+__global__ void __launch_bounds__(256) k_gemm_nt(AL A, BL B, Epilogue ep, int M, int N, int K) {
+  int rt_, ct_;
+  yl_xcd_tile(rt_, ct_);
+  gemm_nt_tile<BM, BN, BK, AL, BL, B_NFAST>(A, B, ep, M, N, K, rt_, ct_);
+}
+
+// Two independent GEMMs with the same M, N <= BN and K in ONE launch (blockIdx.y picks the problem): the
+// root Linear (+ fused CSR mean) and the node-branch Linear+BN+ReLU of a conv layer are 157 workgroups each
+// at cfg 2 — separately they are two launch/drain latencies on a quarter-filled GPU.
+template <int BM, int BN, int BK, class AL, class BL>
+__global__ void __launch_bounds__(256) k_gemm_nt_pair(AL A0, BL B0, Epilogue e0, AL A1, BL B1, Epilogue e1,
+                                                      int M, int N, int K) {
+  if (blockIdx.y == 0) gemm_nt_tile<BM, BN, BK, AL, BL, false>(A0, B0, e0, M, N, K, blockIdx.x, 0);
+  else gemm_nt_tile<BM, BN, BK, AL, BL, false>(A1, B1, e1, M, N, K, blockIdx.x, 0);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -80,6 +80,39 @@ extern "C" int yolat_linear_segmax_fwd(const float* A, int64_t lda, int64_t M, i
   return 0;
 }
 
+// Node side of an eval-mode AttrRelativeEdgeConvGlobalPool2 layer in one launch (torch_vertex.py:324-327):
+//   f_out = mean_{q in CSR row n} H2[q]  +  lin_r(f_in)          (propagate(aggr='mean') ; out += lin_r(x))
+//   s_out = relu(sn * (Wn . s_in + bn) + tn)                      (mlp_node, BN folded)
+// H2 == NULL or E == 0 skips the aggregation term.
+extern "C" int yolat_node_side_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
+                                    int64_t Cin, const float* Wr, const float* br, const float* Wn,
+                                    const float* bn, const float* sn, const float* tn, const float* H2,
+                                    int64_t ldh, const int32_t* row_ptr, int64_t E, int64_t C, float* f_out,
+                                    int64_t ld_fo, float* s_out, int64_t ld_so, yolat_stream_t stream) {
+  if (N <= 0 || Cin <= 0 || C <= 0 || !f_in || !s_in || !Wr || !Wn || !f_out || !s_out) return YOLAT_E_INVALID;
+  if (C > 64) return YOLAT_E_UNSUPPORTED;
+  if (N >= (1LL << 31) || ld_f < Cin || ld_s < Cin || ld_fo < C || ld_so < C) return YOLAT_E_INVALID;
+  if ((sn == nullptr) != (tn == nullptr)) return YOLAT_E_INVALID;
+  if (H2 != nullptr && E > 0 && (!row_ptr || ldh < C)) return YOLAT_E_INVALID;
+  DenseOp a0 = yl_dense(f_in, ld_f, N, Cin), b0 = yl_dense(Wr, Cin, C, Cin);
+  DenseOp a1 = yl_dense(s_in, ld_s, N, Cin), b1 = yl_dense(Wn, Cin, C, Cin);
+  Epilogue e0, e1;
+  e0.bias = br; e0.scale = nullptr; e0.shift = nullptr; e0.relu = 0;
+  e0.Y = f_out; e0.ldy = ld_fo; e0.accumulate = 0; e0.stats = nullptr; e0.seg = nullptr; e0.pool = nullptr; e0.ldpool = 0;
+  if (H2 != nullptr && E > 0) { e0.agg = H2; e0.ldagg = ldh; e0.agg_ptr = row_ptr; e0.agg_rows = (int)E; }
+  e1.bias = bn; e1.scale = sn; e1.shift = tn; e1.relu = 1;
+  e1.Y = s_out; e1.ldy = ld_so; e1.accumulate = 0; e1.stats = nullptr; e1.seg = nullptr; e1.pool = nullptr; e1.ldpool = 0;
+  const dim3 grid(yl_cdiv(N, 64), 2);
+  if (Cin <= 16)
+    hipLaunchKernelGGL((k_gemm_nt_pair<64, 64, 16, DenseOp, DenseOp>), grid, dim3(256), 0, (hipStream_t)stream, a0,
+                       b0, e0, a1, b1, e1, (int)N, (int)C, (int)Cin);
+  else
+    hipLaunchKernelGGL((k_gemm_nt_pair<64, 64, 32, DenseOp, DenseOp>), grid, dim3(256), 0, (hipStream_t)stream, a0,
+                       b0, e0, a1, b1, e1, (int)N, (int)C, (int)Cin);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
                                    const float* Wt, int64_t ldw, int64_t Nout, float* Y,
                                    int64_t ldy, int accumulate, yolat_stream_t stream) {

@@ -52,7 +52,6 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
 #include <stdlib.h>
 #include <string>
 #include <vector>
-#include <mutex>
 namespace {
 struct StageRec { std::string name; double flops, bytes; std::vector<std::pair<hipEvent_t, hipEvent_t>> ev; };
 std::vector<StageRec> g_stages;
@@ -62,26 +61,6 @@ int g_conv_mode = -1;   // conv layer implementation: 0 per-op kernels, 1 conv_f
                         // 3 (default) = by size: measured on MI355X the per-op path wins below ~200k edges
                         // (cfg 2: 85 vs 92 us for both layers) and conv_chain above (cfg 5: 742 vs 800 us
                         // per block layer).  env YOLAT_CONV_MODE overrides (A/B testing).
-
-// Optional side stream (YOLAT_DUAL_STREAM=1, off by default) for the node branch (mlp_node chain ->
-// per-proposal mean -> fusion_block_super), which depends only on x and the proposal segments and could
-// overlap the edge-conv kernels.  Measured on MI355X at cfg 2 it LOSES (181 vs 170 us per forward): the
-// cross-queue fork/join costs more than the ~25 us of small kernels it hides.  Kept for A/B at other sizes.
-// One (stream, fork event, join event) triple per caller stream.
-struct Aux { hipStream_t main; hipStream_t side; hipEvent_t fork, join; };
-std::vector<Aux> g_aux;
-std::mutex g_aux_mu;
-int g_dual = -1;
-Aux* aux_for(hipStream_t main) {
-  std::lock_guard<std::mutex> lk(g_aux_mu);
-  for (auto& a : g_aux) if (a.main == main) return &a;
-  Aux a; a.main = main;
-  if (hipStreamCreateWithFlags(&a.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.fork, hipEventDisableTiming) != hipSuccess) return nullptr;
-  if (hipEventCreateWithFlags(&a.join, hipEventDisableTiming) != hipSuccess) return nullptr;
-  g_aux.push_back(a);
-  return &g_aux.back();
-}
 
 hipEvent_t new_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -94,15 +73,14 @@ StageRec& stage_rec(const char* name, double flops, double bytes) {
 }
 }  // namespace
 
-#define YL_STAGE(name, flops, bytes, call) YL_STAGE_ON(stream, name, flops, bytes, call)
-#define YL_STAGE_ON(strm, name, flops, bytes, call)                         \
+#define YL_STAGE(name, flops, bytes, call)                         \
   do {                                                                      \
     if (g_profile) {                                                        \
       StageRec& sr__ = stage_rec(name, (double)(flops), (double)(bytes));   \
       hipEvent_t a__ = new_event(), b__ = new_event();                      \
-      (void)hipEventRecord(a__, (hipStream_t)(strm));                       \
+      (void)hipEventRecord(a__, (hipStream_t)stream);                       \
       int rc__ = (call);                                                    \
-      (void)hipEventRecord(b__, (hipStream_t)(strm));                       \
+      (void)hipEventRecord(b__, (hipStream_t)stream);                       \
       sr__.ev.push_back({a__, b__});                                        \
       if (rc__ != 0) return rc__;                                           \
     } else {                                                                \
@@ -154,10 +132,6 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     g_conv_mode = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : 3;
   }
   const int conv_mode = (g_conv_mode == 3) ? (E >= 200000 ? 2 : 0) : g_conv_mode;
-  if (g_dual < 0) {
-    const char* e = getenv("YOLAT_DUAL_STREAM");
-    g_dual = (e && e[0] == '1') ? 1 : 0;   // measured at cfg 2: 181 us with the side stream vs 170 us without
-  }
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
   const int lo = m->n_blocks - m->n_blocks_out;
 
@@ -166,15 +140,6 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N,
            yolat_graph_prepare(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
                                p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, stream));
-
-  // ---- node branch on the side stream (per-op mode only: the fused conv kernels compute it themselves)
-  Aux* aux = nullptr;
-  if (g_dual && conv_mode == 0) aux = aux_for((hipStream_t)stream);
-  yolat_stream_t side = aux ? (yolat_stream_t)aux->side : stream;
-  if (aux) {
-    if (hipEventRecord(aux->fork, (hipStream_t)stream) != hipSuccess) return YOLAT_E_INVALID;
-    if (hipStreamWaitEvent(aux->side, aux->fork, 0) != hipSuccess) return YOLAT_E_INVALID;
-  }
 
   // ---- conv layers (torch_vertex.py:319-337), outputs written into their concat slots
   const float* f_in = x; long ld_f = ldx;
@@ -202,6 +167,25 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
                E * (K1 * 4.0 + 8.0) + 4.0 * N * (2.0 * cv.Cin + 2.0 * C),
                yolat_conv_eval_fused(f_in, ld_f, s_in, ld_s, N, cv.Cin, p.row_ptr, p.src, p.dst, p.attr, E, &cv, C,
                                      f_out, ld_out, s_out, ld_out, stream));
+    } else if (C == 64) {
+      // three launches per layer: edge MLP (hidden activation in LDS); root Linear | node-branch Linear as one
+      // paired GEMM launch; CSR mean accumulated into the root output.  (Fusing the mean into the paired
+      // GEMM's epilogue is supported by yolat_node_side_eval but measured slower at cfg 2: 157 workgroups
+      // gathering 64 KB each, 21 us vs 7 + 7 us.)
+      if (E > 0) {
+        snprintf(nm, sizeof nm, "edge_mlp2[E x %ld -> %ld -> %ld, gathered]", (long)K1, C, C);
+        YL_STAGE(nm, 2.0 * E * (K1 * C + C * C), E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
+                 yolat_edge_mlp2_eval(f_in, ld_f, N, cv.Cin, p.src, p.dst, p.attr, E, cv.W1, cv.b1, cv.s1, cv.t1,
+                                      cv.W2, cv.b2, cv.s2, cv.t2, C, p.H2, C, stream));
+      }
+      snprintf(nm, sizeof nm, "node_pair[lin_r | mlp_node, N x %ld -> %ld]", (long)cv.Cin, C);
+      YL_STAGE(nm, 4.0 * N * cv.Cin * C, 8.0 * (N * cv.Cin + N * C),
+               yolat_node_side_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn,
+                                    nullptr, C, p.row_ptr, 0, C, f_out, ld_out, s_out, ld_out, stream));
+      if (E > 0) {
+        YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
+                 yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
+      }
     } else {
     // out = lin_r(x)
     snprintf(nm, sizeof nm, "lin_r[N x %ld -> %ld]", (long)cv.Cin, C);
@@ -209,13 +193,6 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
              yolat_linear_fwd(f_in, ld_f, N, cv.Cin, nullptr, nullptr, 0, cv.Wr, cv.Cin, cv.br, C, nullptr,
                               nullptr, 0, f_out, ld_out, 0, nullptr, stream));
     if (E > 0) {
-      if (C == 64) {
-        // both edge-MLP layers in one kernel, hidden activation in LDS (edge.hip k_edge_mlp2)
-        snprintf(nm, sizeof nm, "edge_mlp2[E x %ld -> %ld -> %ld, gathered]", (long)K1, C, C);
-        YL_STAGE(nm, 2.0 * E * (K1 * C + C * C), E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
-                 yolat_edge_mlp2_eval(f_in, ld_f, N, cv.Cin, p.src, p.dst, p.attr, E, cv.W1, cv.b1, cv.s1, cv.t1,
-                                      cv.W2, cv.b2, cv.s2, cv.t2, C, p.H2, C, stream));
-      } else {
       snprintf(nm, sizeof nm, "edge_lin1[E x %ld -> %ld, gathered]", (long)K1, C);
       YL_STAGE(nm, 2.0 * E * K1 * C, E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
                yolat_edge_lin1_fwd(f_in, ld_f, N, cv.Cin, p.src, p.dst, p.attr, E, cv.W1, 2 * cv.Cin + 4,
@@ -224,43 +201,31 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
       YL_STAGE(nm, 2.0 * E * C * C, 8.0 * E * C,
                yolat_linear_fwd(p.H1, C, E, C, nullptr, nullptr, 0, cv.W2, C, cv.b2, C, cv.s2, cv.t2, 1, p.H2,
                                 C, 0, nullptr, stream));
-      }
       YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
                yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
     }
     // node branch
     snprintf(nm, sizeof nm, "mlp_node[N x %ld -> %ld]", (long)cv.Cin, C);
-    YL_STAGE_ON(side, nm, 2.0 * N * cv.Cin * C, 4.0 * (N * cv.Cin + N * C + C * cv.Cin),
-                yolat_linear_fwd(s_in, ld_s, N, cv.Cin, nullptr, nullptr, 0, cv.Wn, cv.Cin, cv.bn, C, cv.sn, cv.tn,
-                                 1, s_out, ld_out, 0, nullptr, side));
+    YL_STAGE(nm, 2.0 * N * cv.Cin * C, 4.0 * (N * cv.Cin + N * C + C * cv.Cin),
+             yolat_linear_fwd(s_in, ld_s, N, cv.Cin, nullptr, nullptr, 0, cv.Wn, cv.Cin, cv.bn, C, cv.sn, cv.tn, 1,
+                              s_out, ld_out, 0, nullptr, stream));
     }
     f_in = f_out; ld_f = ld_out; s_in = s_out; ld_s = ld_out;
   }
 
   // ---- fusion over nodes + per-proposal max (arch:61-63,122)
   float* sup = p.Z + 2 * F + D;
-  if (aux) {
-    YL_STAGE("pool_prepare[max(feats), zero]", 1.0 * N * D, 4.0 * N * D + 4.0 * P * (F + D),
-             yolat_pool_prepare(p.feats, nullptr, D, D, F, p.seg_ptr, P, p.Z, ZW, stream));
-    YL_STAGE_ON(side, "segment_mean[fsup]", 1.0 * N * D, 4.0 * N * D + 4.0 * P * D,
-                yolat_segment_mean_fwd(p.fsup, D, D, nullptr, nullptr, 0, p.seg_ptr, P, sup, ZW, side));
-  } else {
-    YL_STAGE("pool_prepare[max(feats), mean(fsup), zero]", 2.0 * N * D, 8.0 * N * D + 4.0 * P * (F + 2 * D),
-             yolat_pool_prepare(p.feats, p.fsup, D, D, F, p.seg_ptr, P, p.Z, ZW, stream));
-  }
+  YL_STAGE("pool_prepare[max(feats), mean(fsup), zero]", 2.0 * N * D, 8.0 * N * D + 4.0 * P * (F + 2 * D),
+           yolat_pool_prepare(p.feats, p.fsup, D, D, F, p.seg_ptr, P, p.Z, ZW, stream));
   snprintf(nm, sizeof nm, "fusion_gemm+segmax[N x %ld -> %ld -> P]", D, F);
   YL_STAGE(nm, 2.0 * N * D * F, 4.0 * (N * D + D * F + P * F),
            yolat_linear_segmax_fwd(p.feats, D, N, D, m->Wf, D, m->bf, F, m->sf, m->tf, p.node_seg, p.Z, ZW,
                                    stream));
   // ---- super branch: fusion_block_super on the per-proposal means (arch:65-69)
   snprintf(nm, sizeof nm, "fusion_super_gemm[P x %ld -> %ld]", D, F);
-  YL_STAGE_ON(side, nm, 2.0 * P * D * F, 4.0 * (P * D + D * F + P * F),
-              yolat_linear_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->Wfs, D, m->bfs, F, m->sfs, m->tfs, 1,
-                               p.Z + F + D, ZW, 0, nullptr, side));
-  if (aux) {
-    if (hipEventRecord(aux->join, aux->side) != hipSuccess) return YOLAT_E_INVALID;
-    if (hipStreamWaitEvent((hipStream_t)stream, aux->join, 0) != hipSuccess) return YOLAT_E_INVALID;
-  }
+  YL_STAGE(nm, 2.0 * P * D * F, 4.0 * (P * D + D * F + P * F),
+           yolat_linear_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->Wfs, D, m->bfs, F, m->sfs, m->tfs, 1,
+                            p.Z + F + D, ZW, 0, nullptr, stream));
   // ---- classifier (arch:91-93,127-128)
   snprintf(nm, sizeof nm, "cls1[P x %ld -> %ld]", ZW, (long)m->H1);
   YL_STAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + ZW * m->H1 + P * m->H1),
