@@ -57,10 +57,10 @@ struct StageRec { std::string name; double flops, bytes; std::vector<std::pair<h
 std::vector<StageRec> g_stages;
 std::vector<hipEvent_t> g_pool;
 bool g_profile = false;
-int g_conv_mode = -1;   // conv layer implementation: 0 per-op kernels, 1 conv_fused.hip, 2 conv_chain.hip,
-                        // 3 (default) = by size: measured on MI355X the per-op path wins below ~200k edges
-                        // (cfg 2: 85 vs 92 us for both layers) and conv_chain above (cfg 5: 742 vs 800 us
-                        // per block layer).  env YOLAT_CONV_MODE overrides (A/B testing).
+int g_conv_mode = -1;   // conv layer implementation: 0 (default) tile kernels: edge_mlp2 -> node_pair -> csr_mean;
+                        // 1 conv_fused.hip, 2 conv_chain.hip (whole-layer persistent kernels, kept for A/B:
+                        // measured on MI355X they lose at every size — cfg 2 block layer 46 us (mode 0) vs
+                        // 50-54 us; cfg 5 block layer 543 us vs 767 us).  env YOLAT_CONV_MODE overrides.
 
 hipEvent_t new_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
@@ -129,9 +129,9 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
   if (g_conv_mode < 0) {
     const char* e = getenv("YOLAT_CONV_MODE");
-    g_conv_mode = (e && e[0] >= '0' && e[0] <= '3') ? (e[0] - '0') : 3;
+    g_conv_mode = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 0;
   }
-  const int conv_mode = (g_conv_mode == 3) ? (E >= 200000 ? 2 : 0) : g_conv_mode;
+  const int conv_mode = g_conv_mode;
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
   const int lo = m->n_blocks - m->n_blocks_out;
 
