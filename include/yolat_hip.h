@@ -271,6 +271,31 @@ int yolat_segment_max_bwd(const float* dY, int64_t lddy, int64_t D, const int32_
                           yolat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Training-mode fusion block + per-proposal max pooling without the [N,F] activation
+ * (architecture3cc_rpn_gp_iter2.py:61-63,122: MLP([fusion_dims,1024]) -> scatter(reduce='max')) and its
+ * autograd.  BatchNorm batch statistics come from the K x K centered Gram matrix of the input, the GEMM
+ * epilogue keeps only the per-(proposal, column) extreme pre-activation and its row, the backward is
+ * sparse over those P*F entries (derivation: csrc/fusion_train.hip).
+ *   A [N,K] (lda % 4 == 0, K % 4 == 0), W [F,K] contiguous, node_seg[N] non-decreasing proposal ids,
+ *   Z [P,F] <- max over rows of relu(BN(A W^T + bias)); coef [4,F] <- scale, shift, batch mean, invstd;
+ *   saved: fp32 scratch of yolat_fusion_pool_train_saved_elems(K,F,P) kept until the backward;
+ *   work: fp32 scratch of yolat_fusion_pool_train_work_elems(N,K,F,P).
+ * bwd: gZ [P,F] = dL/dZ; writes dW [F,K], dbias [F] (= 0), dgamma, dbeta [F]; dA [N,K] += dL/dA.
+ * ------------------------------------------------------------------------------------------ */
+size_t yolat_fusion_pool_train_saved_elems(int64_t K, int64_t F, int64_t P);
+size_t yolat_fusion_pool_train_work_elems(int64_t N, int64_t K, int64_t F, int64_t P);
+int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t N, int64_t K, const float* W,
+                                const float* bias, int64_t F, const float* gamma, const float* beta,
+                                float* running_mean, float* running_var, float momentum, float eps,
+                                const int32_t* node_seg, int64_t P, float* Z, int64_t ldz, float* coef,
+                                float* saved, float* work, yolat_stream_t stream);
+int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t N, int64_t K, const float* W,
+                                const float* gamma, int64_t F, const float* coef, const float* saved,
+                                const int32_t* node_seg, const int32_t* seg_ptr, int64_t P, const float* gZ,
+                                int64_t ldg, float* dW, float* dbias, float* dgamma, float* dbeta, float* dA,
+                                int64_t ldda, float* work, yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Loss and optimiser
  * ------------------------------------------------------------------------------------------ */
 

@@ -265,3 +265,39 @@ def test_predict_two_pass_matches_reference_golden(golden_dir):
             last[model.n_classes - 1] = -1e4
             out = model.predict(data, slices)
         assert len(out[3]) == len(data.roots) and out[4][-1] == len(data.roots)
+
+
+def test_train_step_fused_fusion_block_matches_materialising_schedule():
+    """The Gram-matrix / sparse-backward fusion block (csrc/fusion_train.hip, default) and the schedule that
+    materialises the [N,1024] activation must give the same loss, gradients and BatchNorm buffers."""
+    yv = _yv()
+    arrs, optkw = gu.graph_case("medium")
+    outs = []
+    for fused in (True, False):
+        yv.engine.FUSED_FUSION_TRAIN = fused
+        try:
+            model = _model(yv, optkw, 7)
+            model.train()
+            crit = yv.DetectionLoss(yv.Opt(**optkw))
+            data = gu.to_data(arrs, yv.Data)
+            out = model(data, None)
+            loss = crit(out, data)["loss"]
+            loss.backward()
+            grads = {n: p.grad.detach().clone() for n, p in model.named_parameters()}
+            bufs = {n: b.detach().clone() for n, b in model.named_buffers()}
+            outs.append((float(loss), grads, bufs))
+        finally:
+            yv.engine.FUSED_FUSION_TRAIN = True
+    (la, ga, ba), (lb, gb, bb) = outs
+    assert abs(la - lb) <= 1e-5 * abs(lb)
+    gmax = max(float(v.abs().max()) for v in gb.values())
+    for n in ga:
+        scale = max(float(gb[n].abs().max()), 1e-8)
+        err = float((ga[n] - gb[n]).abs().max())
+        # biases in front of a BatchNorm have mathematically zero gradient: only an absolute bound applies
+        assert err <= 2e-4 * scale + 2e-6 * gmax, (n, err, scale)
+    for n in ba:
+        if ba[n].is_floating_point():
+            np.testing.assert_allclose(ba[n].cpu().numpy(), bb[n].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
+        else:
+            assert torch.equal(ba[n], bb[n]), n

@@ -584,3 +584,59 @@ def test_adam_matches_torch_over_several_steps():
     close(pd, p.detach(), rtol=1e-6, atol=1e-7, msg="adam params")
     close(m, opt.state[p]["exp_avg"], rtol=1e-5, msg="exp_avg")
     close(v, opt.state[p]["exp_avg_sq"], rtol=1e-5, msg="exp_avg_sq")
+
+
+@pytest.mark.parametrize("N_P", [(37, 9), (700, 41), (5000, 300)])
+def test_fusion_pool_train_matches_autograd_of_materialised_path(N_P):
+    """csrc/fusion_train.hip (Gram-matrix BatchNorm statistics, extreme-of-z GEMM epilogue, sparse
+    backward) against torch autograd of Linear -> BatchNorm1d(train) -> ReLU -> scatter-max in float64."""
+    yv = _yv()
+    Nn, P = N_P
+    rng = np.random.default_rng(Nn)
+    K, F = 128, 1024
+    n_p = rng.multinomial(Nn - P + 1, np.ones(P - 1) / (P - 1)) + 1
+    n_p = np.concatenate([n_p[:3], [0], n_p[3:]])            # one empty proposal
+    n_p[-1] += Nn - n_p.sum()
+    bb = np.repeat(np.arange(P), n_p).astype(np.int64)
+    tg = torch.Generator().manual_seed(Nn)
+    A = torch.relu(torch.randn(Nn, K, generator=tg)) + 0.3 * torch.rand(1, K, generator=tg)
+    lin = torch.nn.Linear(K, F)
+    bn = torch.nn.BatchNorm1d(F)
+    with torch.no_grad():
+        lin.weight.copy_(torch.randn(F, K, generator=tg) / K ** 0.5)
+        lin.bias.copy_(torch.randn(F, generator=tg) * 0.1)
+        bn.weight.copy_(torch.rand(F, generator=tg) * 1.5 - 0.4)      # some negative gammas
+        bn.bias.copy_(torch.randn(F, generator=tg) * 0.2)
+    gZ = torch.randn(P, F, generator=tg) / P
+    d_in = torch.randn(Nn, K, generator=tg) * 0.01                  # dA is accumulated into
+    # float64 reference
+    lin64, bn64 = torch.nn.Linear(K, F).double(), torch.nn.BatchNorm1d(F).double()
+    lin64.load_state_dict({k: v.double() for k, v in lin.state_dict().items()})
+    bn64.load_state_dict({k: (v.double() if v.is_floating_point() else v) for k, v in bn.state_dict().items()})
+    A64 = A.double().requires_grad_(True)
+    y = torch.relu(bn64(lin64(A64)))
+    pooled = orc.scatter(y, torch.from_numpy(bb), dim=0, dim_size=P, reduce="max")
+    pooled.backward(gZ.double())
+    # HIP
+    g = yv.ops.build_graph(torch.zeros(0, 2, dtype=torch.int64).cuda(), torch.zeros(0, 4).cuda(), dev(bb), Nn, P)
+    lin_d, bn_d = lin.cuda(), bn.cuda()
+    Zbuf = torch.full((P, F + 64), float("nan")).cuda()
+    sv = yv.ops.fusion_pool_train_fwd(A.cuda(), lin_d, bn_d, g, Zbuf[:, :F])
+    close(Zbuf[:, :F], pooled.detach().float(), rtol=2e-4, atol=2e-5, msg="pooled")
+    assert torch.isnan(Zbuf[:, F:]).all()
+    close(bn_d.running_mean, bn64.running_mean.float(), rtol=1e-4, atol=1e-6, msg="running_mean")
+    close(bn_d.running_var, bn64.running_var.float(), rtol=1e-4, atol=1e-6, msg="running_var")
+    dW, db = torch.empty(F, K).cuda(), torch.full((F,), float("nan")).cuda()
+    dg, dbt = torch.empty(F).cuda(), torch.empty(F).cuda()
+    dA = d_in.clone().cuda()
+    yv.ops.fusion_pool_train_bwd(sv, g, gZ.cuda(), dW, db, dg, dbt, dA)
+
+    def rel(got, want, name, tol=2e-4):
+        want = want.float()
+        err = float((got.cpu() - want).abs().max()) / max(float(want.abs().max()), 1e-20)
+        assert err < tol, (name, err)
+    rel(dW, lin64.weight.grad, "dW")
+    rel(dg, bn64.weight.grad, "dgamma")
+    rel(dbt, bn64.bias.grad, "dbeta")
+    rel(dA - d_in.cuda(), A64.grad, "dA")
+    assert float(db.abs().max()) == 0.0 and float(lin64.bias.grad.abs().max()) < 1e-12

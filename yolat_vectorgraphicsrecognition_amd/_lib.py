@@ -45,6 +45,12 @@ SIGNATURES = {
                                       c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_node_side_eval": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64,
                                       c_p, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_fusion_pool_train_saved_elems": (c_sz, [c_i64, c_i64, c_i64]),
+    "yolat_fusion_pool_train_work_elems": (c_sz, [c_i64, c_i64, c_i64, c_i64]),
+    "yolat_fusion_pool_train_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_f, c_f,
+                                             c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_fusion_pool_train_bwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p,
+                                             c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
     "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),

@@ -204,6 +204,10 @@ struct Epilogue {
   const int* seg;  // nullable [M]
   float* pool;
   long ldpool;
+  // training-mode fused pooling (fusion_train.hip): when key64 != nullptr the tile is not stored; for every
+  // (segment, column) the row with the largest s*z (s = sign of `scale`, z = acc + bias) is recorded as
+  //   key = orderable(s*z) << 32 | ~row     via 64-bit atomicMax  (ties -> lowest row)
+  unsigned long long* key64 = nullptr;
   // fused CSR mean aggregation (eval node-side kernel): when agg != nullptr the value stored for row n is
   //   epi(acc)[n] + mean_{q in [agg_ptr[n], agg_ptr[n+1])} agg[q, col]      (ascending q, like k_csr_mean_fwd)
   const float* agg = nullptr;
@@ -265,6 +269,33 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
   }
   const float sc = pre.sc, sh = pre.sh;
   const float floor = ep.relu ? 0.f : -INFINITY;
+  if (ep.key64 != nullptr) {
+    const int segv = pre.segv;
+    int sgs[16];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);
+    const bool neg = sc < 0.f;
+    int cur_seg = -1;
+    unsigned long long cur = 0ull;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      const int sg = sgs[r];
+      const float z = neg ? -acc[r] : acc[r];
+      unsigned int u = __float_as_uint(z);
+      u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);            // order-preserving float -> uint
+      const unsigned long long key = ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - (unsigned)row);
+      if (sg != cur_seg) {
+        if (cur_seg >= 0 && col_ok) atomicMax(ep.key64 + (long)cur_seg * ep.ldpool + col, cur);
+        cur_seg = sg;
+        cur = key;
+      } else {
+        cur = key > cur ? key : cur;
+      }
+    }
+    if (cur_seg >= 0 && col_ok) atomicMax(ep.key64 + (long)cur_seg * ep.ldpool + col, cur);
+    return;
+  }
   if (ep.seg != nullptr) {
     // rows of a proposal are consecutive: run-length max over this lane's 16 rows, one atomic per run.
     // The 32 segment ids of the tile are fetched by ONE coalesced load (lane l31 <- row row_base+l31) and

@@ -14,9 +14,15 @@ Blocks
     lbr_fwd / lbr_bwd         Linear(+BN+ReLU)                      torch_nn.py:50-71
     model_fwd / model_bwd     SparseCADGCN.forward                  architecture3cc_rpn_gp_iter2.py:44-71,106-137
 """
+import os
+
 import torch
 
 from . import ops
+
+# training-mode fusion block + max pooling without the [N, 1024] activation (csrc/fusion_train.hip);
+# YOLAT_FUSED_FUSION_TRAIN=0 selects the materialising schedule (kept as the cross-check in the tests)
+FUSED_FUSION_TRAIN = os.environ.get("YOLAT_FUSED_FUSION_TRAIN", "1") != "0"
 
 
 class Lazy(object):
@@ -255,10 +261,19 @@ def model_fwd(model, g, x, training):
 
     Z = _empty(P, 2 * (F + D), dev)     # [max(fusion) | max(feats) | fusion_super | mean(sup)]  (arch:127)
     # fusion block over nodes, then per-proposal max                                  (arch:61-63,122)
-    fus, sv_fus = lbr_fwd(Lazy(feats), net.fusion_block[0], net.fusion_block[1], True, training)
-    arg_fus = torch.empty(P, F, dtype=torch.int32, device=dev) if training else None
+    arg_fus = None
     arg_feat = torch.empty(P, D, dtype=torch.int32, device=dev) if training else None
-    ops.segment_max_fwd(fus.t, g, Z[:, 0:F], arg_fus, x_pro=fus.pro, x_relu=fus.relu)
+    if training and FUSED_FUSION_TRAIN and D == 128 and net.fusion_block[0].weight.is_contiguous():
+        # no [N,F] activation: batch statistics from the Gram matrix of feats, extreme-of-z GEMM epilogue,
+        # sparse backward (csrc/fusion_train.hip)
+        sv_fus = ops.fusion_pool_train_fwd(feats, net.fusion_block[0], net.fusion_block[1], g, Z[:, 0:F])
+        sv_fus["fused"] = True
+        if net.fusion_block[1].num_batches_tracked is not None:
+            net.fusion_block[1].num_batches_tracked += 1
+    else:
+        fus, sv_fus = lbr_fwd(Lazy(feats), net.fusion_block[0], net.fusion_block[1], True, training)
+        arg_fus = torch.empty(P, F, dtype=torch.int32, device=dev) if training else None
+        ops.segment_max_fwd(fus.t, g, Z[:, 0:F], arg_fus, x_pro=fus.pro, x_relu=fus.relu)
     ops.segment_max_fwd(feats, g, Z[:, F:F + D], arg_feat)
     # super branch: per-proposal mean, then fusion_block_super                        (arch:65-69)
     sup = Z[:, 2 * F + D:2 * F + 2 * D]
@@ -297,11 +312,17 @@ def model_bwd(model, g, sv, dlogits, sink):
     d_fsup = _empty(N, D, dev)                                        # grad w.r.t. post-activation s's
     ops.segment_mean_bwd(d_sup, g, d_fsup)
     # fusion_block + max pooling
-    d_fus = _empty(N, F, dev)
-    ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)
     d_feats = _empty(N, D, dev)
     ops.segment_max_bwd(dZ[:, F:F + D], sv["arg_feat"], g, d_feats)
-    lbr_bwd(sv["fus"], d_fus, sink, dx_out=d_feats, dx_accumulate=True)
+    if sv["fus"].get("fused"):
+        lin, bn = sv["fus"]["lin"], sv["fus"]["bn"]
+        ops.fusion_pool_train_bwd(sv["fus"], g, dZ[:, 0:F], sink.get(lin.weight),
+                                  sink.get(lin.bias) if lin.bias is not None else None, sink.get(bn.weight),
+                                  sink.get(bn.bias), d_feats)
+    else:
+        d_fus = _empty(N, F, dev)
+        ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)
+        lbr_bwd(sv["fus"], d_fus, sink, dx_out=d_feats, dx_accumulate=True)
     # conv layers, last to first
     d_f_next, d_s_next = None, None      # grads flowing into layer l's outputs from layer l+1
     for l in range(L - 1, -1, -1):

@@ -316,6 +316,43 @@ def segment_max_bwd(dY, arg, g, dX):
 
 
 # ---------------------------------------------------------------------------------------------
+# training-mode fusion block + per-proposal max pooling (csrc/fusion_train.hip)
+# ---------------------------------------------------------------------------------------------
+
+def fusion_pool_train_fwd(A, lin, bn, g, Z):
+    """Z[P,F] <- scatter_max(relu(bn(lin(A)))) with batch statistics, without materialising [N,F].
+    Returns the state the backward needs."""
+    N, K = A.shape
+    F = lin.out_features
+    dev = A.device
+    coef = torch.empty(4, F, dtype=torch.float32, device=dev)
+    saved = torch.empty(int(lib.yolat_fusion_pool_train_saved_elems(K, F, g.P)), dtype=torch.float32, device=dev)
+    work = torch.empty(int(lib.yolat_fusion_pool_train_work_elems(N, K, F, g.P)), dtype=torch.float32, device=dev)
+    track = bn.track_running_stats and bn.running_mean is not None
+    mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    W = lin.weight
+    if not W.is_contiguous():
+        raise ValueError("fusion_block weight must be contiguous")
+    check(lib.yolat_fusion_pool_train_fwd(_f(A, "A"), _ld(A), N, K, _f(W), _f(lin.bias, "bias", True), F,
+                                          _f(bn.weight), _f(bn.bias), _f(bn.running_mean if track else None, "rm", True),
+                                          _f(bn.running_var if track else None, "rv", True), mom, float(bn.eps),
+                                          g.node_seg.data_ptr(), g.P, _f(Z), _ld(Z), _f(coef), _f(saved), _f(work),
+                                          _stream()), "yolat_fusion_pool_train_fwd")
+    return {"A": A, "lin": lin, "bn": bn, "coef": coef, "saved": saved, "work": work}
+
+
+def fusion_pool_train_bwd(sv, g, gZ, dW, dbias, dgamma, dbeta, dA):
+    A, lin = sv["A"], sv["lin"]
+    N, K = A.shape
+    F = lin.out_features
+    check(lib.yolat_fusion_pool_train_bwd(_f(A), _ld(A), N, K, _f(lin.weight), _f(sv["bn"].weight), F, _f(sv["coef"]),
+                                          _f(sv["saved"]), g.node_seg.data_ptr(), g.seg_ptr.data_ptr(), g.P,
+                                          _f(gZ, "gZ"), _ld(gZ), _f(dW), _f(dbias, "dbias", True), _f(dgamma),
+                                          _f(dbeta), _f(dA), _ld(dA), _f(sv["work"]), _stream()),
+          "yolat_fusion_pool_train_bwd")
+
+
+# ---------------------------------------------------------------------------------------------
 # loss / optimiser
 # ---------------------------------------------------------------------------------------------
 
