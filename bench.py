@@ -262,11 +262,18 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
-    torch.cuda.set_device(local)
+    # YOLAT_BENCH_DEVICE / YOLAT_BENCH_BACKEND exist only so the N>1 control flow can be exercised on a
+    # one-GPU box (both ranks on cuda:0 over gloo); the driver's multi-GPU runs use one GPU per rank over RCCL.
+    dev_index = int(os.environ.get("YOLAT_BENCH_DEVICE", local))
+    torch.cuda.set_device(dev_index)
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world)   # "nccl" is RCCL on ROCm
+        backend = os.environ.get("YOLAT_BENCH_BACKEND", "nccl")        # "nccl" is RCCL on ROCm
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", dev_index))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     import yolat_vectorgraphicsrecognition_amd as yv
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -314,8 +321,11 @@ def main():
 
     roof = None
     op_table = None
+    nprof = min(args.steps, 50)
+    if args.mode == "train" and world > 1 and rank != 0 and not args.no_roofline:
+        for _ in range(nprof):           # the train step contains a collective: every rank must take part
+            step()                       # in rank 0's profiling steps
     if rank == 0 and not args.no_roofline:
-        nprof = min(args.steps, 50)
         if args.mode == "fwd":
             op_table = plan_profile(step, nprof)
         else:
@@ -333,7 +343,7 @@ def main():
         agg = aggregation_roofline()
 
     cpu = None
-    if rank == 0 and not args.no_cpu_baseline:
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
         cpu = cpu_baseline(cfg, optkw, args.mode)
 
     if world > 1:
