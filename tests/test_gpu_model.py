@@ -301,3 +301,28 @@ def test_train_step_fused_fusion_block_matches_materialising_schedule():
             np.testing.assert_allclose(ba[n].cpu().numpy(), bb[n].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
         else:
             assert torch.equal(ba[n], bb[n]), n
+
+
+def test_eval_forwards_on_concurrent_streams_do_not_interfere():
+    """One eval plan (workspace, status word) per launch stream: forwards of different graphs issued
+    back to back on three streams must give bit-identical logits to the same forwards run alone."""
+    yv = _yv()
+    cases = [gu.graph_case(k) for k in ("small", "medium", "small")]
+    optkw = cases[0][1]
+    model = _model(yv, optkw, 5)
+    model.eval()
+    datas = [gu.to_data(a, yv.Data) for a, _ in cases]
+    with torch.no_grad():
+        alone = [model(d, None)[0].clone() for d in datas]
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in datas]
+    outs = [None] * len(datas)
+    for rep in range(5):
+        for i, (d, s) in enumerate(zip(datas, streams)):
+            d._yolat_stage = None
+            with torch.cuda.stream(s), torch.no_grad():
+                outs[i] = model(d, None)[0]
+    torch.cuda.synchronize()
+    for a, b in zip(alone, outs):
+        assert torch.equal(a, b)
+    assert len(model._yolat_plans) >= 3

@@ -146,10 +146,15 @@ class SparseCADGCN(nn.Module):
         if not self.training and not torch.is_grad_enabled():
             # eval fast path: one call into libyolat_hip.so (plan.EvalPlan / yolat_forward_eval)
             st = self._stage(data, need_graph=False)
-            plan = getattr(self, "_yolat_plan", None)
+            # one plan (folded weights, workspace, status word) per launch stream: independent forwards
+            # issued on different streams overlap on the GPU (no kernel of a 10k-node graph fills 256 CUs)
+            plans = self.__dict__.setdefault("_yolat_plans", {})
+            sid = torch.cuda.current_stream().cuda_stream
+            plan = plans.get(sid)
             if plan is None:
                 from .plan import EvalPlan
-                plan = self._yolat_plan = EvalPlan(self)
+                plan = plans[sid] = EvalPlan(self)
+            self._yolat_plan = plan          # the plan of the most recent forward (status checks)
             pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])
             st["plan_status"] = plan
         else:
