@@ -76,6 +76,27 @@ size_t yolat_csc_work_elems(int64_t N);
 int yolat_csc_by_source(const int32_t* src_csr, int64_t E, int64_t N, int32_t* col_ptr,
                         int32_t* slots, int32_t* work, yolat_stream_t stream);
 
+/* Sub-batch extraction for SparseCADGCN.predict's two passes (architecture3cc_rpn_gp_iter2.py:153-242):
+ * the Python list / dict / per-edge loops become integer kernels, bit-exact with them.
+ *   yolat_expand_ranges:    out[i] = start[j] + (i - prefix[j]) for the range j containing slot i;
+ *                           start[S], prefix[S+1] exclusive prefix of the range lengths, total = prefix[S]
+ *   yolat_subgraph_reindex: node_ids[n_sub] old node ids of the subset (new id = position; on duplicates
+ *                           the later position wins, like the reference's dict), edge_ids[m_sub] rows of the
+ *                           batch edge list -> edge_out[m_sub,2] int64 in new ids (an endpoint outside the
+ *                           subset raises YOLAT_STATUS_EDGE_RANGE: the reference raises KeyError);
+ *                           bbox_idx_out[n_sub] int64 = run-length renumbering of bbox_idx[node_ids]
+ *                           work: int32 scratch of yolat_subgraph_work_elems(N, n_sub)
+ *   yolat_gather_rows_bytes: dst[r] = src[idx[r]] for rows of row_bytes (multiple of 4) bytes            */
+int yolat_expand_ranges(const int32_t* start, const int32_t* prefix, int64_t S, int64_t total, int32_t* out,
+                        yolat_stream_t stream);
+size_t yolat_subgraph_work_elems(int64_t N, int64_t n_sub);
+int yolat_subgraph_reindex(const int32_t* node_ids, int64_t n_sub, int64_t N, const int64_t* edge,
+                           int64_t stride_e, int64_t stride_c, const int32_t* edge_ids, int64_t m_sub,
+                           const int64_t* bbox_idx, int64_t* edge_out, int64_t* bbox_idx_out, int32_t* work,
+                           int32_t* status, yolat_stream_t stream);
+int yolat_gather_rows_bytes(const void* src, int64_t src_row_bytes, const int32_t* idx, int64_t rows,
+                            int64_t row_bytes, void* dst, int64_t dst_row_bytes, yolat_stream_t stream);
+
 /* seg_ptr[P+1] from a non-decreasing int64 bbox_idx[N] (Datasets/graph_dict3.py:732):
  * seg_ptr[p] = first row r with bbox_idx[r] >= p.  Also writes node_seg[N] (int32 copy).
  * Replaces the implicit segmentation done by torch_scatter.scatter(index=bbox_idx)

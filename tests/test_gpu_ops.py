@@ -640,3 +640,39 @@ def test_fusion_pool_train_matches_autograd_of_materialised_path(N_P):
     rel(dbt, bn64.bias.grad, "dbeta")
     rel(dA - d_in.cuda(), A64.grad, "dA")
     assert float(db.abs().max()) == 0.0 and float(lin64.bias.grad.abs().max()) < 1e-12
+
+
+def test_device_subgraph_extraction_equals_loop_oracle():
+    """csrc/subgraph.hip (range expansion, o2n re-indexing, run-length bbox_idx renumbering, gathers) against
+    the oracle's element-wise loops of arch:153-242 — bit-exact, including duplicate ranges (later wins)."""
+    yv = _yv()
+    data, slices = gu.predict_case(yv.synth_batch)
+    dev_batch = {k: getattr(data, k).cuda() for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "stat_feats")}
+    rng = np.random.default_rng(5)
+    n_roots = len(data.roots)
+    for has_object in (None, rng.random(n_roots) < 0.5, np.ones(n_roots, bool)):
+        ps, pe, es, ee, sb, img = yv.data.select_tree_ranges(data, slices, has_object)
+        osp, ose, osb, oimg = orc.predict_gather(data, slices, None if has_object is None else torch.from_numpy(has_object))
+        assert sb == osb and img == oimg
+        if len(osp) == 0:
+            continue
+        got, status = yv.ops.extract_subgraph(yv.Data, dev_batch, ps, pe, es, ee, sb)
+        want = orc.predict_build_data(data, osp, ose, osb)
+        assert int(status.item()) == 0
+        for k in ("x", "pos", "edge", "e_attr", "bbox", "stat_feats", "bbox_idx"):
+            a, b = getattr(got, k).cpu(), getattr(want, k)
+            assert a.dtype == b.dtype and torch.equal(a, b), k
+    # a duplicated range: the later copy wins in the o2n table (dict semantics of the reference)
+    ps, pe, es, ee, sb, _ = yv.data.select_tree_ranges(data, slices)
+    ps2, pe2 = np.concatenate([ps, ps[:1]]), np.concatenate([pe, pe[:1]])
+    got, status = yv.ops.extract_subgraph(yv.Data, dev_batch, ps2, pe2, es, ee, sb)
+    osp = yv.data._expand_ranges(ps2, pe2).tolist()
+    want = orc.predict_build_data(data, osp, yv.data._expand_ranges(es, ee).tolist(), sb)
+    assert torch.equal(got.edge.cpu(), want.edge) and torch.equal(got.bbox_idx.cpu(), want.bbox_idx)
+    # an edge leaving the subset raises the flag (the reference raises KeyError)
+    bad = {k: v.clone() for k, v in dev_batch.items()}
+    inside = set(yv.data._expand_ranges(ps, pe).tolist())
+    outside = next(i for i in range(data.x.shape[0]) if i not in inside)
+    bad["edge"][int(es[0]), 1] = outside
+    _, status = yv.ops.extract_subgraph(yv.Data, bad, ps, pe, es, ee, sb)
+    assert int(status.item()) & yv.ops.STATUS_EDGE_RANGE

@@ -169,19 +169,27 @@ class SparseCADGCN(nn.Module):
         proposals; proposals classified as class ``n_classes-1`` get their children evaluated in a
         second forward; per image the root rows are followed by the child rows; boxes are enlarged by
         5 %.  Returns the reference's 6-tuple ``(pred_cls, pred_bbox, None, slice_bbox,
-        slice_image_bbox, None)``.  The slicing is host work (numpy, `data.select_tree_nodes` /
-        `data.build_subset`); both forwards run through the HIP path."""
-        from .data import select_tree_nodes, build_subset, interleave_root_child
-        sp, se, slice_bbox_root, image_root = select_tree_nodes(data, slices)
-        sub = build_subset(data, sp, se, slice_bbox_root)
+        slice_image_bbox, None)``.  The host walks the proposal tree; node / edge re-indexing and the
+        gathers are device kernels (`ops.extract_subgraph`); both forwards run through the HIP path."""
+        from .data import select_tree_ranges, interleave_root_child
+        # the whole batch goes to the device once; both sub-batches are cut out of it by integer kernels
+        # (csrc/subgraph.hip) — the host only walks the proposal tree (O(#tree nodes))
+        dev = {k: getattr(data, k).cuda(non_blocking=True) for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox",
+                                                                    "stat_feats")}
+        if dev["x"].dtype != torch.float32:
+            dev["x"] = dev["x"].float()
+        ps, pe, es, ee, slice_bbox_root, image_root = select_tree_ranges(data, slices)
+        sub, status1 = ops.extract_subgraph(data.__class__, dev, ps, pe, es, ee, slice_bbox_root)
         pred_cls, pred_bbox = self.forward(sub, slices)
         is_object = pred_cls.max(1)[1]
         has_object = (is_object == self.n_classes - 1).cpu().numpy()     # D2H sync, as in the reference
-        sp, se, slice_bbox_child, image_child = select_tree_nodes(data, slices, has_object)
-        if len(sp) == 0:
+        if int(status1.item()) & ops.STATUS_EDGE_RANGE:
+            raise KeyError("an edge of a root proposal references a node outside the selected sub-batch")
+        ps, pe, es, ee, slice_bbox_child, image_child = select_tree_ranges(data, slices, has_object)
+        if int((pe - ps).sum()) == 0:
             slice_image_bbox, slice_bbox = image_root, slice_bbox_root
         else:
-            sub2 = build_subset(data, sp, se, slice_bbox_child)
+            sub2, status2 = ops.extract_subgraph(data.__class__, dev, ps, pe, es, ee, slice_bbox_child)
             pred_cls2, pred_bbox2 = self.forward(sub2, slices)
             parts, slice_image_bbox = interleave_root_child(image_root, image_child, pred_cls, pred_cls2)
             pred_cls = torch.cat(parts, dim=0)
@@ -190,6 +198,8 @@ class SparseCADGCN(nn.Module):
             parts, _ = interleave_root_child(image_root, image_child, torch.tensor(slice_bbox_root),
                                              torch.tensor(slice_bbox_child))
             slice_bbox = torch.cat(parts, dim=0)
+            if int(status2.item()) & ops.STATUS_EDGE_RANGE:
+                raise KeyError("an edge of a child proposal references a node outside the selected sub-batch")
         w = (pred_bbox[:, 2] - pred_bbox[:, 0]) * 1.05
         h = (pred_bbox[:, 3] - pred_bbox[:, 1]) * 1.05
         cx = (pred_bbox[:, 2] + pred_bbox[:, 0]) / 2

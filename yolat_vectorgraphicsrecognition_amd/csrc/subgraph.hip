@@ -1,0 +1,166 @@
+// subgraph.hip — device-side sub-batch extraction for the two-pass inference of SparseCADGCN.predict
+// (cad_recognition/architecture3cc_rpn_gp_iter2.py:153-242).  The reference walks Python lists: `slice_pos`
+// / `slice_edge` are concatenations of index ranges, `o2n` is a dict old node id -> new node id, every
+// edge is re-indexed through it in a Python loop and `bbox_idx` is renumbered by run length.  Here the
+// host only supplies the (start, exclusive-prefix) pairs of the selected ranges; everything of size O(nodes)
+// or O(edges) is integer work on the GPU, bit-exact with the loops:
+//   node_ids[i]  = start[j] + (i - prefix[j]),  j = the range that contains output slot i (binary search)
+//   o2n[old]     = max new id among duplicates  (== "later assignment wins" of the dict, via atomicMax)
+//   edge'[q]     = (o2n[edge[eid[q],0]], o2n[edge[eid[q],1]]);  an endpoint outside the subset raises the
+//                  YOLAT_STATUS_EDGE_RANGE flag (the reference raises KeyError)
+//   bbox_idx'[i] = number of positions 0 < t <= i with bbox_idx[node_ids[t]] != bbox_idx[node_ids[t-1]]
+#include "common.hpp"
+
+static __global__ void k_expand_ranges(const int* __restrict__ start, const int* __restrict__ prefix, int S,
+                                       int total, int* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  int lo = 0, hi = S;              // largest j with prefix[j] <= i   (prefix[S] = total > i)
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (prefix[mid] <= i) lo = mid; else hi = mid;
+  }
+  out[i] = start[lo] + (i - prefix[lo]);
+}
+
+static __global__ void k_o2n_scatter(const int* __restrict__ node_ids, int n, int* o2n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) atomicMax(&o2n[node_ids[i]], i);
+}
+
+static __global__ void k_edge_remap(const int64_t* __restrict__ edge, long se, long sc,
+                                    const int* __restrict__ edge_ids, int m, const int* __restrict__ o2n, int N,
+                                    int64_t* out, int* status) {
+  const int q = blockIdx.x * blockDim.x + threadIdx.x;
+  if (q >= m) return;
+  const long e = edge_ids[q];
+  const int64_t a = edge[e * se], b = edge[e * se + sc];
+  const int na = (a >= 0 && a < N) ? o2n[a] : -1;
+  const int nb = (b >= 0 && b < N) ? o2n[b] : -1;
+  if (na < 0 || nb < 0) atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
+  out[2 * (long)q] = na;
+  out[2 * (long)q + 1] = nb;
+}
+
+// flag[i] = (i > 0 && bbox_idx[node_ids[i]] != bbox_idx[node_ids[i-1]])
+static __global__ void k_change_flags(const int64_t* __restrict__ bbox_idx, const int* __restrict__ node_ids, int n,
+                                      int* flag) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  flag[i] = (i > 0 && bbox_idx[node_ids[i]] != bbox_idx[node_ids[i - 1]]) ? 1 : 0;
+}
+
+// block-local exclusive scan (4096 elements per workgroup) + block totals, then the inclusive result
+static __global__ void __launch_bounds__(1024) k_scan_local(const int* flag, int n, int* local, int* btot) {
+  __shared__ int wsum[16];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int idx = blockIdx.x * 4096 + tid * 4;
+  int v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (idx + j < n) ? flag[idx + j] : 0;
+  const int t = v[0] + v[1] + v[2] + v[3];
+  int incl = t;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int nb = __shfl_up(incl, off);
+    if (lane >= off) incl += nb;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0, total = 0;
+#pragma unroll
+  for (int w = 0; w < 16; ++w) {
+    const int s = wsum[w];
+    if (w < wave) woff += s;
+    total += s;
+  }
+  int excl = woff + incl - t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    if (idx + j < n) local[idx + j] = excl;
+    excl += v[j];
+  }
+  if (tid == 0) btot[blockIdx.x] = total;
+}
+
+static __global__ void k_renumber(const int* flag, const int* local, const int* btot, int n, int64_t* out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  int base = 0;
+  for (int b = 0; b < i / 4096; ++b) base += btot[b];
+  out[i] = (int64_t)(base + local[i] + flag[i]);
+}
+
+static __global__ void k_gather_rows_any(const char* __restrict__ src, long src_row_bytes,
+                                         const int* __restrict__ idx, long rows, int row_bytes, char* dst,
+                                         long dst_row_bytes) {
+  // rows are multiples of 4 bytes (fp32 / int32 / int64 payloads): one 4-byte word per thread
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int words = row_bytes >> 2;
+  const long r = i / words;
+  const int w = (int)(i % words);
+  if (r >= rows) return;
+  reinterpret_cast<int*>(dst + r * dst_row_bytes)[w] =
+      reinterpret_cast<const int*>(src + (long)idx[r] * src_row_bytes)[w];
+}
+
+extern "C" int yolat_expand_ranges(const int32_t* start, const int32_t* prefix, int64_t S, int64_t total,
+                                   int32_t* out, yolat_stream_t stream) {
+  if (S < 0 || total < 0 || total >= (1LL << 31)) return YOLAT_E_INVALID;
+  if (total == 0) return 0;
+  if (S == 0 || !start || !prefix || !out) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_expand_ranges, dim3(yl_cdiv(total, 256)), dim3(256), 0, (hipStream_t)stream, start, prefix,
+                     (int)S, (int)total, out);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" size_t yolat_subgraph_work_elems(int64_t N, int64_t n_sub) {
+  return (size_t)(N + 2 * n_sub + (n_sub + 4095) / 4096 + 16);
+}
+
+extern "C" int yolat_subgraph_reindex(const int32_t* node_ids, int64_t n_sub, int64_t N, const int64_t* edge,
+                                      int64_t stride_e, int64_t stride_c, const int32_t* edge_ids, int64_t m_sub,
+                                      const int64_t* bbox_idx, int64_t* edge_out, int64_t* bbox_idx_out,
+                                      int32_t* work, int32_t* status, yolat_stream_t stream) {
+  if (N <= 0 || n_sub < 0 || m_sub < 0 || !work || !status || N >= (1LL << 31)) return YOLAT_E_INVALID;
+  if (n_sub > 0 && (!node_ids || !bbox_idx || !bbox_idx_out)) return YOLAT_E_INVALID;
+  if (m_sub > 0 && (!edge || !edge_ids || !edge_out)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  int* o2n = work;                       // [N]
+  int* flag = o2n + N;                   // [n_sub]
+  int* local = flag + n_sub;             // [n_sub]
+  int* btot = local + n_sub;             // [ceil(n_sub / 4096)]
+  if (hipMemsetAsync(o2n, 0xFF, sizeof(int) * (size_t)N, st) != hipSuccess) return YOLAT_E_INVALID;   // -1
+  if (n_sub > 0) {
+    hipLaunchKernelGGL(k_o2n_scatter, dim3(yl_cdiv(n_sub, 256)), dim3(256), 0, st, node_ids, (int)n_sub, o2n);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_change_flags, dim3(yl_cdiv(n_sub, 256)), dim3(256), 0, st, bbox_idx, node_ids, (int)n_sub,
+                       flag);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_scan_local, dim3(yl_cdiv(n_sub, 4096)), dim3(1024), 0, st, flag, (int)n_sub, local, btot);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_renumber, dim3(yl_cdiv(n_sub, 256)), dim3(256), 0, st, flag, local, btot, (int)n_sub,
+                       bbox_idx_out);
+    YL_LAUNCH_CHECK();
+  }
+  if (m_sub > 0) {
+    hipLaunchKernelGGL(k_edge_remap, dim3(yl_cdiv(m_sub, 256)), dim3(256), 0, st, edge, (long)stride_e, (long)stride_c,
+                       edge_ids, (int)m_sub, o2n, (int)N, edge_out, status);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+extern "C" int yolat_gather_rows_bytes(const void* src, int64_t src_row_bytes, const int32_t* idx, int64_t rows,
+                                       int64_t row_bytes, void* dst, int64_t dst_row_bytes, yolat_stream_t stream) {
+  if (rows < 0 || row_bytes <= 0 || row_bytes % 4 != 0 || src_row_bytes < row_bytes || dst_row_bytes < row_bytes)
+    return YOLAT_E_INVALID;
+  if (rows == 0) return 0;
+  if (!src || !idx || !dst) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_gather_rows_any, dim3(yl_cdiv(rows * (row_bytes / 4), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const char*)src, (long)src_row_bytes, idx, (long)rows, (int)row_bytes, (char*)dst,
+                     (long)dst_row_bytes);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

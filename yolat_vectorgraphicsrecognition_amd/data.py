@@ -135,10 +135,11 @@ def _expand_ranges(starts, ends):
     return np.repeat(starts - first, lens) + np.arange(total, dtype=np.int64)
 
 
-def select_tree_nodes(data, slices, has_object=None):
-    """First (``has_object is None``) or second pass selection of arch:153-164 / :277-296.
-    Returns (slice_pos, slice_edge, slice_bbox, slice_image_bbox): global node ids, global edge rows,
-    global proposal rows (python list) and per-image offsets into slice_bbox."""
+def select_tree_ranges(data, slices, has_object=None):
+    """First (``has_object is None``) or second pass selection of arch:153-164 / :277-296 as index RANGES.
+    Returns (pos_s, pos_e, edge_s, edge_e, slice_bbox, slice_image_bbox): int64 arrays of global
+    [start, end) node / edge ranges per selected tree node, the global proposal rows (python list) and the
+    per-image offsets into slice_bbox.  O(#selected tree nodes) host work; nothing of size O(nodes)."""
     roots = data.roots
     slice_root = [int(v) for v in slices["roots"]]
     pos_s, pos_e, edge_s, edge_e, slice_bbox, image_off = [], [], [], [], [], [0]
@@ -160,7 +161,15 @@ def select_tree_nodes(data, slices, has_object=None):
                 edge_e.append(v["idx_edge"][1] + off_edge)
                 slice_bbox.append(int(v["idx_bbox"] + off_bbox))
         image_off.append(len(slice_bbox))
-    return _expand_ranges(pos_s, pos_e), _expand_ranges(edge_s, edge_e), slice_bbox, image_off
+    as64 = lambda a: np.asarray(a, dtype=np.int64)
+    return as64(pos_s), as64(pos_e), as64(edge_s), as64(edge_e), slice_bbox, image_off
+
+
+def select_tree_nodes(data, slices, has_object=None):
+    """`select_tree_ranges` with the ranges expanded on the host: (slice_pos, slice_edge, slice_bbox,
+    slice_image_bbox) exactly as the reference's Python lists (used by the CPU cross-checks)."""
+    ps, pe, es, ee, slice_bbox, image_off = select_tree_ranges(data, slices, has_object)
+    return _expand_ranges(ps, pe), _expand_ranges(es, ee), slice_bbox, image_off
 
 
 def build_subset(data, slice_pos, slice_edge, slice_bbox):

@@ -316,6 +316,69 @@ def segment_max_bwd(dY, arg, g, dX):
 
 
 # ---------------------------------------------------------------------------------------------
+# device-side sub-batch extraction for predict()'s two passes (csrc/subgraph.hip)
+# ---------------------------------------------------------------------------------------------
+
+def _ranges_to_ids(starts, ends, dev):
+    """Concatenation of range(s, e) as an int32 CUDA tensor (ranges given as host int64 arrays)."""
+    import numpy as np
+    lens = ends - starts
+    if (lens < 0).any():
+        raise ValueError("idx range with end < start")
+    prefix = np.zeros(len(lens) + 1, dtype=np.int64)
+    np.cumsum(lens, out=prefix[1:])
+    total = int(prefix[-1])
+    out = torch.empty(total, dtype=torch.int32, device=dev)
+    if total:
+        st = torch.from_numpy(starts.astype(np.int32)).to(dev, non_blocking=True)
+        pf = torch.from_numpy(prefix.astype(np.int32)).to(dev, non_blocking=True)
+        check(lib.yolat_expand_ranges(st.data_ptr(), pf.data_ptr(), len(lens), total, out.data_ptr(), _stream()),
+              "yolat_expand_ranges")
+        out._keep = (st, pf)
+    return out
+
+
+def _gather(src, idx):
+    """dst[r] = src[idx[r]] for a contiguous 2-D tensor of a 4-/8-byte dtype."""
+    if not src.is_contiguous() or src.dim() != 2:
+        raise ValueError("gather source must be a contiguous 2-D tensor")
+    rb = src.shape[1] * src.element_size()
+    dst = torch.empty(idx.numel(), src.shape[1], dtype=src.dtype, device=src.device)
+    check(lib.yolat_gather_rows_bytes(src.data_ptr(), rb, idx.data_ptr(), idx.numel(), rb, dst.data_ptr(), rb, _stream()),
+          "yolat_gather_rows_bytes")
+    return dst
+
+
+def extract_subgraph(data_cls, dev_batch, pos_s, pos_e, edge_s, edge_e, slice_bbox):
+    """`build_data` of arch:166-242 on the device.  dev_batch: dict of CUDA tensors x, pos, edge [E,2] int64,
+    e_attr, bbox_idx int64, bbox, stat_feats.  Returns (Data of CUDA tensors, status word)."""
+    import numpy as np
+    x, edge, bbox_idx = dev_batch["x"], dev_batch["edge"], dev_batch["bbox_idx"]
+    dev = x.device
+    N = x.shape[0]
+    node_ids = _ranges_to_ids(pos_s, pos_e, dev)
+    edge_ids = _ranges_to_ids(edge_s, edge_e, dev)
+    bbox_ids = torch.from_numpy(np.asarray(slice_bbox, dtype=np.int32)).to(dev, non_blocking=True)
+    n_sub, m_sub = node_ids.numel(), edge_ids.numel()
+    new = data_cls(x=_gather(x, node_ids), pos=_gather(dev_batch["pos"], node_ids))
+    new.e_attr = _gather(dev_batch["e_attr"], edge_ids)
+    new.bbox = _gather(dev_batch["bbox"], bbox_ids)
+    new.stat_feats = _gather(dev_batch["stat_feats"], bbox_ids)
+    new.edge = torch.empty(m_sub, 2, dtype=torch.int64, device=dev)
+    new.bbox_idx = torch.empty(n_sub, dtype=torch.int64, device=dev)
+    status = torch.zeros(1, dtype=torch.int32, device=dev)
+    work = torch.empty(int(lib.yolat_subgraph_work_elems(N, n_sub)), dtype=torch.int32, device=dev)
+    if edge.dim() != 2 or edge.shape[1] != 2:
+        raise ValueError("edge must be [E,2]")
+    check(lib.yolat_subgraph_reindex(node_ids.data_ptr(), n_sub, N, _i(edge, torch.int64, "edge"), edge.stride(0),
+                                     edge.stride(1), edge_ids.data_ptr(), m_sub, _i(bbox_idx, torch.int64, "bbox_idx"),
+                                     new.edge.data_ptr(), new.bbox_idx.data_ptr(), work.data_ptr(), status.data_ptr(),
+                                     _stream()), "yolat_subgraph_reindex")
+    new._keep = (node_ids, edge_ids, bbox_ids, work)
+    return new, status
+
+
+# ---------------------------------------------------------------------------------------------
 # training-mode fusion block + per-proposal max pooling (csrc/fusion_train.hip)
 # ---------------------------------------------------------------------------------------------
 
