@@ -97,6 +97,14 @@ int yolat_subgraph_reindex(const int32_t* node_ids, int64_t n_sub, int64_t N, co
 int yolat_gather_rows_bytes(const void* src, int64_t src_row_bytes, const int32_t* idx, int64_t rows,
                             int64_t row_bytes, void* dst, int64_t dst_row_bytes, yolat_stream_t stream);
 
+/* Offset fix-up of a collated batch of B images (cad_recognition/train.py:238-258), one launch:
+ *   edge[e,:]  += node_off[b]  for edge_ptr[b] <= e < edge_ptr[b+1]     (edge [E,2] int64 contiguous)
+ *   bbox_idx[n] += prop_off[b] for node_ptr[b] <= n < node_ptr[b+1]
+ * edge_ptr / node_ptr [B+1], node_off / prop_off [B], all int64 on the device.                          */
+int yolat_fixup_offsets(int64_t* edge, int64_t E, const int64_t* edge_ptr, int64_t* bbox_idx, int64_t N,
+                        const int64_t* node_ptr, const int64_t* node_off, const int64_t* prop_off, int64_t B,
+                        yolat_stream_t stream);
+
 /* seg_ptr[P+1] from a non-decreasing int64 bbox_idx[N] (Datasets/graph_dict3.py:732):
  * seg_ptr[p] = first row r with bbox_idx[r] >= p.  Also writes node_seg[N] (int32 copy).
  * Replaces the implicit segmentation done by torch_scatter.scatter(index=bbox_idx)

@@ -676,3 +676,44 @@ def test_device_subgraph_extraction_equals_loop_oracle():
     bad["edge"][int(es[0]), 1] = outside
     _, status = yv.ops.extract_subgraph(yv.Data, bad, ps, pe, es, ee, sb)
     assert int(status.item()) & yv.ops.STATUS_EDGE_RANGE
+
+
+def test_collate_to_device_equals_collate_fixup_and_golden(golden_dir):
+    """data.collate_to_device (one pinned staging buffer, one H2D copy, offsets added by yolat_fixup_offsets)
+    against collate + fixup_offsets on the host, and against the committed collate fixture."""
+    yv = _yv()
+    items = [yv.synth_graph(seed=900 + i, num_proposals=5 + 3 * i, nodes_lo=3, nodes_hi=9, with_roots=True)
+             for i in range(4)]
+    want, wslices = yv.collate([it for it in items])
+    yv.fixup_offsets(want, wslices)
+    got, gslices = yv.collate_to_device(items)
+    for k in want.keys:
+        a, b = want[k], got[k]
+        if isinstance(a, torch.Tensor):
+            assert b.dtype == a.dtype and tuple(b.shape) == tuple(a.shape), k
+            assert torch.equal(a, b.cpu()), k
+            assert torch.equal(wslices[k], gslices[k]), k
+    assert all(got[k].is_cuda for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "stat_feats", "labels"))
+    assert len(got.roots) == len(want.roots) and torch.equal(wslices["roots"], gslices["roots"])
+    # all device tensors are views of ONE buffer (one H2D copy)
+    base = got._device_buffer
+    lo, hi = base.data_ptr(), base.data_ptr() + base.numel()
+    assert all(lo <= got[k].data_ptr() < hi for k in ("x", "edge", "e_attr", "bbox_idx", "bbox"))
+    # the committed fixture (naive-loop oracle of train.py:123-171,238-258)
+    z = np.load(os.path.join(golden_dir, "collate.npz"))
+    n_items = len({k.split("/")[0] for k in z.files if k.startswith("item")})
+    its = []
+    for i in range(n_items):
+        d = yv.Data()
+        for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "labels"):
+            d[k] = torch.from_numpy(z["item%d/%s" % (i, k)].copy())
+        its.append(d)
+    got, gslices = yv.collate_to_device(its)
+    for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "labels"):
+        np.testing.assert_array_equal(got[k].cpu().numpy(), z["batch/" + k], err_msg=k)
+        np.testing.assert_array_equal(gslices[k].numpy(), z["slices/" + k], err_msg=k)
+    # and it is a valid forward input
+    model = yv.SparseCADGCN(yv.Opt()).cuda().eval()
+    with torch.no_grad():
+        out = model(got, gslices)[0]
+    assert out.shape[0] == got.bbox.shape[0] and torch.isfinite(out).all()

@@ -55,6 +55,7 @@ SIGNATURES = {
     "yolat_subgraph_work_elems": (c_sz, [c_i64, c_i64]),
     "yolat_subgraph_reindex": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_gather_rows_bytes": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+    "yolat_fixup_offsets": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p]),
     "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),

@@ -164,3 +164,43 @@ extern "C" int yolat_gather_rows_bytes(const void* src, int64_t src_row_bytes, c
   YL_LAUNCH_CHECK();
   return 0;
 }
+
+// -------------------------------------------------------------------------------------------------
+// Offset fix-up of a collated batch (cad_recognition/train.py:238-258): every edge endpoint of image b gets
+// + node_off[b] (= slices['pos'][b]) and every bbox_idx entry + prop_off[b] (= slices['labels'][b]).  The
+// reference loops over the images with sliced in-place adds; here one launch, the image of an element is
+// found by binary search in the per-image slice pointers.  Integer, bit-exact.
+// -------------------------------------------------------------------------------------------------
+static __device__ __forceinline__ int item_of(const int64_t* ptr, int B, long i) {
+  int lo = 0, hi = B;               // largest b with ptr[b] <= i
+  while (hi - lo > 1) {
+    const int mid = (lo + hi) >> 1;
+    if (ptr[mid] <= i) lo = mid; else hi = mid;
+  }
+  return lo;
+}
+
+static __global__ void k_fixup_offsets(int64_t* edge, long E, const int64_t* edge_ptr, int64_t* bbox_idx, long N,
+                                       const int64_t* node_ptr, const int64_t* node_off, const int64_t* prop_off,
+                                       int B) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < E) {
+    const int64_t o = node_off[item_of(edge_ptr, B, i)];
+    edge[2 * i] += o;
+    edge[2 * i + 1] += o;
+  }
+  if (i < N) bbox_idx[i] += prop_off[item_of(node_ptr, B, i)];
+}
+
+extern "C" int yolat_fixup_offsets(int64_t* edge, int64_t E, const int64_t* edge_ptr, int64_t* bbox_idx, int64_t N,
+                                   const int64_t* node_ptr, const int64_t* node_off, const int64_t* prop_off,
+                                   int64_t B, yolat_stream_t stream) {
+  if (E < 0 || N < 0 || B <= 0 || !edge_ptr || !node_ptr || !node_off || !prop_off) return YOLAT_E_INVALID;
+  if ((E > 0 && !edge) || (N > 0 && !bbox_idx)) return YOLAT_E_INVALID;
+  const long n = E > N ? E : N;
+  if (n == 0) return 0;
+  hipLaunchKernelGGL(k_fixup_offsets, dim3(yl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, edge, (long)E, edge_ptr,
+                     bbox_idx, (long)N, node_ptr, node_off, prop_off, (int)B);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

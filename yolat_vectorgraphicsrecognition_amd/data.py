@@ -109,6 +109,86 @@ def fixup_offsets(data, slices):
 
 
 # --------------------------------------------------------------------------------------
+# collate + offset fix-up + host->device in one go (train.py:123-171,238-258 and the six synchronous
+# .cuda() copies of architecture3cc_rpn_gp_iter2.py:107-115)
+# --------------------------------------------------------------------------------------
+
+_DEVICE_KEYS = ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "stat_feats", "labels")
+_PINNED = {}
+
+
+def collate_to_device(data_list, device="cuda"):
+    """List of per-image ``Data`` (CPU tensors) -> (batched ``Data`` of CUDA tensors, ``slices``).
+
+    Same result as ``collate`` + ``fixup_offsets`` + ``.cuda()`` of every tensor, but: the items' arrays are
+    packed into ONE pinned staging buffer, moved with ONE asynchronous H2D copy, the batched tensors are
+    views of that single device buffer, and the per-image index offsets are added by one device kernel
+    (``yolat_fixup_offsets``) instead of Python loops over the images.  Non-tensor keys (``roots`` ...)
+    and ``slices`` are assembled on the host exactly like ``collate`` does."""
+    from . import ops
+    from ._lib import lib, check
+    keys = data_list[0].keys
+    tkeys = [k for k in keys if isinstance(data_list[0][k], torch.Tensor) and data_list[0][k].dim() > 0 and k in _DEVICE_KEYS]
+    rest = [k for k in keys if k not in tkeys]
+    B = len(data_list)
+    # host-side assembly of everything that is not a device tensor, and of the slices
+    host_items = [data_list[0].__class__(**{k: it[k] for k in rest}) for it in data_list] if rest else None
+    slices = {}
+    for k in tkeys:
+        sizes = [int(it[k].shape[0]) for it in data_list]
+        slices[k] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.long)
+    batch = data_list[0].__class__()
+    if rest:
+        hb, hs = collate(host_items)
+        for k in rest:
+            batch[k] = hb[k]
+            slices[k] = hs[k]
+        node_slices = slices["pos"] if "pos" in slices else slices["x"]
+        for k in rest:                 # host-resident index tensors get the reference's fix-up too (train.py:244)
+            if "edge" in k and isinstance(batch[k], torch.Tensor) and batch[k].dtype == torch.long:
+                for i in range(B):
+                    batch[k][int(slices[k][i]):int(slices[k][i + 1])] += node_slices[i]
+    # layout of the packed buffer (256-byte aligned fields) + the 4 small index tables of the fix-up
+    tables = {"edge_ptr": slices["edge"], "node_ptr": slices["pos"] if "pos" in slices else slices["x"],
+              "node_off": (slices["pos"] if "pos" in slices else slices["x"])[:-1],
+              "prop_off": slices["labels"][:-1] if "labels" in slices else slices["bbox"][:-1]}
+    fields, off = [], 0
+    for k in tkeys:
+        first = data_list[0][k]
+        shape = (int(slices[k][-1]),) + tuple(first.shape[1:])
+        nbytes = int(np.prod(shape)) * first.element_size()
+        fields.append((k, first.dtype, shape, off, nbytes))
+        off = (off + nbytes + 255) // 256 * 256
+    for k, t in tables.items():
+        nbytes = t.numel() * 8
+        fields.append((k, torch.int64, (t.numel(),), off, nbytes))
+        off = (off + nbytes + 255) // 256 * 256
+    total = max(off, 256)
+    pin = _PINNED.get("buf")
+    if pin is None or pin.numel() < total:
+        pin = _PINNED["buf"] = torch.empty(int(total * 1.5), dtype=torch.uint8).pin_memory()
+    dbuf = torch.empty(total, dtype=torch.uint8, device=device)
+    for k, dtype, shape, o, nbytes in fields:
+        dst = pin[o:o + nbytes].view(dtype).view(shape)
+        if k in tables:
+            dst.copy_(tables[k])
+        else:
+            torch.cat([it[k] for it in data_list], dim=0, out=dst) if nbytes else None
+    dbuf.copy_(pin[:total], non_blocking=True)                  # the one H2D copy
+    dv = {}
+    for k, dtype, shape, o, nbytes in fields:
+        dv[k] = dbuf[o:o + nbytes].view(dtype).view(shape)
+    for k in tkeys:
+        batch[k] = dv[k]
+    E, N = dv["edge"].shape[0], dv["bbox_idx"].shape[0]
+    check(lib.yolat_fixup_offsets(dv["edge"].data_ptr(), E, dv["edge_ptr"].data_ptr(), dv["bbox_idx"].data_ptr(), N,
+                                  dv["node_ptr"].data_ptr(), dv["node_off"].data_ptr(), dv["prop_off"].data_ptr(), B,
+                                  ops._stream()), "yolat_fixup_offsets")
+    batch._device_buffer = dbuf
+    return batch, slices
+
+
+# --------------------------------------------------------------------------------------
 # two-pass inference support: root / children proposal tree and sub-batch extraction
 # (architecture3cc_rpn_gp_iter2.py:139-242; tree nodes: Datasets/graph_dict3.py:24-27,745-767)
 # --------------------------------------------------------------------------------------
