@@ -326,3 +326,46 @@ def test_eval_forwards_on_concurrent_streams_do_not_interfere():
     for a, b in zip(alone, outs):
         assert torch.equal(a, b)
     assert len(model._yolat_plans) >= 3
+
+
+def test_edge_cases_no_edges_and_more_than_65535_proposals():
+    """(1) a graph without a single edge (every aggregation term is absent); (2) P = 70 000 one-to-three-node
+    proposals: more proposals than the 65 535 grid.y limit the per-proposal kernels are chunked by."""
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2)
+    model = _model(yv, optkw, 3)
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 3)
+    model.eval(); ref.eval()
+    # (1) E = 0
+    d = yv.synth_graph(num_proposals=7, nodes_lo=3, nodes_hi=6, seed=11)
+    d.edge = torch.zeros((0, 2), dtype=torch.long)
+    d.e_attr = torch.zeros((0, 4))
+    with torch.no_grad():
+        got = model(d, None)[0].cpu()
+        want = ref(d, None)[0]
+    assert float((got - want).abs().max()) <= RTOL_FWD * float(want.abs().max())
+    model._yolat_plan.check_status()
+    # (2) P > 65535
+    big = yv.synth_graph(num_proposals=70000, nodes_lo=1, nodes_hi=3, edge_factor=0.0, seed=12,
+                         edges_per_proposal=0)
+    rng = np.random.default_rng(0)
+    N = big.x.shape[0]
+    owner = big.bbox_idx.numpy()
+    first = np.searchsorted(owner, owner)                  # first node of each node's proposal
+    src = np.arange(N)
+    has_pair = first != src                                # nodes that are not the first of their proposal
+    e = np.stack([src[has_pair], first[has_pair]], 1)      # edge to the proposal's first node
+    big.edge = torch.from_numpy(e.astype(np.int64))
+    big.e_attr = torch.from_numpy((rng.standard_normal((len(e), 4)) * 0.05).astype(np.float32))
+    with torch.no_grad():
+        got = model(big, None)[0].cpu()
+        want = ref(big, None)[0]
+    assert got.shape == (70000, 17)
+    assert float((got - want).abs().max()) <= RTOL_FWD * float(want.abs().max())
+    model._yolat_plan.check_status()
+    # training-mode forward/backward at the same size exercises the chunked backward kernels
+    model.train()
+    crit = yv.DetectionLoss(yv.Opt(**optkw))
+    loss = crit(model(big, None), big)["loss"]
+    loss.backward()
+    assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters())
