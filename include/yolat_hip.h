@@ -249,6 +249,24 @@ int yolat_edge_mlp2_eval(const float* x, int64_t ldx, int64_t N, int64_t Cin, co
                          const float* b2, const float* s2, const float* t2, int64_t C, float* H2,
                          int64_t ldh, yolat_stream_t stream);
 
+/* Factorised edge MLP (eval).  The first edge Linear acts on [x_i | x_j - x_i | attr], so
+ *   W1.[x_i | x_j-x_i | attr] = (W1a - W1b).x_i + W1b.x_j + W1c.attr      (torch_vertex.py:331 + torch_nn.py:58)
+ * and the two node terms can be computed ONCE PER NODE (N rows) instead of once per edge (E = 4..6 N rows):
+ *   yolat_conv_split_w1:   Wuv[0:C] = W1a - W1b, Wuv[C:2C] = W1b   ([2C,Cin]);  Wc4 = W1c  ([C,4])
+ *   yolat_node_uv_eval:    UV[N,2C] = f_in . Wuv^T  |  f_out = lin_r(f_in)  |  s_out = relu(BN(mlp_node(s_in)))
+ *                          as one launch (the node side of the layer; csr_mean is accumulated into f_out later)
+ *   yolat_edge_uv_mlp2_eval: H2[q] = relu(s2*(W2.relu(s1*(U[dst_q] + V[src_q] + Wc4.attr_q + b1) + t1) + b2) + t2)
+ * Exact algebra, different summation order than yolat_edge_mlp2_eval (agrees to ~1e-6 relative).  C = 64.   */
+int yolat_conv_split_w1(const float* W1, int64_t Cin, int64_t C, float* Wuv, float* Wc4, yolat_stream_t stream);
+int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N, int64_t Cin,
+                       const float* Wuv, const float* Wr, const float* br, const float* Wn, const float* bn,
+                       const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv, float* f_out,
+                       int64_t ld_fo, float* s_out, int64_t ld_so, yolat_stream_t stream);
+int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                            const float* attr_csr, int64_t E, const float* Wc4, const float* b1, const float* s1,
+                            const float* t1, const float* W2, const float* b2, const float* s2, const float* t2,
+                            int64_t C, float* H2, int64_t ldh, yolat_stream_t stream);
+
 /* Node side of an eval-mode conv layer in one launch (torch_vertex.py:324-327), BatchNorm folded:
  *   f_out[n] = mean_{q in [row_ptr[n], row_ptr[n+1])} H2[q]  +  Wr.f_in[n] + br
  *   s_out[n] = relu(sn*(Wn.s_in[n] + bn) + tn)
@@ -358,6 +376,7 @@ typedef struct {
   const float *Wr, *br;                       /* gconv.lin_r [C,Cin]                             */
   const float *Wn, *bn, *sn, *tn;             /* gconv.mlp_node.0 [C,Cin], mlp_node.1 folded     */
   const float *packed;                        /* nullable: yolat_conv_pack_weights(W1, W2) output  */
+  const float *Wuv, *Wc4;                     /* nullable: yolat_conv_split_w1(W1) outputs, [2C,Cin], [C,4] */
 } yolat_conv_eval;
 
 typedef struct {

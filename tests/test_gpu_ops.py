@@ -717,3 +717,47 @@ def test_collate_to_device_equals_collate_fixup_and_golden(golden_dir):
     with torch.no_grad():
         out = model(got, gslices)[0]
     assert out.shape[0] == got.bbox.shape[0] and torch.isfinite(out).all()
+
+
+@pytest.mark.parametrize("N,E,Cin", [(6, 7, 5), (70, 300, 64), (1000, 4000, 64), (2500, 3000, 5), (9000, 30000, 64)])
+def test_factorised_edge_layer_matches_unfactorised(N, E, Cin):
+    """W1.[x_i | x_j-x_i | attr] = (W1a-W1b).x_i + W1b.x_j + W1c.attr: the per-node products (yolat_node_uv_eval)
+    + per-edge gather-add kernel (yolat_edge_uv_mlp2_eval) against yolat_edge_mlp2_eval; the node-side launch's
+    root / node-branch outputs against yolat_linear_fwd."""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    src, dst, xfull, attr = _edge_case(N, E, Cin, 11 * N + E, ldx=Cin)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    tg = torch.Generator().manual_seed(N * 3 + E)
+    K1 = 2 * Cin + 4
+    W1 = (torch.randn(64, K1, generator=tg) / K1 ** 0.5).cuda()
+    W2 = (torch.randn(64, 64, generator=tg) / 8).cuda()
+    Wr = (torch.randn(64, Cin, generator=tg) / Cin ** 0.5).cuda()
+    Wn = (torch.randn(64, Cin, generator=tg) / Cin ** 0.5).cuda()
+    b1, b2, br, bn = [(torch.randn(64, generator=tg) * 0.1).cuda() for _ in range(4)]
+    p1, p2, pn = [((torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda())
+                  for _ in range(3)]
+    x = dev(xfull)
+    s_in = torch.randn(N, Cin, generator=tg).cuda()
+    want = torch.empty(E, 64).cuda()
+    yv.ops.edge_mlp2_eval(x, g, W1, b1, p1, W2, b2, p2, want)
+    wuv, wc4 = torch.empty(128, Cin).cuda(), torch.empty(64, 4).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    check(lib.yolat_conv_split_w1(W1.data_ptr(), Cin, 64, wuv.data_ptr(), wc4.data_ptr(), st))
+    assert torch.equal(wuv[:64], W1[:, :Cin] - W1[:, Cin:2 * Cin]) and torch.equal(wuv[64:], W1[:, Cin:2 * Cin])
+    assert torch.equal(wc4, W1[:, 2 * Cin:])
+    UV = torch.empty(N, 128).cuda()
+    f_out, s_out = torch.empty(N, 64).cuda(), torch.empty(N, 64).cuda()
+    check(lib.yolat_node_uv_eval(x.data_ptr(), Cin, s_in.data_ptr(), Cin, N, Cin, wuv.data_ptr(), Wr.data_ptr(),
+                                 br.data_ptr(), Wn.data_ptr(), bn.data_ptr(), pn[0].data_ptr(), pn[1].data_ptr(), 64,
+                                 UV.data_ptr(), 128, f_out.data_ptr(), 64, s_out.data_ptr(), 64, st))
+    fa, sa = torch.empty(N, 64).cuda(), torch.empty(N, 64).cuda()
+    yv.ops.linear_fwd(x, Wr, br, fa)
+    yv.ops.linear_fwd(s_in, Wn, bn, sa, o_pro=pn, o_relu=True)
+    assert torch.equal(fa, f_out) and torch.equal(sa, s_out)
+    got = torch.full((E, 96), float("nan")).cuda()
+    check(lib.yolat_edge_uv_mlp2_eval(UV.data_ptr(), 128, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E,
+                                      wc4.data_ptr(), b1.data_ptr(), p1[0].data_ptr(), p1[1].data_ptr(), W2.data_ptr(),
+                                      b2.data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), 64, got.data_ptr(), 96, st))
+    close(got[:, :64], want, rtol=2e-5, msg="factorised edge MLP")
+    assert torch.isnan(got[:, 64:]).all()

@@ -23,7 +23,7 @@ class ConvEval(ctypes.Structure):
     """yolat_conv_eval (include/yolat_hip.h)"""
     _fields_ = [("Cin", c_i64)] + [(n, c_p) for n in
                                    ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn",
-                                    "packed")]
+                                    "packed", "Wuv", "Wc4")]
 
 
 class ModelEval(ctypes.Structure):
@@ -56,6 +56,11 @@ SIGNATURES = {
     "yolat_subgraph_reindex": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_gather_rows_bytes": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_fixup_offsets": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p]),
+    "yolat_conv_split_w1": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p]),
+    "yolat_node_uv_eval": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p,
+                                    c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_edge_uv_mlp2_eval": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64,
+                                         c_p, c_i64, c_p]),
     "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),

@@ -512,6 +512,17 @@ __global__ void __launch_bounds__(256) k_gemm_nt_pair(AL A0, BL B0, Epilogue e0,
   else gemm_nt_tile<BM, BN, BK, AL, BL, false>(A1, B1, e1, M, N, K, blockIdx.x, 0);
 }
 
+// Node side of a factorised conv layer in one launch: blockIdx.y = 0,1 -> the two 64-column halves of
+// UV = f_in.Wuv^T (N = 128 outputs), 2 -> root Linear, 3 -> node-branch Linear+BN+ReLU.
+template <int BK>
+__global__ void __launch_bounds__(256) k_gemm_nt_node3(DenseOp Af, DenseOp Wuv, Epilogue euv, DenseOp Wr, Epilogue er,
+                                                       DenseOp As, DenseOp Wn, Epilogue en, int M, int C, int K) {
+  const int y = blockIdx.y;
+  if (y < 2) gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(Af, Wuv, euv, M, 2 * C, K, blockIdx.x, y);
+  else if (y == 2) gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(Af, Wr, er, M, C, K, blockIdx.x, 0);
+  else gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(As, Wn, en, M, C, K, blockIdx.x, 0);
+}
+
 // ------------------------------------------------------------------------------------------------
 // Skinny NT GEMM with split-K inside the workgroup, for few rows x long K (the per-proposal
 // classifier layers: P x 2304 -> 512 ...).  One workgroup = one 32x32 output tile; its 4 waves each

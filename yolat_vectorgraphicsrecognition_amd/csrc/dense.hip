@@ -113,6 +113,55 @@ extern "C" int yolat_node_side_eval(const float* f_in, int64_t ld_f, const float
   return 0;
 }
 
+static __global__ void k_conv_split_w1(const float* __restrict__ W1, int Cin, int C, float* Wuv, float* Wc4) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int K1 = 2 * Cin + 4;
+  if (i < C * Cin) {
+    const int c = i / Cin, k = i % Cin;
+    const float a = W1[(long)c * K1 + k], b = W1[(long)c * K1 + Cin + k];
+    Wuv[(long)c * Cin + k] = a - b;
+    Wuv[(long)(C + c) * Cin + k] = b;
+  }
+  if (i < C * 4) Wc4[i] = W1[(long)(i / 4) * K1 + 2 * Cin + (i % 4)];
+}
+
+extern "C" int yolat_conv_split_w1(const float* W1, int64_t Cin, int64_t C, float* Wuv, float* Wc4,
+                                   yolat_stream_t stream) {
+  if (!W1 || !Wuv || !Wc4 || Cin <= 0 || C <= 0) return YOLAT_E_INVALID;
+  const long n = C * (Cin > 4 ? Cin : 4);
+  hipLaunchKernelGGL(k_conv_split_w1, dim3(yl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, W1, (int)Cin, (int)C,
+                     Wuv, Wc4);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
+                                  int64_t Cin, const float* Wuv, const float* Wr, const float* br, const float* Wn,
+                                  const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
+                                  int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
+                                  yolat_stream_t stream) {
+  if (N <= 0 || Cin <= 0 || !f_in || !s_in || !Wuv || !Wr || !Wn || !UV || !f_out || !s_out) return YOLAT_E_INVALID;
+  if (C != 64) return YOLAT_E_UNSUPPORTED;
+  if (N >= (1LL << 31) || ld_f < Cin || ld_s < Cin || ld_uv < 2 * C || ld_fo < C || ld_so < C) return YOLAT_E_INVALID;
+  if ((sn == nullptr) != (tn == nullptr)) return YOLAT_E_INVALID;
+  DenseOp af = yl_dense(f_in, ld_f, N, Cin), as = yl_dense(s_in, ld_s, N, Cin);
+  DenseOp wuv = yl_dense(Wuv, Cin, 2 * C, Cin), wr = yl_dense(Wr, Cin, C, Cin), wn = yl_dense(Wn, Cin, C, Cin);
+  Epilogue euv, er, en;
+  euv.bias = nullptr; euv.scale = nullptr; euv.shift = nullptr; euv.relu = 0;
+  euv.Y = UV; euv.ldy = ld_uv; euv.accumulate = 0; euv.stats = nullptr; euv.seg = nullptr; euv.pool = nullptr; euv.ldpool = 0;
+  er = euv; er.bias = br; er.Y = f_out; er.ldy = ld_fo;
+  en = euv; en.bias = bn; en.scale = sn; en.shift = tn; en.relu = 1; en.Y = s_out; en.ldy = ld_so;
+  const dim3 grid(yl_cdiv(N, 64), 4);
+  if (Cin <= 16)
+    hipLaunchKernelGGL(k_gemm_nt_node3<16>, grid, dim3(256), 0, (hipStream_t)stream, af, wuv, euv, wr, er, as, wn, en,
+                       (int)N, (int)C, (int)Cin);
+  else
+    hipLaunchKernelGGL(k_gemm_nt_node3<32>, grid, dim3(256), 0, (hipStream_t)stream, af, wuv, euv, wr, er, as, wn, en,
+                       (int)N, (int)C, (int)Cin);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
                                    const float* Wt, int64_t ldw, int64_t Nout, float* Y,
                                    int64_t ldy, int accumulate, yolat_stream_t stream) {

@@ -180,6 +180,110 @@ extern "C" int yolat_edge_mlp2_eval(const float* x, int64_t ldx, int64_t N, int6
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Factorised eval-mode edge MLP: layer 1 is a gather-add of per-node products (see yolat_hip.h):
+//   h1[q] = relu(s1*(U[dst_q] + V[src_q] + Wc4.attr_q + b1) + t1)   (VALU, 64 floats per edge)
+//   H2[q] = relu(s2*(W2.h1[q] + b2) + t2)                            (MFMA, 32 per wave per 64-edge tile)
+// The K = 2*Cin part of the per-edge GEMM (64 of the 98 MFMAs of k_edge_mlp2) is gone: it was computed
+// once per node by k_gemm_nt_node3.  Thread (row r, float4 column q): the 16 threads of a row share its
+// two index loads; all 8 index loads and then all 12 row gathers of a thread are issued together.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_uv_mlp2(const float* __restrict__ UV, long ld_uv,
+                                                      const int* __restrict__ src, const int* __restrict__ dst,
+                                                      const float* __restrict__ attr,
+                                                      const float* __restrict__ Wc4, const float* __restrict__ b1,
+                                                      const float* __restrict__ s1, const float* __restrict__ t1,
+                                                      DenseOp W2, Epilogue ep2, int E) {
+  constexpr int LDH = 65;
+  __shared__ float Hs[64 * LDH];
+  __shared__ float W2s[64 * LDH];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = blockIdx.x * 64;
+  const int q = tid & 15, rb = tid >> 4;             // this thread: columns 4q..4q+3 of rows rb, rb+16, rb+32, rb+48
+  const EpiPre pre2 = epi_prefetch(ep2, row0 + wm * 32, wn * 32 + l31, E, 64);
+  // W2 -> registers -> LDS, per-column constants of layer 1
+  float rw2[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = tid + t * 256;
+    W2.template load4<false>(i >> 4, 4 * (i & 15), rw2[t]);
+  }
+  float4 wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
+  const float4 bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
+  int di[4], si[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = yl_min(row0 + rb + 16 * t, E - 1);
+    di[t] = dst[e]; si[t] = src[e];
+  }
+  float4 u[4], v[4], a[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = yl_min(row0 + rb + 16 * t, E - 1);
+    u[t] = *reinterpret_cast<const float4*>(UV + (long)di[t] * ld_uv + 4 * q);
+    v[t] = *reinterpret_cast<const float4*>(UV + (long)si[t] * ld_uv + 64 + 4 * q);
+    a[t] = *reinterpret_cast<const float4*>(attr + (long)e * 4);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = tid + t * 256;
+    float* d = W2s + (i >> 4) * LDH + 4 * (i & 15);
+    d[0] = rw2[t][0]; d[1] = rw2[t][1]; d[2] = rw2[t][2]; d[3] = rw2[t][3];
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    auto one = [&](float uu, float vv, const float4& w, float b, float s, float h) {
+      float z = uu + vv;
+      z = fmaf(a[t].x, w.x, z); z = fmaf(a[t].y, w.y, z); z = fmaf(a[t].z, w.z, z); z = fmaf(a[t].w, w.w, z);
+      return fmaxf(fmaf(z + b, s, h), 0.f);
+    };
+    float* hrow = Hs + (rb + 16 * t) * LDH + 4 * q;
+    hrow[0] = one(u[t].x, v[t].x, wc[0], bb.x, sc.x, sh.x);
+    hrow[1] = one(u[t].y, v[t].y, wc[1], bb.y, sc.y, sh.y);
+    hrow[2] = one(u[t].z, v[t].z, wc[2], bb.z, sc.z, sh.z);
+    hrow[3] = one(u[t].w, v[t].w, wc[3], bb.w, sc.w, sh.w);
+  }
+  __syncthreads();
+  f32x16 acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll 8
+  for (int kk = 0; kk < 64; kk += 2) {
+    const float av = Hs[(wm * 32 + l31) * LDH + kk + lhi];
+    const float bv = W2s[(wn * 32 + l31) * LDH + kk + lhi];
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2, 0, 0, 0);
+  }
+  wave_epilogue(acc2, row0 + wm * 32, wn * 32 + l31, lhi, ep2, E, 64, pre2);
+}
+
+extern "C" int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,
+                                       const int32_t* dst_csr, const float* attr_csr, int64_t E, const float* Wc4,
+                                       const float* b1, const float* s1, const float* t1, const float* W2,
+                                       const float* b2, const float* s2, const float* t2, int64_t C, float* H2,
+                                       int64_t ldh, yolat_stream_t stream) {
+  if (E < 0 || !UV || !Wc4 || !b1 || !W2) return YOLAT_E_INVALID;
+  if (C != 64) return YOLAT_E_UNSUPPORTED;
+  if (E == 0) return 0;
+  if (!src_csr || !dst_csr || !attr_csr || !H2 || E >= (1LL << 31) || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return YOLAT_E_INVALID;
+  if (ld_uv % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) || !yl_aligned16(b1) ||
+      (s1 && (!yl_aligned16(s1) || !yl_aligned16(t1))))
+    return YOLAT_E_UNSUPPORTED;
+  DenseOp w2 = yl_dense(W2, C, C, C);
+  Epilogue ep;
+  ep.bias = b2; ep.scale = s2; ep.shift = t2; ep.relu = 1;
+  ep.Y = H2; ep.ldy = ldh; ep.accumulate = 0; ep.stats = nullptr; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
+  hipLaunchKernelGGL(k_edge_uv_mlp2, dim3(yl_cdiv(E, 64)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv, src_csr,
+                     dst_csr, attr_csr, Wc4, b1, s1, t1, w2, ep, (int)E);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_edge_lin1_bwd_w(const float* dH1, int64_t lddh, int64_t E, int64_t C,
                                      const float* x, int64_t ldx, int64_t N, int64_t Cin,
                                      const int32_t* src_csr, const int32_t* dst_csr,

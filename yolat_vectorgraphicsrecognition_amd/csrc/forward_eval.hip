@@ -17,7 +17,7 @@ struct Carver {
 
 struct Plan {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
-  float* H1; float* H2; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
+  float* H1; float* H2; float* UV; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
   float* feats; float* fsup; float* Z; float* c1; float* c2;
   size_t bytes;
 };
@@ -29,7 +29,7 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   p.row_ptr = c.take<int>(N + 1); p.perm = c.take<int>(Ee); p.src = c.take<int>(Ee); p.dst = c.take<int>(Ee);
   p.attr = c.take<float>(Ee * 4); p.work = c.take<int>(yolat_graph_work_elems(N, E));
   p.seg_ptr = c.take<int>(P + 1); p.node_seg = c.take<int>(N);
-  p.H1 = c.take<float>(Ee * C); p.H2 = c.take<float>(Ee * C);
+  p.H1 = c.take<float>(Ee * C); p.H2 = c.take<float>(Ee * C); p.UV = c.take<float>(N * 2 * C);
   const int lo = m->n_blocks - m->n_blocks_out;
   for (int l = 0; l < m->n_blocks; ++l) {
     p.f_tmp[l] = (l < lo) ? c.take<float>(N * C) : nullptr;
@@ -168,10 +168,26 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
                yolat_conv_eval_fused(f_in, ld_f, s_in, ld_s, N, cv.Cin, p.row_ptr, p.src, p.dst, p.attr, E, &cv, C,
                                      f_out, ld_out, s_out, ld_out, stream));
     } else if (C == 64) {
+      if (cv.Wuv != nullptr && cv.Wc4 != nullptr) {
+        // factorised layer, three launches: (1) node side — UV = f_in.[W1a-W1b | W1b]^T, root Linear and
+        // node-branch Linear in one launch; (2) per-edge gather-add of U[dst] + V[src] + W1c.attr, BN+ReLU,
+        // second edge Linear (hidden activation in LDS); (3) CSR mean accumulated into the root output.
+        // The K = 2*Cin GEMM runs once per node instead of once per edge (E = 4..6 N).
+        snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
+        YL_STAGE(nm, 8.0 * N * cv.Cin * C, 4.0 * (2.0 * N * cv.Cin + 4.0 * N * C),
+                 yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, cv.Wuv, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn,
+                                    C, p.UV, 2 * C, f_out, ld_out, s_out, ld_out, stream));
+        if (E > 0) {
+          snprintf(nm, sizeof nm, "edge_uv_mlp2[E x (U+V+attr) -> %ld -> %ld]", C, C);
+          YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 4.0 * E * C,
+                   yolat_edge_uv_mlp2_eval(p.UV, 2 * C, p.src, p.dst, p.attr, E, cv.Wc4, cv.b1, cv.s1, cv.t1, cv.W2,
+                                           cv.b2, cv.s2, cv.t2, C, p.H2, C, stream));
+          YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
+                   yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
+        }
+      } else {
       // three launches per layer: edge MLP (hidden activation in LDS); root Linear | node-branch Linear as one
-      // paired GEMM launch; CSR mean accumulated into the root output.  (Fusing the mean into the paired
-      // GEMM's epilogue is supported by yolat_node_side_eval but measured slower at cfg 2: 157 workgroups
-      // gathering 64 KB each, 21 us vs 7 + 7 us.)
+      // paired GEMM launch; CSR mean accumulated into the root output.
       if (E > 0) {
         snprintf(nm, sizeof nm, "edge_mlp2[E x %ld -> %ld -> %ld, gathered]", (long)K1, C, C);
         YL_STAGE(nm, 2.0 * E * (K1 * C + C * C), E * (K1 * 4.0 + 8.0) + 4.0 * E * C,
@@ -185,6 +201,7 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
       if (E > 0) {
         YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
                  yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
+      }
       }
     } else {
     // out = lin_r(x)

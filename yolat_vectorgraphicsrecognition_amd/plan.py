@@ -5,6 +5,7 @@ the ``yolat_model_eval`` descriptor with device pointers and owns a grow-only wo
 is then a single ctypes call; the C++ side enqueues graph pre-processing and all layers back to back.
 """
 import ctypes
+import os
 
 import torch
 
@@ -71,6 +72,15 @@ class EvalPlan(object):
                   "yolat_conv_pack_weights")
             keep.append(pk)
             c.packed = pk.data_ptr()
+            # factorised first edge Linear: per-node weights [W1a - W1b | W1b] and the 4 attr columns
+            C = cv.nn[0].out_features
+            wuv = torch.empty(2 * C, cv.in_channels, dtype=torch.float32, device=dev)
+            wc4 = torch.empty(C, 4, dtype=torch.float32, device=dev)
+            check(lib.yolat_conv_split_w1(c.W1, cv.in_channels, C, wuv.data_ptr(), wc4.data_ptr(), ops._stream()),
+                  "yolat_conv_split_w1")
+            keep += [wuv, wc4]
+            if os.environ.get("YOLAT_EDGE_FACTORISED", "1") != "0":
+                c.Wuv, c.Wc4 = wuv.data_ptr(), wc4.data_ptr()
         fb, fs = net.fusion_block, net.fusion_block_super
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
