@@ -262,6 +262,14 @@ int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64
                        const float* Wuv, const float* Wr, const float* br, const float* Wn, const float* bn,
                        const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv, float* f_out,
                        int64_t ld_fo, float* s_out, int64_t ld_so, yolat_stream_t stream);
+/* yolat_edge_uv_mlp2_mean_eval: the same edge MLP with the mean aggregation fused in:
+ *   f_out[n] += mean_{q in CSR row n} H2[q]       (H2 is never written; f_out already holds lin_r(f_in))
+ * per-node summation in CSR order -> bit-identical to yolat_edge_uv_mlp2_eval + yolat_csr_mean_fwd(accumulate). */
+int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                                 const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E,
+                                 const float* Wc4, const float* b1, const float* s1, const float* t1,
+                                 const float* W2, const float* b2, const float* s2, const float* t2, int64_t C,
+                                 float* f_out, int64_t ld_fo, yolat_stream_t stream);
 int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                             const float* attr_csr, int64_t E, const float* Wc4, const float* b1, const float* s1,
                             const float* t1, const float* W2, const float* b2, const float* s2, const float* t2,

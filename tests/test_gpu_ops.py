@@ -761,3 +761,36 @@ def test_factorised_edge_layer_matches_unfactorised(N, E, Cin):
                                       b2.data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), 64, got.data_ptr(), 96, st))
     close(got[:, :64], want, rtol=2e-5, msg="factorised edge MLP")
     assert torch.isnan(got[:, 64:]).all()
+
+
+@pytest.mark.parametrize("N,E", [(6, 7), (70, 300), (1000, 4000), (500, 9001), (2500, 3000), (9000, 54000)])
+def test_fused_edge_mean_is_bit_identical_to_edge_kernel_plus_csr_mean(N, E):
+    """yolat_edge_uv_mlp2_mean_eval (node-tiled: edge MLP + mean aggregation, no [E,64] tensor) against
+    yolat_edge_uv_mlp2_eval + yolat_csr_mean_fwd(accumulate); one node gets > 64 in-edges (multi-pass)."""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    src, dst, _, attr = _edge_case(N, E, 64, 13 * N + E, ldx=64)
+    if E > 200:
+        dst[:150] = N // 3                            # a node spanning three 64-edge passes
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    tg = torch.Generator().manual_seed(N + 7 * E)
+    UV = torch.randn(N, 128, generator=tg).cuda()
+    W2 = (torch.randn(64, 64, generator=tg) / 8).cuda()
+    wc4 = (torch.randn(64, 4, generator=tg) * 0.3).cuda()
+    b1, b2 = (torch.randn(64, generator=tg) * 0.1).cuda(), (torch.randn(64, generator=tg) * 0.1).cuda()
+    p1 = ((torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda())
+    p2 = ((torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda())
+    base = torch.randn(N, 128, generator=tg).cuda()   # f_out lives in a column slot of a wider buffer
+    st = torch.cuda.current_stream().cuda_stream
+    H2 = torch.empty(E, 64).cuda()
+    check(lib.yolat_edge_uv_mlp2_eval(UV.data_ptr(), 128, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E,
+                                      wc4.data_ptr(), b1.data_ptr(), p1[0].data_ptr(), p1[1].data_ptr(), W2.data_ptr(),
+                                      b2.data_ptr(), p2[0].data_ptr(), p2[1].data_ptr(), 64, H2.data_ptr(), 64, st))
+    want = base.clone()
+    yv.ops.csr_mean_fwd(H2, g, want[:, 64:], accumulate=True)
+    got = base.clone()
+    check(lib.yolat_edge_uv_mlp2_mean_eval(UV.data_ptr(), 128, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(),
+                                           g.row_ptr.data_ptr(), N, E, wc4.data_ptr(), b1.data_ptr(), p1[0].data_ptr(),
+                                           p1[1].data_ptr(), W2.data_ptr(), b2.data_ptr(), p2[0].data_ptr(),
+                                           p2[1].data_ptr(), 64, got[:, 64:].data_ptr(), 128, st))
+    assert torch.equal(got, want)

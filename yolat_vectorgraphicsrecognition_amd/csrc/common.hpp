@@ -29,6 +29,14 @@ static inline int yl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool yl_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
 
 __device__ __forceinline__ int yl_min(int a, int b) { return a < b ? a : b; }
+// a*b rounded on its own: the empty asm keeps the compiler from contracting it with a following add into an
+// fma (-ffp-contract=fast does that even through __fmul_rn/__fadd_rn), so two kernels that must agree bit
+// for bit can pin the same two roundings
+__device__ __forceinline__ float yl_mul_rn(float a, float b) {
+  float p = a * b;
+  asm volatile("" : "+v"(p));
+  return p;
+}
 
 // ------------------------------------------------------------------------------------------------
 // Operand loaders.  load4<FAST>(r, k, v): 4 consecutive k-elements of logical row r (k % 4 == 0).
@@ -352,7 +360,7 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
 #pragma unroll
         for (int e = 0; e < 4; ++e) sacc += (e < deg) ? v[j][e] : 0.f;
         for (int q = q0 + 4; q < q1; ++q) sacc += hp[(long)q * ep.ldagg];
-        old[r0 + j] = sacc * (1.f / (float)(deg > 1 ? deg : 1));
+        old[r0 + j] = yl_mul_rn(sacc, 1.f / (float)(deg > 1 ? deg : 1));
       }
     }
   } else if (ep.accumulate) {   // all 16 reads issued back to back (clamped rows), one wait

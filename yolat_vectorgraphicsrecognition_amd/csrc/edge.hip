@@ -261,6 +261,157 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2(const float* __restrict__ 
   wave_epilogue(acc2, row0 + wm * 32, wn * 32 + l31, lhi, ep2, E, 64, pre2);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Factorised edge MLP + mean aggregation in one kernel (eval): the [E,64] message matrix never reaches HBM.
+// One workgroup = `npt` consecutive destination nodes (<= 16) = the contiguous CSR edge range
+// [row_ptr[n0], row_ptr[n0+npt]) processed in passes of 64 edges (npt is chosen by the host so that one pass
+// is the common case).  Per pass: gather-add layer 1 -> LDS -> MFMA layer 2 -> BN+ReLU -> LDS; then thread
+// (node j, float4 column q) adds the pass's rows of node j in ascending edge order to its running sum.  At
+// the end  f_out[n] += sum / deg  on top of the root Linear the node-side launch wrote.  No atomics; the
+// per-node summation order is the CSR order, bit-identical to k_edge_uv_mlp2 + k_csr_mean_fwd.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restrict__ UV, long ld_uv,
+                                                           const int* __restrict__ src,
+                                                           const int* __restrict__ dst,
+                                                           const float* __restrict__ attr,
+                                                           const int* __restrict__ row_ptr, int N, int npt,
+                                                           const float* __restrict__ Wc4,
+                                                           const float* __restrict__ b1,
+                                                           const float* __restrict__ s1,
+                                                           const float* __restrict__ t1, DenseOp W2,
+                                                           const float* __restrict__ b2,
+                                                           const float* __restrict__ s2,
+                                                           const float* __restrict__ t2, float* f_out, long ld_fo,
+                                                           int E) {
+  constexpr int LDH = 65;
+  __shared__ float Hs[64 * LDH];      // layer-1 activations of the pass, then the layer-2 messages
+  __shared__ float W2s[64 * LDH];
+  __shared__ int rp[17];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = blockIdx.x * npt;
+  const int nn = yl_min(npt, N - n0);                 // nodes of this tile
+  if (tid <= 16) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
+  const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t
+  const int col = wn * 32 + l31;                      // MFMA role: output column of this lane
+  float rw2[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = tid + t * 256;
+    W2.template load4<false>(i >> 4, 4 * (i & 15), rw2[t]);
+  }
+  float4 wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
+  const float4 bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
+  const float bias2 = b2 ? b2[col] : 0.f, sc2 = s2 ? s2[col] : 1.f, sh2 = s2 ? t2[col] : 0.f;
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = tid + t * 256;
+    float* d = W2s + (i >> 4) * LDH + 4 * (i & 15);
+    d[0] = rw2[t][0]; d[1] = rw2[t][1]; d[2] = rw2[t][2]; d[3] = rw2[t][3];
+  }
+  __syncthreads();
+  const int e0 = rp[0], e1 = rp[nn];
+  const int my_b = rp[yl_min(rb, nn)], my_e = rp[yl_min(rb + 1, nn)];   // aggregation role: node rb, columns 4q..
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c0 = e0; c0 < e1; c0 += 64) {
+    int di[4], si[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = yl_min(c0 + rb + 16 * t, E - 1);
+      di[t] = dst[e]; si[t] = src[e];
+    }
+    float4 u[4], v[4], a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = yl_min(c0 + rb + 16 * t, E - 1);
+      u[t] = *reinterpret_cast<const float4*>(UV + (long)di[t] * ld_uv + 4 * q);
+      v[t] = *reinterpret_cast<const float4*>(UV + (long)si[t] * ld_uv + 64 + 4 * q);
+      a[t] = *reinterpret_cast<const float4*>(attr + (long)e * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      auto one = [&](float uu, float vv, const float4& w, float b, float s, float h) {
+        float z = uu + vv;
+        z = fmaf(a[t].x, w.x, z); z = fmaf(a[t].y, w.y, z); z = fmaf(a[t].z, w.z, z); z = fmaf(a[t].w, w.w, z);
+        return fmaxf(fmaf(z + b, s, h), 0.f);
+      };
+      float* hrow = Hs + (rb + 16 * t) * LDH + 4 * q;
+      hrow[0] = one(u[t].x, v[t].x, wc[0], bb.x, sc.x, sh.x);
+      hrow[1] = one(u[t].y, v[t].y, wc[1], bb.y, sc.y, sh.y);
+      hrow[2] = one(u[t].z, v[t].z, wc[2], bb.z, sc.z, sh.z);
+      hrow[3] = one(u[t].w, v[t].w, wc[3], bb.w, sc.w, sh.w);
+    }
+    __syncthreads();
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; kk += 2) {
+      const float av = Hs[(wm * 32 + l31) * LDH + kk + lhi];
+      const float bv = W2s[(wn * 32 + l31) * LDH + kk + lhi];
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2, 0, 0, 0);
+    }
+    __syncthreads();                      // every wave is done reading Hs as the layer-1 tile
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      Hs[row * LDH + col] = fmaxf(fmaf(acc2[r] + bias2, sc2, sh2), 0.f);
+    }
+    __syncthreads();
+    if (rb < nn) {                        // rows of node rb inside this pass, ascending edge order
+      const int lo = my_b > c0 ? my_b : c0;
+      const int hi = my_e < c0 + 64 ? my_e : c0 + 64;
+      for (int e = lo; e < hi; ++e) {
+        const float* m = Hs + (e - c0) * LDH + 4 * q;
+        sum.x += m[0]; sum.y += m[1]; sum.z += m[2]; sum.w += m[3];
+      }
+    }
+    __syncthreads();
+  }
+  if (rb < nn) {
+    const int deg = my_e - my_b;
+    if (deg > 0) {
+      const float inv = 1.f / (float)deg;
+      float4* o = reinterpret_cast<float4*>(f_out + (long)(n0 + rb) * ld_fo + 4 * q);
+      float4 d = *o;
+      // explicit mul then add (no fma contraction): the same two roundings as k_csr_mean_fwd*
+      d.x = yl_mul_rn(sum.x, inv) + d.x; d.y = yl_mul_rn(sum.y, inv) + d.y;
+      d.z = yl_mul_rn(sum.z, inv) + d.z; d.w = yl_mul_rn(sum.w, inv) + d.w;
+      *o = d;
+    }
+  }
+}
+
+extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,
+                                            const int32_t* dst_csr, const float* attr_csr,
+                                            const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                                            const float* b1, const float* s1, const float* t1, const float* W2,
+                                            const float* b2, const float* s2, const float* t2, int64_t C,
+                                            float* f_out, int64_t ld_fo, yolat_stream_t stream) {
+  if (E < 0 || N <= 0 || !UV || !Wc4 || !b1 || !W2 || !row_ptr || !f_out) return YOLAT_E_INVALID;
+  if (C != 64) return YOLAT_E_UNSUPPORTED;
+  if (E == 0) return 0;
+  if (!src_csr || !dst_csr || !attr_csr || E >= (1LL << 31) || ld_fo < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return YOLAT_E_INVALID;
+  if (ld_uv % 4 != 0 || ld_fo % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) ||
+      !yl_aligned16(b1) || !yl_aligned16(f_out) || (s1 && (!yl_aligned16(s1) || !yl_aligned16(t1))))
+    return YOLAT_E_UNSUPPORTED;
+  // nodes per workgroup: ~56 edges on average so that a single 64-edge pass is the common case
+  long npt = (56 * N) / E;
+  if (npt < 1) npt = 1;
+  if (npt > 16) npt = 16;
+  DenseOp w2 = yl_dense(W2, C, C, C);
+  hipLaunchKernelGGL(k_edge_uv_mlp2_mean, dim3(yl_cdiv(N, npt)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
+                     src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
+                     (long)ld_fo, (int)E);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,
                                        const int32_t* dst_csr, const float* attr_csr, int64_t E, const float* Wc4,
                                        const float* b1, const float* s1, const float* t1, const float* W2,
@@ -361,7 +512,7 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd(const float* H, long ldh, 
       for (int j = 0; j < 4; ++j) s += fmaxf(fmaf(v[j], sc, sh), floor);
     }
     for (; q < q1; ++q) s += fmaxf(fmaf(H[(long)q * ldh + c], sc, sh), floor);
-    s *= inv;
+    s = yl_mul_rn(s, inv);
     float* o = out + (long)n * ldo + c;
     if (accumulate) s += *o;
     *o = s;
@@ -411,9 +562,12 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd_v4(const float* __restrict
     for (int j = 0; j < 7; ++j)
       if (q + j < q1) add(v[j]);
   }
-  s.x *= inv; s.y *= inv; s.z *= inv; s.w *= inv;
+  s.x = yl_mul_rn(s.x, inv); s.y = yl_mul_rn(s.y, inv); s.z = yl_mul_rn(s.z, inv); s.w = yl_mul_rn(s.w, inv);
   float4* o = reinterpret_cast<float4*>(out + (long)n * ldo + 4 * sub);
-  if (accumulate) { const float4 p = *o; s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w; }
+  if (accumulate) {
+    const float4 p = *o;
+    s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+  }
   *o = s;
 }
 

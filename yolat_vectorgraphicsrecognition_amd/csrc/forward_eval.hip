@@ -169,21 +169,20 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
                                      f_out, ld_out, s_out, ld_out, stream));
     } else if (C == 64) {
       if (cv.Wuv != nullptr && cv.Wc4 != nullptr) {
-        // factorised layer, three launches: (1) node side — UV = f_in.[W1a-W1b | W1b]^T, root Linear and
-        // node-branch Linear in one launch; (2) per-edge gather-add of U[dst] + V[src] + W1c.attr, BN+ReLU,
-        // second edge Linear (hidden activation in LDS); (3) CSR mean accumulated into the root output.
-        // The K = 2*Cin GEMM runs once per node instead of once per edge (E = 4..6 N).
+        // factorised layer, two launches: (1) node side — UV = f_in.[W1a-W1b | W1b]^T, root Linear and
+        // node-branch Linear in one launch; (2) per destination-node tile: gather-add of U[dst] + V[src] +
+        // W1c.attr, BN+ReLU, second edge Linear, BN+ReLU and the CSR mean, accumulated into the root output
+        // (neither [E,64] activation reaches HBM).  The K = 2*Cin GEMM runs once per node instead of once
+        // per edge (E = 4..6 N).
         snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
         YL_STAGE(nm, 8.0 * N * cv.Cin * C, 4.0 * (2.0 * N * cv.Cin + 4.0 * N * C),
                  yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, cv.Wuv, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn,
                                     C, p.UV, 2 * C, f_out, ld_out, s_out, ld_out, stream));
         if (E > 0) {
-          snprintf(nm, sizeof nm, "edge_uv_mlp2[E x (U+V+attr) -> %ld -> %ld]", C, C);
-          YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 4.0 * E * C,
-                   yolat_edge_uv_mlp2_eval(p.UV, 2 * C, p.src, p.dst, p.attr, E, cv.Wc4, cv.b1, cv.s1, cv.t1, cv.W2,
-                                           cv.b2, cv.s2, cv.t2, C, p.H2, C, stream));
-          YL_STAGE("csr_mean[E x C -> N x C]", 1.0 * E * C, 4.0 * (E * C + 2.0 * N * C) + 4.0 * N,
-                   yolat_csr_mean_fwd(p.H2, C, C, nullptr, nullptr, 0, p.row_ptr, N, f_out, ld_out, 1, stream));
+          snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
+          YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C,
+                   yolat_edge_uv_mlp2_mean_eval(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.b1,
+                                                cv.s1, cv.t1, cv.W2, cv.b2, cv.s2, cv.t2, C, f_out, ld_out, stream));
         }
       } else {
       // three launches per layer: edge MLP (hidden activation in LDS); root Linear | node-branch Linear as one
