@@ -310,6 +310,15 @@ int yolat_segment_max_fwd(const float* X, int64_t ldx, int64_t D, const float* x
                           const float* x_shift, int x_relu, const int32_t* seg_ptr, int64_t P,
                           int64_t N, float* Y, int64_t ldy, int32_t* arg /* nullable [P,D] */,
                           yolat_stream_t stream);
+/* Eval-mode fusion stage in one launch (arch:61-69,122): yolat_linear_segmax_fwd over the N nodes together
+ * with fusion_block_super (Linear + folded BatchNorm + ReLU) over the P per-proposal means — two independent
+ * GEMMs, one flattened grid.  Wf, Wfs: [F, D] contiguous.  `pool` must be zero-filled (yolat_pool_prepare).  */
+int yolat_fusion_pair_eval(const float* A, int64_t lda, int64_t N, int64_t D, const float* Wf, const float* bf,
+                           const float* sf, const float* tf, int64_t F, const int32_t* node_seg, float* pool,
+                           int64_t ldpool, const float* S, int64_t lds, int64_t P, const float* Wfs,
+                           const float* bfs, const float* sfs, const float* tfs, float* Ys, int64_t ldys,
+                           yolat_stream_t stream);
+
 /* Pooling prologue of the eval forward in one launch, Z = [P, 2(F+D)] (arch:127 layout):
  *   Z[:,0:F] = 0;  Z[:,F:F+D] = segment-max of feats[N,D];  Z[:,2F+D:2F+2D] = segment-mean of fsup[N,D]
  * (fsup may be NULL: the mean part is skipped, e.g. when it is computed on another stream).              */

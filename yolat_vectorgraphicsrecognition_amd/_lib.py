@@ -63,6 +63,8 @@ SIGNATURES = {
                                          c_p, c_i64, c_p]),
     "yolat_edge_uv_mlp2_mean_eval": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p,
                                               c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_fusion_pair_eval": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
+                                        c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),

@@ -520,6 +520,28 @@ __global__ void __launch_bounds__(256) k_gemm_nt_pair(AL A0, BL B0, Epilogue e0,
   else gemm_nt_tile<BM, BN, BK, AL, BL, false>(A1, B1, e1, M, N, K, blockIdx.x, 0);
 }
 
+// Two independent 64x64x32 GEMMs in one flattened 1-D launch: the first (padded) tm1*tn1 workgroups tile
+// problem 1 row-major, the rest tile problem 0 with the XCD-aware map over its tm0 x tn0 tiles.  Used for the fusion block over the N
+// nodes (+ segment-max epilogue) together with fusion_block_super over the P proposals: the small GEMM's
+// 112 workgroups ride along with the big one's 2512 instead of being a launch of their own.
+static __global__ void __launch_bounds__(256) k_gemm_nt_two(DenseOp A0, DenseOp B0, Epilogue e0, int M0, int N0, int K0, int tm0,
+                                                     int tn0, DenseOp A1, DenseOp B1, Epilogue e1, int M1, int N1,
+                                                     int K1, int tm1, int tn1) {
+  // the small problem's workgroups come FIRST (padded to a multiple of 8 so that the big problem's ids keep
+  // their id % 8 = XCD alignment): they start with the first wave of workgroups instead of forming a tail
+  const int n1 = tm1 * tn1, n1p = (n1 + 7) & ~7;
+  const int id = blockIdx.x;
+  if (id < n1p) {
+    if (id < n1) gemm_nt_tile<64, 64, 32, DenseOp, DenseOp, false>(A1, B1, e1, M1, N1, K1, id / tn1, id % tn1);
+    return;
+  }
+  const int n0 = tm0 * tn0, j = id - n1p;
+  const int chunk = n0 >> 3, rem = n0 & 7;
+  const int xcd = j & 7, slot = j >> 3;
+  const int logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
+  gemm_nt_tile<64, 64, 32, DenseOp, DenseOp, false>(A0, B0, e0, M0, N0, K0, logical / tn0, logical % tn0);
+}
+
 // Node side of a factorised conv layer in one launch: blockIdx.y = 0,1 -> the two 64-column halves of
 // UV = f_in.Wuv^T (N = 128 outputs), 2 -> root Linear, 3 -> node-branch Linear+BN+ReLU.
 template <int BK>

@@ -162,6 +162,34 @@ extern "C" int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* 
   return 0;
 }
 
+// Eval-mode fusion stage in one launch (arch:61-69,122):
+//   pool[p, 0:F]  = max over the rows of proposal p of relu((A.Wf^T + bf)*sf + tf)        (A = feats [N,D])
+//   Ys[P, F]      = relu((S.Wfs^T + bfs)*sfs + tfs)                                       (S = mean(fsup) [P,D])
+// `pool` must be zero-filled first (yolat_pool_prepare).
+extern "C" int yolat_fusion_pair_eval(const float* A, int64_t lda, int64_t N, int64_t D, const float* Wf,
+                                      const float* bf, const float* sf, const float* tf, int64_t F,
+                                      const int32_t* node_seg, float* pool, int64_t ldpool, const float* S,
+                                      int64_t lds, int64_t P, const float* Wfs, const float* bfs, const float* sfs,
+                                      const float* tfs, float* Ys, int64_t ldys, yolat_stream_t stream) {
+  if (N <= 0 || P <= 0 || D <= 0 || F <= 0 || !A || !Wf || !node_seg || !pool || !S || !Wfs || !Ys) return YOLAT_E_INVALID;
+  if (N >= (1LL << 31) || lda < D || lds < D || ldpool < F || ldys < F) return YOLAT_E_INVALID;
+  if ((sf == nullptr) != (tf == nullptr) || (sfs == nullptr) != (tfs == nullptr)) return YOLAT_E_INVALID;
+  DenseOp a0 = yl_dense(A, lda, N, D), b0 = yl_dense(Wf, D, F, D);
+  DenseOp a1 = yl_dense(S, lds, P, D), b1 = yl_dense(Wfs, D, F, D);
+  Epilogue e0, e1;
+  e0.bias = bf; e0.scale = sf; e0.shift = tf; e0.relu = 1;
+  e0.Y = nullptr; e0.ldy = 0; e0.accumulate = 0; e0.stats = nullptr; e0.seg = node_seg; e0.pool = pool; e0.ldpool = ldpool;
+  e1.bias = bfs; e1.scale = sfs; e1.shift = tfs; e1.relu = 1;
+  e1.Y = Ys; e1.ldy = ldys; e1.accumulate = 0; e1.stats = nullptr; e1.seg = nullptr; e1.pool = nullptr; e1.ldpool = 0;
+  const int tm0 = yl_cdiv(N, 64), tn0 = yl_cdiv(F, 64), tm1 = yl_cdiv(P, 64), tn1 = yl_cdiv(F, 64);
+  const long total = (long)tm0 * tn0 + (((long)tm1 * tn1 + 7) & ~7L);
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gemm_nt_two, dim3((unsigned)total), dim3(256), 0, (hipStream_t)stream, a0, b0, e0, (int)N, (int)F,
+                     (int)D, tm0, tn0, a1, b1, e1, (int)P, (int)F, (int)D, tm1, tn1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64_t K,
                                    const float* Wt, int64_t ldw, int64_t Nout, float* Y,
                                    int64_t ldy, int accumulate, yolat_stream_t stream) {

@@ -233,15 +233,12 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   float* sup = p.Z + 2 * F + D;
   YL_STAGE("pool_prepare[max(feats), mean(fsup), zero]", 2.0 * N * D, 8.0 * N * D + 4.0 * P * (F + 2 * D),
            yolat_pool_prepare(p.feats, p.fsup, D, D, F, p.seg_ptr, P, p.Z, ZW, stream));
-  snprintf(nm, sizeof nm, "fusion_gemm+segmax[N x %ld -> %ld -> P]", D, F);
-  YL_STAGE(nm, 2.0 * N * D * F, 4.0 * (N * D + D * F + P * F),
-           yolat_linear_segmax_fwd(p.feats, D, N, D, m->Wf, D, m->bf, F, m->sf, m->tf, p.node_seg, p.Z, ZW,
-                                   stream));
-  // ---- super branch: fusion_block_super on the per-proposal means (arch:65-69)
-  snprintf(nm, sizeof nm, "fusion_super_gemm[P x %ld -> %ld]", D, F);
-  YL_STAGE(nm, 2.0 * P * D * F, 4.0 * (P * D + D * F + P * F),
-           yolat_linear_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->Wfs, D, m->bfs, F, m->sfs, m->tfs, 1,
-                            p.Z + F + D, ZW, 0, nullptr, stream));
+  // fusion block over the nodes + per-proposal max, and fusion_block_super over the per-proposal means
+  // (arch:61-63,65-69,122): two independent GEMMs in one flattened launch
+  snprintf(nm, sizeof nm, "fusion_gemm+segmax[N x %ld -> %ld -> P] | super[P x %ld -> %ld]", D, F, D, F);
+  YL_STAGE(nm, 2.0 * (N + P) * D * F, 4.0 * (N * D + 2.0 * D * F + 2.0 * P * F + N + P * D),
+           yolat_fusion_pair_eval(p.feats, D, N, D, m->Wf, m->bf, m->sf, m->tf, F, p.node_seg, p.Z, ZW, sup, ZW, P,
+                                  m->Wfs, m->bfs, m->sfs, m->tfs, p.Z + F + D, ZW, stream));
   // ---- classifier (arch:91-93,127-128)
   snprintf(nm, sizeof nm, "cls1[P x %ld -> %ld]", ZW, (long)m->H1);
   YL_STAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + ZW * m->H1 + P * m->H1),
