@@ -249,6 +249,18 @@ int yolat_edge_mlp2_eval(const float* x, int64_t ldx, int64_t N, int64_t Cin, co
                          const float* b2, const float* s2, const float* t2, int64_t C, float* H2,
                          int64_t ldh, yolat_stream_t stream);
 
+/* yolat_graph_prepare + yolat_node_uv_eval of the FIRST conv layer in the same launches: the node side of
+ * layer 0 reads only the raw node features x (both of its inputs, arch:45), so its GEMM tiles ride in the last,
+ * latency-bound pre-processing launch.  Same outputs as the two calls made separately.                     */
+int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                                const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr,
+                                int32_t* perm, int32_t* src_csr, int32_t* dst_csr, float* attr_csr,
+                                int32_t* seg_ptr, int32_t* node_seg, int32_t* work, int32_t* status, const float* x,
+                                int64_t ldx, int64_t Cin, const float* Wuv, const float* Wr, const float* br,
+                                const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C,
+                                float* UV, int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
+                                yolat_stream_t stream);
+
 /* Factorised edge MLP (eval).  The first edge Linear acts on [x_i | x_j - x_i | attr], so
  *   W1.[x_i | x_j-x_i | attr] = (W1a - W1b).x_i + W1b.x_j + W1c.attr      (torch_vertex.py:331 + torch_nn.py:58)
  * and the two node terms can be computed ONCE PER NODE (N rows) instead of once per edge (E = 4..6 N rows):

@@ -65,6 +65,8 @@ SIGNATURES = {
                                               c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_fusion_pair_eval": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
                                         c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "yolat_graph_prepare_node_uv": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64] + [c_p] * 9 +
+                                    [c_p, c_i64, c_i64] + [c_p] * 7 + [c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),

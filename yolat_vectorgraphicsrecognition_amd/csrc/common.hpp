@@ -542,15 +542,29 @@ static __global__ void __launch_bounds__(256) k_gemm_nt_two(DenseOp A0, DenseOp 
   gemm_nt_tile<64, 64, 32, DenseOp, DenseOp, false>(A0, B0, e0, M0, N0, K0, logical / tn0, logical % tn0);
 }
 
+// Operands / epilogues of the node side of a factorised conv layer (built by yl_build_node_uv, dense.hip)
+struct NodeUv {
+  DenseOp af, wuv, wr, as, wn;
+  Epilogue euv, er, en;
+  int N, C, Cin;
+};
+int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
+                     int64_t Cin, const float* Wuv, const float* Wr, const float* br, const float* Wn,
+                     const float* bn, const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv,
+                     float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so);
+// tile y of row tile x: y = 0,1 -> UV halves, 2 -> root Linear, 3 -> node-branch Linear
+template <int BK>
+__device__ __forceinline__ void node_uv_tile(const NodeUv& a, int x, int y) {
+  if (y < 2) gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y);
+  else if (y == 2) gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0);
+  else gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0);
+}
+
 // Node side of a factorised conv layer in one launch: blockIdx.y = 0,1 -> the two 64-column halves of
 // UV = f_in.Wuv^T (N = 128 outputs), 2 -> root Linear, 3 -> node-branch Linear+BN+ReLU.
 template <int BK>
-__global__ void __launch_bounds__(256) k_gemm_nt_node3(DenseOp Af, DenseOp Wuv, Epilogue euv, DenseOp Wr, Epilogue er,
-                                                       DenseOp As, DenseOp Wn, Epilogue en, int M, int C, int K) {
-  const int y = blockIdx.y;
-  if (y < 2) gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(Af, Wuv, euv, M, 2 * C, K, blockIdx.x, y);
-  else if (y == 2) gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(Af, Wr, er, M, C, K, blockIdx.x, 0);
-  else gemm_nt_tile<64, 64, BK, DenseOp, DenseOp, false>(As, Wn, en, M, C, K, blockIdx.x, 0);
+__global__ void __launch_bounds__(256) k_gemm_nt_node3(NodeUv a) {
+  node_uv_tile<BK>(a, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------

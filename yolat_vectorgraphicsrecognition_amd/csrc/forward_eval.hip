@@ -137,9 +137,26 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
 
   // ---- graph structure (CSR by destination, e_attr in CSR order, proposal segments)
   char nm[96];
+  // The node side of layer 0 (UV products, root Linear, node-branch Linear) reads only x: its GEMM tiles are
+  // co-scheduled with the last, latency-bound pre-processing launch instead of being a launch of their own.
+  const yolat_conv_eval& cv0 = m->conv[0];
+  const bool node0_in_prep = (conv_mode == 0) && C == 64 && cv0.Wuv != nullptr && cv0.Wc4 != nullptr;
+  if (node0_in_prep) {
+    const int slot0 = 0 - lo;
+    float* f0 = slot0 >= 0 ? p.feats + slot0 * C : p.f_tmp[0];
+    float* s0 = slot0 >= 0 ? p.fsup + slot0 * C : p.s_tmp[0];
+    const long ld0 = slot0 >= 0 ? D : C;
+    YL_STAGE("graph_prep[csr+attr+segments] + node_uv[layer 0]", 8.0 * N * cv0.Cin * C,
+             16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N + 4.0 * (2.0 * N * cv0.Cin + 4.0 * N * C),
+             yolat_graph_prepare_node_uv(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
+                                         p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, x, ldx, cv0.Cin,
+                                         cv0.Wuv, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C, p.UV, 2 * C, f0,
+                                         ld0, s0, ld0, stream));
+  } else {
   YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N,
            yolat_graph_prepare(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
                                p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, stream));
+  }
 
   // ---- conv layers (torch_vertex.py:319-337), outputs written into their concat slots
   const float* f_in = x; long ld_f = ldx;
@@ -174,10 +191,12 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
         // W1c.attr, BN+ReLU, second edge Linear, BN+ReLU and the CSR mean, accumulated into the root output
         // (neither [E,64] activation reaches HBM).  The K = 2*Cin GEMM runs once per node instead of once
         // per edge (E = 4..6 N).
-        snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
-        YL_STAGE(nm, 8.0 * N * cv.Cin * C, 4.0 * (2.0 * N * cv.Cin + 4.0 * N * C),
-                 yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, cv.Wuv, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn,
-                                    C, p.UV, 2 * C, f_out, ld_out, s_out, ld_out, stream));
+        if (!(l == 0 && node0_in_prep)) {
+          snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
+          YL_STAGE(nm, 8.0 * N * cv.Cin * C, 4.0 * (2.0 * N * cv.Cin + 4.0 * N * C),
+                   yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, cv.Wuv, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn,
+                                      cv.tn, C, p.UV, 2 * C, f_out, ld_out, s_out, ld_out, stream));
+        }
         if (E > 0) {
           snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
           YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C,

@@ -297,10 +297,9 @@ __global__ void k_prep_fill(const int* dst32, const int* rank, int E, const int*
   items[local[d] + prep_prefix(btot, d / PREP_BLK) + rank[e]] = e;
 }
 
-__global__ void k_prep_rows(const int* local, const int* btot, int N, int* items, const int* src32,
-                            const float4* attr, int* row_ptr, int* perm, int* src_csr, int* dst_csr,
-                            float4* attr_csr) {
-  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+__device__ __forceinline__ void prep_rows_body(int n, const int* local, const int* btot, int N, int* items,
+                                               const int* src32, const float4* attr, int* row_ptr, int* perm,
+                                               int* src_csr, int* dst_csr, float4* attr_csr) {
   if (n > N) return;
   const int b = local[n] + prep_prefix(btot, n / PREP_BLK);
   row_ptr[n] = b;
@@ -365,15 +364,40 @@ __global__ void k_prep_rows(const int* local, const int* btot, int N, int* items
   }
 }
 
+__global__ void k_prep_rows(const int* local, const int* btot, int N, int* items, const int* src32,
+                            const float4* attr, int* row_ptr, int* perm, int* src_csr, int* dst_csr,
+                            float4* attr_csr) {
+  prep_rows_body(blockIdx.x * blockDim.x + threadIdx.x, local, btot, N, items, src32, attr, row_ptr, perm, src_csr,
+                 dst_csr, attr_csr);
+}
+
+// The last pre-processing kernel co-scheduled with the node side of the FIRST conv layer (which depends only
+// on x, not on the graph): workgroups [0, rows_blocks) sort / emit the CSR rows, the rest are the 64x64 GEMM
+// tiles of yolat_node_uv_eval.  The row kernel alone is 40 workgroups of integer latency (~10 us at
+// N = 10k); the GEMM tiles fill the other CUs meanwhile instead of being a launch of their own.
+template <int BK>
+__global__ void __launch_bounds__(256) k_prep_rows_node3(const int* local, const int* btot, int N, int* items,
+                                                         const int* src32, const float4* attr, int* row_ptr,
+                                                         int* perm, int* src_csr, int* dst_csr, float4* attr_csr,
+                                                         int rows_blocks, NodeUv a) {
+  if ((int)blockIdx.x < rows_blocks) {
+    prep_rows_body(blockIdx.x * 256 + threadIdx.x, local, btot, N, items, src32, attr, row_ptr, perm, src_csr, dst_csr,
+                   attr_csr);
+    return;
+  }
+  const int t = blockIdx.x - rows_blocks;
+  node_uv_tile<BK>(a, t >> 2, t & 3);
+}
+
 extern "C" size_t yolat_graph_work_elems(int64_t N, int64_t E) {
   return (size_t)(2 * (((N + 1) + 63) / 64 * 64) + 4 * E + (N + 1) / PREP_BLK + 16);
 }
 
-extern "C" int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_t stride_c,
-                                   const float* e_attr, const int64_t* bbox_idx, int64_t E, int64_t N,
-                                   int64_t P, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
-                                   int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
-                                   int32_t* work, int32_t* status, yolat_stream_t stream) {
+static int graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                              const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr,
+                              int32_t* perm, int32_t* src_csr, int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr,
+                              int32_t* node_seg, int32_t* work, int32_t* status, const NodeUv* extra,
+                              yolat_stream_t stream) {
   if (N <= 0 || E < 0 || N >= (1LL << 31) - 8192 || E >= (1LL << 31) - 256) return YOLAT_E_INVALID;
   if (!row_ptr || !work || !status) return YOLAT_E_INVALID;
   if (E > 0 && (!edge || !e_attr || !perm || !src_csr || !dst_csr || !attr_csr)) return YOLAT_E_INVALID;
@@ -404,11 +428,52 @@ extern "C" int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_
                        items);
     YL_LAUNCH_CHECK();
   }
-  hipLaunchKernelGGL(k_prep_rows, dim3(yl_cdiv(n1, 256)), dim3(256), 0, st, local, btot, (int)N, items, src32,
-                     reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
-                     reinterpret_cast<float4*>(attr_csr));
+  const int rows_blocks = yl_cdiv(n1, 256);
+  if (extra != nullptr) {
+    const unsigned total = (unsigned)rows_blocks + 4u * (unsigned)yl_cdiv(extra->N, 64);
+    if (extra->Cin <= 16)
+      hipLaunchKernelGGL(k_prep_rows_node3<16>, dim3(total), dim3(256), 0, st, local, btot, (int)N, items, src32,
+                         reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
+                         reinterpret_cast<float4*>(attr_csr), rows_blocks, *extra);
+    else
+      hipLaunchKernelGGL(k_prep_rows_node3<32>, dim3(total), dim3(256), 0, st, local, btot, (int)N, items, src32,
+                         reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
+                         reinterpret_cast<float4*>(attr_csr), rows_blocks, *extra);
+  } else {
+    hipLaunchKernelGGL(k_prep_rows, dim3(rows_blocks), dim3(256), 0, st, local, btot, (int)N, items, src32,
+                       reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
+                       reinterpret_cast<float4*>(attr_csr));
+  }
   YL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_t stride_c,
+                                   const float* e_attr, const int64_t* bbox_idx, int64_t E, int64_t N,
+                                   int64_t P, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
+                                   int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
+                                   int32_t* work, int32_t* status, yolat_stream_t stream) {
+  return graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
+                            attr_csr, seg_ptr, node_seg, work, status, nullptr, stream);
+}
+
+// yolat_graph_prepare with the node side of the first conv layer (yolat_node_uv_eval on the raw node
+// features, independent of the graph) riding in its last launch.
+extern "C" int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e, int64_t stride_c,
+                                           const float* e_attr, const int64_t* bbox_idx, int64_t E, int64_t N,
+                                           int64_t P, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
+                                           int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
+                                           int32_t* work, int32_t* status, const float* x, int64_t ldx, int64_t Cin,
+                                           const float* Wuv, const float* Wr, const float* br, const float* Wn,
+                                           const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
+                                           int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
+                                           yolat_stream_t stream) {
+  NodeUv a;
+  const int rc = yl_build_node_uv(&a, x, ldx, x, ldx, N, Cin, Wuv, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv, f_out, ld_fo,
+                                  s_out, ld_so);
+  if (rc != 0) return rc;
+  return graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
+                            attr_csr, seg_ptr, node_seg, work, status, &a, stream);
 }
 
 __global__ void k_gather_rows(const float* src, long ld_src, const int* idx, long rows, int width,
