@@ -369,3 +369,54 @@ def test_edge_cases_no_edges_and_more_than_65535_proposals():
     loss = crit(model(big, None), big)["loss"]
     loss.backward()
     assert torch.isfinite(loss) and all(torch.isfinite(p.grad).all() for p in model.parameters())
+
+
+def test_full_size_cfg5_size_independent_properties():
+    """BASELINE.json configs[4] size (N=200k / E=1.2M / P=8000, n_blocks=4), too big for the CPU oracle:
+    (1) run-to-run determinism, bit for bit; (2) block-diagonal batching: the forward of the graph equals the
+    forwards of its two proposal halves stacked (no edge crosses a proposal, eval BatchNorm is per row);
+    (3) proposal-order equivariance: reversing the order of the proposals (nodes, edges and boxes moved with
+    them) reverses the rows of the logits."""
+    yv = _yv()
+    data, slices, optkw, _ = yv.config("5")
+    model = _model(yv, optkw, 9)
+    model.eval()
+    with torch.no_grad():
+        full = model(data, slices)[0].clone()
+        data._yolat_stage = None
+        again = model(data, slices)[0]
+    assert torch.equal(full, again)
+    model._yolat_plan.check_status()
+    N, P = data.x.shape[0], data.bbox.shape[0]
+    bb = data.bbox_idx.numpy()
+    owner_e = bb[data.edge[:, 0].numpy()]
+    assert (owner_e == bb[data.edge[:, 1].numpy()]).all()
+
+    def sub(p_lo, p_hi, reverse=False):
+        order = np.arange(p_lo, p_hi)
+        if reverse:
+            order = order[::-1]
+        node_ptr = np.searchsorted(bb, np.arange(P + 1))
+        nodes = np.concatenate([np.arange(node_ptr[p], node_ptr[p + 1]) for p in order])
+        o2n = np.full(N, -1, dtype=np.int64)
+        o2n[nodes] = np.arange(len(nodes))
+        rank = np.full(P, -1, dtype=np.int64)
+        rank[order] = np.arange(len(order))
+        emask = (owner_e >= p_lo) & (owner_e < p_hi)
+        eidx = np.nonzero(emask)[0]
+        eidx = eidx[np.argsort(rank[owner_e[eidx]], kind="stable")]
+        d = yv.Data(x=data.x[nodes], pos=data.pos[nodes])
+        d.edge = torch.from_numpy(o2n[data.edge.numpy()[eidx]])
+        d.e_attr = data.e_attr[eidx]
+        d.bbox_idx = torch.from_numpy(rank[bb[nodes]])
+        d.bbox = data.bbox[order.copy()]
+        d.stat_feats = data.stat_feats[order.copy()]
+        return d
+
+    with torch.no_grad():
+        a = model(sub(0, P // 2), None)[0]
+        b = model(sub(P // 2, P), None)[0]
+        rev = model(sub(0, P, reverse=True), None)[0]
+    scale = float(full.abs().max())
+    assert float((torch.cat([a, b], 0) - full).abs().max()) <= 1e-5 * scale
+    assert float((rev.flip(0) - full).abs().max()) <= 1e-5 * scale
