@@ -168,12 +168,18 @@ def collate_to_device(data_list, device="cuda"):
     if pin is None or pin.numel() < total:
         pin = _PINNED["buf"] = torch.empty(int(total * 1.5), dtype=torch.uint8).pin_memory()
     dbuf = torch.empty(total, dtype=torch.uint8, device=device)
+    pin_np = pin.numpy()                       # plain memcpy per item (torch.cat / copy_ wake a thread pool per call)
     for k, dtype, shape, o, nbytes in fields:
-        dst = pin[o:o + nbytes].view(dtype).view(shape)
+        if not nbytes:
+            continue
         if k in tables:
-            dst.copy_(tables[k])
-        else:
-            torch.cat([it[k] for it in data_list], dim=0, out=dst) if nbytes else None
+            pin_np[o:o + nbytes] = tables[k].numpy().view(np.uint8).reshape(-1)
+            continue
+        pos = o
+        for it in data_list:
+            src = it[k].contiguous().numpy().view(np.uint8).reshape(-1)
+            pin_np[pos:pos + src.size] = src
+            pos += src.size
     dbuf.copy_(pin[:total], non_blocking=True)                  # the one H2D copy
     dv = {}
     for k, dtype, shape, o, nbytes in fields:
