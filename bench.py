@@ -40,6 +40,9 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--keep-csr", action="store_true", help="re-use the CSR across steps (fwd mode)")
+    ap.add_argument("--graphs", action="store_true",
+                    help="fwd mode: replay a captured hipGraph per stream instead of launching every kernel "
+                         "(measured: no gain at cfg 2 — with 8 streams the GPU, not the host, is the limit)")
     ap.add_argument("--streams", type=int, default=8,
                     help="fwd mode: independent forwards are issued round-robin on this many HIP streams "
                          "(1 = strictly one forward at a time)")
@@ -321,7 +324,10 @@ def main():
             torch.distributed.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
+    use_graphs = args.mode == "fwd" and args.graphs
+    if use_graphs:
+        model.use_hip_graphs(True)        # throughput phase: every stream's plan captures once, then replays
+    for _ in range(max(args.warmup, 3 * n_streams if use_graphs else 0)):
         step()
     barrier()
     t0 = time.perf_counter()
@@ -334,6 +340,8 @@ def main():
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if use_graphs:
+        model.use_hip_graphs(False)       # latency / per-stage profiling below use direct launches
     latency_ms = None
     if args.mode == "fwd":
         # ms/forward: latency of ONE forward with nothing else in flight (single stream)
@@ -423,7 +431,7 @@ def main():
                                                               optkw["n_blocks"], n_graphs),
                        "nodes": N, "edges": E, "proposals": P, "n_classes": optkw["n_classes"],
                        "csr_rebuilt_each_step": not args.keep_csr,
-                       "streams_in_flight": n_streams,
+                       "streams_in_flight": n_streams, "hip_graph_replay": bool(args.mode == "fwd" and args.graphs),
                        "parallelism": "replicas (graph-id sharding)" if args.mode == "fwd" else "dp%d" % world},
             "roofline": roof,
             "roofline_aggregation": agg,

@@ -461,6 +461,7 @@ int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx, c
  * reset.  yolat_profile_get must be called after the stream has been synchronised.  `flops` / `bytes`
  * are the ALGORITHMIC work of one call of the stage.                                */
 int yolat_profile_enable(int on);
+int yolat_profile_enabled(void);
 int yolat_profile_reset(void);
 int yolat_profile_count(void);
 int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms, int* calls,

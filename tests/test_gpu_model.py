@@ -420,3 +420,40 @@ def test_full_size_cfg5_size_independent_properties():
     scale = float(full.abs().max())
     assert float((torch.cat([a, b], 0) - full).abs().max()) <= 1e-5 * scale
     assert float((rev.flip(0) - full).abs().max()) <= 1e-5 * scale
+
+
+def test_hip_graph_replay_matches_direct_launches_and_follows_weight_updates():
+    """EvalPlan hipGraph replay: same logits bit for bit as direct launches; keyed by the input buffers (a
+    different batch falls back to direct launches); invalidated when a weight changes."""
+    yv = _yv()
+    arrs, optkw = gu.graph_case("medium")
+    model = _model(yv, optkw, 4)
+    model.eval()
+    d = gu.to_data(arrs, yv.Data)
+    for k in ("x", "edge", "e_attr", "bbox_idx", "bbox"):
+        d[k] = d[k].cuda()
+    with torch.no_grad():
+        want = model(d, None)[0].clone()
+    model.use_hip_graphs(True)
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s), torch.no_grad():
+        outs = [model(d, None)[0] for _ in range(5)]         # direct, capture, replay x3
+    torch.cuda.synchronize()
+    assert all(torch.equal(o, want) for o in outs)
+    plan = model._yolat_plans[s.cuda_stream]
+    assert any(v not in (False, None) for v in plan._graphs.values())
+    arrs2, _ = gu.graph_case("small")
+    d2 = gu.to_data(arrs2, yv.Data)
+    with torch.cuda.stream(s), torch.no_grad():
+        other = model(d2, None)[0]
+    model.use_hip_graphs(False)
+    with torch.no_grad():
+        assert torch.equal(other, model(d2, None)[0])
+    model.use_hip_graphs(True)
+    with torch.no_grad():
+        model.prediction_cls[2][0].bias += 1.0
+    with torch.cuda.stream(s), torch.no_grad():
+        shifted = [model(d, None)[0] for _ in range(3)]
+    torch.cuda.synchronize()
+    for o in shifted:
+        np.testing.assert_allclose(o.cpu().numpy(), (want + 1.0).cpu().numpy(), rtol=0, atol=1e-5)

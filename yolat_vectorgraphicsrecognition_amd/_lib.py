@@ -107,6 +107,7 @@ SIGNATURES = {
     "yolat_softmax_ce_work_elems": (c_sz, [c_i64]),
     "yolat_softmax_ce": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p]),
     "yolat_adam_step": (c_int, [c_p, c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_f, c_i64, c_f, c_p]),
+    "yolat_profile_enabled": (c_int, []),
     "yolat_profile_enable": (c_int, [c_int]),
     "yolat_profile_reset": (c_int, []),
     "yolat_profile_count": (c_int, []),

@@ -89,6 +89,7 @@ StageRec& stage_rec(const char* name, double flops, double bytes) {
   } while (0)
 
 extern "C" int yolat_profile_enable(int on) { g_profile = on != 0; return 0; }
+extern "C" int yolat_profile_enabled(void) { return g_profile ? 1 : 0; }
 extern "C" int yolat_profile_reset(void) {
   for (auto& s : g_stages) for (auto& e : s.ev) { g_pool.push_back(e.first); g_pool.push_back(e.second); }
   g_stages.clear();

@@ -28,6 +28,8 @@ class EvalPlan(object):
         self._keep = None
         self._ws = None
         self._status = None
+        self._graphs = {}
+        self.use_graph = os.environ.get("YOLAT_HIP_GRAPH", "0") == "1"
 
     def _version_key(self):
         return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(),)
@@ -102,6 +104,7 @@ class EvalPlan(object):
         if key != self._key:
             self._build()
             self._key = key
+            self._graphs.clear()
         N, P = x.shape[0], int(num_proposals)
         if edge.dim() != 2 or (edge.shape[1] != 2 and edge.shape[0] != 2):
             raise ValueError("edge must be [E,2] or [2,E]")
@@ -112,6 +115,14 @@ class EvalPlan(object):
         need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=x.device)
+            self._graphs.clear()
+        if self.use_graph:
+            out = self._run_graph(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
+            if out is not None:
+                return out
+        return self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
+
+    def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
         check(lib.yolat_forward_eval(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x),
                                      ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
@@ -119,6 +130,35 @@ class EvalPlan(object):
                                      logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
                                      self._status.data_ptr(), ops._stream()), "yolat_forward_eval")
         return logits
+
+    def _run_graph(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
+        """hipGraph replay of the whole forward (memset + 12 launches -> one graph launch: host enqueue
+        ~60 -> ~25 us).  A graph bakes in its input addresses, so it is keyed by them: the FIRST call with a
+        given set of input buffers launches directly and only marks the key, the second captures, later ones
+        replay.  Callers that stage every batch into the same device buffers (a serving loop, bench.py) hit
+        the replay path; one-off inputs (predict's sub-batches) never pay a capture.  The result is copied
+        out of the graph's static output, so the returned tensor is owned by the caller as usual."""
+        if lib.yolat_profile_enabled():
+            return None
+        gkey = (x.data_ptr(), edge.data_ptr(), e_attr.data_ptr(), bbox_idx.data_ptr(), ops._ld(x), se, sc, N, E, P)
+        ent = self._graphs.get(gkey)
+        if ent is None:
+            if len(self._graphs) >= 8:
+                self._graphs.pop(next(iter(self._graphs)))
+            self._graphs[gkey] = False                      # seen once: capture next time
+            return None
+        if ent is False:
+            torch.cuda.current_stream().synchronize()
+            g = torch.cuda.CUDAGraph()
+            cur = torch.cuda.current_stream()
+            # capture on the caller's stream when it is a side stream (torch refuses the default stream)
+            ctx = torch.cuda.graph(g) if cur == torch.cuda.default_stream() else torch.cuda.graph(g, stream=cur)
+            with ctx:
+                static_out = self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
+            ent = self._graphs[gkey] = (g, static_out, (x, edge, e_attr, bbox_idx))   # keep the inputs alive
+        g, static_out, _ = ent
+        g.replay()
+        return static_out.clone()
 
     def check_status(self):
         g = ops.Graph()
