@@ -2,6 +2,7 @@
 // gathered edge-feature GEMM, CSR mean aggregation and their backward.  All [E,*] tensors are in
 // destination-sorted (CSR) order, so aggregation reads contiguous rows and needs no atomics.
 #include "common.hpp"
+#include <stdlib.h>
 
 extern "C" int yolat_edge_lin1_fwd(const float* x, int64_t ldx, int64_t N, int64_t Cin,
                                    const int32_t* src_csr, const int32_t* dst_csr,
@@ -401,7 +402,12 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, cons
       !yl_aligned16(b1) || !yl_aligned16(f_out) || (s1 && (!yl_aligned16(s1) || !yl_aligned16(t1))))
     return YOLAT_E_UNSUPPORTED;
   // nodes per workgroup: ~56 edges on average so that a single 64-edge pass is the common case
+  // (measured at cfg 5: 9 nodes / one pass 208 us, 12 nodes / a second mostly-empty pass 242 us, 16 nodes /
+  // two full passes 194 us — on big graphs two passes halve the per-workgroup W2 staging)
   long npt = (56 * N) / E;
+  const long npt2 = (112 * N) / E < 16 ? (112 * N) / E : 16;
+  if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
+  if (const char* e = getenv("YOLAT_EDGE_NPT")) npt = atol(e);     // tuning hook
   if (npt < 1) npt = 1;
   if (npt > 16) npt = 16;
   DenseOp w2 = yl_dense(W2, C, C, C);
