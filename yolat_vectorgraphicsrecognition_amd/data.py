@@ -164,9 +164,14 @@ def collate_to_device(data_list, device="cuda"):
         fields.append((k, torch.int64, (t.numel(),), off, nbytes))
         off = (off + nbytes + 255) // 256 * 256
     total = max(off, 256)
-    pin = _PINNED.get("buf")
+    # two pinned staging buffers used alternately; a buffer is only re-packed after the H2D copy that last read
+    # it has completed (event recorded right after that copy)
+    slot = _PINNED["next"] = 1 - _PINNED.get("next", 1)
+    pin, ev = _PINNED.get(("buf", slot)), _PINNED.get(("ev", slot))
+    if ev is not None:
+        ev.synchronize()
     if pin is None or pin.numel() < total:
-        pin = _PINNED["buf"] = torch.empty(int(total * 1.5), dtype=torch.uint8).pin_memory()
+        pin = _PINNED[("buf", slot)] = torch.empty(int(total * 1.5), dtype=torch.uint8).pin_memory()
     dbuf = torch.empty(total, dtype=torch.uint8, device=device)
     pin_np = pin.numpy()                       # plain memcpy per item (torch.cat / copy_ wake a thread pool per call)
     for k, dtype, shape, o, nbytes in fields:
@@ -181,6 +186,10 @@ def collate_to_device(data_list, device="cuda"):
             pin_np[pos:pos + src.size] = src
             pos += src.size
     dbuf.copy_(pin[:total], non_blocking=True)                  # the one H2D copy
+    ev = _PINNED.get(("ev", slot))
+    if ev is None:
+        ev = _PINNED[("ev", slot)] = torch.cuda.Event()
+    ev.record()
     dv = {}
     for k, dtype, shape, o, nbytes in fields:
         dv[k] = dbuf[o:o + nbytes].view(dtype).view(shape)
