@@ -457,3 +457,36 @@ def test_hip_graph_replay_matches_direct_launches_and_follows_weight_updates():
     torch.cuda.synchronize()
     for o in shifted:
         np.testing.assert_allclose(o.cpu().numpy(), (want + 1.0).cpu().numpy(), rtol=0, atol=1e-5)
+
+
+@pytest.mark.parametrize("cin,blocks,blocks_out,classes", [(6, 3, 2, 22), (3, 2, 1, 5), (5, 4, 4, 17)])
+def test_other_model_shapes_match_oracle(cin, blocks, blocks_out, classes):
+    """in_channels / n_blocks / n_blocks_out / n_classes other than the README recipe: eval forward (plan) and
+    one training forward/backward against the CPU oracle (fp64 for the gradients)."""
+    yv = _yv()
+    optkw = dict(n_classes=classes, n_blocks=blocks, n_blocks_out=blocks_out, in_channels=cin)
+    d = yv.synth_graph(num_proposals=23, nodes_lo=3, nodes_hi=17, edge_factor=2.3, n_classes=classes, seed=50 + cin)
+    x = torch.randn(d.x.shape[0], cin, generator=torch.Generator().manual_seed(cin)) * 0.7
+    d.x = x
+    model = _model(yv, optkw, 31)
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 31)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        got = model(d, None)[0].cpu()
+        want = ref(d, None)[0]
+    assert float((got - want).abs().max()) <= RTOL_FWD * float(want.abs().max())
+    model.train()
+    ref64 = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 31).double().train()
+    loss = yv.DetectionLoss(yv.Opt(**optkw))(model(d, None), d)["loss"]
+    loss.backward()
+    d64 = yv.Data(x=d.x.double(), pos=d.pos)
+    for k in ("edge", "bbox_idx", "bbox", "labels", "stat_feats"):
+        d64[k] = d[k]
+    d64.e_attr = d.e_attr.double()
+    rloss = orc.DetectionLoss(orc.Opt(**optkw))(ref64(d64, None), d64)["loss"]
+    rloss.backward()
+    assert abs(float(loss) - float(rloss)) <= RTOL_FWD * abs(float(rloss))
+    gmax = max(float(p.grad.abs().max()) for p in ref64.parameters())
+    for (n, p), (_, q) in zip(model.named_parameters(), ref64.named_parameters()):
+        err = float((p.grad.cpu().double() - q.grad).abs().max())
+        assert err <= 1e-3 * max(float(q.grad.abs().max()), 1e-12) + 2e-5 * gmax, (n, err)
