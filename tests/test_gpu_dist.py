@@ -1,0 +1,88 @@
+"""Data-parallel training step with two ranks sharing one GPU (-m gpu): the real Trainer.step (HIP forward /
+backward, flat-gradient all-reduce, fused Adam) over a gloo process group, checked against a single-process
+computation of the averaged gradient.  (The multi-GPU run over RCCL is the driver's; this pins the logic.)"""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _batch(yv, rank):
+    return yv.synth_batch(2, 40 + rank, num_proposals=30, nodes_lo=4, nodes_hi=20, edge_factor=1.5, augmented=True)
+
+
+def _worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import yolat_vectorgraphicsrecognition_amd as yv
+    import golden_util as gu
+    opt = yv.Opt()
+    model = gu.fill_state_(yv.SparseCADGCN(opt), 60 + rank).cuda()     # ranks start DIFFERENT: broadcast must fix it
+    tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5)
+    data, slices = _batch(yv, rank)
+    losses = [float(tr.step(data, slices)) for _ in range(2)]
+    torch.cuda.synchronize()
+    np.savez(os.path.join(outdir, "rank%d.npz" % rank), param=tr.flat.param.cpu().numpy(), losses=np.array(losses))
+    dist.destroy_process_group()
+
+
+def test_dp_train_step_two_ranks_matches_single_process_average(tmp_path):
+    sys.path.insert(0, os.path.dirname(HERE))
+    import yolat_vectorgraphicsrecognition_amd as yv
+    import golden_util as gu
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
+    np.testing.assert_array_equal(r0["param"], r1["param"])           # replicas stay bit-identical
+    # single process: same start (rank 0's weights), gradient = mean of the two ranks' gradients, same Adam
+    opt = yv.Opt()
+    model = gu.fill_state_(yv.SparseCADGCN(opt), 60).cuda()
+    flat = yv.FlatParams(model)
+    adam = yv.FlatAdam(flat, lr=1e-3, weight_decay=1e-5)
+    crit = yv.DetectionLoss(opt)
+    batches = [_batch(yv, r) for r in range(2)]
+    losses = []
+    for _ in range(2):
+        model.train()
+        gsum = torch.zeros_like(flat.grad)
+        bufs = None
+        step_losses = []
+        for r, (data, slices) in enumerate(batches):
+            if r == 1:      # BatchNorm running stats are per replica: rank 0's are the ones compared below
+                saved = {n: b.clone() for n, b in model.named_buffers()}
+            adam.zero_grad()
+            loss = crit(model(data, slices), data)["loss"]
+            loss.backward()
+            gsum += flat.grad
+            step_losses.append(float(loss))
+            if r == 1:
+                for n, b in model.named_buffers():
+                    b.copy_(saved[n])
+        flat.grad.copy_(gsum)
+        adam.step(grad_scale=0.5)
+        losses.append(step_losses)
+    np.testing.assert_allclose(r0["losses"], [l[0] for l in losses], rtol=2e-6)
+    np.testing.assert_allclose(r1["losses"], [l[1] for l in losses], rtol=2e-6)
+    ref = flat.param.cpu().numpy()
+    scale = np.abs(ref).max()
+    assert np.abs(r0["param"] - ref).max() <= 2e-6 * scale
