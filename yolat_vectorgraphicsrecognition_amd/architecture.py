@@ -82,7 +82,7 @@ class _ModelFn(torch.autograd.Function):
         dl = dlogits.contiguous().clone()
         if flat is not None and flat.direct_grads:
             # trainer path: gradients land in the flat buffer, autograd sees no per-tensor grads
-            engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink(flat.grad_views))
+            engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink(flat.grad_views, getattr(flat, "on_head_done", None)))
             flat.grads_ready = True
             return (None, None, None) + tuple(None for _ in ctx.params)
         sink = engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink())

@@ -55,9 +55,13 @@ class GradSink(object):
     """Where parameter gradients are written: fresh tensors (autograd path) or views of one flat
     buffer (trainer / data-parallel path)."""
 
-    def __init__(self, views=None):
+    def __init__(self, views=None, on_head_done=None):
         self.views = views          # dict id(param) -> tensor view, or None
         self.out = {}
+        # called once by model_bwd when every gradient EXCEPT the conv layers' is final (classifier, fusion
+        # blocks = 93 % of the parameters): the data-parallel trainer starts their all-reduce there, so that it
+        # overlaps the conv-layer backward
+        self.on_head_done = on_head_done
 
     def get(self, p):
         if self.views is not None:
@@ -323,6 +327,8 @@ def model_bwd(model, g, sv, dlogits, sink):
         d_fus = _empty(N, F, dev)
         ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)
         lbr_bwd(sv["fus"], d_fus, sink, dx_out=d_feats, dx_accumulate=True)
+    if sink.on_head_done is not None:
+        sink.on_head_done()
     # conv layers, last to first
     d_f_next, d_s_next = None, None      # grads flowing into layer l's outputs from layer l+1
     for l in range(L - 1, -1, -1):

@@ -43,6 +43,18 @@ class FlatParams(object):
             off += k
         self.direct_grads = True      # _ModelFn.backward writes straight into self.grad
         self.grads_ready = False
+        # [0, conv_end) = parameters of the conv layers (cls_net.head / cls_net.backbone come first in
+        # model.parameters()); [conv_end, n) = fusion blocks + classifier, whose gradients are final first
+        self.conv_end = 0
+        net = getattr(model, "cls_net", None)
+        if net is not None:
+            conv_ids = {id(p) for m in [net.head] + list(net.backbone) for p in m.parameters()}
+            lead = 0
+            while lead < len(params) and id(params[lead]) in conv_ids:
+                lead += 1
+            if 0 < lead < len(params) and not any(id(p) in conv_ids for p in params[lead:]):
+                self.conv_end = sum(p.numel() for p in params[:lead])
+        self.on_head_done = None
         model._yolat_flat = self
 
 
@@ -113,7 +125,23 @@ class Trainer(object):
         self.optimizer.zero_grad()
         out = self.model(data, slices)
         loss = self.criterion(out, data)["loss"]
-        loss.backward()
-        scale = allreduce_mean_(self.flat.grad)
+        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if world > 1 and self.flat.conv_end > 0:
+            # bucket 1 (fusion blocks + classifier, 93 % of the bytes) is all-reduced while the conv layers'
+            # backward still runs; bucket 2 (conv layers) after the backward
+            handles = []
+            tail = self.flat.grad[self.flat.conv_end:]
+            self.flat.on_head_done = lambda: handles.append(dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True))
+            try:
+                loss.backward()
+            finally:
+                self.flat.on_head_done = None
+            handles.append(dist.all_reduce(self.flat.grad[:self.flat.conv_end], op=dist.ReduceOp.SUM, async_op=True))
+            for h in handles:
+                h.wait()
+            scale = 1.0 / world
+        else:
+            loss.backward()
+            scale = allreduce_mean_(self.flat.grad)
         self.optimizer.step(grad_scale=scale)
         return loss.detach()
