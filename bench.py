@@ -211,6 +211,57 @@ def aggregation_roofline(cfg_name="5", C=64, reps=20):
             "avg_launch_us": t * 1e6, "bytes_per_launch": by}
 
 
+def edge_layer_roofline(cfg_name="5", reps=10):
+    """Roofline of the fused, factorised edge kernel of a block layer (gather-add of the per-node products + BN/ReLU
+    + second Linear + BN/ReLU + mean aggregation: everything `propagate(aggr='mean')` does, torch_vertex.py:324) on
+    a cfg-5-sized graph.  Reported as SURVEY.md section 8(d) prescribes for a fused kernel: max(bytes/BW, flops/peak)/t with
+    the ALGORITHMIC aggregation bytes of the unfactorised layer, B_agg = E*((2*Cin+4)*4 + 8) + N*C*4, and its edge-MLP
+    flops F_edge = 2*E*((2*Cin+4)*C + C*C)."""
+    import ctypes
+    import yolat_vectorgraphicsrecognition_amd as yv
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    data, _, _, _ = yv.config(cfg_name)
+    g = yv.ops.build_graph(data.edge.cuda(), data.e_attr.cuda(), data.bbox_idx.cuda(), int(data.x.shape[0]),
+                           int(data.bbox.shape[0]))
+    E, N, C, Cin = g.E, g.N, 64, 64
+    gen = torch.Generator().manual_seed(0)
+    UV = torch.randn(N, 2 * C, generator=gen).cuda()
+    W2 = (torch.randn(C, C, generator=gen) / 8).cuda()
+    wc4 = torch.randn(C, 4, generator=gen).cuda()
+    vec = [torch.randn(C, generator=gen).cuda() for _ in range(6)]
+    f_out = torch.zeros(N, C, device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run():
+        check(lib.yolat_edge_uv_mlp2_mean_eval(UV.data_ptr(), 2 * C, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(),
+                                               g.row_ptr.data_ptr(), N, E, wc4.data_ptr(), vec[0].data_ptr(),
+                                               vec[1].data_ptr(), vec[2].data_ptr(), W2.data_ptr(), vec[3].data_ptr(),
+                                               vec[4].data_ptr(), vec[5].data_ptr(), C, f_out.data_ptr(), C, st))
+    for _ in range(3):
+        run()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(reps):
+        run()
+    e.record()
+    torch.cuda.synchronize()
+    t = s.elapsed_time(e) * 1e-3 / reps
+    b_agg = E * ((2 * Cin + 4) * 4.0 + 8) + N * C * 4.0
+    f_edge = 2.0 * E * ((2 * Cin + 4) * C + C * C)
+    t_bytes, t_flops = b_agg / (PEAK_HBM_GBS * 1e9), f_edge / (PEAK_MFMA_F32_TFLOPS * 1e12)
+    out = {"kernel": "edge_uv_mlp2_mean[E=%d, N=%d, C=%d] (factorised edge MLP + mean aggregation, one kernel)" % (E, N, C),
+           "traffic": None, "avg_launch_us": t * 1e6, "algorithmic_bytes": b_agg, "algorithmic_flops": f_edge,
+           "hbm_equivalent_GBs": b_agg / t / 1e9, "frac": max(t_bytes, t_flops) / t,
+           "note": "bytes / flops are those of the UNFACTORISED layer (SURVEY 8d: B_agg, F_edge), i.e. what a per-edge "
+                   "gathered GEMM has to move / compute; the kernel itself gathers 2*C*4 B per edge and executes "
+                   "2*E*(4*C + C*C) flop because the K = 2*Cin part of the first Linear runs once per node"}
+    if t_flops > t_bytes:
+        out.update(bound="mfma", achieved=f_edge / t / 1e12, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s")
+    else:
+        out.update(bound="hbm", achieved=b_agg / t / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")
+    return out
+
+
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the op-for-op torch oracle on the host cores (bounded sample)
 # ---------------------------------------------------------------------------------------------
@@ -403,9 +454,10 @@ def main():
                         "DESIGN.md; traffic: from the committed separate --pmc passes (null when none exists for "
                         "this workload)")
 
-    agg = None
+    agg = edge_roof = None
     if rank == 0 and not args.no_roofline:
         agg = aggregation_roofline()
+        edge_roof = edge_layer_roofline()
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
@@ -441,6 +493,7 @@ def main():
                        "parallelism": "replicas (graph-id sharding)" if args.mode == "fwd" else "dp%d" % world},
             "roofline": roof,
             "roofline_aggregation": agg,
+            "roofline_edge_layer": edge_roof,
             "cpu_baseline": cpu,
         }
         if op_table is not None:
