@@ -43,6 +43,10 @@ def parse():
     ap.add_argument("--graphs", action="store_true",
                     help="fwd mode: replay a captured hipGraph per stream instead of launching every kernel "
                          "(measured: no gain at cfg 2 — with 8 streams the GPU, not the host, is the limit)")
+    ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
+                    help="fwd mode: storage precision of the eval forward.  fp32 (default) is the parity mode the "
+                         "headline metric is quoted in; bf16 = bf16 node activations / weights with fp32 accumulation "
+                         "(csrc/bf16_eval.hip), the mode BASELINE.json's configs[4] names — use with --config 5")
     ap.add_argument("--streams", type=int, default=8,
                     help="fwd mode: independent forwards are issued round-robin on this many HIP streams "
                          "(1 = strictly one forward at a time)")
@@ -167,15 +171,19 @@ def roofline_entry(summary, cfg=None):
     return r
 
 
+PEAK_MFMA_BF16_TFLOPS = 2500.0   # dense bf16 MFMA peak (MI355X_MICROARCH.md; AMD's 5 PF figure is 2:1 sparse)
+
+
 def _roofline_entry(summary):
     label, rec = max(summary.items(), key=lambda kv: kv[1]["ms_total"])
     t = rec["ms_avg"] * 1e-3
     intensity = rec["flops"] / max(rec["bytes"], 1.0)
-    ridge = PEAK_MFMA_F32_TFLOPS * 1e12 / (PEAK_HBM_GBS * 1e9)
+    peak = PEAK_MFMA_BF16_TFLOPS if "bf16" in label else PEAK_MFMA_F32_TFLOPS
+    ridge = peak * 1e12 / (PEAK_HBM_GBS * 1e9)
     if intensity >= ridge:
         ach = rec["flops"] / t / 1e12
-        return {"kernel": label, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS,
-                "unit": "TFLOP/s", "frac": ach / PEAK_MFMA_F32_TFLOPS, "traffic": None,
+        return {"kernel": label, "bound": "mfma", "achieved": ach, "peak": peak,
+                "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
                 "avg_launch_us": rec["ms_avg"] * 1e3}
     ach = rec["bytes"] / t / 1e9
     return {"kernel": label, "bound": "hbm", "achieved": ach, "peak": PEAK_HBM_GBS, "unit": "GB/s",
@@ -348,6 +356,7 @@ def main():
     n_streams = max(1, min(args.streams, args.steps // 16)) if args.mode == "fwd" else 1
     if args.mode == "fwd":
         model.eval()
+        model.set_eval_precision(args.precision)
         streams = [torch.cuda.Stream() for _ in range(n_streams)] if n_streams > 1 else [torch.cuda.current_stream()]
         counter = [0]
 
@@ -481,14 +490,14 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": "f32" if (args.mode != "fwd" or args.precision == "fp32") else "bf16 storage / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": "cfg%s %s: synthetic Bezier graph(s), in_channels=5, n_blocks=%d, "
                                    "%d graph(s)/rank/step" % (cfg, "eval forward" if args.mode == "fwd"
                                                               else "train step (fwd+CE+bwd+Adam)",
                                                               optkw["n_blocks"], n_graphs),
                        "nodes": N, "edges": E, "proposals": P, "n_classes": optkw["n_classes"],
-                       "csr_rebuilt_each_step": not args.keep_csr,
+                       "csr_rebuilt_each_step": not args.keep_csr, "precision": args.precision,
                        "streams_in_flight": n_streams, "hip_graph_replay": bool(args.mode == "fwd" and args.graphs),
                        "parallelism": "replicas (graph-id sharding)" if args.mode == "fwd" else "dp%d" % world},
             "roofline": roof,

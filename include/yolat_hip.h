@@ -456,6 +456,35 @@ int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx, c
                        int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
                        yolat_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16-storage eval forward (bf16_eval.hip): the precision mode of BASELINE.json's large-graph
+ * configuration ("N=200k / E=1.2M, n_blocks=4, bf16").  Same contract and kernel sequence as
+ * yolat_forward_eval; node activations cross HBM as bfloat16, every Linear with K >= 64 runs on
+ * v_mfma_f32_32x32x16_bf16 with fp32 accumulation, bias / folded BatchNorm / ReLU / mean / max stay
+ * fp32.  The first layer's K = Cin0 products, the e_attr term, the pooled matrix and the logits are fp32.
+ * `base` carries the fp32 parameters (biases, folded BN, first-layer weights, Wuv/Wc4 of every layer are
+ * REQUIRED); the bf16 members are yolat_f32_to_bf16 copies of the named fp32 weights (row-major, same
+ * shapes).  Wuv/Wr/Wn[0] are unused (layer 0 multiplies the raw fp32 features).
+ * Supported shapes: C = 64, Cin0 <= 16, F, C*n_blocks_out, H1, H2 multiples of 64; else YOLAT_E_UNSUPPORTED.
+ * Accuracy: <= 1e-2 of the logits' scale against the fp32 path (tests/test_gpu_bf16.py).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+  const yolat_model_eval* base;
+  const uint16_t* Wuv[YOLAT_MAX_LAYERS];      /* bf16 of conv[l].Wuv [2C,Cin]                   */
+  const uint16_t* Wr[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].Wr  [C,Cin]                    */
+  const uint16_t* Wn[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].Wn  [C,Cin]                    */
+  const uint16_t* W2[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].W2  [C,C]                      */
+  const uint16_t *Wf, *Wfs, *Wc1, *Wc2, *Wc3; /* bf16 of the fusion / classifier weights        */
+} yolat_model_eval_bf16;
+
+/* dst[i] = bfloat16(src[i]), round-to-nearest-even (what torch's .to(torch.bfloat16) does); dst 4-byte aligned */
+int yolat_f32_to_bf16(const float* src, int64_t n, uint16_t* dst, yolat_stream_t stream);
+size_t yolat_forward_eval_bf16_workspace_bytes(const yolat_model_eval_bf16* m, int64_t N, int64_t E, int64_t P);
+int yolat_forward_eval_bf16(const yolat_model_eval_bf16* m, const float* x, int64_t ldx, const int64_t* edge,
+                            int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                            int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                            size_t workspace_bytes, int32_t* status, yolat_stream_t stream);
+
 /* Stage profiler of yolat_forward_eval: when enabled, a hipEvent pair is recorded on `stream` around
  * every stage (each stage = the launch(es) of one kernel family); totals accumulate across calls until
  * reset.  yolat_profile_get must be called after the stream has been synchronised.  `flops` / `bytes`

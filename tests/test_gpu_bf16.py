@@ -1,0 +1,198 @@
+"""GPU tests (-m gpu) of the bf16-storage eval forward (csrc/bf16_eval.hip, yolat_forward_eval_bf16): the precision
+mode of BASELINE.json configs[4] ("N=200k / E=1.2M, n_blocks=4, bf16").  SURVEY.md §8c: "bf16 variant compared to the
+fp32 oracle at <= 1e-2 rel with fp32 accumulation" — here 1e-2 of the logits' scale, against the golden vectors of
+the reference's own modules, the CPU oracle, and the fp32 HIP path at full size."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import oracle_torch as orc
+
+pytestmark = pytest.mark.gpu
+
+# What bf16 STORAGE can deliver: every stored activation / weight is rounded to 8 mantissa bits (relative error up
+# to 2^-9, rms 2^-9/sqrt(3) = 1.1e-3) and a 4-block forward has ~27 such roundings between x and the logits (per
+# layer: layer output, [W1a-W1b | W1b], U|V, hidden activation, W2; then Wf, the pooled matrix, the classifier
+# weights/activations) -> expected rms error sqrt(27) * 1.1e-3 = 5.7e-3 of the logits' rms.  Measured
+# (tools/exp/bf16_err.py, 2000 proposals): rms 4.0e-3 (2 blocks) .. 6.4e-3 (4 blocks), max 0.65e-2 .. 1.2e-2 of
+# the scale, arg-max agreement >= 98 %.  SURVEY.md 8c's "<= 1e-2 rel" is asserted on the rms; the element-wise
+# maximum (a 4-5 sigma event over 10^4..10^6 logits) gets 2e-2.
+RTOL_BF16 = 2e-2        # max |logit error| / max |logit|
+RMS_BF16 = 1e-2         # rms error / rms logit
+
+
+def _yv():
+    import yolat_vectorgraphicsrecognition_amd as yv
+    return yv
+
+
+def _model(yv, optkw, seed):
+    return gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), seed).cuda().eval()
+
+
+def _check(name, got, want):
+    got, want = got.double().cpu(), want.double().cpu()
+    assert got.shape == want.shape and torch.isfinite(got).all(), name
+    scale = float(want.abs().max())
+    err = float((got - want).abs().max())
+    rms = float((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
+    assert err <= RTOL_BF16 * scale, "%s: max err %.3e of scale %.3e (rel %.2e)" % (name, err, scale, err / scale)
+    assert rms <= RMS_BF16, "%s: rms rel err %.2e" % (name, rms)
+    return err / scale
+
+
+def test_f32_to_bf16_is_round_to_nearest_even():
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    g = torch.Generator().manual_seed(0)
+    x = torch.cat([torch.randn(100001, generator=g) * 3.0, torch.tensor([0.0, -0.0, 1.0, -1.0, 65504.0, 1e-30, 3.3895e38]),
+                   # exact ties: mantissa bits below bf16 precision = 0x8000 with even / odd kept bit
+                   torch.tensor([0x3F808000, 0x3F818000, 0xBF808000, 0x3F80FFFF], dtype=torch.int64).to(torch.int32)
+                   .view(torch.float32)]).cuda()
+    out = torch.empty(x.numel() + (x.numel() & 1), dtype=torch.bfloat16, device="cuda")
+    check(lib.yolat_f32_to_bf16(x.data_ptr(), x.numel(), out.data_ptr(), torch.cuda.current_stream().cuda_stream),
+          "yolat_f32_to_bf16")
+    want = x.to(torch.bfloat16)
+    assert torch.equal(out[:x.numel()].view(torch.int16), want.view(torch.int16))
+
+
+@pytest.mark.parametrize("kind", ["small", "medium", "deep"])
+def test_bf16_eval_forward_vs_reference_golden(kind, golden_dir):
+    yv = _yv()
+    z = np.load(os.path.join(golden_dir, "model_%s.npz" % kind))
+    arrs, optkw = gu.graph_case(kind)
+    model = _model(yv, optkw, int(z["seed"])).set_eval_precision("bf16")
+    with torch.no_grad():
+        pred, bbox = model(gu.to_data(arrs, yv.Data), None)
+    model._yolat_plan.check_status()
+    assert model._yolat_plan.precision == "bf16"
+    ref = gu.unpack("eval_logits", z)
+    got = pred.detach().cpu().double().numpy().reshape(-1)
+    want = ref["full"].astype(np.float64) if "full" in ref else None
+    if want is None:
+        got, want = got[::int(ref["stride"])], ref["sample"].astype(np.float64)
+    scale = np.abs(want).max()
+    assert np.abs(got - want).max() <= RTOL_BF16 * scale
+    assert np.sqrt(np.mean((got - want) ** 2) / np.mean(want ** 2)) <= RMS_BF16
+    np.testing.assert_array_equal(bbox.cpu().numpy(), arrs["bbox"])
+
+
+@pytest.mark.parametrize("cin,blocks,blocks_out,classes,seed", [(5, 2, 2, 17, 1), (6, 3, 2, 22, 2), (5, 4, 2, 17, 3),
+                                                                 (3, 2, 1, 5, 4), (5, 4, 4, 17, 5)])
+def test_bf16_eval_forward_vs_cpu_oracle(cin, blocks, blocks_out, classes, seed):
+    """model shapes incl. the YOLaT++ depth (n_blocks=4, n_blocks_out=2) on a ragged graph (proposals of 2..40 nodes,
+    nodes without in-edges, duplicate edges) against the CPU oracle in fp32."""
+    yv = _yv()
+    optkw = dict(n_classes=classes, n_blocks=blocks, n_blocks_out=blocks_out, in_channels=cin)
+    d = yv.synth_graph(num_proposals=211, nodes_lo=2, nodes_hi=40, edge_factor=2.1, n_classes=classes, seed=70 + seed)
+    if cin != 5:
+        d.x = torch.randn(d.x.shape[0], cin, generator=torch.Generator().manual_seed(cin)) * 0.7
+    d.edge = torch.cat([d.edge, d.edge[:17]], 0)            # duplicate edges are defined by the PyG semantics
+    d.e_attr = torch.cat([d.e_attr, d.e_attr[:17]], 0)
+    model = _model(yv, optkw, 40 + seed).set_eval_precision("bf16")
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 40 + seed).eval()
+    with torch.no_grad():
+        got = model(d, None)[0]
+        want = ref(d, None)[0]
+    model._yolat_plan.check_status()
+    _check("logits", got, want)
+    # the same model object switches back to the fp32 plan (1e-4 bar) on request
+    model.set_eval_precision("fp32")
+    with torch.no_grad():
+        got32 = model(d, None)[0].cpu()
+    assert model._yolat_plan.precision == "fp32"
+    assert float((got32 - want).abs().max()) <= 1e-4 * float(want.abs().max())
+
+
+def test_bf16_edge_cases_no_edges_and_single_node_proposals():
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2)
+    model = _model(yv, optkw, 3).set_eval_precision("bf16")
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 3).eval()
+    d = yv.synth_graph(num_proposals=7, nodes_lo=3, nodes_hi=6, seed=11)
+    d.edge = torch.zeros((0, 2), dtype=torch.long)
+    d.e_attr = torch.zeros((0, 4))
+    with torch.no_grad():
+        _check("E=0", model(d, None)[0], ref(d, None)[0])
+    model._yolat_plan.check_status()
+    # P > 65535 one-to-three-node proposals (grid.y chunking of the pooling prologue), star edges
+    big = yv.synth_graph(num_proposals=70000, nodes_lo=1, nodes_hi=3, edge_factor=0.0, seed=12, edges_per_proposal=0)
+    N = big.x.shape[0]
+    owner = big.bbox_idx.numpy()
+    first = np.searchsorted(owner, owner)
+    src = np.arange(N)
+    has_pair = first != src
+    e = np.stack([src[has_pair], first[has_pair]], 1)
+    big.edge = torch.from_numpy(e.astype(np.int64))
+    big.e_attr = torch.from_numpy((np.random.default_rng(0).standard_normal((len(e), 4)) * 0.05).astype(np.float32))
+    with torch.no_grad():
+        got = model(big, None)[0]
+        want = ref(big, None)[0]
+    assert got.shape == (70000, 17)
+    _check("P=70000", got, want)
+    model._yolat_plan.check_status()
+
+
+def test_bf16_full_size_cfg2_vs_oracle_and_determinism():
+    yv = _yv()
+    data, slices, optkw, _ = yv.config("2")
+    model = _model(yv, optkw, 7).set_eval_precision("bf16")
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 7).eval()
+    with torch.no_grad():
+        got = model(data, slices)[0].clone()
+        again = model(data, slices)[0]
+        want = ref(data, slices)[0]
+    assert torch.equal(got, again)                      # integer-atomic max + fixed summation orders
+    _check("cfg2", got, want)
+
+
+def test_bf16_full_size_cfg5_vs_fp32_path_and_size_independent_properties():
+    """configs[4] (N=200k / E=1.2M / P=8000, n_blocks=4) — too big for the CPU oracle: the bf16 forward is compared
+    with the fp32 HIP forward (itself pinned to 1e-4 by the other tests) and must be deterministic and
+    block-diagonal (the forward of the two proposal halves stacked equals the forward of the whole graph)."""
+    yv = _yv()
+    data, slices, optkw, _ = yv.config("5")
+    model = _model(yv, optkw, 9)
+    with torch.no_grad():
+        want = model(data, slices)[0].clone()
+        model.set_eval_precision("bf16")
+        got = model(data, slices)[0].clone()
+        again = model(data, slices)[0]
+    model._yolat_plan.check_status()
+    assert torch.equal(got, again)
+    _check("cfg5 bf16 vs fp32", got, want)
+    N, P = data.x.shape[0], data.bbox.shape[0]
+    bb = data.bbox_idx.numpy()
+    node_ptr = np.searchsorted(bb, np.arange(P + 1))
+    owner_e = bb[data.edge[:, 0].numpy()]
+
+    def sub(p_lo, p_hi):
+        n_lo, n_hi = node_ptr[p_lo], node_ptr[p_hi]
+        em = (owner_e >= p_lo) & (owner_e < p_hi)
+        d = yv.Data(x=data.x[n_lo:n_hi], pos=data.pos[n_lo:n_hi])
+        d.edge = data.edge[em] - int(n_lo)
+        d.e_attr = data.e_attr[em]
+        d.bbox_idx = data.bbox_idx[n_lo:n_hi] - p_lo
+        d.bbox = data.bbox[p_lo:p_hi]
+        d.stat_feats = data.stat_feats[p_lo:p_hi]
+        return d
+
+    with torch.no_grad():
+        a = model(sub(0, P // 2), None)[0]
+        b = model(sub(P // 2, P), None)[0]
+    # every row's arithmetic is identical in the split run (per-row GEMMs, per-node sums in CSR order)
+    assert torch.equal(torch.cat([a, b], 0), got)
+
+
+def test_bf16_unsupported_shapes_fail_loudly():
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import YolatLibraryError
+    optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2, n_filters=32)
+    model = yv.SparseCADGCN(yv.Opt(**optkw)).cuda().eval().set_eval_precision("bf16")
+    d = yv.synth_graph(num_proposals=5, nodes_lo=3, nodes_hi=6, seed=1)
+    with pytest.raises((YolatLibraryError, ValueError)), torch.no_grad():
+        model(d, None)
+    with pytest.raises(ValueError):
+        model.set_eval_precision("fp16")

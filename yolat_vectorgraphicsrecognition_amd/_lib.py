@@ -35,6 +35,13 @@ class ModelEval(ctypes.Structure):
                                     "Wc2", "bc2", "sc2", "tc2", "Wc3", "bc3")])
 
 
+class ModelEvalBf16(ctypes.Structure):
+    """yolat_model_eval_bf16 (include/yolat_hip.h)"""
+    _fields_ = ([("base", ctypes.POINTER(ModelEval))] +
+                [(n, c_p * YOLAT_MAX_LAYERS) for n in ("Wuv", "Wr", "Wn", "W2")] +
+                [(n, c_p) for n in ("Wf", "Wfs", "Wc1", "Wc2", "Wc3")])
+
+
 # name -> (restype, argtypes); order mirrors include/yolat_hip.h
 SIGNATURES = {
     "yolat_abi_version": (c_int, []),
@@ -122,6 +129,10 @@ SIGNATURES = {
     "yolat_forward_eval_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEval), c_i64, c_i64, c_i64]),
     "yolat_forward_eval": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64,
                                    c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_f32_to_bf16": (c_int, [c_p, c_i64, c_p, c_p]),
+    "yolat_forward_eval_bf16_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEvalBf16), c_i64, c_i64, c_i64]),
+    "yolat_forward_eval_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
+                                        c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
 }
 
 

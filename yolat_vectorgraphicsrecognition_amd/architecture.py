@@ -153,7 +153,7 @@ class SparseCADGCN(nn.Module):
             plan = plans.get(sid)
             if plan is None:
                 from .plan import EvalPlan
-                plan = plans[sid] = EvalPlan(self)
+                plan = plans[sid] = EvalPlan(self, self.__dict__.get("_yolat_precision", "fp32"))
             ug = self.__dict__.get("_yolat_use_graph")
             if ug is not None:
                 plan.use_graph = ug
@@ -209,6 +209,17 @@ class SparseCADGCN(nn.Module):
         cy = (pred_bbox[:, 3] + pred_bbox[:, 1]) / 2
         pred_bbox = torch.stack([cx - w / 2, cy - h / 2, cx + w / 2, cy + h / 2], dim=1)
         return pred_cls, pred_bbox, None, slice_bbox, slice_image_bbox, None
+
+    def set_eval_precision(self, precision="fp32"):
+        """Storage precision of the eval fast path: "fp32" (default, 1e-4 parity with the reference) or "bf16"
+        (bf16 node activations / weights, fp32 accumulation — csrc/bf16_eval.hip; ~1e-2 of the logits' scale).
+        Training always runs in fp32."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        if self.__dict__.get("_yolat_precision", "fp32") != precision:
+            self.__dict__["_yolat_precision"] = precision
+            self.__dict__.pop("_yolat_plans", None)
+        return self
 
     def use_hip_graphs(self, on=True):
         """Eval forwards replay a captured hipGraph when they are called again with the same input buffers

@@ -1,0 +1,550 @@
+// bf16_eval.hip — SparseCADGCN.forward (eval) with bfloat16 STORAGE and fp32 accumulation: the precision mode
+// BASELINE.json's large-graph configuration names (N = 200k / E = 1.2M / n_blocks = 4, "bf16").
+//
+// Same kernel sequence as forward_eval.hip (cad_recognition/architecture3cc_rpn_gp_iter2.py:44-71,106-137;
+// gcn_lib/sparse/torch_vertex.py:319-337), with
+//   * every [N,*] activation that crosses HBM stored as bf16: the per-node U|V products the edge kernel
+//     gathers (256 -> 128 B per row), the layer outputs / concat slots, the node branch;
+//   * every Linear with K >= 64 on v_mfma_f32_32x32x16_bf16 (16x the fp32 MFMA rate), weights converted to
+//     bf16 once per weight version, accumulators / bias / folded BatchNorm / ReLU / mean / max in fp32;
+//   * the first layer's K = Cin0 = 5 products, the e_attr term (W1c.attr), the per-proposal pooled matrix Z
+//     and the classifier activations stay fp32 (small or precision-critical).
+// Rounding to bf16 is round-to-nearest-even (v_cvt_pk_bf16_f32).  Parity target: <= 1e-2 of the logits'
+// scale against the fp32 oracle (SURVEY.md §8c "bf16 variant"); the fp32 path keeps the 1e-4 bar.
+#include "common.hpp"
+
+typedef unsigned short u16;
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------
+// fp32 -> bf16 (weights, once per weight version)
+// ------------------------------------------------------------------------------------------------
+static __global__ void k_f32_to_bf16(const float* __restrict__ src, long n, u16* __restrict__ dst) {
+  const long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 2;
+  if (i + 1 < n) *reinterpret_cast<unsigned*>(dst + i) = yl_pack_bf16(src[i], src[i + 1]);
+  else if (i < n) dst[i] = (u16)(yl_pack_bf16(src[i], 0.f) & 0xFFFFu);
+}
+
+extern "C" int yolat_f32_to_bf16(const float* src, int64_t n, uint16_t* dst, yolat_stream_t stream) {
+  if (n < 0 || (n > 0 && (!src || !dst))) return YOLAT_E_INVALID;
+  if (n == 0) return 0;
+  if ((((uintptr_t)dst) & 3) != 0) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_f32_to_bf16, dim3(yl_cdiv((n + 1) / 2, 256)), dim3(256), 0, (hipStream_t)stream, src, (long)n, dst);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// NT GEMM on bf16 MFMAs:  Y[M,N] = epi( A[M,K] . B[N,K]^T ),  K % 64 == 0.
+// 256 threads = 2x2 waves, wave tile (32 TM) x (32 TN); K step 64 bf16 = 128 B per row.  LDS rows are padded
+// to 144 B so that both the 16-byte staging writes (8 lanes = one row) and the 16-byte fragment reads
+// (8 consecutive rows at one k offset) hit 8 distinct 16-byte bank groups.
+//   MFMA operand layout: A/B lane l holds the 8 consecutive k = 16 ks + 8 (l>>5) .. +7 of row / column l&31;
+//   C/D layout as for the fp32 MFMA, so wave_epilogue (common.hpp) is shared with the fp32 kernels.
+// A operand: bf16 rows (HOp) or fp32 rows converted while staging (FOp); B operand: bf16 weight rows.
+// Rows beyond M / N are clamped (their outputs are masked by the epilogue).
+// ------------------------------------------------------------------------------------------------
+struct HOp {
+  const u16* p; long ld; int rows;
+  static constexpr int NR = 1;
+  __device__ __forceinline__ void load(int r, int k, u32x4* raw) const {
+    raw[0] = *reinterpret_cast<const u32x4*>(p + (long)yl_min(r, rows - 1) * ld + k);
+  }
+  static __device__ __forceinline__ u32x4 pack(const u32x4* raw) { return raw[0]; }
+};
+struct FOp {
+  const float* p; long ld; int rows;
+  static constexpr int NR = 2;
+  __device__ __forceinline__ void load(int r, int k, u32x4* raw) const {
+    const float* q = p + (long)yl_min(r, rows - 1) * ld + k;
+    raw[0] = *reinterpret_cast<const u32x4*>(q);
+    raw[1] = *reinterpret_cast<const u32x4*>(q + 4);
+  }
+  static __device__ __forceinline__ u32x4 pack(const u32x4* raw) {
+    u32x4 o;
+    o.x = yl_pack_bf16(__uint_as_float(raw[0].x), __uint_as_float(raw[0].y));
+    o.y = yl_pack_bf16(__uint_as_float(raw[0].z), __uint_as_float(raw[0].w));
+    o.z = yl_pack_bf16(__uint_as_float(raw[1].x), __uint_as_float(raw[1].y));
+    o.w = yl_pack_bf16(__uint_as_float(raw[1].z), __uint_as_float(raw[1].w));
+    return o;
+  }
+};
+
+constexpr int YL_HRS = 72;   // LDS row stride in bf16 elements (144 B)
+template <int TM, int TN> struct HTileSmem { static constexpr int elems = 64 * (TM + TN) * YL_HRS; };
+
+template <int TM, int TN, class AL>
+__device__ __forceinline__ void hgemm_tile(const AL& A, const HOp& B, const Epilogue& ep, int M, int N, int K, int rt_,
+                                           int ct_, u16* smem) {
+  constexpr int BM = 64 * TM, BN = 64 * TN, NA = 2 * TM, NB = 2 * TN;   // 16-byte slots per thread per K step
+  u16* As = smem;
+  u16* Bs = smem + BM * YL_HRS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = rt_ * BM, col0 = ct_ * BN;
+  const int sr = tid >> 3, sc = (tid & 7) * 8;          // staging role: row sr (+32 per slot), k chunk sc
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  u32x4 ra[NA * AL::NR], rb[NB];
+#pragma unroll
+  for (int t = 0; t < NA; ++t) A.load(row0 + sr + 32 * t, sc, ra + t * AL::NR);
+#pragma unroll
+  for (int t = 0; t < NB; ++t) B.load(col0 + sr + 32 * t, sc, rb + t);
+
+  EpiPre pre[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+      pre[i][j] = epi_prefetch(ep, row0 + (wm * TM + i) * 32, col0 + (wn * TN + j) * 32 + l31, M, N);
+
+  for (int k0 = 0; k0 < K; k0 += 64) {
+#pragma unroll
+    for (int t = 0; t < NA; ++t)
+      *reinterpret_cast<u32x4*>(As + (sr + 32 * t) * YL_HRS + sc) = AL::pack(ra + t * AL::NR);
+#pragma unroll
+    for (int t = 0; t < NB; ++t) *reinterpret_cast<u32x4*>(Bs + (sr + 32 * t) * YL_HRS + sc) = rb[t];
+    __syncthreads();
+    if (k0 + 64 < K) {                      // next K step in flight while the MFMAs below run
+#pragma unroll
+      for (int t = 0; t < NA; ++t) A.load(row0 + sr + 32 * t, k0 + 64 + sc, ra + t * AL::NR);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) B.load(col0 + sr + 32 * t, k0 + 64 + sc, rb + t);
+    }
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      bf16x8 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        a[i] = *reinterpret_cast<const bf16x8*>(As + ((wm * TM + i) * 32 + l31) * YL_HRS + ks * 16 + lhi * 8);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        b[j] = *reinterpret_cast<const bf16x8*>(Bs + ((wn * TN + j) * 32 + l31) * YL_HRS + ks * 16 + lhi * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
+    }
+    __syncthreads();
+  }
+  static_assert(TM <= 2 && TN <= 2, "epilogue expansion covers up to 2x2 sub-tiles");
+#define YL_EPI(i, j)                                                                                                 \
+  if constexpr ((i) < TM && (j) < TN)                                                                                \
+    wave_epilogue(acc[i][j], row0 + (wm * TM + (i)) * 32, col0 + (wn * TN + (j)) * 32 + l31, lhi, ep, M, N, pre[i][j]);
+  YL_EPI(0, 0) YL_EPI(0, 1) YL_EPI(1, 0) YL_EPI(1, 1)
+#undef YL_EPI
+}
+
+template <int TM, int TN, class AL>
+static __global__ void __launch_bounds__(256) k_hgemm(AL A, HOp B, Epilogue ep, int M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<TM, TN>::elems];
+  int rt_, ct_;
+  yl_xcd_tile(rt_, ct_);
+  hgemm_tile<TM, TN, AL>(A, B, ep, M, N, K, rt_, ct_, smem);
+}
+
+// fusion block over the nodes (+ per-proposal max epilogue) and fusion_block_super over the per-proposal
+// means in one flattened launch, like k_gemm_nt_two: the small problem's 64x64 tiles come first (padded to a
+// multiple of 8 so that the big problem keeps its id % 8 = XCD alignment), then the big problem's tiles.
+template <int T0>
+static __global__ void __launch_bounds__(256) k_hgemm_two(HOp A0, HOp B0, Epilogue e0, int M0, int N0, int K0, int tm0,
+                                                          int tn0, FOp A1, HOp B1, Epilogue e1, int M1, int N1, int K1,
+                                                          int tm1, int tn1) {
+  __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<T0, T0>::elems];
+  const int n1 = tm1 * tn1, n1p = (n1 + 7) & ~7;
+  const int id = blockIdx.x;
+  if (id < n1p) {
+    if (id < n1) hgemm_tile<1, 1, FOp>(A1, B1, e1, M1, N1, K1, id / tn1, id % tn1, smem);
+    return;
+  }
+  const int n0 = tm0 * tn0, j = id - n1p;
+  const int chunk = n0 >> 3, rem = n0 & 7;
+  const int xcd = j & 7, slot = j >> 3;
+  const int logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
+  hgemm_tile<T0, T0, HOp>(A0, B0, e0, M0, N0, K0, logical / tn0, logical % tn0, smem);
+}
+
+// node side of a factorised conv layer with Cin = 64 (bf16 in / bf16 weights):
+//   y = 0,1 -> the two 64-column halves of UV = f_in.[W1a-W1b | W1b]^T   (stored bf16)
+//   y = 2   -> root Linear lin_r(f_in) + br                               (stored fp32: the edge kernel adds the mean)
+//   y = 3   -> node branch relu(bn(mlp_node(s_in)))                       (stored bf16)
+struct NodeUvH {
+  HOp af, as, wuv, wr, wn;
+  Epilogue euv, er, en;
+  int N, C, Cin;
+};
+static __global__ void __launch_bounds__(256) k_hgemm_node3(NodeUvH a) {
+  __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<1, 1>::elems];
+  const int x = blockIdx.x, y = blockIdx.y;
+  if (y < 2) hgemm_tile<1, 1, HOp>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y, smem);
+  else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
+  else hgemm_tile<1, 1, HOp>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0, smem);
+}
+
+static Epilogue plain_epilogue() {
+  Epilogue e;
+  e.bias = nullptr; e.scale = nullptr; e.shift = nullptr; e.relu = 0;
+  e.Y = nullptr; e.ldy = 0; e.accumulate = 0; e.stats = nullptr; e.seg = nullptr; e.pool = nullptr; e.ldpool = 0;
+  return e;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Factorised edge MLP + mean aggregation, bf16 storage (see k_edge_uv_mlp2_mean, edge.hip, for the scheme).
+// One workgroup = npt (<= 16) consecutive destination nodes = a contiguous CSR edge range, in passes of 64
+// edges.  Per pass: gather U[dst] + V[src] (bf16, 128 B per row) + W1c.attr -> BN+ReLU (fp32) -> bf16 tile in
+// LDS -> second Linear on bf16 MFMAs (this wave's W2 fragments live in registers for the whole kernel) ->
+// BN+ReLU -> fp32 tile in LDS -> per-node running sums in CSR order.  Output: f_out = bf16(root + sum/deg)
+// for EVERY node of the tile (nodes without in-edges get the root Linear alone, torch_vertex.py:324,337).
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean_h(
+    const u16* __restrict__ UV, long ld_uv, const int* __restrict__ src, const int* __restrict__ dst,
+    const float* __restrict__ attr, const int* __restrict__ row_ptr, int N, int npt, const float* __restrict__ Wc4,
+    const float* __restrict__ b1, const float* __restrict__ s1, const float* __restrict__ t1,
+    const u16* __restrict__ W2h, const float* __restrict__ b2, const float* __restrict__ s2,
+    const float* __restrict__ t2, const float* __restrict__ root, long ld_r, u16* __restrict__ f_out, long ld_fo,
+    int E) {
+  constexpr int LDM = 65;
+  __shared__ __attribute__((aligned(16))) u16 Hs[64 * YL_HRS];   // layer-1 activations of the pass (bf16)
+  __shared__ float Ms[64 * LDM];                                // layer-2 messages of the pass (fp32)
+  __shared__ int rp[17];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int n0 = blockIdx.x * npt;
+  const int nn = yl_min(npt, N - n0);
+  if (tid <= 16) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
+  const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t
+  const int col = wn * 32 + l31;                      // MFMA role: output column of this lane
+  bf16x8 w2f[4];
+#pragma unroll
+  for (int ks = 0; ks < 4; ++ks)
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(W2h + (long)col * 64 + ks * 16 + lhi * 8);
+  float4 wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
+  const float4 bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
+  const float bias2 = b2 ? b2[col] : 0.f, sc2 = s2 ? s2[col] : 1.f, sh2 = s2 ? t2[col] : 0.f;
+  __syncthreads();
+  const int e0 = rp[0], e1 = rp[nn];
+  const int my_b = rp[yl_min(rb, nn)], my_e = rp[yl_min(rb + 1, nn)];   // aggregation role: node rb, columns 4q..
+  float4 rootv = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (rb < nn) rootv = *reinterpret_cast<const float4*>(root + (long)(n0 + rb) * ld_r + 4 * q);
+  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int c0 = e0; c0 < e1; c0 += 64) {
+    int di[4], si[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = yl_min(c0 + rb + 16 * t, E - 1);
+      di[t] = dst[e]; si[t] = src[e];
+    }
+    u32x2 u[4], v[4];
+    float4 a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = yl_min(c0 + rb + 16 * t, E - 1);
+      u[t] = *reinterpret_cast<const u32x2*>(UV + (long)di[t] * ld_uv + 4 * q);
+      v[t] = *reinterpret_cast<const u32x2*>(UV + (long)si[t] * ld_uv + 64 + 4 * q);
+      a[t] = *reinterpret_cast<const float4*>(attr + (long)e * 4);
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      auto one = [&](float uu, float vv, const float4& w, float b, float s, float h) {
+        float z = uu + vv;
+        z = fmaf(a[t].x, w.x, z); z = fmaf(a[t].y, w.y, z); z = fmaf(a[t].z, w.z, z); z = fmaf(a[t].w, w.w, z);
+        return fmaxf(fmaf(z + b, s, h), 0.f);
+      };
+      const float h0 = one(yl_bf16_lo(u[t].x), yl_bf16_lo(v[t].x), wc[0], bb.x, sc.x, sh.x);
+      const float h1 = one(yl_bf16_hi(u[t].x), yl_bf16_hi(v[t].x), wc[1], bb.y, sc.y, sh.y);
+      const float h2 = one(yl_bf16_lo(u[t].y), yl_bf16_lo(v[t].y), wc[2], bb.z, sc.z, sh.z);
+      const float h3 = one(yl_bf16_hi(u[t].y), yl_bf16_hi(v[t].y), wc[3], bb.w, sc.w, sh.w);
+      u32x2 hp; hp.x = yl_pack_bf16(h0, h1); hp.y = yl_pack_bf16(h2, h3);
+      *reinterpret_cast<u32x2*>(Hs + (rb + 16 * t) * YL_HRS + 4 * q) = hp;
+    }
+    __syncthreads();                      // Hs complete; also: every thread is past the previous pass's Ms reads
+    f32x16 acc2;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 av = *reinterpret_cast<const bf16x8*>(Hs + (wm * 32 + l31) * YL_HRS + ks * 16 + lhi * 8);
+      acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, w2f[ks], acc2, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      Ms[row * LDM + col] = fmaxf(fmaf(acc2[r] + bias2, sc2, sh2), 0.f);
+    }
+    __syncthreads();                      // Ms complete; every wave is done reading Hs
+    if (rb < nn) {                        // rows of node rb inside this pass, ascending edge order
+      const int lo = my_b > c0 ? my_b : c0;
+      const int hi = my_e < c0 + 64 ? my_e : c0 + 64;
+      for (int e = lo; e < hi; ++e) {
+        const float* m = Ms + (e - c0) * LDM + 4 * q;
+        sum.x += m[0]; sum.y += m[1]; sum.z += m[2]; sum.w += m[3];
+      }
+    }
+  }
+  if (rb < nn) {
+    const int deg = my_e - my_b;
+    const float inv = 1.f / (float)(deg > 1 ? deg : 1);
+    u32x2 o;
+    o.x = yl_pack_bf16(fmaf(sum.x, inv, rootv.x), fmaf(sum.y, inv, rootv.y));
+    o.y = yl_pack_bf16(fmaf(sum.z, inv, rootv.z), fmaf(sum.w, inv, rootv.w));
+    *reinterpret_cast<u32x2*>(f_out + (long)(n0 + rb) * ld_fo + 4 * q) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Pooling prologue on bf16 node features (k_pool_prepare of segment.hip): for proposal p
+//   Z[p, 0:F] = 0;  Z[p, F:F+D] = max over rows of feats;  Z[p, 2F+D:2F+2D] = mean over rows of fsup   (fp32)
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) k_pool_prepare_h(const u16* feats, const u16* fsup, long ld, int D, int F,
+                                                               const int* seg_ptr, float* Z, long ldz) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int p = blockIdx.y;
+  float* z = Z + (long)p * ldz;
+  if (c < F) { z[c] = 0.f; return; }
+  if (c >= F + 2 * D) return;
+  const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
+  const bool is_max = c < F + D;
+  const int k = is_max ? c - F : c - F - D;
+  const u16* srcp = (is_max ? feats : fsup) + k;
+  float best = 0.f, s = 0.f;
+  bool any = false;
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = __uint_as_float((unsigned)srcp[(long)(r + j) * ld] << 16);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (!any || v[j] > best) { best = v[j]; any = true; }
+      s += v[j];
+    }
+  }
+  for (; r < r1; ++r) {
+    const float v = __uint_as_float((unsigned)srcp[(long)r * ld] << 16);
+    if (!any || v > best) { best = v; any = true; }
+    s += v;
+  }
+  if (is_max) {
+    z[F + k] = best;
+  } else {
+    const int cnt = r1 - r0;
+    z[2 * F + D + k] = s / (float)(cnt > 1 ? cnt : 1);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+// ------------------------------------------------------------------------------------------------
+namespace {
+struct Carver {
+  char* base; size_t off;
+  template <class T> T* take(size_t n) {
+    off = (off + 255) & ~(size_t)255;
+    T* p = reinterpret_cast<T*>(base + off);
+    off += n * sizeof(T);
+    return p;
+  }
+};
+struct PlanH {
+  int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
+  u16* UV; float* root; u16* f_tmp[YOLAT_MAX_LAYERS]; u16* s_tmp[YOLAT_MAX_LAYERS];
+  u16* feats; u16* fsup; float* Z; float* c1; float* c2;
+  size_t bytes;
+};
+PlanH carve_h(const yolat_model_eval* m, long N, long E, long P, void* ws) {
+  Carver c; c.base = reinterpret_cast<char*>(ws); c.off = 0;
+  PlanH p;
+  const long C = m->C, F = m->F, D = C * m->n_blocks_out, Ee = E > 0 ? E : 1;
+  p.row_ptr = c.take<int>(N + 1); p.perm = c.take<int>(Ee); p.src = c.take<int>(Ee); p.dst = c.take<int>(Ee);
+  p.attr = c.take<float>(Ee * 4); p.work = c.take<int>(yolat_graph_work_elems(N, E));
+  p.seg_ptr = c.take<int>(P + 1); p.node_seg = c.take<int>(N);
+  p.UV = c.take<u16>(N * 2 * C); p.root = c.take<float>(N * C);
+  const int lo = m->n_blocks - m->n_blocks_out;
+  for (int l = 0; l < m->n_blocks; ++l) {
+    p.f_tmp[l] = (l < lo) ? c.take<u16>(N * C) : nullptr;
+    p.s_tmp[l] = (l < lo) ? c.take<u16>(N * C) : nullptr;
+  }
+  p.feats = c.take<u16>(N * D); p.fsup = c.take<u16>(N * D);
+  p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
+  p.bytes = c.off + 256;
+  return p;
+}
+
+int model_ok(const yolat_model_eval_bf16* mh) {
+  if (!mh || !mh->base) return YOLAT_E_INVALID;
+  const yolat_model_eval* m = mh->base;
+  if (m->n_blocks < 1 || m->n_blocks > YOLAT_MAX_LAYERS || m->n_blocks_out < 1 || m->n_blocks_out > m->n_blocks)
+    return YOLAT_E_INVALID;
+  const long D = m->C * m->n_blocks_out;
+  // shapes the bf16 kernels are written for (the reference's: n_filters 64, fusion 1024, classifier 512/256)
+  if (m->C != 64 || m->F % 64 != 0 || D % 64 != 0 || (2 * (m->F + D)) % 64 != 0 || m->H1 % 64 != 0 || m->H2 % 64 != 0)
+    return YOLAT_E_UNSUPPORTED;
+  for (int l = 0; l < m->n_blocks; ++l) {
+    const yolat_conv_eval& cv = m->conv[l];
+    if (!cv.Wuv || !cv.Wc4 || !mh->W2[l]) return YOLAT_E_INVALID;
+    if (l == 0 ? (cv.Cin > 16) : (cv.Cin != 64)) return YOLAT_E_UNSUPPORTED;
+    if (l > 0 && (!mh->Wuv[l] || !mh->Wr[l] || !mh->Wn[l])) return YOLAT_E_INVALID;
+  }
+  if (!mh->Wf || !mh->Wfs || !mh->Wc1 || !mh->Wc2 || !mh->Wc3) return YOLAT_E_INVALID;
+  return 0;
+}
+
+template <class AL>
+int launch_hgemm(const AL& A, const HOp& B, const Epilogue& ep, long M, long N, long K, hipStream_t st) {
+  if (K % 64 != 0 || M <= 0 || N <= 0) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL((k_hgemm<1, 1, AL>), dim3(yl_cdiv(M, 64), yl_cdiv(N, 64)), dim3(256), 0, st, A, B, ep, (int)M, (int)N,
+                     (int)K);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+}  // namespace
+
+#define YL_TRY(call)            \
+  do {                          \
+    int rc__ = (call);          \
+    if (rc__ != 0) return rc__; \
+  } while (0)
+// one profiled stage: `body` is a statement block that may `return` an error code
+#define YL_HSTAGE(name, flops, bytes, ...)                                    \
+  do {                                                                        \
+    const bool prof__ = yl_profile_on();                                      \
+    if (prof__) yl_stage_begin(name, (double)(flops), (double)(bytes), stream); \
+    __VA_ARGS__                                                               \
+    if (prof__) yl_stage_end(stream);                                         \
+  } while (0)
+
+extern "C" size_t yolat_forward_eval_bf16_workspace_bytes(const yolat_model_eval_bf16* mh, int64_t N, int64_t E,
+                                                          int64_t P) {
+  if (!mh || !mh->base || N <= 0 || E < 0 || P <= 0) return 0;
+  return carve_h(mh->base, N, E, P, nullptr).bytes;
+}
+
+extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
+                                       const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                                       const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, float* logits,
+                                       int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
+                                       yolat_stream_t stream) {
+  if (!x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0) return YOLAT_E_INVALID;
+  YL_TRY(model_ok(mh));
+  if (N >= (1LL << 31) - 8192 || E >= (1LL << 31) - 256) return YOLAT_E_INVALID;
+  const yolat_model_eval* m = mh->base;
+  PlanH p = carve_h(m, N, E, P, workspace);
+  if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
+  const int lo = m->n_blocks - m->n_blocks_out;
+  auto f_slot = [&](int l) { return l - lo >= 0 ? p.feats + (l - lo) * C : p.f_tmp[l]; };
+  auto s_slot = [&](int l) { return l - lo >= 0 ? p.fsup + (l - lo) * C : p.s_tmp[l]; };
+  auto ld_slot = [&](int l) { return l - lo >= 0 ? D : C; };
+
+  // ---- graph structure + node side of layer 0 (fp32 MFMA on the raw K = Cin0 features, bf16 / fp32 outputs)
+  char nm[112];
+  YL_HSTAGE("graph_prep[csr+attr+segments] + node_uv[layer 0, bf16 out]", 8.0 * N * m->conv[0].Cin * C,
+            16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N + 4.0 * N * m->conv[0].Cin + 2.0 * N * 3 * C + 4.0 * N * C, {
+    const yolat_conv_eval& cv0 = m->conv[0];
+    NodeUv a;
+    // the fp32 destinations are placeholders for the builder's checks; UV and the node branch go to bf16
+    YL_TRY(yl_build_node_uv(&a, x, ldx, x, ldx, N, cv0.Cin, cv0.Wuv, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C,
+                            p.root, 2 * C, p.root, C, p.root, C));
+    a.euv.Y = nullptr; a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
+    a.en.Y = nullptr; a.en.Yh = s_slot(0); a.en.ldy = ld_slot(0);
+    YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
+                                 p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, stream));
+  });
+  long npt = E > 0 ? (56 * N) / E : 16;
+  {
+    const long npt2 = E > 0 ? ((112 * N) / E < 16 ? (112 * N) / E : 16) : 16;
+    if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
+    if (npt < 1) npt = 1;
+    if (npt > 16) npt = 16;
+  }
+  for (int l = 0; l < m->n_blocks; ++l) {
+    const yolat_conv_eval& cv = m->conv[l];
+    if (l > 0) {
+      snprintf(nm, sizeof nm, "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> %ld+%ld+%ld]", 2 * C, C, C);
+      YL_HSTAGE(nm, 8.0 * N * 64 * C, 2.0 * (2.0 * N * 64 + 3.0 * N * C) + 4.0 * N * C, {
+      NodeUvH a;
+      a.af = HOp{f_slot(l - 1), ld_slot(l - 1), (int)N};
+      a.as = HOp{s_slot(l - 1), ld_slot(l - 1), (int)N};
+      a.wuv = HOp{mh->Wuv[l], 64, (int)(2 * C)}; a.wr = HOp{mh->Wr[l], 64, (int)C}; a.wn = HOp{mh->Wn[l], 64, (int)C};
+      a.euv = plain_epilogue(); a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
+      a.er = plain_epilogue(); a.er.bias = cv.br; a.er.Y = p.root; a.er.ldy = C;
+      a.en = plain_epilogue(); a.en.bias = cv.bn; a.en.scale = cv.sn; a.en.shift = cv.tn; a.en.relu = 1;
+      a.en.Yh = s_slot(l); a.en.ldy = ld_slot(l);
+      a.N = (int)N; a.C = (int)C; a.Cin = 64;
+      hipLaunchKernelGGL(k_hgemm_node3, dim3(yl_cdiv(N, 64), 4), dim3(256), 0, st, a);
+      YL_LAUNCH_CHECK();
+      });
+    }
+    snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
+    YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 2.0 + 16.0 + 8.0) + 4.0 * N * C + 2.0 * N * C + 4.0 * N, {
+    hipLaunchKernelGGL(k_edge_uv_mlp2_mean_h, dim3(yl_cdiv(N, npt)), dim3(256), 0, st, p.UV, 2 * C, p.src, p.dst, p.attr,
+                       p.row_ptr, (int)N, (int)npt, cv.Wc4, cv.b1, cv.s1, cv.t1, mh->W2[l], cv.b2, cv.s2, cv.t2, p.root,
+                       C, f_slot(l), ld_slot(l), (int)(E > 0 ? E : 1));
+    YL_LAUNCH_CHECK();
+    });
+  }
+
+  // ---- pooling prologue, fusion block (+ per-proposal max) | fusion_block_super, classifier
+  YL_HSTAGE("pool_prepare_bf16[max(feats), mean(fsup), zero]", 2.0 * N * D, 4.0 * N * D + 4.0 * P * (F + 2 * D), {
+  for (int64_t p0 = 0; p0 < P; p0 += 65535) {
+    const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
+    hipLaunchKernelGGL(k_pool_prepare_h, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)np), dim3(256), 0, st, p.feats, p.fsup, D,
+                       (int)D, (int)F, p.seg_ptr + p0, p.Z + p0 * ZW, ZW);
+    YL_LAUNCH_CHECK();
+  }
+  });
+  snprintf(nm, sizeof nm, "fusion_gemm_bf16+segmax[N x %ld -> %ld -> P] | super[P x %ld -> %ld]", D, F, D, F);
+  YL_HSTAGE(nm, 2.0 * (N + P) * D * F, 2.0 * (N * D + 2.0 * D * F) + 4.0 * (2.0 * P * F + N + P * D), {
+    HOp a0{p.feats, D, (int)N}, b0{mh->Wf, D, (int)F}, b1{mh->Wfs, D, (int)F};
+    FOp a1{p.Z + 2 * F + D, ZW, (int)P};
+    Epilogue e0 = plain_epilogue(), e1 = plain_epilogue();
+    e0.bias = m->bf; e0.scale = m->sf; e0.shift = m->tf; e0.relu = 1; e0.seg = p.node_seg; e0.pool = p.Z; e0.ldpool = ZW;
+    e1.bias = m->bfs; e1.scale = m->sfs; e1.shift = m->tfs; e1.relu = 1; e1.Y = p.Z + F + D; e1.ldy = ZW;
+    const int tm1 = yl_cdiv(P, 64), tn1 = yl_cdiv(F, 64);
+    const bool big = N >= 65536;                       // 128x128 tiles once there are enough of them to fill the GPU
+    const int tm0 = yl_cdiv(N, big ? 128 : 64), tn0 = yl_cdiv(F, big ? 128 : 64);
+    const long total = (long)tm0 * tn0 + (((long)tm1 * tn1 + 7) & ~7L);
+    if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+    if (big)
+      hipLaunchKernelGGL(k_hgemm_two<2>, dim3((unsigned)total), dim3(256), 0, st, a0, b0, e0, (int)N, (int)F, (int)D, tm0,
+                         tn0, a1, b1, e1, (int)P, (int)F, (int)D, tm1, tn1);
+    else
+      hipLaunchKernelGGL(k_hgemm_two<1>, dim3((unsigned)total), dim3(256), 0, st, a0, b0, e0, (int)N, (int)F, (int)D, tm0,
+                         tn0, a1, b1, e1, (int)P, (int)F, (int)D, tm1, tn1);
+    YL_LAUNCH_CHECK();
+  });
+  {
+    Epilogue e = plain_epilogue();
+    e.bias = m->bc1; e.scale = m->sc1; e.shift = m->tc1; e.relu = 1; e.Y = p.c1; e.ldy = m->H1;
+    snprintf(nm, sizeof nm, "cls1_bf16[P x %ld -> %ld]", ZW, (long)m->H1);
+    YL_HSTAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + P * m->H1) + 2.0 * ZW * m->H1,
+              { YL_TRY(launch_hgemm(FOp{p.Z, ZW, (int)P}, HOp{mh->Wc1, ZW, (int)m->H1}, e, P, m->H1, ZW, st)); });
+    e.bias = m->bc2; e.scale = m->sc2; e.shift = m->tc2; e.Y = p.c2; e.ldy = m->H2;
+    snprintf(nm, sizeof nm, "cls2_bf16[P x %ld -> %ld]", (long)m->H1, (long)m->H2);
+    YL_HSTAGE(nm, 2.0 * P * m->H1 * m->H2, 4.0 * (P * m->H1 + P * m->H2) + 2.0 * m->H1 * m->H2,
+              { YL_TRY(launch_hgemm(FOp{p.c1, m->H1, (int)P}, HOp{mh->Wc2, m->H1, (int)m->H2}, e, P, m->H2, m->H1, st)); });
+    e = plain_epilogue();
+    e.bias = m->bc3; e.Y = logits; e.ldy = ld_logits;
+    snprintf(nm, sizeof nm, "cls3_bf16[P x %ld -> %d]", (long)m->H2, (int)m->n_classes);
+    YL_HSTAGE(nm, 2.0 * P * m->H2 * m->n_classes, 4.0 * (P * m->H2 + P * m->n_classes) + 2.0 * m->H2 * m->n_classes, {
+      YL_TRY(launch_hgemm(FOp{p.c2, m->H2, (int)P}, HOp{mh->Wc3, m->H2, (int)m->n_classes}, e, P, m->n_classes, m->H2, st));
+    });
+  }
+  return 0;
+}

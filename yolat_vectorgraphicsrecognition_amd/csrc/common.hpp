@@ -38,6 +38,17 @@ __device__ __forceinline__ float yl_mul_rn(float a, float b) {
   return p;
 }
 
+// two floats -> packed bfloat16 pair (a in the low half), round-to-nearest-even: v_cvt_pk_bf16_f32
+typedef __bf16 yl_bf16x2 __attribute__((ext_vector_type(2)));
+typedef float yl_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned yl_pack_bf16(float a, float b) {
+  yl_f32x2 v; v.x = a; v.y = b;
+  yl_bf16x2 h = __builtin_convertvector(v, yl_bf16x2);
+  return *reinterpret_cast<unsigned*>(&h);
+}
+__device__ __forceinline__ float yl_bf16_lo(unsigned u) { return __uint_as_float(u << 16); }
+__device__ __forceinline__ float yl_bf16_hi(unsigned u) { return __uint_as_float(u & 0xFFFF0000u); }
+
 // ------------------------------------------------------------------------------------------------
 // Operand loaders.  load4<FAST>(r, k, v): 4 consecutive k-elements of logical row r (k % 4 == 0).
 //   FAST  : caller guarantees `vec` (16-byte loads legal) and k + 3 < cols.
@@ -222,6 +233,9 @@ struct Epilogue {
   long ldagg = 0;
   const int* agg_ptr = nullptr;
   int agg_rows = 0;     // number of rows of agg (E), for address clamping
+  // bf16 storage mode (bf16_eval.hip): when Yh != nullptr the tile is stored as bfloat16 (round-to-nearest-even)
+  // at Yh[row*ldy + col] instead of fp32 at Y; ldy even, Yh 4-byte aligned.  Not combined with accumulate / agg.
+  unsigned short* Yh = nullptr;
 };
 
 // Epilogue of one 32x32 MFMA sub-tile held by one wave (C/D layout: col = lane&31,
@@ -329,6 +343,34 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
     }
     if (cur_seg >= 0 && col_ok && cur > 0.f)
       atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
+    return;
+  }
+  if (ep.Yh != nullptr) {
+    // lanes l and l^1 hold neighbouring columns: each pair exchanges one value per two rows so that every lane
+    // stores one packed 4-byte (col, col+1) pair for 8 of its 16 rows (even lanes: even r, odd lanes: odd r)
+    const bool odd = (threadIdx.x & 1) != 0;
+    const bool pair_ok = (col | 1) < N;          // both columns of the pair inside N (col < N is implied)
+#pragma unroll
+    for (int r = 0; r < 16; r += 2) {
+      const float v0 = fmaxf(fmaf(acc[r], sc, sh), floor), v1 = fmaxf(fmaf(acc[r + 1], sc, sh), floor);
+      const float got = __shfl_xor(odd ? v0 : v1, 1);
+      const int row = row_base + ((r + (odd ? 1 : 0)) & 3) + 8 * (r >> 2) + 4 * lhi;
+      const float lo = odd ? got : v0, hi = odd ? v1 : got;
+      unsigned short* dst = ep.Yh + (long)row * ep.ldy + (col & ~1);
+      if (row < M) {
+        if (pair_ok) *reinterpret_cast<unsigned*>(dst) = yl_pack_bf16(lo, hi);
+        else if (!odd && col_ok) *dst = (unsigned short)(yl_pack_bf16(lo, 0.f) & 0xFFFFu);
+      }
+    }
+    // when N is odd the last column's even-lane owner also has to store the rows its odd partner would have
+    if (!pair_ok && !odd && col_ok) {
+#pragma unroll
+      for (int r = 1; r < 16; r += 2) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float v = fmaxf(fmaf(acc[r], sc, sh), floor);
+        if (row < M) ep.Yh[(long)row * ep.ldy + col] = (unsigned short)(yl_pack_bf16(v, 0.f) & 0xFFFFu);
+      }
+    }
     return;
   }
   float old[16];
@@ -496,11 +538,14 @@ __device__ __forceinline__ void gemm_nt_tile(const AL& A, const BL& B, const Epi
     __syncthreads();
   }
 
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-      wave_epilogue(acc[i][j], row0 + wm * WM + i * 32, col0 + wn * WN + j * 32 + l31, lhi, ep, M, N, pre[i][j]);
+  // spelled out with compile-time indices: the compiler refuses to unroll a loop around the (large) inlined
+  // epilogue for TM*TN = 4, and a rolled loop indexes acc[][] dynamically = accumulators in scratch memory
+  static_assert(TM <= 2 && TN <= 2, "epilogue expansion covers up to 2x2 sub-tiles");
+#define YL_EPI(i, j)                                                                                              \
+  if constexpr ((i) < TM && (j) < TN)                                                                             \
+    wave_epilogue(acc[i][j], row0 + wm * WM + (i) * 32, col0 + wn * WN + (j) * 32 + l31, lhi, ep, M, N, pre[i][j]);
+  YL_EPI(0, 0) YL_EPI(0, 1) YL_EPI(1, 0) YL_EPI(1, 1)
+#undef YL_EPI
 }
 
 template <int BM, int BN, int BK, class AL, class BL, bool B_NFAST>
@@ -552,6 +597,16 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
                      int64_t Cin, const float* Wuv, const float* Wr, const float* br, const float* Wn,
                      const float* bn, const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv,
                      float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so);
+// stage profiler hooks (forward_eval.hip): HIP-event pair around one stage of a whole-forward entry point
+bool yl_profile_on();
+void yl_stage_begin(const char* name, double flops, double bytes, yolat_stream_t stream);
+void yl_stage_end(yolat_stream_t stream);
+
+// yolat_graph_prepare with an optional co-scheduled node-side GEMM set (graph.hip)
+int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                          const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr, int32_t* perm,
+                          int32_t* src_csr, int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
+                          int32_t* work, int32_t* status, const NodeUv* extra, yolat_stream_t stream);
 // tile y of row tile x: y = 0,1 -> UV halves, 2 -> root Linear, 3 -> node-branch Linear
 template <int BK>
 __device__ __forceinline__ void node_uv_tile(const NodeUv& a, int x, int y) {

@@ -88,6 +88,21 @@ StageRec& stage_rec(const char* name, double flops, double bytes) {
     }                                                                       \
   } while (0)
 
+// stage hooks for the other whole-forward entry points (bf16_eval.hip)
+namespace { int g_open_stage = -1; }
+bool yl_profile_on() { return g_profile; }
+void yl_stage_begin(const char* name, double flops, double bytes, yolat_stream_t stream) {
+  stage_rec(name, flops, bytes);
+  for (size_t i = 0; i < g_stages.size(); ++i) if (g_stages[i].name == name) g_open_stage = (int)i;
+  hipEvent_t a = new_event(), b = new_event();
+  (void)hipEventRecord(a, (hipStream_t)stream);
+  g_stages[g_open_stage].ev.push_back({a, b});
+}
+void yl_stage_end(yolat_stream_t stream) {
+  if (g_open_stage >= 0) (void)hipEventRecord(g_stages[g_open_stage].ev.back().second, (hipStream_t)stream);
+  g_open_stage = -1;
+}
+
 extern "C" int yolat_profile_enable(int on) { g_profile = on != 0; return 0; }
 extern "C" int yolat_profile_enabled(void) { return g_profile ? 1 : 0; }
 extern "C" int yolat_profile_reset(void) {

@@ -393,7 +393,7 @@ extern "C" size_t yolat_graph_work_elems(int64_t N, int64_t E) {
   return (size_t)(2 * (((N + 1) + 63) / 64 * 64) + 4 * E + (N + 1) / PREP_BLK + 16);
 }
 
-static int graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
                               const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr,
                               int32_t* perm, int32_t* src_csr, int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr,
                               int32_t* node_seg, int32_t* work, int32_t* status, const NodeUv* extra,
@@ -453,7 +453,7 @@ extern "C" int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_
                                    int64_t P, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
                                    int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
                                    int32_t* work, int32_t* status, yolat_stream_t stream) {
-  return graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
+  return yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
                             attr_csr, seg_ptr, node_seg, work, status, nullptr, stream);
 }
 
@@ -472,7 +472,7 @@ extern "C" int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e
   const int rc = yl_build_node_uv(&a, x, ldx, x, ldx, N, Cin, Wuv, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv, f_out, ld_fo,
                                   s_out, ld_so);
   if (rc != 0) return rc;
-  return graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
+  return yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
                             attr_csr, seg_ptr, node_seg, work, status, &a, stream);
 }
 

@@ -10,7 +10,7 @@ import os
 import torch
 
 from . import ops
-from ._lib import lib, check, ModelEval, YOLAT_MAX_LAYERS
+from ._lib import lib, check, ModelEval, ModelEvalBf16, YOLAT_MAX_LAYERS
 
 
 def _fold(bn, dev):
@@ -20,7 +20,14 @@ def _fold(bn, dev):
 
 
 class EvalPlan(object):
-    def __init__(self, model):
+    """precision: "fp32" (default) or "bf16" — bf16 STORAGE of the node activations / weights with fp32
+    accumulation (csrc/bf16_eval.hip, yolat_forward_eval_bf16), the mode of the large-graph configuration."""
+
+    def __init__(self, model, precision="fp32"):
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.precision = precision
+        self._desc_h = None
         self.model = model
         self._tensors = [t for t in model.parameters()] + [b for b in model.buffers()]
         self._key = None
@@ -58,6 +65,7 @@ class EvalPlan(object):
         d.n_blocks, d.n_blocks_out, d.n_classes = net.n_blocks, net.n_blocks_out, m.n_classes
         d.C = convs[0].nn[0].out_features
         d.F = net.fusion_block[0].out_features
+        wuvs = []
         for l, cv in enumerate(convs):
             c = d.conv[l]
             c.Cin = cv.in_channels
@@ -81,7 +89,8 @@ class EvalPlan(object):
             check(lib.yolat_conv_split_w1(c.W1, cv.in_channels, C, wuv.data_ptr(), wc4.data_ptr(), ops._stream()),
                   "yolat_conv_split_w1")
             keep += [wuv, wc4]
-            if os.environ.get("YOLAT_EDGE_FACTORISED", "1") != "0":
+            wuvs.append(wuv)
+            if self.precision == "bf16" or os.environ.get("YOLAT_EDGE_FACTORISED", "1") != "0":
                 c.Wuv, c.Wc4 = wuv.data_ptr(), wc4.data_ptr()
         fb, fs = net.fusion_block, net.fusion_block_super
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
@@ -96,6 +105,24 @@ class EvalPlan(object):
         d.sc2, d.tc2 = folded(m2[1])
         d.Wc3, d.bc3 = ptr(m3[0].weight), ptr(m3[0].bias)
         self._desc, self._keep = d, keep
+        self._desc_h = None
+        if self.precision == "bf16":
+            h = ModelEvalBf16()
+            h.base = ctypes.pointer(d)
+
+            def half(t):
+                o = torch.empty(t.numel(), dtype=torch.bfloat16, device=dev)
+                check(lib.yolat_f32_to_bf16(t.data_ptr(), t.numel(), o.data_ptr(), ops._stream()), "yolat_f32_to_bf16")
+                keep.append(o)
+                return o.data_ptr()
+
+            for l, cv in enumerate(convs):
+                h.W2[l] = half(cv.nn[3].weight)
+                if l > 0:
+                    h.Wuv[l], h.Wr[l], h.Wn[l] = half(wuvs[l]), half(cv.lin_r.weight), half(cv.mlp_node[0].weight)
+            h.Wf, h.Wfs = half(fb[0].weight), half(fs[0].weight)
+            h.Wc1, h.Wc2, h.Wc3 = half(m1[0].weight), half(m2[0].weight), half(m3[0].weight)
+            self._desc_h = h
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
 
@@ -112,7 +139,10 @@ class EvalPlan(object):
             E, se, sc = edge.shape[0], edge.stride(0), edge.stride(1)
         else:
             E, se, sc = edge.shape[1], edge.stride(1), edge.stride(0)
-        need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
+        if self._desc_h is not None:
+            need = int(lib.yolat_forward_eval_bf16_workspace_bytes(ctypes.byref(self._desc_h), N, E, P))
+        else:
+            need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=x.device)
             self._graphs.clear()
@@ -124,6 +154,13 @@ class EvalPlan(object):
 
     def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
+        if self._desc_h is not None:
+            check(lib.yolat_forward_eval_bf16(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x),
+                                              ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
+                                              ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
+                                              logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
+                                              self._status.data_ptr(), ops._stream()), "yolat_forward_eval_bf16")
+            return logits
         check(lib.yolat_forward_eval(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x),
                                      ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
                                      ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
