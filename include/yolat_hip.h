@@ -465,7 +465,8 @@ int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx, c
  * `base` carries the fp32 parameters (biases, folded BN, first-layer weights, Wuv/Wc4 of every layer are
  * REQUIRED); the bf16 members are yolat_f32_to_bf16 copies of the named fp32 weights (row-major, same
  * shapes).  Wuv/Wr/Wn[0] are unused (layer 0 multiplies the raw fp32 features).
- * Supported shapes: C = 64, Cin0 <= 16, F, C*n_blocks_out, H1, H2 multiples of 64; else YOLAT_E_UNSUPPORTED.
+ * Supported shapes: C = 64, Cin0 <= 16, F, C*n_blocks_out, H1, H2 multiples of 64, N <= 2^23, E <= 2^29;
+ * else YOLAT_E_UNSUPPORTED.
  * Accuracy: <= 1e-2 of the logits' scale against the fp32 path (tests/test_gpu_bf16.py).
  * ------------------------------------------------------------------------------------------ */
 typedef struct {
@@ -474,6 +475,10 @@ typedef struct {
   const uint16_t* Wr[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].Wr  [C,Cin]                    */
   const uint16_t* Wn[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].Wn  [C,Cin]                    */
   const uint16_t* W2[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].W2  [C,C]                      */
+  /* layer 1's folded BatchNorm, applied by the node-side GEMM epilogue instead of per edge:
+   * uv_scale[l] = [s1 | s1], uv_shift[l] = [s1*b1 + t1 | 0]   (fp32 [2C] each; s1 = 1, t1 = 0 without a norm) */
+  const float* uv_scale[YOLAT_MAX_LAYERS];
+  const float* uv_shift[YOLAT_MAX_LAYERS];
   const uint16_t *Wf, *Wfs, *Wc1, *Wc2, *Wc3; /* bf16 of the fusion / classifier weights        */
 } yolat_model_eval_bf16;
 

@@ -38,7 +38,7 @@ class ModelEval(ctypes.Structure):
 class ModelEvalBf16(ctypes.Structure):
     """yolat_model_eval_bf16 (include/yolat_hip.h)"""
     _fields_ = ([("base", ctypes.POINTER(ModelEval))] +
-                [(n, c_p * YOLAT_MAX_LAYERS) for n in ("Wuv", "Wr", "Wn", "W2")] +
+                [(n, c_p * YOLAT_MAX_LAYERS) for n in ("Wuv", "Wr", "Wn", "W2", "uv_scale", "uv_shift")] +
                 [(n, c_p) for n in ("Wf", "Wfs", "Wc1", "Wc2", "Wc3")])
 
 

@@ -12,6 +12,7 @@
 // Rounding to bf16 is round-to-nearest-even (v_cvt_pk_bf16_f32).  Parity target: <= 1e-2 of the logits'
 // scale against the fp32 oracle (SURVEY.md §8c "bf16 variant"); the fp32 path keeps the 1e-4 bar.
 #include "common.hpp"
+#include <stdlib.h>
 
 typedef unsigned short u16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -175,6 +176,115 @@ static __global__ void __launch_bounds__(256) k_hgemm_two(HOp A0, HOp B0, Epilog
   hgemm_tile<T0, T0, HOp>(A0, B0, e0, M0, N0, K0, logical / tn0, logical % tn0, smem);
 }
 
+// ------------------------------------------------------------------------------------------------
+// A-resident GEMM for a SHORT K (the fusion block: K = 128, N = 1024): with one (row, column) tile per workgroup
+// every tile is two dependent global->LDS round trips in front of 16 MFMAs — at N = 200k rows the launch was
+// bound by that latency (211 us; 21 us of MFMA work).  Here a workgroup keeps its (64 TM) x K row tile of A in
+// LDS and walks `ng` consecutive 64-column tiles of W: the NEXT tile's weights and epilogue constants are loaded
+// into registers while the current tile's MFMAs and pooling epilogue run, so only the first round trip of a
+// workgroup is exposed.  K <= KD (compile-time LDS extent); columns k >= K are zero-filled.
+// ------------------------------------------------------------------------------------------------
+template <int TM, int KD> struct HRowsSmem { static constexpr int elems = 64 * (TM + 1) * (KD + 8); };
+
+template <int TM, int KD>
+__device__ __forceinline__ void hgemm_rows(const HOp& A, const HOp& B, const Epilogue& ep, int M, int N, int K, int rt_,
+                                           int ct0, int ng, u16* smem) {
+  constexpr int BM = 64 * TM, RS = KD + 8, CPR = KD / 8;     // row stride (elements), 16-byte chunks per row
+  constexpr int NA = TM * KD / 32, NW = KD / 32;            // chunks per thread: A tile, one 64-column W tile
+  u16* As = smem;
+  u16* Bs = smem + BM * RS;
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = rt_ * BM;
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_w = [&](int ct, u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int c = tid + 256 * t, r = c / CPR, kc = (c % CPR) * 8;
+      const u32x4 v = *reinterpret_cast<const u32x4*>(B.p + (long)yl_min(ct * 64 + r, B.rows - 1) * B.ld + yl_min(kc, K - 8));
+      rw[t] = kc < K ? v : zero4;
+    }
+  };
+  u32x4 rw[NW];
+  load_w(ct0, rw);
+#pragma unroll
+  for (int t = 0; t < NA; ++t) {
+    const int c = tid + 256 * t, r = c / CPR, kc = (c % CPR) * 8;
+    const u32x4 v = *reinterpret_cast<const u32x4*>(A.p + (long)yl_min(row0 + r, A.rows - 1) * A.ld + yl_min(kc, K - 8));
+    *reinterpret_cast<u32x4*>(As + r * RS + kc) = kc < K ? v : zero4;
+  }
+  EpiPre pre[TM], nxt;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) pre[i] = epi_prefetch(ep, row0 + (wm * TM + i) * 32, ct0 * 64 + wn * 32 + l31, M, N);
+  nxt = pre[0];
+  int sgs[TM][16];                        // the rows' segment ids are the same for every column tile
+#pragma unroll
+  for (int i = 0; i < TM; ++i) yl_tile_segs(pre[i].segv, lhi, sgs[i]);
+  for (int j = 0; j < ng; ++j) {
+    const int ct = ct0 + j;
+    __syncthreads();                      // the previous tile's fragment reads of Bs are done
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int c = tid + 256 * t;
+      *reinterpret_cast<u32x4*>(Bs + (c / CPR) * RS + (c % CPR) * 8) = rw[t];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < TM; ++i) { pre[i].bias = nxt.bias; pre[i].sc = nxt.sc; pre[i].sh = nxt.sh; }
+    if (j + 1 < ng) {                     // in flight while the MFMAs and the epilogue below run
+      load_w(ct + 1, rw);
+      nxt = epi_prefetch(ep, row0, (ct + 1) * 64 + wn * 32 + l31, M, N);
+    }
+    f32x16 acc[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KD / 16; ++ks) {
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Bs + (wn * 32 + l31) * RS + ks * 16 + lhi * 8);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        const bf16x8 a = *reinterpret_cast<const bf16x8*>(As + ((wm * TM + i) * 32 + l31) * RS + ks * 16 + lhi * 8);
+        acc[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc[i], 0, 0, 0);
+      }
+    }
+    // pooling epilogue (this kernel exists for the fused per-proposal max): bias, folded BN + ReLU, run-length max
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][r] += pre[i].bias;
+      wave_epilogue_segmax(acc[i], ct * 64 + wn * 32 + l31, ep, N, pre[i].sc, pre[i].sh, sgs[i]);
+    }
+  }
+}
+
+// fusion block over the nodes (A-resident rows kernel, + per-proposal max epilogue) and fusion_block_super over the
+// per-proposal means (plain 64x64 tiles, first and padded to a multiple of 8) in one flattened launch.  The big
+// problem's workgroups are (row tile, column group) pairs, column group fastest, dealt to the XCDs in contiguous
+// ranges so that the sharers of an A row tile hit one L2.
+template <int TM, int KD>
+static __global__ void __launch_bounds__(256) k_hfusion_rows(HOp A0, HOp B0, Epilogue e0, int M0, int N0, int K0, int tm0,
+                                                             int groups, int ng, FOp A1, HOp B1, Epilogue e1, int M1,
+                                                             int N1, int K1, int tm1, int tn1) {
+  constexpr int SM = HRowsSmem<TM, KD>::elems > HTileSmem<1, 1>::elems ? HRowsSmem<TM, KD>::elems : HTileSmem<1, 1>::elems;
+  __shared__ __attribute__((aligned(16))) u16 smem[SM];
+  const int n1 = tm1 * tn1, n1p = (n1 + 7) & ~7;
+  const int id = blockIdx.x;
+  if (id < n1p) {
+    if (id < n1) hgemm_tile<1, 1, FOp>(A1, B1, e1, M1, N1, K1, id / tn1, id % tn1, smem);
+    return;
+  }
+  const int n0 = tm0 * groups, j = id - n1p;
+  const int chunk = n0 >> 3, rem = n0 & 7;
+  const int xcd = j & 7, slot = j >> 3;
+  const int logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
+  const int rt = logical / groups, g = logical - rt * groups;
+  const int tn = (N0 + 63) / 64;
+  const int c0 = g * ng, cn = yl_min(ng, tn - c0);
+  if (cn > 0) hgemm_rows<TM, KD>(A0, B0, e0, M0, N0, K0, rt, c0, cn, smem);
+}
+
 // node side of a factorised conv layer with Cin = 64 (bf16 in / bf16 weights):
 //   y = 0,1 -> the two 64-column halves of UV = f_in.[W1a-W1b | W1b]^T   (stored bf16)
 //   y = 2   -> root Linear lin_r(f_in) + br                               (stored fp32: the edge kernel adds the mean)
@@ -202,21 +312,30 @@ static Epilogue plain_epilogue() {
 // ------------------------------------------------------------------------------------------------
 // Factorised edge MLP + mean aggregation, bf16 storage (see k_edge_uv_mlp2_mean, edge.hip, for the scheme).
 // One workgroup = npt (<= 16) consecutive destination nodes = a contiguous CSR edge range, in passes of 64
-// edges.  Per pass: gather U[dst] + V[src] (bf16, 128 B per row) + W1c.attr -> BN+ReLU (fp32) -> bf16 tile in
+// edges.  Per pass: gather U'[dst] + V'[src] (bf16, 128 B per row) + W1c'.attr -> ReLU (fp32) -> bf16 tile in
 // LDS -> second Linear on bf16 MFMAs (this wave's W2 fragments live in registers for the whole kernel) ->
 // BN+ReLU -> fp32 tile in LDS -> per-node running sums in CSR order.  Output: f_out = bf16(root + sum/deg)
 // for EVERY node of the tile (nodes without in-edges get the root Linear alone, torch_vertex.py:324,337).
-// ------------------------------------------------------------------------------------------------
-static __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean_h(
-    const u16* __restrict__ UV, long ld_uv, const int* __restrict__ src, const int* __restrict__ dst,
+//
+// Built to cut VALU work (PMC at cfg 5: a first version that applied layer 1's BatchNorm per edge in scalar fp32
+// kept the vector ALUs ~60 % busy — the kernel is instruction-bound, not latency-bound; a higher-occupancy variant
+// with the per-column constants in LDS was slower, 480 vs 435 us for the 4 layers; this one takes 383 us):
+//   * layer 1's folded BatchNorm is applied where it is cheap: the node-side GEMM epilogue stores
+//     U' = s1*U + (s1*b1 + t1) and V' = s1*V (uv_scale / uv_shift of yolat_model_eval_bf16), this kernel scales the
+//     four W1c columns once per workgroup, so a hidden activation is relu(U' + V' + W1c'.attr): 6 flops instead of 8;
+//   * those run as packed fp32 pairs (v_pk_add_f32 / v_pk_fma_f32), as does layer 2's folded BN (bias folded into
+//     the shift);
+//   * 32-bit element offsets for the gathers, 16-byte message rows (LDM = 68) for the per-node sums.
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+static __global__ void __launch_bounds__(256, 4) k_edge_uv_mlp2_mean_h(
+    const u16* __restrict__ UV, unsigned ld_uv, const int* __restrict__ src, const int* __restrict__ dst,
     const float* __restrict__ attr, const int* __restrict__ row_ptr, int N, int npt, const float* __restrict__ Wc4,
-    const float* __restrict__ b1, const float* __restrict__ s1, const float* __restrict__ t1,
-    const u16* __restrict__ W2h, const float* __restrict__ b2, const float* __restrict__ s2,
-    const float* __restrict__ t2, const float* __restrict__ root, long ld_r, u16* __restrict__ f_out, long ld_fo,
-    int E) {
-  constexpr int LDM = 65;
+    const float* __restrict__ s1, const u16* __restrict__ W2h, const float* __restrict__ b2,
+    const float* __restrict__ s2, const float* __restrict__ t2, const float* __restrict__ root, unsigned ld_r,
+    u16* __restrict__ f_out, unsigned ld_fo, int E) {
+  constexpr int LDM = 68;
   __shared__ __attribute__((aligned(16))) u16 Hs[64 * YL_HRS];   // layer-1 activations of the pass (bf16)
-  __shared__ float Ms[64 * LDM];                                // layer-2 messages of the pass (fp32)
+  __shared__ __attribute__((aligned(16))) float Ms[64 * LDM];   // layer-2 messages of the pass (fp32)
   __shared__ int rp[17];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
@@ -228,48 +347,59 @@ static __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean_h(
   bf16x8 w2f[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks)
-    w2f[ks] = *reinterpret_cast<const bf16x8*>(W2h + (long)col * 64 + ks * 16 + lhi * 8);
-  float4 wc[4];
+    w2f[ks] = *reinterpret_cast<const bf16x8*>(W2h + col * 64 + ks * 16 + lhi * 8);
+  // W1c' = s1 * W1c for this thread's 4 columns, as (column pair) x (attr component) packed pairs
+  f32x2 wp[2][4];
+  {
+    float4 sc = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (s1) sc = *reinterpret_cast<const float4*>(s1 + 4 * q);
+    const float scv[4] = {sc.x, sc.y, sc.z, sc.w};
 #pragma unroll
-  for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
-  const float4 bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
-  float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
-  const float bias2 = b2 ? b2[col] : 0.f, sc2 = s2 ? s2[col] : 1.f, sh2 = s2 ? t2[col] : 0.f;
+    for (int j = 0; j < 4; ++j) {
+      const float4 w = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
+      wp[j >> 1][0][j & 1] = w.x * scv[j]; wp[j >> 1][1][j & 1] = w.y * scv[j];
+      wp[j >> 1][2][j & 1] = w.z * scv[j]; wp[j >> 1][3][j & 1] = w.w * scv[j];
+    }
+  }
+  const float sc2 = s2 ? s2[col] : 1.f;
+  const float sh2 = fmaf(b2 ? b2[col] : 0.f, sc2, s2 ? t2[col] : 0.f);    // (acc + b2)*s2 + t2 = acc*s2 + sh2
   __syncthreads();
   const int e0 = rp[0], e1 = rp[nn];
   const int my_b = rp[yl_min(rb, nn)], my_e = rp[yl_min(rb + 1, nn)];   // aggregation role: node rb, columns 4q..
   float4 rootv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (rb < nn) rootv = *reinterpret_cast<const float4*>(root + (long)(n0 + rb) * ld_r + 4 * q);
+  if (rb < nn) rootv = *reinterpret_cast<const float4*>(root + (unsigned)(n0 + rb) * ld_r + 4 * q);
   float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
   for (int c0 = e0; c0 < e1; c0 += 64) {
-    int di[4], si[4];
+    unsigned di[4], si[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int e = yl_min(c0 + rb + 16 * t, E - 1);
-      di[t] = dst[e]; si[t] = src[e];
+      di[t] = (unsigned)dst[e]; si[t] = (unsigned)src[e];
     }
     u32x2 u[4], v[4];
     float4 a[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int e = yl_min(c0 + rb + 16 * t, E - 1);
-      u[t] = *reinterpret_cast<const u32x2*>(UV + (long)di[t] * ld_uv + 4 * q);
-      v[t] = *reinterpret_cast<const u32x2*>(UV + (long)si[t] * ld_uv + 64 + 4 * q);
-      a[t] = *reinterpret_cast<const float4*>(attr + (long)e * 4);
+      const unsigned e = (unsigned)yl_min(c0 + rb + 16 * t, E - 1);
+      u[t] = *reinterpret_cast<const u32x2*>(UV + (di[t] * ld_uv + 4 * q));
+      v[t] = *reinterpret_cast<const u32x2*>(UV + (si[t] * ld_uv + 64 + 4 * q));
+      a[t] = *reinterpret_cast<const float4*>(attr + e * 4u);
     }
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      auto one = [&](float uu, float vv, const float4& w, float b, float s, float h) {
-        float z = uu + vv;
-        z = fmaf(a[t].x, w.x, z); z = fmaf(a[t].y, w.y, z); z = fmaf(a[t].z, w.z, z); z = fmaf(a[t].w, w.w, z);
-        return fmaxf(fmaf(z + b, s, h), 0.f);
-      };
-      const float h0 = one(yl_bf16_lo(u[t].x), yl_bf16_lo(v[t].x), wc[0], bb.x, sc.x, sh.x);
-      const float h1 = one(yl_bf16_hi(u[t].x), yl_bf16_hi(v[t].x), wc[1], bb.y, sc.y, sh.y);
-      const float h2 = one(yl_bf16_lo(u[t].y), yl_bf16_lo(v[t].y), wc[2], bb.z, sc.z, sh.z);
-      const float h3 = one(yl_bf16_hi(u[t].y), yl_bf16_hi(v[t].y), wc[3], bb.w, sc.w, sh.w);
-      u32x2 hp; hp.x = yl_pack_bf16(h0, h1); hp.y = yl_pack_bf16(h2, h3);
+      f32x2 z0, z1, uu, vv;
+      uu.x = yl_bf16_lo(u[t].x); uu.y = yl_bf16_hi(u[t].x); vv.x = yl_bf16_lo(v[t].x); vv.y = yl_bf16_hi(v[t].x);
+      z0 = uu + vv;
+      uu.x = yl_bf16_lo(u[t].y); uu.y = yl_bf16_hi(u[t].y); vv.x = yl_bf16_lo(v[t].y); vv.y = yl_bf16_hi(v[t].y);
+      z1 = uu + vv;
+      const f32x2 ax = {a[t].x, a[t].x}, ay = {a[t].y, a[t].y}, az = {a[t].z, a[t].z}, aw = {a[t].w, a[t].w};
+      z0 = __builtin_elementwise_fma(ax, wp[0][0], z0); z1 = __builtin_elementwise_fma(ax, wp[1][0], z1);
+      z0 = __builtin_elementwise_fma(ay, wp[0][1], z0); z1 = __builtin_elementwise_fma(ay, wp[1][1], z1);
+      z0 = __builtin_elementwise_fma(az, wp[0][2], z0); z1 = __builtin_elementwise_fma(az, wp[1][2], z1);
+      z0 = __builtin_elementwise_fma(aw, wp[0][3], z0); z1 = __builtin_elementwise_fma(aw, wp[1][3], z1);
+      u32x2 hp;
+      hp.x = yl_pack_bf16(fmaxf(z0.x, 0.f), fmaxf(z0.y, 0.f));
+      hp.y = yl_pack_bf16(fmaxf(z1.x, 0.f), fmaxf(z1.y, 0.f));
       *reinterpret_cast<u32x2*>(Hs + (rb + 16 * t) * YL_HRS + 4 * q) = hp;
     }
     __syncthreads();                      // Hs complete; also: every thread is past the previous pass's Ms reads
@@ -281,18 +411,24 @@ static __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean_h(
       const bf16x8 av = *reinterpret_cast<const bf16x8*>(Hs + (wm * 32 + l31) * YL_HRS + ks * 16 + lhi * 8);
       acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, w2f[ks], acc2, 0, 0, 0);
     }
+    {
+      const f32x2 s2p = {sc2, sc2}, h2p = {sh2, sh2};
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-      Ms[row * LDM + col] = fmaxf(fmaf(acc2[r] + bias2, sc2, sh2), 0.f);
+      for (int r = 0; r < 16; r += 2) {
+        f32x2 m = {acc2[r], acc2[r + 1]};
+        m = __builtin_elementwise_fma(m, s2p, h2p);
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        Ms[row * LDM + col] = fmaxf(m.x, 0.f);
+        Ms[(row + 1) * LDM + col] = fmaxf(m.y, 0.f);
+      }
     }
     __syncthreads();                      // Ms complete; every wave is done reading Hs
     if (rb < nn) {                        // rows of node rb inside this pass, ascending edge order
-      const int lo = my_b > c0 ? my_b : c0;
-      const int hi = my_e < c0 + 64 ? my_e : c0 + 64;
+      const int lo = (my_b > c0 ? my_b : c0) - c0;
+      const int hi = (my_e < c0 + 64 ? my_e : c0 + 64) - c0;
       for (int e = lo; e < hi; ++e) {
-        const float* m = Ms + (e - c0) * LDM + 4 * q;
-        sum.x += m[0]; sum.y += m[1]; sum.z += m[2]; sum.w += m[3];
+        const float4 m = *reinterpret_cast<const float4*>(Ms + e * LDM + 4 * q);
+        sum.x += m.x; sum.y += m.y; sum.z += m.z; sum.w += m.w;
       }
     }
   }
@@ -302,7 +438,7 @@ static __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean_h(
     u32x2 o;
     o.x = yl_pack_bf16(fmaf(sum.x, inv, rootv.x), fmaf(sum.y, inv, rootv.y));
     o.y = yl_pack_bf16(fmaf(sum.z, inv, rootv.z), fmaf(sum.w, inv, rootv.w));
-    *reinterpret_cast<u32x2*>(f_out + (long)(n0 + rb) * ld_fo + 4 * q) = o;
+    *reinterpret_cast<u32x2*>(f_out + ((unsigned)(n0 + rb) * ld_fo + 4 * q)) = o;
   }
 }
 
@@ -396,7 +532,7 @@ int model_ok(const yolat_model_eval_bf16* mh) {
     return YOLAT_E_UNSUPPORTED;
   for (int l = 0; l < m->n_blocks; ++l) {
     const yolat_conv_eval& cv = m->conv[l];
-    if (!cv.Wuv || !cv.Wc4 || !mh->W2[l]) return YOLAT_E_INVALID;
+    if (!cv.Wuv || !cv.Wc4 || !mh->W2[l] || !mh->uv_scale[l] || !mh->uv_shift[l]) return YOLAT_E_INVALID;
     if (l == 0 ? (cv.Cin > 16) : (cv.Cin != 64)) return YOLAT_E_UNSUPPORTED;
     if (l > 0 && (!mh->Wuv[l] || !mh->Wr[l] || !mh->Wn[l])) return YOLAT_E_INVALID;
   }
@@ -441,7 +577,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
                                        yolat_stream_t stream) {
   if (!x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0) return YOLAT_E_INVALID;
   YL_TRY(model_ok(mh));
-  if (N >= (1LL << 31) - 8192 || E >= (1LL << 31) - 256) return YOLAT_E_INVALID;
+  if (N > (1LL << 23) || E > (1LL << 29)) return YOLAT_E_UNSUPPORTED;     // 32-bit element offsets in the gathers
   const yolat_model_eval* m = mh->base;
   PlanH p = carve_h(m, N, E, P, workspace);
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
@@ -462,6 +598,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     YL_TRY(yl_build_node_uv(&a, x, ldx, x, ldx, N, cv0.Cin, cv0.Wuv, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C,
                             p.root, 2 * C, p.root, C, p.root, C));
     a.euv.Y = nullptr; a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
+    a.euv.scale = mh->uv_scale[0]; a.euv.shift = mh->uv_shift[0];
     a.en.Y = nullptr; a.en.Yh = s_slot(0); a.en.ldy = ld_slot(0);
     YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
                                  p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, stream));
@@ -483,6 +620,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
       a.as = HOp{s_slot(l - 1), ld_slot(l - 1), (int)N};
       a.wuv = HOp{mh->Wuv[l], 64, (int)(2 * C)}; a.wr = HOp{mh->Wr[l], 64, (int)C}; a.wn = HOp{mh->Wn[l], 64, (int)C};
       a.euv = plain_epilogue(); a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
+      a.euv.scale = mh->uv_scale[l]; a.euv.shift = mh->uv_shift[l];
       a.er = plain_epilogue(); a.er.bias = cv.br; a.er.Y = p.root; a.er.ldy = C;
       a.en = plain_epilogue(); a.en.bias = cv.bn; a.en.scale = cv.sn; a.en.shift = cv.tn; a.en.relu = 1;
       a.en.Yh = s_slot(l); a.en.ldy = ld_slot(l);
@@ -493,9 +631,9 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     }
     snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
     YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 2.0 + 16.0 + 8.0) + 4.0 * N * C + 2.0 * N * C + 4.0 * N, {
-    hipLaunchKernelGGL(k_edge_uv_mlp2_mean_h, dim3(yl_cdiv(N, npt)), dim3(256), 0, st, p.UV, 2 * C, p.src, p.dst, p.attr,
-                       p.row_ptr, (int)N, (int)npt, cv.Wc4, cv.b1, cv.s1, cv.t1, mh->W2[l], cv.b2, cv.s2, cv.t2, p.root,
-                       C, f_slot(l), ld_slot(l), (int)(E > 0 ? E : 1));
+    hipLaunchKernelGGL(k_edge_uv_mlp2_mean_h, dim3(yl_cdiv(N, npt)), dim3(256), 0, st, p.UV, (unsigned)(2 * C), p.src,
+                         p.dst, p.attr, p.row_ptr, (int)N, (int)npt, cv.Wc4, cv.s1, mh->W2[l], cv.b2, cv.s2, cv.t2, p.root,
+                         (unsigned)C, f_slot(l), (unsigned)ld_slot(l), (int)(E > 0 ? E : 1));
     YL_LAUNCH_CHECK();
     });
   }
@@ -517,9 +655,35 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     e0.bias = m->bf; e0.scale = m->sf; e0.shift = m->tf; e0.relu = 1; e0.seg = p.node_seg; e0.pool = p.Z; e0.ldpool = ZW;
     e1.bias = m->bfs; e1.scale = m->sfs; e1.shift = m->tfs; e1.relu = 1; e1.Y = p.Z + F + D; e1.ldy = ZW;
     const int tm1 = yl_cdiv(P, 64), tn1 = yl_cdiv(F, 64);
+    const long n1p = ((long)tm1 * tn1 + 7) & ~7L;
+    if (D <= 256) {
+      // A-resident rows kernel: at least 4 column groups, and as many as it takes to put >= ~1024 workgroups on
+      // the GPU (each group walks tn / groups consecutive 64-column tiles)
+      const int tn = yl_cdiv(F, 64);
+      // measured at cfg 5 (N = 200k): 64-row tiles x 4 column groups 160 us, x 1 group 166 us, 128-row tiles 181 us
+      // (x 1) / 161 us (x 4); cfg 2 (N = 10k): 8 groups 16.1 us, 16 groups 16.8 us, 2 groups 21.2 us
+      bool big = false;
+      long min_wgs = 1024;
+      if (const char* e = getenv("YOLAT_HFUSION_TM")) big = e[0] == '2';          // tuning hooks
+      if (const char* e = getenv("YOLAT_HFUSION_WGS")) min_wgs = atol(e);
+      const int tm0 = yl_cdiv(N, big ? 128 : 64);
+      int groups = 4;
+      while ((long)tm0 * groups < min_wgs && groups < tn) groups *= 2;
+      if (groups > tn) groups = tn;
+      const int ng = yl_cdiv(tn, groups);
+      groups = yl_cdiv(tn, ng);
+      const long total = (long)tm0 * groups + n1p;
+      if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+      auto go = [&](auto kern) {
+        hipLaunchKernelGGL(kern, dim3((unsigned)total), dim3(256), 0, st, a0, b0, e0, (int)N, (int)F, (int)D, tm0, groups, ng,
+                           a1, b1, e1, (int)P, (int)F, (int)D, tm1, tn1);
+      };
+      if (D <= 128) { if (big) go(k_hfusion_rows<2, 128>); else go(k_hfusion_rows<1, 128>); }
+      else { if (big) go(k_hfusion_rows<2, 256>); else go(k_hfusion_rows<1, 256>); }
+    } else {
     const bool big = N >= 65536;                       // 128x128 tiles once there are enough of them to fill the GPU
     const int tm0 = yl_cdiv(N, big ? 128 : 64), tn0 = yl_cdiv(F, big ? 128 : 64);
-    const long total = (long)tm0 * tn0 + (((long)tm1 * tn1 + 7) & ~7L);
+    const long total = (long)tm0 * tn0 + n1p;
     if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
     if (big)
       hipLaunchKernelGGL(k_hgemm_two<2>, dim3((unsigned)total), dim3(256), 0, st, a0, b0, e0, (int)N, (int)F, (int)D, tm0,
@@ -527,6 +691,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     else
       hipLaunchKernelGGL(k_hgemm_two<1>, dim3((unsigned)total), dim3(256), 0, st, a0, b0, e0, (int)N, (int)F, (int)D, tm0,
                          tn0, a1, b1, e1, (int)P, (int)F, (int)D, tm1, tn1);
+    }
     YL_LAUNCH_CHECK();
   });
   {

@@ -256,6 +256,38 @@ __device__ __forceinline__ EpiPre epi_prefetch(const Epilogue& ep, int row_base,
   return p;
 }
 
+// Fused per-proposal max pooling of one 32x32 sub-tile (bias already added to acc): rows of a proposal are
+// consecutive -> run-length max over this lane's 16 rows, one integer atomicMax per run (values are post-ReLU,
+// i.e. >= 0, so int order == float order; exact and order-independent).  The 32 segment ids of the tile come from
+// ONE coalesced load (pre.segv: lane l31 <- row row_base+l31, -1 beyond M) distributed by cross-lane reads; 16
+// dependent per-row loads cost more than the tile's MFMAs.
+// sgs[r] = segment id of this lane's r-th row (-1 beyond M), from the tile's coalesced id vector
+__device__ __forceinline__ void yl_tile_segs(int segv, int lhi, int sgs[16]) {
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);   // all lanes active here
+}
+__device__ __forceinline__ void wave_epilogue_segmax(const f32x16& acc, int col, const Epilogue& ep, int N, float sc,
+                                                     float sh, const int sgs[16]) {
+  const bool col_ok = col < N;
+  int cur_seg = -1;
+  float cur = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int sg = sgs[r];
+    const float v = fmaxf(fmaf(acc[r], sc, sh), 0.f);
+    if (sg != cur_seg) {
+      if (cur_seg >= 0 && col_ok && cur > 0.f)
+        atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
+      cur_seg = sg;
+      cur = v;
+    } else {
+      cur = fmaxf(cur, v);
+    }
+  }
+  if (cur_seg >= 0 && col_ok && cur > 0.f)
+    atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
+}
+
 __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col, int lhi,
                                               const Epilogue& ep, int M, int N, const EpiPre& pre) {
   const bool col_ok = col < N;
@@ -319,30 +351,9 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
     return;
   }
   if (ep.seg != nullptr) {
-    // rows of a proposal are consecutive: run-length max over this lane's 16 rows, one atomic per run.
-    // The 32 segment ids of the tile are fetched by ONE coalesced load (lane l31 <- row row_base+l31) and
-    // distributed by cross-lane reads; 16 dependent per-row loads cost more than the tile's 64 MFMAs.
-    const int segv = pre.segv;
     int sgs[16];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);   // all lanes active here
-    int cur_seg = -1;
-    float cur = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int sg = sgs[r];
-      const float v = fmaxf(fmaf(acc[r], sc, sh), 0.f);
-      if (sg != cur_seg) {
-        if (cur_seg >= 0 && col_ok && cur > 0.f)
-          atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
-        cur_seg = sg;
-        cur = v;
-      } else {
-        cur = fmaxf(cur, v);
-      }
-    }
-    if (cur_seg >= 0 && col_ok && cur > 0.f)
-      atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
+    yl_tile_segs(pre.segv, lhi, sgs);
+    wave_epilogue_segmax(acc, col, ep, N, pre.sc, pre.sh, sgs);
     return;
   }
   if (ep.Yh != nullptr) {

@@ -65,25 +65,27 @@ class EvalPlan(object):
         d.n_blocks, d.n_blocks_out, d.n_classes = net.n_blocks, net.n_blocks_out, m.n_classes
         d.C = convs[0].nn[0].out_features
         d.F = net.fusion_block[0].out_features
-        wuvs = []
+        wuvs, folds1 = [], []
         for l, cv in enumerate(convs):
             c = d.conv[l]
             c.Cin = cv.in_channels
             c.W1, c.b1 = ptr(cv.nn[0].weight), ptr(cv.nn[0].bias)
             c.s1, c.t1 = folded(cv.nn[1])
+            folds1.append((keep[-1][0], keep[-1][1]))
             c.W2, c.b2 = ptr(cv.nn[3].weight), ptr(cv.nn[3].bias)
             c.s2, c.t2 = folded(cv.nn[4])
             c.Wr, c.br = ptr(cv.lin_r.weight), ptr(cv.lin_r.bias)
             c.Wn, c.bn = ptr(cv.mlp_node[0].weight), ptr(cv.mlp_node[0].bias)
             c.sn, c.tn = folded(cv.mlp_node[1])
-            # W1 / W2 in MFMA fragment order for the register-chained conv kernel (conv_chain.hip)
-            pk = torch.empty(int(lib.yolat_conv_pack_elems(cv.in_channels)), dtype=torch.float32, device=dev)
-            check(lib.yolat_conv_pack_weights(c.W1, c.W2, cv.in_channels, pk.data_ptr(), ops._stream()),
-                  "yolat_conv_pack_weights")
-            keep.append(pk)
-            c.packed = pk.data_ptr()
-            # factorised first edge Linear: per-node weights [W1a - W1b | W1b] and the 4 attr columns
             C = cv.nn[0].out_features
+            if C == 64:
+                # W1 / W2 in MFMA fragment order for the register-chained conv kernel (conv_chain.hip, C = 64 only)
+                pk = torch.empty(int(lib.yolat_conv_pack_elems(cv.in_channels)), dtype=torch.float32, device=dev)
+                check(lib.yolat_conv_pack_weights(c.W1, c.W2, cv.in_channels, pk.data_ptr(), ops._stream()),
+                      "yolat_conv_pack_weights")
+                keep.append(pk)
+                c.packed = pk.data_ptr()
+            # factorised first edge Linear: per-node weights [W1a - W1b | W1b] and the 4 attr columns
             wuv = torch.empty(2 * C, cv.in_channels, dtype=torch.float32, device=dev)
             wc4 = torch.empty(C, 4, dtype=torch.float32, device=dev)
             check(lib.yolat_conv_split_w1(c.W1, cv.in_channels, C, wuv.data_ptr(), wc4.data_ptr(), ops._stream()),
@@ -118,6 +120,12 @@ class EvalPlan(object):
 
             for l, cv in enumerate(convs):
                 h.W2[l] = half(cv.nn[3].weight)
+                # layer 1's folded BatchNorm moves into the node-side epilogue: U' = s1*U + (s1*b1 + t1), V' = s1*V
+                s1, t1 = folds1[l]
+                uvs = torch.cat([s1, s1]).contiguous()
+                uvt = torch.cat([s1 * cv.nn[0].bias.detach() + t1, torch.zeros_like(t1)]).contiguous()
+                keep += [uvs, uvt]
+                h.uv_scale[l], h.uv_shift[l] = uvs.data_ptr(), uvt.data_ptr()
                 if l > 0:
                     h.Wuv[l], h.Wr[l], h.Wn[l] = half(wuvs[l]), half(cv.lin_r.weight), half(cv.mlp_node[0].weight)
             h.Wf, h.Wfs = half(fb[0].weight), half(fs[0].weight)
