@@ -210,8 +210,8 @@ extern "C" int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, 
 //                     only used to place e somewhere inside its row); row r: segment pointers
 //   2. k_prep_scan    per-4096-element-block exclusive scan of cnt (multi-workgroup) + block totals
 //   3. k_prep_fill    items[local[dst] + blockprefix + rank[e]] = e
-//   4. k_prep_rows    node n: insertion-sort its row by edge id (restores the stable order), emit
-//                     perm / src / dst / attr in CSR order, write the final row_ptr
+//   4. k_prep_rows    slot t: rank of items[t] among its row's items by edge id (restores the stable order),
+//                     emit perm / src / dst / attr at row start + rank; row n: the final row_ptr
 // ------------------------------------------------------------------------------------------------
 #define PREP_BLK 4096
 __global__ void k_prep_count(const int64_t* edge, long se, long sc, int E, int N, int* src32, int* dst32,
@@ -282,6 +282,38 @@ __device__ __forceinline__ int prep_prefix(const int* btot, int b) {
   return s;
 }
 
+// Exclusive scan of the block totals into LDS (sh[b] = sum_{i<b} btot[i], b <= nblk <= PREP_OFFS), built by every
+// 256-thread workgroup for itself (a per-thread prep_prefix() is a loop over up to N/4096 block totals).
+// Returns false (sh unused) when there are more blocks than the table holds.  Whole workgroup must call.
+#define PREP_OFFS 1024
+__device__ __forceinline__ bool prep_offsets_lds(const int* btot, int nblk, int* sh, int* wsum) {
+  if (nblk > PREP_OFFS) return false;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int v[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) v[j] = (tid * 4 + j < nblk) ? btot[tid * 4 + j] : 0;
+  const int t = v[0] + v[1] + v[2] + v[3];
+  int incl = t;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int nb = __shfl_up(incl, off);
+    if (lane >= off) incl += nb;
+  }
+  if (lane == 63) wsum[wave] = incl;
+  __syncthreads();
+  int woff = 0;
+#pragma unroll
+  for (int w = 0; w < 4; ++w) woff += (w < wave) ? wsum[w] : 0;
+  int excl = woff + incl - t;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    sh[tid * 4 + j] = excl;
+    excl += v[j];
+  }
+  __syncthreads();
+  return true;
+}
+
 __global__ void k_csc_ptr(int* local, const int* btot, int n, int* ptr) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
@@ -297,77 +329,44 @@ __global__ void k_prep_fill(const int* dst32, const int* rank, int E, const int*
   items[local[d] + prep_prefix(btot, d / PREP_BLK) + rank[e]] = e;
 }
 
-__device__ __forceinline__ void prep_rows_body(int n, const int* local, const int* btot, int N, int* items,
-                                               const int* src32, const float4* attr, int* row_ptr, int* perm,
-                                               int* src_csr, int* dst_csr, float4* attr_csr) {
-  if (n > N) return;
-  const int b = local[n] + prep_prefix(btot, n / PREP_BLK);
-  row_ptr[n] = b;
-  if (n == N) return;
-  const int e = local[n + 1] + prep_prefix(btot, (n + 1) / PREP_BLK);
-  const int deg = e - b;
-  if (deg <= 0) return;
-  constexpr int RMAX = 16;
-  if (deg <= RMAX) {
-    // the whole row in registers: RMAX independent (clamped) loads, an odd-even transposition
-    // network, then independent gathers + stores  => one memory latency per phase instead of one
-    // dependent global round trip per insertion-sort step
-    int it[RMAX];
+// One thread per CSR SLOT (and per row for row_ptr): thread t takes the t-th entry of `items` (edges grouped by
+// destination, arbitrary order inside a row), finds its rank among the row's items by edge id — that restores the
+// stable order of the reference's index_select / scatter — and emits the edge at row start + rank.  The loads of
+// items and the four stores are (nearly) coalesced because neighbouring threads work on the same or adjacent rows.
+// (A thread-per-row version with the row sorted in registers was TA-bound on its scattered accesses:
+// 66 us for 1.2 M edges.)
+__device__ __forceinline__ void prep_rows_body(int t, const int* local, const int* btot, int N, int E, const int* items,
+                                               const int* src32, const int* dst32, const float4* attr, int* row_ptr,
+                                               int* perm, int* src_csr, int* dst_csr, float4* attr_csr) {
+  __shared__ int sh[PREP_OFFS + 4], wsum[4];
+  const bool have = prep_offsets_lds(btot, (N + 1 + PREP_BLK - 1) / PREP_BLK, sh, wsum);   // whole workgroup
+  auto off = [&](int i) { return local[i] + (have ? sh[i / PREP_BLK] : prep_prefix(btot, i / PREP_BLK)); };
+  if (t <= N) row_ptr[t] = off(t);
+  if (t >= E) return;
+  const int e = items[t];
+  const int i = dst32[e];
+  const int b = off(i), en = off(i + 1);
+  int r = 0;
+  for (int j = b; j < en; j += 8) {          // 8 independent (clamped) loads per step
+    int v[8];
 #pragma unroll
-    for (int j = 0; j < RMAX; ++j) {
-      const int v = items[b + (j < deg ? j : deg - 1)];
-      it[j] = j < deg ? v : 0x7fffffff;
-    }
+    for (int k = 0; k < 8; ++k) v[k] = items[yl_min(j + k, en - 1)];
 #pragma unroll
-    for (int round = 0; round < RMAX; ++round) {
-#pragma unroll
-      for (int j = (round & 1); j + 1 < RMAX; j += 2) {
-        const int lo = it[j] < it[j + 1] ? it[j] : it[j + 1];
-        const int hi = it[j] < it[j + 1] ? it[j + 1] : it[j];
-        it[j] = lo; it[j + 1] = hi;
-      }
-    }
-#pragma unroll
-    for (int j0 = 0; j0 < RMAX; j0 += 8) {
-      int sv[8];
-      float4 av[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int ed = it[(j0 + j) < deg ? (j0 + j) : 0];
-        sv[j] = src32[ed];
-        av[j] = attr[ed];
-      }
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        if (j0 + j < deg) {
-          perm[b + j0 + j] = it[j0 + j];
-          src_csr[b + j0 + j] = sv[j];
-          dst_csr[b + j0 + j] = n;
-          attr_csr[b + j0 + j] = av[j];
-        }
-      }
-    }
-    return;
+    for (int k = 0; k < 8; ++k) r += (j + k < en && v[k] < e) ? 1 : 0;
   }
-  for (int i = b + 1; i < e; ++i) {
-    const int v = items[i];
-    int j = i - 1;
-    while (j >= b && items[j] > v) { items[j + 1] = items[j]; --j; }
-    items[j + 1] = v;
-  }
-  for (int q = b; q < e; ++q) {
-    const int ed = items[q];
-    perm[q] = ed;
-    src_csr[q] = src32[ed];
-    dst_csr[q] = n;
-    attr_csr[q] = attr[ed];
-  }
+  const int pos = b + r;
+  const int sv = src32[e];
+  const float4 av = attr[e];
+  perm[pos] = e;
+  src_csr[pos] = sv;
+  dst_csr[pos] = i;
+  attr_csr[pos] = av;
 }
 
-__global__ void k_prep_rows(const int* local, const int* btot, int N, int* items, const int* src32,
-                            const float4* attr, int* row_ptr, int* perm, int* src_csr, int* dst_csr,
-                            float4* attr_csr) {
-  prep_rows_body(blockIdx.x * blockDim.x + threadIdx.x, local, btot, N, items, src32, attr, row_ptr, perm, src_csr,
+__global__ void __launch_bounds__(256) k_prep_rows(const int* local, const int* btot, int N, int E, const int* items,
+                                                   const int* src32, const int* dst32, const float4* attr, int* row_ptr,
+                                                   int* perm, int* src_csr, int* dst_csr, float4* attr_csr) {
+  prep_rows_body(blockIdx.x * 256 + threadIdx.x, local, btot, N, E, items, src32, dst32, attr, row_ptr, perm, src_csr,
                  dst_csr, attr_csr);
 }
 
@@ -376,13 +375,13 @@ __global__ void k_prep_rows(const int* local, const int* btot, int N, int* items
 // tiles of yolat_node_uv_eval.  The row kernel alone is 40 workgroups of integer latency (~10 us at
 // N = 10k); the GEMM tiles fill the other CUs meanwhile instead of being a launch of their own.
 template <int BK>
-__global__ void __launch_bounds__(256) k_prep_rows_node3(const int* local, const int* btot, int N, int* items,
-                                                         const int* src32, const float4* attr, int* row_ptr,
-                                                         int* perm, int* src_csr, int* dst_csr, float4* attr_csr,
-                                                         int rows_blocks, NodeUv a) {
+__global__ void __launch_bounds__(256) k_prep_rows_node3(const int* local, const int* btot, int N, int E,
+                                                         const int* items, const int* src32, const int* dst32,
+                                                         const float4* attr, int* row_ptr, int* perm, int* src_csr,
+                                                         int* dst_csr, float4* attr_csr, int rows_blocks, NodeUv a) {
   if ((int)blockIdx.x < rows_blocks) {
-    prep_rows_body(blockIdx.x * 256 + threadIdx.x, local, btot, N, items, src32, attr, row_ptr, perm, src_csr, dst_csr,
-                   attr_csr);
+    prep_rows_body(blockIdx.x * 256 + threadIdx.x, local, btot, N, E, items, src32, dst32, attr, row_ptr, perm, src_csr,
+                   dst_csr, attr_csr);
     return;
   }
   const int t = blockIdx.x - rows_blocks;
@@ -428,19 +427,19 @@ int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_
                        items);
     YL_LAUNCH_CHECK();
   }
-  const int rows_blocks = yl_cdiv(n1, 256);
+  const int rows_blocks = yl_cdiv(E > n1 ? E : n1, 256);
   if (extra != nullptr) {
     const unsigned total = (unsigned)rows_blocks + 4u * (unsigned)yl_cdiv(extra->N, 64);
     if (extra->Cin <= 16)
-      hipLaunchKernelGGL(k_prep_rows_node3<16>, dim3(total), dim3(256), 0, st, local, btot, (int)N, items, src32,
+      hipLaunchKernelGGL(k_prep_rows_node3<16>, dim3(total), dim3(256), 0, st, local, btot, (int)N, (int)E, items, src32, dst32,
                          reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
                          reinterpret_cast<float4*>(attr_csr), rows_blocks, *extra);
     else
-      hipLaunchKernelGGL(k_prep_rows_node3<32>, dim3(total), dim3(256), 0, st, local, btot, (int)N, items, src32,
+      hipLaunchKernelGGL(k_prep_rows_node3<32>, dim3(total), dim3(256), 0, st, local, btot, (int)N, (int)E, items, src32, dst32,
                          reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
                          reinterpret_cast<float4*>(attr_csr), rows_blocks, *extra);
   } else {
-    hipLaunchKernelGGL(k_prep_rows, dim3(rows_blocks), dim3(256), 0, st, local, btot, (int)N, items, src32,
+    hipLaunchKernelGGL(k_prep_rows, dim3(rows_blocks), dim3(256), 0, st, local, btot, (int)N, (int)E, items, src32, dst32,
                        reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
                        reinterpret_cast<float4*>(attr_csr));
   }
