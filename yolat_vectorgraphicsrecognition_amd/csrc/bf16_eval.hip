@@ -184,6 +184,39 @@ static __global__ void __launch_bounds__(256) k_hgemm_two(HOp A0, HOp B0, Epilog
 // into registers while the current tile's MFMAs and pooling epilogue run, so only the first round trip of a
 // workgroup is exposed.  K <= KD (compile-time LDS extent); columns k >= K are zero-filled.
 // ------------------------------------------------------------------------------------------------
+// Run structure of a lane's 16 rows, derived ONCE per row tile from their segment ids (it is the same for every
+// column and every column tile): keep[r] = 1 if row r continues the run of row r-1 else 0; off[r] = 32-bit element
+// offset of the row's proposal in the pooled matrix; flush_bits bit r = a run of a valid segment ends at row r;
+// uflush bit r = some lane of the wave flushes at r (wave-uniform: rows where nobody flushes cost no exec traffic).
+struct SegRuns { float keep[16]; unsigned off[16]; unsigned flush_bits, uflush; };
+__device__ __forceinline__ void yl_seg_runs(const int sgs[16], unsigned ldpool, SegRuns& sr) {
+  unsigned fb = 0, uf = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    sr.keep[r] = (r > 0 && sgs[r] == sgs[r - 1]) ? 1.f : 0.f;
+    sr.off[r] = (unsigned)(sgs[r] < 0 ? 0 : sgs[r]) * ldpool;
+    const bool fl = sgs[r] >= 0 && (r == 15 || sgs[r] != sgs[r + 1]);
+    fb |= fl ? (1u << r) : 0u;
+    uf |= (__builtin_amdgcn_ballot_w64(fl) != 0ull) ? (1u << r) : 0u;
+  }
+  sr.flush_bits = fb; sr.uflush = uf;
+}
+// Pooling epilogue on that structure: per row one multiply (run reset: values are >= 0, so cur*0 restarts the max)
+// and one 3-operand max (run max, activation, ReLU floor); the integer atomicMax (exact, order-independent) uses a
+// 32-bit offset from a per-lane column pointer.  Same values as wave_epilogue_segmax's compare/select walk.
+__device__ __forceinline__ void segmax_runs(const f32x16& acc, float* pool, unsigned col, bool col_ok, float sc,
+                                            float sh, const SegRuns& sr) {
+  float cur = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cur = fmaxf(fmaxf(cur * sr.keep[r], fmaf(acc[r], sc, sh)), 0.f);
+    if ((sr.uflush >> r) & 1u) {
+      if (((sr.flush_bits >> r) & 1u) && col_ok && cur > 0.f)
+        atomicMax(reinterpret_cast<int*>(pool) + (sr.off[r] + col), __float_as_int(cur));   // uniform base + 32-bit offset
+    }
+  }
+}
+
 template <int TM, int KD> struct HRowsSmem { static constexpr int elems = 64 * (TM + 1) * (KD + 8); };
 
 template <int TM, int KD>
@@ -217,9 +250,13 @@ __device__ __forceinline__ void hgemm_rows(const HOp& A, const HOp& B, const Epi
 #pragma unroll
   for (int i = 0; i < TM; ++i) pre[i] = epi_prefetch(ep, row0 + (wm * TM + i) * 32, ct0 * 64 + wn * 32 + l31, M, N);
   nxt = pre[0];
-  int sgs[TM][16];                        // the rows' segment ids are the same for every column tile
+  SegRuns runs[TM];                       // the rows' run structure is the same for every column tile
 #pragma unroll
-  for (int i = 0; i < TM; ++i) yl_tile_segs(pre[i].segv, lhi, sgs[i]);
+  for (int i = 0; i < TM; ++i) {
+    int sgs[16];
+    yl_tile_segs(pre[i].segv, lhi, sgs);
+    yl_seg_runs(sgs, (unsigned)ep.ldpool, runs[i]);
+  }
   for (int j = 0; j < ng; ++j) {
     const int ct = ct0 + j;
     __syncthreads();                      // the previous tile's fragment reads of Bs are done
@@ -252,9 +289,9 @@ __device__ __forceinline__ void hgemm_rows(const HOp& A, const HOp& B, const Epi
     // pooling epilogue (this kernel exists for the fused per-proposal max): bias, folded BN + ReLU, run-length max
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][r] += pre[i].bias;
-      wave_epilogue_segmax(acc[i], ct * 64 + wn * 32 + l31, ep, N, pre[i].sc, pre[i].sh, sgs[i]);
+      // (acc + bias)*sc + sh = acc*sc + (bias*sc + sh)
+      const int colj = ct * 64 + wn * 32 + l31;
+      segmax_runs(acc[i], ep.pool, (unsigned)colj, colj < N, pre[i].sc, fmaf(pre[i].bias, pre[i].sc, pre[i].sh), runs[i]);
     }
   }
 }
@@ -578,6 +615,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
   if (!x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0) return YOLAT_E_INVALID;
   YL_TRY(model_ok(mh));
   if (N > (1LL << 23) || E > (1LL << 29)) return YOLAT_E_UNSUPPORTED;     // 32-bit element offsets in the gathers
+  if (P * 2 * (mh->base->F + mh->base->C * mh->base->n_blocks_out) >= (1LL << 32)) return YOLAT_E_UNSUPPORTED;
   const yolat_model_eval* m = mh->base;
   PlanH p = carve_h(m, N, E, P, workspace);
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
