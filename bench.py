@@ -155,10 +155,10 @@ def plan_profile(step, n):
 
 
 # HBM/fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-# runs of this same command: profiles/r01_fwd_cfg2_pmc_{fetch,write}_v6.txt; FETCH_SIZE doubled per the gfx950
+# runs of this same command: profiles/r01_fwd_cfg2_pmc_{fetch,write}_v7.txt; FETCH_SIZE doubled per the gfx950
 # note in MI355X_MICROARCH.md §HBM, KiB -> bytes).  Only valid for the default cfg-2 workload.
 PMC_TRAFFIC_CFG2 = {
-    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": 2 * 5963.2 * 1024 + 7980.3 * 1024,
+    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": 2 * 5974.7 * 1024 + 7980.3 * 1024,
 }
 
 
@@ -166,7 +166,7 @@ def roofline_entry(summary, cfg=None):
     r = _roofline_entry(summary)
     if cfg == "2" and r["kernel"] in PMC_TRAFFIC_CFG2:
         r["traffic"] = PMC_TRAFFIC_CFG2[r["kernel"]]
-        r["traffic_source"] = "profiles/r01_fwd_cfg2_pmc_fetch_v6.txt (x2, gfx950) + r01_fwd_cfg2_pmc_write_v6.txt"
+        r["traffic_source"] = "profiles/r01_fwd_cfg2_pmc_fetch_v7.txt (x2, gfx950) + r01_fwd_cfg2_pmc_write_v7.txt"
         r["algorithmic_bytes"] = summary[r["kernel"]]["bytes"]
     return r
 
