@@ -490,6 +490,19 @@ int yolat_forward_eval_bf16(const yolat_model_eval_bf16* m, const float* x, int6
                             int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                             size_t workspace_bytes, int32_t* status, yolat_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------
+ * Post-processing: torchvision.ops.nms(boxes, scores, iou_threshold) as called by the
+ * reference's non_max_suppression (cad_recognition/train.py:34-121 at :105; detect.py:118).
+ * boxes [n,4] fp32 (x1,y1,x2,y2; 16-byte aligned), scores [n] fp32.  keep[0 .. *num_keep) = indices of the kept
+ * boxes in descending score order (ties: ascending index); greedy: a box is dropped when its IoU with a kept,
+ * higher-scored box is > iou_threshold (fp32 arithmetic as in torchvision's kernels).  keep has room for n
+ * entries; num_keep is a DEVICE int32.  work: yolat_nms_work_bytes(n) bytes, 256-byte aligned.
+ * n <= 524288 (the reference caps at max_nms = 30000, train.py:47), else YOLAT_E_UNSUPPORTED.
+ * ------------------------------------------------------------------------------------------ */
+size_t yolat_nms_work_bytes(int64_t n);
+int yolat_nms(const float* boxes, const float* scores, int64_t n, float iou_threshold, int64_t* keep,
+              int32_t* num_keep, void* work, size_t work_bytes, yolat_stream_t stream);
+
 /* Stage profiler of yolat_forward_eval: when enabled, a hipEvent pair is recorded on `stream` around
  * every stage (each stage = the launch(es) of one kernel family); totals accumulate across calls until
  * reset.  yolat_profile_get must be called after the stream has been synchronised.  `flops` / `bytes`

@@ -151,3 +151,34 @@ def conv_gp2_eval(x, x_node, src, dst, attr, p, eps=1e-5):
     out = scatter_mean(m.astype(np.float32), dst, x.shape[0]) + lin(x, p["lin_r.weight"], p["lin_r.bias"])
     xn = np.maximum(bn(lin(x_node, p["mlp_node.0.weight"], p["mlp_node.0.bias"]), "mlp_node.1"), 0)
     return out.astype(np.float32), xn.astype(np.float32)
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms restated (third-party, absent from the image; installed unpinned next to pytorch 1.7.1 by
+    the reference's deepgcn_env_install.sh:21; call site cad_recognition/train.py:105).  Published algorithm
+    (torchvision/csrc/cpu/nms_kernel.cpp): visit boxes in descending score order; a box is kept unless an already
+    kept box overlaps it with IoU > threshold, IoU = inter / (area_i + area_j - inter) in float32 with
+    area = (x2-x1)*(y2-y1) and inter = max(0, min(x2)-max(x1)) * max(0, min(y2)-max(y1)).
+    Ties in score keep ascending index order (torchvision's sort is unstable; fixtures avoid ties).
+    Plain loops: TEST INFRASTRUCTURE for small cases."""
+    b = np.asarray(boxes, dtype=np.float32)
+    s = np.asarray(scores, dtype=np.float32)
+    n = b.shape[0]
+    order = np.argsort(-s, kind="stable")
+    area = ((b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])).astype(np.float32)
+    dead = np.zeros(n, dtype=bool)
+    keep = []
+    for a in range(n):
+        i = order[a]
+        if dead[i]:
+            continue
+        keep.append(i)
+        rest = order[a + 1:]
+        xx1 = np.maximum(b[i, 0], b[rest, 0]); yy1 = np.maximum(b[i, 1], b[rest, 1])
+        xx2 = np.minimum(b[i, 2], b[rest, 2]); yy2 = np.minimum(b[i, 3], b[rest, 3])
+        w = np.maximum(np.float32(0), (xx2 - xx1).astype(np.float32))
+        h = np.maximum(np.float32(0), (yy2 - yy1).astype(np.float32))
+        inter = (w * h).astype(np.float32)
+        ovr = inter / ((area[i] + area[rest]).astype(np.float32) - inter).astype(np.float32)
+        dead[rest[ovr > np.float32(iou_threshold)]] = True
+    return np.asarray(keep, dtype=np.int64)

@@ -1,0 +1,104 @@
+"""GPU tests (-m gpu) of yolat_nms (csrc/nms.hip) and the device post-processing path: indices bit-exact against the
+oracle restatement of torchvision.ops.nms and against the detections of the reference's own non_max_suppression
+(tests/golden/postprocess.npz); size-independent validity properties at the reference's max_nms = 30 000."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import oracle_np as onp
+
+pytestmark = pytest.mark.gpu
+
+
+def _yv():
+    import yolat_vectorgraphicsrecognition_amd as yv
+    return yv
+
+
+def _boxes(rng, n, size=600.0, spread=5.0):
+    centers = rng.random((max(n // 8, 1), 2)) * size
+    c = centers[rng.integers(0, len(centers), size=n)] + rng.normal(0, spread, size=(n, 2))
+    wh = 10 + rng.random((n, 2)) * 50
+    b = np.concatenate([c - wh / 2, c + wh / 2], 1).astype(np.float32)
+    s = rng.permutation(n).astype(np.float32) / n          # distinct scores: no ties
+    return b, s
+
+
+@pytest.mark.parametrize("n", [1, 2, 63, 64, 65, 129, 1000, 4097])
+@pytest.mark.parametrize("thr", [0.3, 0.5])
+def test_nms_matches_oracle_bit_exact(n, thr):
+    yv = _yv()
+    b, s = _boxes(np.random.default_rng(n), n)
+    got = yv.ops.nms(torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda(), thr).cpu().numpy()
+    want = onp.nms(b, s, thr)
+    np.testing.assert_array_equal(got, want)
+    assert 0 < len(got) <= n
+
+
+def test_nms_edge_cases(golden_dir):
+    yv = _yv()
+    z = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    b, s = torch.from_numpy(z["tiny/boxes"]).cuda(), torch.from_numpy(z["tiny/scores"]).cuda()
+    assert yv.ops.nms(b, s, 0.5).tolist() == [0, 2, 4, 5]              # IoU == threshold is kept (strict >)
+    assert yv.ops.nms(b, s, 0.49).tolist() == [0, 2, 4]
+    assert yv.ops.nms(b[:0], s[:0], 0.5).shape == (0,)
+    # score ties resolve by ascending index; identical boxes collapse to the first
+    bb = torch.tensor([[0, 0, 10, 10]] * 5, dtype=torch.float32).cuda()
+    assert yv.ops.nms(bb, torch.ones(5).cuda(), 0.5).tolist() == [0]
+    # degenerate (zero-area) boxes: IoU = 0/0 = nan, never > threshold -> all kept
+    zz = torch.zeros(3, 4).cuda()
+    assert yv.ops.nms(zz, torch.tensor([0.3, 0.2, 0.1]).cuda(), 0.5).tolist() == [0, 1, 2]
+    with pytest.raises(ValueError):
+        yv.ops.nms(torch.zeros(3, 5).cuda(), torch.zeros(3).cuda(), 0.5)
+
+
+@pytest.mark.parametrize("name", ["a", "b", "c", "d"])
+def test_non_max_suppression_on_device_matches_reference(name, golden_dir):
+    yv = _yv()
+    z = np.load(os.path.join(golden_dir, "postprocess.npz"))
+    pred = torch.from_numpy(z["nms_%s/pred" % name].copy()).cuda()
+    if name == "d":
+        out = yv.non_max_suppression(pred, conf_thres=0.1, iou_thres=0.5, classes=[2, 5],
+                                     labels=[torch.from_numpy(z["nms_d/labels"]).cuda()])
+    else:
+        conf, iou, agn = z["nms_%s/args" % name]
+        out = yv.non_max_suppression(pred, conf_thres=float(conf), iou_thres=float(iou), agnostic=bool(agn))
+    assert out[0].is_cuda
+    np.testing.assert_array_equal(out[0].cpu().numpy(), z["nms_%s/out" % name])
+
+
+def test_nms_full_size_validity_properties():
+    """n = 30 000 (the reference's max_nms): (1) deterministic; (2) kept indices in descending score order; (3) no
+    kept pair overlaps above the threshold; (4) every dropped box has a kept, higher-scored box above the threshold;
+    (5) idempotent: NMS of the kept set keeps all of it."""
+    yv = _yv()
+    n, thr = 30000, 0.5
+    b, s = _boxes(np.random.default_rng(3), n, size=3000.0, spread=8.0)
+    bt, st = torch.from_numpy(b).cuda(), torch.from_numpy(s).cuda()
+    keep = yv.ops.nms(bt, st, thr)
+    assert torch.equal(keep, yv.ops.nms(bt, st, thr))
+    assert bool((st[keep][1:] < st[keep][:-1]).all())
+
+    def iou(a, c):
+        lt = torch.max(a[:, None, :2], c[None, :, :2]); rb = torch.min(a[:, None, 2:], c[None, :, 2:])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        aa = ((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]))[:, None]; ac = ((c[:, 2] - c[:, 0]) * (c[:, 3] - c[:, 1]))[None]
+        return inter / (aa + ac - inter)
+
+    kb, ks = bt[keep], st[keep]
+    m = iou(kb, kb)
+    m.fill_diagonal_(0)
+    assert float(m.max()) <= thr
+    dropped = torch.ones(n, dtype=torch.bool, device="cuda")
+    dropped[keep] = False
+    di = dropped.nonzero().flatten()
+    for c0 in range(0, len(di), 4096):
+        d = di[c0:c0 + 4096]
+        ov = iou(bt[d], kb) > thr
+        ov &= ks[None, :] > st[d][:, None]
+        assert bool(ov.any(1).all())
+    assert torch.equal(yv.ops.nms(kb, ks, thr), torch.arange(len(keep), device="cuda"))
+    assert 1000 < len(keep) < n

@@ -434,3 +434,26 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
     check(lib.yolat_adam_step(_f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(),
                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                               int(step), float(grad_scale), _stream()), "yolat_adam_step")
+
+
+def nms(boxes, scores, iou_threshold):
+    """torchvision.ops.nms(boxes, scores, iou_threshold) on the HIP path (csrc/nms.hip, yolat_nms): indices of the
+    kept boxes in descending score order.  boxes [n,4] (x1,y1,x2,y2), scores [n]; both CUDA tensors."""
+    n = int(boxes.shape[0])
+    if boxes.dim() != 2 or boxes.shape[1] != 4 or scores.dim() != 1 or scores.shape[0] != n:
+        raise ValueError("nms expects boxes [n,4] and scores [n]")
+    if n == 0:
+        return torch.empty(0, dtype=torch.int64, device=boxes.device)
+    b = boxes.detach().to(torch.float32).contiguous()
+    s = scores.detach().to(torch.float32).contiguous()
+    if not b.is_cuda or not s.is_cuda:
+        raise ValueError("nms expects CUDA tensors")
+    need = int(lib.yolat_nms_work_bytes(n))
+    if need == 0:
+        raise ValueError("nms supports up to 524288 boxes")
+    work = torch.empty(need, dtype=torch.uint8, device=b.device)
+    keep = torch.empty(n, dtype=torch.int64, device=b.device)
+    cnt = torch.empty(1, dtype=torch.int32, device=b.device)
+    check(lib.yolat_nms(b.data_ptr(), s.data_ptr(), n, float(iou_threshold), keep.data_ptr(), cnt.data_ptr(),
+                        work.data_ptr(), work.numel(), _stream()), "yolat_nms")
+    return keep[:int(cnt.item())]          # D2H sync, as torchvision's sized result implies
