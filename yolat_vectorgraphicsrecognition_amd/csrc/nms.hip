@@ -11,7 +11,7 @@
 //   1. rocPRIM stable radix sort of (score, index) pairs, descending;
 //   2. k_nms_mask: 64 x 64 tiles of the upper triangle, one 64-bit word per (sorted box, column tile);
 //   3. k_nms_reduce: ONE workgroup walks the sorted boxes 64 at a time — the intra-chunk dependency is resolved by
-//      one wave on the diagonal 64 x 64 bit block, then all threads OR the kept rows' words into the removed-set
+//      one wave on the diagonal 64 x 64 bit block, then 16 waves OR the kept rows' words into the removed-set
 //      (LDS) of the later chunks.  n <= 524 288 (the reference caps at max_nms = 30 000, train.py:47).
 #include "common.hpp"
 
@@ -54,41 +54,65 @@ static __global__ void __launch_bounds__(64) k_nms_mask(const float4* __restrict
   mask[(size_t)ri * cb + ct] = bits;
 }
 
-static __global__ void __launch_bounds__(256) k_nms_reduce(const u64* __restrict__ mask, const int* __restrict__ order,
-                                                          int n, int cb, long long* __restrict__ keep,
-                                                          int* __restrict__ num_keep) {
+// One workgroup of 16 waves.  Per chunk c of 64 sorted boxes: wave 0 resolves the chunk on its diagonal bit block
+// (loaded one chunk ahead), then the kept rows' words of the LATER chunks are OR-ed into the removed-set: wave v
+// takes the kept rows v, v+16, ... (at most 4), its 64 lanes cover 64 consecutive words (512 contiguous bytes of
+// a mask row), all of a block's loads are issued before the first is used, one LDS atomic OR per (lane, block).
+// (A first version walked each word's kept rows in a dependent load loop: 12-20 us per chunk, 9.7 ms at n = 30 000.)
+static __global__ void __launch_bounds__(1024) k_nms_reduce(const u64* __restrict__ mask, const int* __restrict__ order,
+                                                           int n, int cb, long long* __restrict__ keep,
+                                                           int* __restrict__ num_keep) {
   extern __shared__ u64 remv[];          // [cb] removed-set, one bit per sorted box
   __shared__ u64 kept_s;
-  const int tid = threadIdx.x;
-  for (int w = tid; w < cb; w += 256) remv[w] = 0ull;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int w = tid; w < cb; w += 1024) remv[w] = 0ull;
+  u64 diag = 0ull;                        // wave 0: lane l holds the diagonal word of sorted box 64 c + l
+  if (wave == 0 && lane < n) diag = mask[(size_t)lane * cb];
   __syncthreads();
   int out = 0;                            // number of boxes kept so far (same value in every thread)
   for (int c = 0; c < cb; ++c) {
-    if (tid < 64) {                       // wave 0: resolve the chunk on its diagonal bit block
-      const int i = c * 64 + tid;
-      const u64 diag = i < n ? mask[(size_t)i * cb + c] : 0ull;
+    if (wave == 0) {
+      u64 next = 0ull;                    // next chunk's diagonal: independent of the removed-set, fetched early
+      if (c + 1 < cb && (c + 1) * 64 + lane < n) next = mask[(size_t)((c + 1) * 64 + lane) * cb + c + 1];
       u64 r = remv[c];
       if (n - c * 64 < 64) r |= ~0ull << (n - c * 64);          // boxes beyond n count as removed
       u64 kept = 0ull;
+#pragma unroll 8
       for (int k = 0; k < 64; ++k) {
         const u64 dk = __shfl(diag, k);
         if (!((r >> k) & 1ull)) { kept |= 1ull << k; r |= dk; }
       }
-      if ((kept >> tid) & 1ull) keep[out + __popcll(kept & ((1ull << tid) - 1ull))] = order[i];
-      if (tid == 0) kept_s = kept;
+      if ((kept >> lane) & 1ull) keep[out + __popcll(kept & ((1ull << lane) - 1ull))] = order[c * 64 + lane];
+      if (lane == 0) kept_s = kept;
+      diag = next;
     }
     __syncthreads();
     const u64 kept = kept_s;
     out += __popcll(kept);
-    for (int w = c + 1 + tid; w < cb; w += 256) {               // later chunks: OR in the kept rows' words
-      u64 acc = 0ull;
+    // this wave's kept rows: the (wave)-th, (wave+16)-th, ... set bits of `kept`
+    int rows[4], nr = 0;
+    {
       u64 kk = kept;
+      int idx = 0;
       while (kk) {
         const int k = __ffsll((long long)kk) - 1;
         kk &= kk - 1;
-        acc |= mask[(size_t)(c * 64 + k) * cb + w];
+        if ((idx & 15) == wave && nr < 4) rows[nr++] = c * 64 + k;
+        ++idx;
       }
-      remv[w] |= acc;
+    }
+    if (nr > 0) {
+      for (int w0 = c + 1; w0 < cb; w0 += 64) {
+        const int w = w0 + lane;
+        const int wc = w < cb ? w : cb - 1;
+        u64 v[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[j] = mask[(size_t)rows[j < nr ? j : 0] * cb + wc];
+        u64 acc = 0ull;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc |= (j < nr) ? v[j] : 0ull;
+        if (w < cb && acc) atomicOr(&remv[w], acc);
+      }
     }
     __syncthreads();
   }
@@ -143,7 +167,7 @@ extern "C" int yolat_nms(const float* boxes, const float* scores, int64_t n, flo
   hipLaunchKernelGGL(k_nms_mask, dim3(p.cb, p.cb), dim3(64), 0, st, reinterpret_cast<const float4*>(boxes), order, (int)n,
                      iou_threshold, p.cb, mask);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(256), sizeof(u64) * (size_t)p.cb, st, mask, order, (int)n, p.cb,
+  hipLaunchKernelGGL(k_nms_reduce, dim3(1), dim3(1024), sizeof(u64) * (size_t)p.cb, st, mask, order, (int)n, p.cb,
                      reinterpret_cast<long long*>(keep), num_keep);
   YL_LAUNCH_CHECK();
   return 0;
