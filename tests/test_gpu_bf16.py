@@ -33,14 +33,17 @@ def _model(yv, optkw, seed):
     return gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), seed).cuda().eval()
 
 
-def _check(name, got, want):
+def _check(name, got, want, depth_factor=1.0):
+    """depth_factor: the error budget grows with the number of rounding stages (~5 per conv layer); the stated
+    bounds are for the reference's depths (n_blocks <= 4), deeper stacks get a proportionally wider band."""
     got, want = got.double().cpu(), want.double().cpu()
     assert got.shape == want.shape and torch.isfinite(got).all(), name
     scale = float(want.abs().max())
     err = float((got - want).abs().max())
     rms = float((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt())
-    assert err <= RTOL_BF16 * scale, "%s: max err %.3e of scale %.3e (rel %.2e)" % (name, err, scale, err / scale)
-    assert rms <= RMS_BF16, "%s: rms rel err %.2e" % (name, rms)
+    assert err <= RTOL_BF16 * depth_factor * scale, "%s: max err %.3e of scale %.3e (rel %.2e)" % (name, err, scale,
+                                                                                                    err / scale)
+    assert rms <= RMS_BF16 * depth_factor, "%s: rms rel err %.2e" % (name, rms)
     return err / scale
 
 
@@ -80,9 +83,10 @@ def test_bf16_eval_forward_vs_reference_golden(kind, golden_dir):
 
 
 @pytest.mark.parametrize("cin,blocks,blocks_out,classes,seed", [(5, 2, 2, 17, 1), (6, 3, 2, 22, 2), (5, 4, 2, 17, 3),
-                                                                 (3, 2, 1, 5, 4), (5, 4, 4, 17, 5)])
+                                                                 (3, 2, 1, 5, 4), (5, 4, 4, 17, 5), (5, 6, 5, 17, 6)])
 def test_bf16_eval_forward_vs_cpu_oracle(cin, blocks, blocks_out, classes, seed):
-    """model shapes incl. the YOLaT++ depth (n_blocks=4, n_blocks_out=2) on a ragged graph (proposals of 2..40 nodes,
+    """model shapes incl. the YOLaT++ depth (n_blocks=4, n_blocks_out=2), the 256-wide (n_blocks_out=4) and the
+    > 256-wide (n_blocks_out=5: per-tile fallback of the fusion GEMM) concatenations, on a ragged graph (proposals of 2..40 nodes,
     nodes without in-edges, duplicate edges) against the CPU oracle in fp32."""
     yv = _yv()
     optkw = dict(n_classes=classes, n_blocks=blocks, n_blocks_out=blocks_out, in_channels=cin)
@@ -97,7 +101,7 @@ def test_bf16_eval_forward_vs_cpu_oracle(cin, blocks, blocks_out, classes, seed)
         got = model(d, None)[0]
         want = ref(d, None)[0]
     model._yolat_plan.check_status()
-    _check("logits", got, want)
+    _check("logits", got, want, depth_factor=max(1.0, blocks / 4.0))
     # the same model object switches back to the fp32 plan (1e-4 bar) on request
     model.set_eval_precision("fp32")
     with torch.no_grad():
