@@ -364,7 +364,9 @@ static Epilogue plain_epilogue() {
 //     the shift);
 //   * 32-bit element offsets for the gathers, 16-byte message rows (LDM = 68) for the per-node sums.
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-static __global__ void __launch_bounds__(256, 4) k_edge_uv_mlp2_mean_h(
+// NG = 16-node groups per tile: 1 (<= 16 nodes) or 4 (<= 64 nodes, for graphs with ~1 edge per node).
+template <int NG>
+static __global__ void __launch_bounds__(256, (NG == 1 ? 4 : 3)) k_edge_uv_mlp2_mean_h(
     const u16* __restrict__ UV, unsigned ld_uv, const int* __restrict__ src, const int* __restrict__ dst,
     const float* __restrict__ attr, const int* __restrict__ row_ptr, int N, int npt, const float* __restrict__ Wc4,
     const float* __restrict__ s1, const u16* __restrict__ W2h, const float* __restrict__ b2,
@@ -373,12 +375,12 @@ static __global__ void __launch_bounds__(256, 4) k_edge_uv_mlp2_mean_h(
   constexpr int LDM = 68;
   __shared__ __attribute__((aligned(16))) u16 Hs[64 * YL_HRS];   // layer-1 activations of the pass (bf16)
   __shared__ __attribute__((aligned(16))) float Ms[64 * LDM];   // layer-2 messages of the pass (fp32)
-  __shared__ int rp[17];
+  __shared__ int rp[16 * NG + 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
   const int n0 = blockIdx.x * npt;
   const int nn = yl_min(npt, N - n0);
-  if (tid <= 16) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
+  if (tid <= 16 * NG) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
   const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t
   const int col = wn * 32 + l31;                      // MFMA role: output column of this lane
   bf16x8 w2f[4];
@@ -402,10 +404,15 @@ static __global__ void __launch_bounds__(256, 4) k_edge_uv_mlp2_mean_h(
   const float sh2 = fmaf(b2 ? b2[col] : 0.f, sc2, s2 ? t2[col] : 0.f);    // (acc + b2)*s2 + t2 = acc*s2 + sh2
   __syncthreads();
   const int e0 = rp[0], e1 = rp[nn];
-  const int my_b = rp[yl_min(rb, nn)], my_e = rp[yl_min(rb + 1, nn)];   // aggregation role: node rb, columns 4q..
-  float4 rootv = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (rb < nn) rootv = *reinterpret_cast<const float4*>(root + (unsigned)(n0 + rb) * ld_r + 4 * q);
-  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  int my_b[NG], my_e[NG];                             // aggregation role: nodes rb + 16 j, columns 4q..
+  float4 rootv[NG], sum[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    my_b[j] = rp[yl_min(rb + 16 * j, nn)]; my_e[j] = rp[yl_min(rb + 16 * j + 1, nn)];
+    rootv[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (rb + 16 * j < nn) rootv[j] = *reinterpret_cast<const float4*>(root + (unsigned)(n0 + rb + 16 * j) * ld_r + 4 * q);
+    sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int c0 = e0; c0 < e1; c0 += 64) {
     unsigned di[4], si[4];
 #pragma unroll
@@ -460,22 +467,28 @@ static __global__ void __launch_bounds__(256, 4) k_edge_uv_mlp2_mean_h(
       }
     }
     __syncthreads();                      // Ms complete; every wave is done reading Hs
-    if (rb < nn) {                        // rows of node rb inside this pass, ascending edge order
-      const int lo = (my_b > c0 ? my_b : c0) - c0;
-      const int hi = (my_e < c0 + 64 ? my_e : c0 + 64) - c0;
-      for (int e = lo; e < hi; ++e) {
-        const float4 m = *reinterpret_cast<const float4*>(Ms + e * LDM + 4 * q);
-        sum.x += m.x; sum.y += m.y; sum.z += m.z; sum.w += m.w;
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      if (rb + 16 * j < nn) {             // rows of node rb + 16 j inside this pass, ascending edge order
+        const int lo = (my_b[j] > c0 ? my_b[j] : c0) - c0;
+        const int hi = (my_e[j] < c0 + 64 ? my_e[j] : c0 + 64) - c0;
+        for (int e = lo; e < hi; ++e) {
+          const float4 m = *reinterpret_cast<const float4*>(Ms + e * LDM + 4 * q);
+          sum[j].x += m.x; sum[j].y += m.y; sum[j].z += m.z; sum[j].w += m.w;
+        }
       }
     }
   }
-  if (rb < nn) {
-    const int deg = my_e - my_b;
-    const float inv = 1.f / (float)(deg > 1 ? deg : 1);
-    u32x2 o;
-    o.x = yl_pack_bf16(fmaf(sum.x, inv, rootv.x), fmaf(sum.y, inv, rootv.y));
-    o.y = yl_pack_bf16(fmaf(sum.z, inv, rootv.z), fmaf(sum.w, inv, rootv.w));
-    *reinterpret_cast<u32x2*>(f_out + ((unsigned)(n0 + rb) * ld_fo + 4 * q)) = o;
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    if (rb + 16 * j < nn) {
+      const int deg = my_e[j] - my_b[j];
+      const float inv = 1.f / (float)(deg > 1 ? deg : 1);
+      u32x2 o;
+      o.x = yl_pack_bf16(fmaf(sum[j].x, inv, rootv[j].x), fmaf(sum[j].y, inv, rootv[j].y));
+      o.y = yl_pack_bf16(fmaf(sum[j].z, inv, rootv[j].z), fmaf(sum[j].w, inv, rootv[j].w));
+      *reinterpret_cast<u32x2*>(f_out + ((unsigned)(n0 + rb + 16 * j) * ld_fo + 4 * q)) = o;
+    }
   }
 }
 
@@ -641,12 +654,12 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
                                  p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, stream));
   });
-  long npt = E > 0 ? (56 * N) / E : 16;
+  long npt = E > 0 ? (56 * N) / E : 64;
   {
     const long npt2 = E > 0 ? ((112 * N) / E < 16 ? (112 * N) / E : 16) : 16;
     if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
     if (npt < 1) npt = 1;
-    if (npt > 16) npt = 16;
+    if (npt > 64) npt = 64;
   }
   for (int l = 0; l < m->n_blocks; ++l) {
     const yolat_conv_eval& cv = m->conv[l];
@@ -669,7 +682,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     }
     snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
     YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 2.0 + 16.0 + 8.0) + 4.0 * N * C + 2.0 * N * C + 4.0 * N, {
-    hipLaunchKernelGGL(k_edge_uv_mlp2_mean_h, dim3(yl_cdiv(N, npt)), dim3(256), 0, st, p.UV, (unsigned)(2 * C), p.src,
+    hipLaunchKernelGGL((npt <= 16 ? k_edge_uv_mlp2_mean_h<1> : k_edge_uv_mlp2_mean_h<4>), dim3(yl_cdiv(N, npt)), dim3(256), 0, st, p.UV, (unsigned)(2 * C), p.src,
                          p.dst, p.attr, p.row_ptr, (int)N, (int)npt, cv.Wc4, cv.s1, mh->W2[l], cv.b2, cv.s2, cv.t2, p.root,
                          (unsigned)C, f_slot(l), (unsigned)ld_slot(l), (int)(E > 0 ? E : 1));
     YL_LAUNCH_CHECK();

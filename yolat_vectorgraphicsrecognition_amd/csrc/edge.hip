@@ -271,6 +271,9 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2(const float* __restrict__ 
 // the end  f_out[n] += sum / deg  on top of the root Linear the node-side launch wrote.  No atomics; the
 // per-node summation order is the CSR order, bit-identical to k_edge_uv_mlp2 + k_csr_mean_fwd.
 // ------------------------------------------------------------------------------------------------
+// NG = 16-node groups per tile: 1 (<= 16 nodes, the dense-graph case) or 4 (<= 64 nodes: graphs with ~1 edge per
+// node — the Floorplans shape — would otherwise fill a 64-edge pass to a third).
+template <int NG>
 __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restrict__ UV, long ld_uv,
                                                            const int* __restrict__ src,
                                                            const int* __restrict__ dst,
@@ -287,12 +290,12 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   constexpr int LDH = 65;
   __shared__ float Hs[64 * LDH];      // layer-1 activations of the pass, then the layer-2 messages
   __shared__ float W2s[64 * LDH];
-  __shared__ int rp[17];
+  __shared__ int rp[16 * NG + 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
   const int n0 = blockIdx.x * npt;
   const int nn = yl_min(npt, N - n0);                 // nodes of this tile
-  if (tid <= 16) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
+  if (tid <= 16 * NG) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
   const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t
   const int col = wn * 32 + l31;                      // MFMA role: output column of this lane
   float rw2[4][4];
@@ -316,8 +319,13 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   }
   __syncthreads();
   const int e0 = rp[0], e1 = rp[nn];
-  const int my_b = rp[yl_min(rb, nn)], my_e = rp[yl_min(rb + 1, nn)];   // aggregation role: node rb, columns 4q..
-  float4 sum = make_float4(0.f, 0.f, 0.f, 0.f);
+  int my_b[NG], my_e[NG];                             // aggregation role: nodes rb + 16 j, columns 4q..
+  float4 sum[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    my_b[j] = rp[yl_min(rb + 16 * j, nn)]; my_e[j] = rp[yl_min(rb + 16 * j + 1, nn)];
+    sum[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+  }
   for (int c0 = e0; c0 < e1; c0 += 64) {
     int di[4], si[4];
 #pragma unroll
@@ -363,25 +371,29 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       Hs[row * LDH + col] = fmaxf(fmaf(acc2[r] + bias2, sc2, sh2), 0.f);
     }
     __syncthreads();
-    if (rb < nn) {                        // rows of node rb inside this pass, ascending edge order
-      const int lo = my_b > c0 ? my_b : c0;
-      const int hi = my_e < c0 + 64 ? my_e : c0 + 64;
-      for (int e = lo; e < hi; ++e) {
-        const float* m = Hs + (e - c0) * LDH + 4 * q;
-        sum.x += m[0]; sum.y += m[1]; sum.z += m[2]; sum.w += m[3];
+#pragma unroll
+    for (int j = 0; j < NG; ++j) {
+      if (rb + 16 * j < nn) {             // rows of node rb + 16 j inside this pass, ascending edge order
+        const int lo = my_b[j] > c0 ? my_b[j] : c0;
+        const int hi = my_e[j] < c0 + 64 ? my_e[j] : c0 + 64;
+        for (int e = lo; e < hi; ++e) {
+          const float* m = Hs + (e - c0) * LDH + 4 * q;
+          sum[j].x += m[0]; sum[j].y += m[1]; sum[j].z += m[2]; sum[j].w += m[3];
+        }
       }
     }
     __syncthreads();
   }
-  if (rb < nn) {
-    const int deg = my_e - my_b;
-    if (deg > 0) {
+#pragma unroll
+  for (int j = 0; j < NG; ++j) {
+    const int deg = my_e[j] - my_b[j];
+    if (rb + 16 * j < nn && deg > 0) {
       const float inv = 1.f / (float)deg;
-      float4* o = reinterpret_cast<float4*>(f_out + (long)(n0 + rb) * ld_fo + 4 * q);
+      float4* o = reinterpret_cast<float4*>(f_out + (long)(n0 + rb + 16 * j) * ld_fo + 4 * q);
       float4 d = *o;
       // explicit mul then add (no fma contraction): the same two roundings as k_csr_mean_fwd*
-      d.x = yl_mul_rn(sum.x, inv) + d.x; d.y = yl_mul_rn(sum.y, inv) + d.y;
-      d.z = yl_mul_rn(sum.z, inv) + d.z; d.w = yl_mul_rn(sum.w, inv) + d.w;
+      d.x = yl_mul_rn(sum[j].x, inv) + d.x; d.y = yl_mul_rn(sum[j].y, inv) + d.y;
+      d.z = yl_mul_rn(sum[j].z, inv) + d.z; d.w = yl_mul_rn(sum[j].w, inv) + d.w;
       *o = d;
     }
   }
@@ -409,11 +421,16 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, cons
   if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
   if (const char* e = getenv("YOLAT_EDGE_NPT")) npt = atol(e);     // tuning hook
   if (npt < 1) npt = 1;
-  if (npt > 16) npt = 16;
+  if (npt > 64) npt = 64;
   DenseOp w2 = yl_dense(W2, C, C, C);
-  hipLaunchKernelGGL(k_edge_uv_mlp2_mean, dim3(yl_cdiv(N, npt)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
-                     src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
-                     (long)ld_fo, (int)E);
+  if (npt <= 16)
+    hipLaunchKernelGGL(k_edge_uv_mlp2_mean<1>, dim3(yl_cdiv(N, npt)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
+                       src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
+                       (long)ld_fo, (int)E);
+  else
+    hipLaunchKernelGGL(k_edge_uv_mlp2_mean<4>, dim3(yl_cdiv(N, npt)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
+                       src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
+                       (long)ld_fo, (int)E);
   YL_LAUNCH_CHECK();
   return 0;
 }
