@@ -593,6 +593,11 @@ int model_ok(const yolat_model_eval_bf16* mh) {
 template <class AL>
 int launch_hgemm(const AL& A, const HOp& B, const Epilogue& ep, long M, long N, long K, hipStream_t st) {
   if (K % 64 != 0 || M <= 0 || N <= 0) return YOLAT_E_UNSUPPORTED;
+  static const int wide = getenv("YOLAT_HGEMM_WIDE") ? atoi(getenv("YOLAT_HGEMM_WIDE")) : 1;   // 64x128 tiles once they still fill the GPU (cfg 5 classifier 1: 55 -> 45 us)
+  if (wide && N % 128 == 0 && (long)yl_cdiv(M, 64) * (N / 128) >= 256)
+    hipLaunchKernelGGL((k_hgemm<1, 2, AL>), dim3(yl_cdiv(M, 64), N / 128), dim3(256), 0, st, A, B, ep, (int)M, (int)N,
+                       (int)K);
+  else
   hipLaunchKernelGGL((k_hgemm<1, 1, AL>), dim3(yl_cdiv(M, 64), yl_cdiv(N, 64)), dim3(256), 0, st, A, B, ep, (int)M, (int)N,
                      (int)K);
   YL_LAUNCH_CHECK();
