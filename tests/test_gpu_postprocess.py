@@ -102,3 +102,50 @@ def test_nms_full_size_validity_properties():
         assert bool(ov.any(1).all())
     assert torch.equal(yv.ops.nms(kb, ks, thr), torch.arange(len(keep), device="cuda"))
     assert 1000 < len(keep) < n
+
+
+def test_evaluation_loop_predict_softmax_nms_metrics_end_to_end():
+    """The reference's evaluation loop on one batch (train.py:371-460): two-pass predict -> per image softmax ->
+    [1 - P(last class), P(other classes)] -> class-aware NMS -> true-positive statistics -> AP, everything on the
+    device path, against the same pipeline built from the CPU oracle (oracle predict + oracle nms)."""
+    import golden_util as gu
+    from oracle import oracle_torch as orc
+    from yolat_vectorgraphicsrecognition_amd import postprocess
+    yv = _yv()
+    data, slices = gu.predict_case(yv.synth_batch)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**gu.PREDICT_OPT)), 5).cuda().eval()
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**gu.PREDICT_OPT)), 5).eval()
+    with torch.no_grad():
+        cls, box, _, _, img_ptr, _ = model.predict(data, slices)
+        rcls, rbox, _, _, rimg_ptr, _ = ref.predict(data, slices)
+    assert list(img_ptr) == list(rimg_ptr)
+
+    def per_image(pc, pb, nms_fn, dev):
+        outs = []
+        for i in range(len(img_ptr) - 1):
+            c = torch.softmax(pc[img_ptr[i]:img_ptr[i + 1]].float(), dim=1)
+            b = pb[img_ptr[i]:img_ptr[i + 1]].float() * 1000.0          # boxes in pixels of a 1000 x 1000 page
+            conf = torch.cat((1 - c[:, -1:], c[:, :-1]), 1)
+            pred = torch.cat((b, conf), 1).unsqueeze(0).to(dev)
+            outs.append(nms_fn(pred)[0].cpu())
+        return outs
+
+    got = per_image(cls, box, lambda p: yv.non_max_suppression(p, conf_thres=0.0, iou_thres=0.5), "cuda")
+    saved = postprocess.ops.nms
+    try:      # the oracle pipeline: same host logic, numpy nms, CPU tensors
+        postprocess.ops.nms = lambda b, s, t: torch.from_numpy(onp.nms(b.numpy(), s.numpy(), float(t)))
+        want = per_image(rcls, rbox, lambda p: yv.non_max_suppression(p, conf_thres=0.0, iou_thres=0.5), "cpu")
+    finally:
+        postprocess.ops.nms = saved
+    for g, w in zip(got, want):
+        assert g.shape == w.shape and g.shape[0] > 0
+        np.testing.assert_array_equal(g[:, 5].numpy(), w[:, 5].numpy())                      # classes, in order
+        np.testing.assert_allclose(g[:, :5].numpy(), w[:, :5].numpy(), rtol=1e-4, atol=1e-4)  # boxes, conf
+    # metrics: every image's own top detections as its targets -> all of them are true positives, AP = 1
+    for g in got:
+        k = min(10, g.shape[0])
+        targets = torch.cat((torch.zeros(k, 1), g[:k, 5:6], g[:k, :4]), 1)
+        tp = yv.get_batch_statistics([g], targets, iou_threshold=0.5)[0][0]
+        assert tp[:k].sum() >= 1 and tp.sum() <= k
+        p, r, ap, f1, c = yv.ap_per_class(tp, g[:, 4].numpy(), g[:, 5].numpy(), targets[:, 1].numpy())
+        assert ((0 <= ap) & (ap <= 1)).all() and len(c) == len(np.unique(targets[:, 1].numpy()))
