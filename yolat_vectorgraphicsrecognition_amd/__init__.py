@@ -19,6 +19,7 @@ from .architecture import Backbone, SparseCADGCN, DetectionLoss, Opt  # noqa: F4
 from .data import (Data, collate, collate_to_device, fixup_offsets, synth_graph, synth_batch, synth_roots, idxTree, config,  # noqa: F401
                    select_tree_nodes, build_subset)
 from .postprocess import non_max_suppression, get_batch_statistics, ap_per_class, compute_ap, bbox_iou  # noqa: F401
+from .evaluation import evaluate_batch, test as evaluate  # noqa: F401
 from .trainer import FlatParams, FlatAdam, Trainer, shard_graph_ids, allreduce_mean_, broadcast_parameters  # noqa: F401
 
 __version__ = "0.1.0"
