@@ -47,7 +47,7 @@ def parse():
                     help="fwd mode: storage precision of the eval forward.  fp32 (default) is the parity mode the "
                          "headline metric is quoted in; bf16 = bf16 node activations / weights with fp32 accumulation "
                          "(csrc/bf16_eval.hip), the mode BASELINE.json's configs[4] names — use with --config 5")
-    ap.add_argument("--streams", type=int, default=16,
+    ap.add_argument("--streams", type=int, default=32,
                     help="fwd mode: independent forwards are issued round-robin on this many HIP streams "
                          "(1 = strictly one forward at a time)")
     return ap.parse_args()
