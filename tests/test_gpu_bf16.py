@@ -200,3 +200,31 @@ def test_bf16_unsupported_shapes_fail_loudly():
         model(d, None)
     with pytest.raises(ValueError):
         model.set_eval_precision("fp16")
+
+
+def test_bf16_hip_graph_replay_and_concurrent_streams_match_direct_launches():
+    """the bf16 plan under the two serving-side mechanisms of the fp32 plan: hipGraph replay (same input buffers) and
+    independent forwards on concurrent streams — both bit-identical to a direct launch on the default stream."""
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2)
+    model = _model(yv, optkw, 21).set_eval_precision("bf16")
+    d = yv.synth_graph(num_proposals=150, nodes_lo=5, nodes_hi=30, edge_factor=2.5, seed=5)
+    for k in ("x", "edge", "e_attr", "bbox_idx", "bbox"):
+        d[k] = d[k].cuda()
+    with torch.no_grad():
+        want = model(d, None)[0].clone()
+        model.use_hip_graphs(True)
+        outs = [model(d, None)[0].clone() for _ in range(4)]       # launch, capture, replay, replay
+        model.use_hip_graphs(False)
+    for o in outs:
+        assert torch.equal(o, want)
+    streams = [torch.cuda.Stream() for _ in range(4)]
+    res = []
+    with torch.no_grad():
+        for rep in range(3):
+            for s in streams:
+                with torch.cuda.stream(s):
+                    res.append(model(d, None)[0])
+    torch.cuda.synchronize()
+    for o in res:
+        assert torch.equal(o, want)
