@@ -166,6 +166,36 @@ __global__ void __launch_bounds__(256) k_segment_max_bwd(const float* dY, long l
   }
 }
 
+// D % 128 == 0, aligned rows: 32 lanes x float4 per row (a wave writes 2 rows = 1 KiB per store)
+__global__ void __launch_bounds__(256) k_segment_mean_bwd_v4(const float* __restrict__ dY, long lddy, int D,
+                                                             const int* __restrict__ seg_ptr,
+                                                             const int* __restrict__ node_seg, long N,
+                                                             float* __restrict__ dX, long lddx) {
+  const int c = blockIdx.x * 128 + (threadIdx.x & 31) * 4;
+  for (long r = (long)blockIdx.y * 8 + (threadIdx.x >> 5); r < N; r += (long)gridDim.y * 8) {
+    const int p = node_seg[r];
+    const int cnt = seg_ptr[p + 1] - seg_ptr[p];
+    const float d = (float)(cnt > 1 ? cnt : 1);
+    const float4 g = *reinterpret_cast<const float4*>(dY + (long)p * lddy + c);
+    *reinterpret_cast<float4*>(dX + r * lddx + c) = make_float4(g.x / d, g.y / d, g.z / d, g.w / d);
+  }
+}
+
+__global__ void __launch_bounds__(256) k_segment_max_bwd_v4(const float* __restrict__ dY, long lddy, int D,
+                                                            const int* __restrict__ arg,
+                                                            const int* __restrict__ node_seg, long N,
+                                                            float* __restrict__ dX, long lddx) {
+  const int c = blockIdx.x * 128 + (threadIdx.x & 31) * 4;
+  for (long r = (long)blockIdx.y * 8 + (threadIdx.x >> 5); r < N; r += (long)gridDim.y * 8) {
+    const int p = node_seg[r];
+    const int4 a = *reinterpret_cast<const int4*>(arg + (long)p * D + c);
+    const float4 g = *reinterpret_cast<const float4*>(dY + (long)p * lddy + c);
+    const int ri = (int)r;
+    *reinterpret_cast<float4*>(dX + r * lddx + c) =
+        make_float4(a.x == ri ? g.x : 0.f, a.y == ri ? g.y : 0.f, a.z == ri ? g.z : 0.f, a.w == ri ? g.w : 0.f);
+  }
+}
+
 extern "C" int yolat_segment_mean_bwd(const float* dY, int64_t lddy, int64_t D,
                                       const int32_t* seg_ptr, const int32_t* node_seg, int64_t N,
                                       float* dX, int64_t lddx, yolat_stream_t stream) {
@@ -174,6 +204,10 @@ extern "C" int yolat_segment_mean_bwd(const float* dY, int64_t lddy, int64_t D,
   if (!dY || !seg_ptr || !node_seg || !dX) return YOLAT_E_INVALID;
   int gy = yl_cdiv(N, 4);
   if (gy > 4096) gy = 4096;
+  if (D % 128 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && yl_aligned16(dY) && yl_aligned16(dX))
+    hipLaunchKernelGGL(k_segment_mean_bwd_v4, dim3(D / 128, gy), dim3(256), 0, (hipStream_t)stream, dY, (long)lddy, (int)D,
+                       seg_ptr, node_seg, (long)N, dX, (long)lddx);
+  else
   hipLaunchKernelGGL(k_segment_mean_bwd, dim3(yl_cdiv(D, 64), gy), dim3(256), 0,
                      (hipStream_t)stream, dY, (long)lddy, (int)D, seg_ptr, node_seg, (long)N, dX,
                      (long)lddx);
@@ -189,6 +223,10 @@ extern "C" int yolat_segment_max_bwd(const float* dY, int64_t lddy, int64_t D, c
   if (!dY || !arg || !node_seg || !dX) return YOLAT_E_INVALID;
   int gy = yl_cdiv(N, 4);
   if (gy > 4096) gy = 4096;
+  if (D % 128 == 0 && lddy % 4 == 0 && lddx % 4 == 0 && yl_aligned16(dY) && yl_aligned16(dX) && yl_aligned16(arg))
+    hipLaunchKernelGGL(k_segment_max_bwd_v4, dim3(D / 128, gy), dim3(256), 0, (hipStream_t)stream, dY, (long)lddy, (int)D,
+                       arg, node_seg, (long)N, dX, (long)lddx);
+  else
   hipLaunchKernelGGL(k_segment_max_bwd, dim3(yl_cdiv(D, 64), gy), dim3(256), 0,
                      (hipStream_t)stream, dY, (long)lddy, (int)D, arg, node_seg, (long)N, dX,
                      (long)lddx);
