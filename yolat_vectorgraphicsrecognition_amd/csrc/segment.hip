@@ -15,7 +15,21 @@ __global__ void __launch_bounds__(256) k_segment_mean_fwd(const float* X, long l
   const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
   const float sc = xs ? xs[c] : 1.f, sh = xs ? xb[c] : 0.f;
   float s = 0.f;
-  for (int r = r0; r < r1; ++r) {
+  // rows are read 8 at a time (independent loads in flight); the sum itself still runs in row order
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = X[(long)(r + j) * ldx + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = v[j];
+      if (xs) t = fmaf(t, sc, sh);
+      if (relu) t = fmaxf(t, 0.f);
+      s += t;
+    }
+  }
+  for (; r < r1; ++r) {
     float v = X[(long)r * ldx + c];
     if (xs) v = fmaf(v, sc, sh);
     if (relu) v = fmaxf(v, 0.f);
@@ -36,7 +50,20 @@ __global__ void __launch_bounds__(256) k_segment_max_fwd(const float* X, long ld
   const float sc = xs ? xs[c] : 1.f, sh = xs ? xb[c] : 0.f;
   float best = 0.f;
   int a = N;  // empty segment -> 0, arg = N   (torch_scatter semantics)
-  for (int r = r0; r < r1; ++r) {
+  int r = r0;
+  for (; r + 8 <= r1; r += 8) {                  // 8 independent loads in flight, compared in row order
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = X[(long)(r + j) * ldx + c];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = v[j];
+      if (xs) t = fmaf(t, sc, sh);
+      if (relu) t = fmaxf(t, 0.f);
+      if (a == N || t > best) { best = t; a = r + j; }
+    }
+  }
+  for (; r < r1; ++r) {
     float v = X[(long)r * ldx + c];
     if (xs) v = fmaf(v, sc, sh);
     if (relu) v = fmaxf(v, 0.f);

@@ -85,6 +85,7 @@ class _MLPFn(torch.autograd.Function):
                 raise NotImplementedError("training-mode Dropout2d has no MI355X kernel (recipe uses dropout 0.0)")
             a, sv = engine.lbr_fwd(a, lin, bn, relu, training)
             saved.append(sv)
+        engine.flush_batch_counters()
         ctx.mlp, ctx.saved_blocks, ctx.params = mlp, saved, params
         if not training:
             ctx.saved_blocks = None
@@ -151,6 +152,7 @@ class _ConvFn(torch.autograd.Function):
     def forward(ctx, conv, g, x, x_node, *params):
         training = conv.training
         f, s, sv = engine.conv_fwd(conv, g, x, Lazy(x_node), None, None, training)
+        engine.flush_batch_counters()
         ctx.conv, ctx.g, ctx.params = conv, g, params
         ctx.sv = sv if training else None
         return f, s.materialise()
