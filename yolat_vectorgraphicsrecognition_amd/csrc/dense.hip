@@ -456,9 +456,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_partial(const float* dZ, long ld
 }
 
 // Same partial sums for the common case (C % 4 == 0, 16-byte aligned rows): float4 columns per lane (a wave covers
-// 4 rows = 1 KiB per load), 4 independent row loads in flight per thread, 1024-row blocks (4x fewer partials for
+// 4 rows = 1 KiB per load), 4 independent row loads in flight per thread, 512-row blocks (half the partials for
 // the finalize kernel).  The one-float-per-lane kernel above ran at 3 TB/s (36 us for 2 x 54 MB at E = 212k).
-#define BNB_ROWS_V4 1024
+#define BNB_ROWS_V4 512
 __global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const float* __restrict__ dZ, long lddz,
                                                            const float* __restrict__ Y, long ldy, long M, int C,
                                                            const float* __restrict__ mean,
