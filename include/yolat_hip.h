@@ -274,6 +274,15 @@ int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64
                        const float* Wuv, const float* Wr, const float* br, const float* Wn, const float* bn,
                        const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv, float* f_out,
                        int64_t ld_fo, float* s_out, int64_t ld_so, yolat_stream_t stream);
+/* Training-forward form of the factorised first edge Linear (no BatchNorm applied):
+ *   H1[q] = U[dst_q] + V[src_q] + W1c.attr_q + b1,   UV [N,2C] = x.[W1a-W1b | W1b]^T from a dense Linear
+ * (yolat_conv_split_w1 + yolat_linear_fwd).  stats (nullable): BatchNorm partial statistics in the format of
+ * yolat_linear_fwd's `stats` (yolat_bn_stats_elems(E, C) floats) for yolat_bn_finalize.  Replaces
+ * yolat_edge_lin1_fwd (torch_vertex.py:324,331,335 + nn.0) when E >> N.  C must be 64.                */
+int yolat_edge_uv_lin1_fwd(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                           const float* attr_csr, int64_t E, const float* Wc4, const float* b1, int64_t C,
+                           float* H1, int64_t ldh, float* stats, yolat_stream_t stream);
+
 /* yolat_edge_uv_mlp2_mean_eval: the same edge MLP with the mean aggregation fused in:
  *   f_out[n] += mean_{q in CSR row n} H2[q]       (H2 is never written; f_out already holds lin_r(f_in))
  * per-node summation in CSR order -> bit-identical to yolat_edge_uv_mlp2_eval + yolat_csr_mean_fwd(accumulate). */

@@ -794,3 +794,35 @@ def test_fused_edge_mean_is_bit_identical_to_edge_kernel_plus_csr_mean(N, E):
                                            p1[1].data_ptr(), W2.data_ptr(), b2.data_ptr(), p2[0].data_ptr(),
                                            p2[1].data_ptr(), 64, got[:, 64:].data_ptr(), 128, st))
     assert torch.equal(got, want)
+
+
+@pytest.mark.parametrize("N,E", [(300, 1000), (50, 31), (2000, 9001), (64, 64), (1000, 4097)])
+def test_factorised_training_edge_lin1_matches_gathered_gemm(N, E):
+    """training-forward form of the factorised first edge Linear (yolat_edge_uv_lin1_fwd): the pre-activation H1 and
+    the BatchNorm batch statistics agree with the float64 restatement of cat[x_i, x_j - x_i, attr] @ W1^T + b1 and
+    with the gathered-GEMM kernel."""
+    yv = _yv()
+    C = Cin = 64
+    src, dst, xfull, attr = _edge_case(N, E, Cin, 3 * N + E, ldx=Cin + 64)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    order = np.argsort(dst, kind="stable")
+    tg = torch.Generator().manual_seed(2)
+    W1 = torch.randn(C, 2 * Cin + 4, generator=tg) / (2 * Cin + 4) ** 0.5
+    b1 = torch.randn(C, generator=tg)
+    xt = torch.from_numpy(xfull[:, :Cin].copy())
+    s_c, d_c = torch.from_numpy(src[order]), torch.from_numpy(dst[order])
+    F = torch.cat([xt[d_c], xt[s_c] - xt[d_c], torch.from_numpy(attr[order])], 1).double()
+    want = F @ W1.double().T + b1.double()
+    xd = dev(xfull)[:, :Cin]
+    H1 = torch.empty(E, C).cuda()
+    stats = yv.ops.stats_buffer(E, C, "cuda")
+    yv.ops.edge_lin1_fwd_factorised(xd, g, W1.cuda(), b1.cuda(), H1, stats=stats)
+    close(H1, want, msg="H1 (factorised)")
+    H1g = torch.empty(E, C).cuda()
+    yv.ops.edge_lin1_fwd(xd, g, W1.cuda(), b1.cuda(), H1g)
+    assert float((H1 - H1g).abs().max()) <= 1e-5 * float(want.abs().max())
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    coef = torch.empty(4, C).cuda()
+    yv.ops.bn_finalize(stats, E, bn, coef[0], coef[1], coef[2], coef[3])
+    close(coef[2], want.mean(0), msg="edge batch mean (factorised)")
+    close(coef[3], 1 / torch.sqrt(want.var(0, unbiased=False) + 1e-5), msg="edge invstd (factorised)")

@@ -129,6 +129,7 @@ SIGNATURES = {
     "yolat_forward_eval_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEval), c_i64, c_i64, c_i64]),
     "yolat_forward_eval": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64,
                                    c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_edge_uv_lin1_fwd": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_nms_work_bytes": (c_sz, [c_i64]),
     "yolat_nms": (c_int, [c_p, c_p, c_i64, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "yolat_f32_to_bf16": (c_int, [c_p, c_i64, c_p, c_p]),

@@ -435,6 +435,90 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, cons
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Factorised FIRST edge Linear for the training forward:  H1[q] = U[dst_q] + V[src_q] + W1c.attr_q + b1
+// (UV = x.[W1a-W1b | W1b]^T computed once per node by a dense GEMM), plus the BatchNorm partial statistics in the
+// GEMM epilogue's format (float2 (sum, M2 about the group mean) per 32-row group and column).  Replaces the
+// gathered K = 2 Cin + 4 GEMM when E >> N: at E = 1.2 M / N = 200 k that GEMM ran at 17 TFLOP/s (1.19 ms) because
+// its A operand is two random 256-B row gathers per edge.  One workgroup = 64 edges: thread (row rb + 16 t,
+// columns 4q..) writes its 16 bytes of H1 and parks them in LDS; 128 threads then reduce the two 32-row groups.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_uv_lin1(const float* __restrict__ UV, long ld_uv,
+                                                      const int* __restrict__ src, const int* __restrict__ dst,
+                                                      const float* __restrict__ attr, int E,
+                                                      const float* __restrict__ Wc4, const float* __restrict__ b1,
+                                                      float* __restrict__ H1, long ldh, float2* __restrict__ stats) {
+  constexpr int LDT = 65;
+  __shared__ float T[64 * LDT];
+  const int tid = threadIdx.x, q = tid & 15, rb = tid >> 4;
+  const int row0 = blockIdx.x * 64;
+  float4 wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (b1) bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+  int di[4], si[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = yl_min(row0 + rb + 16 * t, E - 1);
+    di[t] = dst[e]; si[t] = src[e];
+  }
+  float4 u[4], v[4], a[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = yl_min(row0 + rb + 16 * t, E - 1);
+    u[t] = *reinterpret_cast<const float4*>(UV + (long)di[t] * ld_uv + 4 * q);
+    v[t] = *reinterpret_cast<const float4*>(UV + (long)si[t] * ld_uv + 64 + 4 * q);
+    a[t] = *reinterpret_cast<const float4*>(attr + (long)e * 4);
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    auto one = [&](float uu, float vv, const float4& w, float b) {
+      float z = uu + vv;
+      z = fmaf(a[t].x, w.x, z); z = fmaf(a[t].y, w.y, z); z = fmaf(a[t].z, w.z, z); z = fmaf(a[t].w, w.w, z);
+      return z + b;
+    };
+    const float4 h = make_float4(one(u[t].x, v[t].x, wc[0], bb.x), one(u[t].y, v[t].y, wc[1], bb.y),
+                                 one(u[t].z, v[t].z, wc[2], bb.z), one(u[t].w, v[t].w, wc[3], bb.w));
+    const int r = rb + 16 * t;
+    if (row0 + r < E) *reinterpret_cast<float4*>(H1 + (long)(row0 + r) * ldh + 4 * q) = h;
+    float* tr = T + r * LDT + 4 * q;
+    tr[0] = h.x; tr[1] = h.y; tr[2] = h.z; tr[3] = h.w;
+  }
+  if (stats == nullptr) return;
+  __syncthreads();
+  if (tid < 128) {
+    const int c = tid & 63, grp = tid >> 6;
+    const int base = row0 + 32 * grp;
+    int cnt = E - base;
+    cnt = cnt > 32 ? 32 : cnt;
+    if (cnt > 0) {
+      float sum = 0.f;
+      for (int r = 0; r < cnt; ++r) sum += T[(32 * grp + r) * LDT + c];
+      const float mu = sum / (float)cnt;
+      float m2 = 0.f;
+      for (int r = 0; r < cnt; ++r) { const float d = T[(32 * grp + r) * LDT + c] - mu; m2 += d * d; }
+      stats[(long)(base >> 5) * 64 + c] = make_float2(sum, m2);
+    }
+  }
+}
+
+extern "C" int yolat_edge_uv_lin1_fwd(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                                      const float* attr_csr, int64_t E, const float* Wc4, const float* b1, int64_t C,
+                                      float* H1, int64_t ldh, float* stats, yolat_stream_t stream) {
+  if (E < 0 || !UV || !Wc4) return YOLAT_E_INVALID;
+  if (C != 64) return YOLAT_E_UNSUPPORTED;
+  if (E == 0) return 0;
+  if (!src_csr || !dst_csr || !attr_csr || !H1 || E >= (1LL << 31) || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if (ld_uv % 4 != 0 || ldh % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) ||
+      !yl_aligned16(H1) || (b1 && !yl_aligned16(b1)) || (stats && (((uintptr_t)stats) & 7) != 0))
+    return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_edge_uv_lin1, dim3(yl_cdiv(E, 64)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv, src_csr,
+                     dst_csr, attr_csr, (int)E, Wc4, b1, H1, (long)ldh, reinterpret_cast<float2*>(stats));
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,
                                        const int32_t* dst_csr, const float* attr_csr, int64_t E, const float* Wc4,
                                        const float* b1, const float* s1, const float* t1, const float* W2,

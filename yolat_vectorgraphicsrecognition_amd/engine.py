@@ -22,6 +22,7 @@ from . import ops
 
 # training-mode fusion block + max pooling without the [N, 1024] activation (csrc/fusion_train.hip);
 # YOLAT_FUSED_FUSION_TRAIN=0 selects the materialising schedule (kept as the cross-check in the tests)
+FACTORISED_TRAIN = os.environ.get("YOLAT_FACTORISED_TRAIN", "1") != "0"
 FUSED_FUSION_TRAIN = os.environ.get("YOLAT_FUSED_FUSION_TRAIN", "1") != "0"
 
 
@@ -181,7 +182,11 @@ def conv_fwd(conv, g, x, xn, out_f, out_s, training):
         H1, H2 = _empty(E, C, dev), _empty(E, C, dev)
         if training:
             st1 = ops.stats_buffer(E, C, dev)
-            ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, stats=st1)
+            if FACTORISED_TRAIN and C == 64 and x.shape[1] == 64 and E >= 2 * N and nn0.weight.is_contiguous():
+                # per-node products + gather-add instead of the gathered K = 132 GEMM (pays when E >> N)
+                ops.edge_lin1_fwd_factorised(x, g, nn0.weight, nn0.bias, H1, stats=st1)
+            else:
+                ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, stats=st1)
             c1 = _bn_train(st1, E, bn1, dev)
             st2 = ops.stats_buffer(E, C, dev)
             ops.linear_fwd(H1, nn3.weight, nn3.bias, H2, a_pro=(c1[0], c1[1]), a_relu=True, stats=st2)

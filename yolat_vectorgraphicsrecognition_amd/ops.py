@@ -222,6 +222,25 @@ def edge_lin1_fwd(x, g, W1, b1, H1, o_pro=None, o_relu=False, stats=None):
     return H1
 
 
+def edge_lin1_fwd_factorised(x, g, W1, b1, H1, stats=None):
+    """Same result as edge_lin1_fwd (to fp32 rounding) through the per-node products: UV = x.[W1a-W1b | W1b]^T by a
+    dense GEMM over the N nodes, then a gather-add over the E edges (csrc/edge.hip, yolat_edge_uv_lin1_fwd).  Pays
+    when E >> N; Cin == C == 64 only."""
+    N, Cin = x.shape
+    C = W1.shape[0]
+    if not W1.is_contiguous():
+        raise ValueError("W1 must be contiguous")
+    wuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
+    wc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
+    check(lib.yolat_conv_split_w1(_f(W1), Cin, C, wuv.data_ptr(), wc4.data_ptr(), _stream()), "yolat_conv_split_w1")
+    uv = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
+    linear_fwd(x, wuv, None, uv)
+    check(lib.yolat_edge_uv_lin1_fwd(uv.data_ptr(), 2 * C, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), g.E,
+                                     wc4.data_ptr(), _f(b1, "b1", True), C, _f(H1), _ld(H1),
+                                     _f(stats, "stats", True), _stream()), "yolat_edge_uv_lin1_fwd")
+    return H1
+
+
 def edge_mlp2_eval(x, g, W1, b1, pro1, W2, b2, pro2, H2):
     """Eval-mode two-layer edge MLP in one kernel (BN folded into pro1/pro2 = (scale, shift))."""
     N, Cin = x.shape
