@@ -256,7 +256,8 @@ int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e, int64_t s
                                 const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr,
                                 int32_t* perm, int32_t* src_csr, int32_t* dst_csr, float* attr_csr,
                                 int32_t* seg_ptr, int32_t* node_seg, int32_t* work, int32_t* status, const float* x,
-                                int64_t ldx, int64_t Cin, const float* Wuv, const float* Wr, const float* br,
+                                int64_t ldx, int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr,
+                                const float* br,
                                 const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C,
                                 float* UV, int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
                                 yolat_stream_t stream);
@@ -270,10 +271,12 @@ int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e, int64_t s
  *   yolat_edge_uv_mlp2_eval: H2[q] = relu(s2*(W2.relu(s1*(U[dst_q] + V[src_q] + Wc4.attr_q + b1) + t1) + b2) + t2)
  * Exact algebra, different summation order than yolat_edge_mlp2_eval (agrees to ~1e-6 relative).  C = 64.   */
 int yolat_conv_split_w1(const float* W1, int64_t Cin, int64_t C, float* Wuv, float* Wc4, yolat_stream_t stream);
+/* uv_bias (nullable, [2C]): added to UV by the GEMM epilogue — the folded form of the layer puts s1*b1 + t1 there
+ * (see yolat_conv_eval.uvb).                                                                                 */
 int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N, int64_t Cin,
-                       const float* Wuv, const float* Wr, const float* br, const float* Wn, const float* bn,
-                       const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv, float* f_out,
-                       int64_t ld_fo, float* s_out, int64_t ld_so, yolat_stream_t stream);
+                       const float* Wuv, const float* uv_bias, const float* Wr, const float* br, const float* Wn,
+                       const float* bn, const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv,
+                       float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so, yolat_stream_t stream);
 /* Training-forward form of the factorised first edge Linear (no BatchNorm applied):
  *   H1[q] = U[dst_q] + V[src_q] + W1c.attr_q + b1,   UV [N,2C] = x.[W1a-W1b | W1b]^T from a dense Linear
  * (yolat_conv_split_w1 + yolat_linear_fwd).  stats (nullable): BatchNorm partial statistics in the format of
@@ -285,12 +288,32 @@ int yolat_edge_uv_lin1_fwd(const float* UV, int64_t ld_uv, const int32_t* src_cs
 
 /* yolat_edge_uv_mlp2_mean_eval: the same edge MLP with the mean aggregation fused in:
  *   f_out[n] += mean_{q in CSR row n} H2[q]       (H2 is never written; f_out already holds lin_r(f_in))
- * per-node summation in CSR order -> bit-identical to yolat_edge_uv_mlp2_eval + yolat_csr_mean_fwd(accumulate). */
+ * b1, (s1, t1), b2, (s2, t2) are each nullable (0 / identity); b1 = s1 = t1 = b2 = NULL is the folded form of
+ * yolat_conv_eval.{Wc4f, t2f} and takes the shorter per-edge arithmetic.
+ * `variant` selects the kernel (yolat_edge_uv_mlp2_mean_eval = YOLAT_EDGE_AUTO):
+ *   YOLAT_EDGE_TILES   one workgroup per tile of destination nodes, layer 2 on fp32-input MFMAs; per-node summation
+ *                      in CSR order: bit-identical to yolat_edge_uv_mlp2_eval + yolat_csr_mean_fwd(accumulate)
+ *   YOLAT_EDGE_WS_F32  persistent wave-specialised workgroups over edge ranges, same arithmetic in the same order
+ *                      (bit-identical to YOLAT_EDGE_TILES)
+ *   YOLAT_EDGE_WS_X6   the same structure with layer 2 as an fp32 GEMM emulated on the bf16 matrix cores (three-term
+ *                      exact bfloat16 splits of both operands, six products, fp32 accumulation): differs from the
+ *                      fp32-MFMA variants by the summation order only (~3e-7 of scale), deterministic
+ *   YOLAT_EDGE_AUTO    WS_X6 for E >= 131072 (where the persistent workgroups are amortised), else TILES         */
+#define YOLAT_EDGE_AUTO 0
+#define YOLAT_EDGE_TILES 1
+#define YOLAT_EDGE_WS_F32 2
+#define YOLAT_EDGE_WS_X6 3
 int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                                  const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E,
                                  const float* Wc4, const float* b1, const float* s1, const float* t1,
                                  const float* W2, const float* b2, const float* s2, const float* t2, int64_t C,
                                  float* f_out, int64_t ld_fo, yolat_stream_t stream);
+int yolat_edge_uv_mlp2_mean_eval_variant(const float* UV, int64_t ld_uv, const int32_t* src_csr,
+                                         const int32_t* dst_csr, const float* attr_csr, const int32_t* row_ptr,
+                                         int64_t N, int64_t E, const float* Wc4, const float* b1, const float* s1,
+                                         const float* t1, const float* W2, const float* b2, const float* s2,
+                                         const float* t2, int64_t C, float* f_out, int64_t ld_fo, int variant,
+                                         yolat_stream_t stream);
 int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                             const float* attr_csr, int64_t E, const float* Wc4, const float* b1, const float* s1,
                             const float* t1, const float* W2, const float* b2, const float* s2, const float* t2,
@@ -413,8 +436,12 @@ typedef struct {
   const float *W2, *b2, *s2, *t2;             /* gconv.nn.3 [C,C],     gconv.nn.4 folded        */
   const float *Wr, *br;                       /* gconv.lin_r [C,Cin]                             */
   const float *Wn, *bn, *sn, *tn;             /* gconv.mlp_node.0 [C,Cin], mlp_node.1 folded     */
-  const float *packed;                        /* nullable: yolat_conv_pack_weights(W1, W2) output  */
   const float *Wuv, *Wc4;                     /* nullable: yolat_conv_split_w1(W1) outputs, [2C,Cin], [C,4] */
+  /* nullable (all four or none): the same layer with nn.1 (BatchNorm, folded s1/t1) and the biases b1, b2 moved
+   * out of the per-edge arithmetic — Wuvf = [s1 | s1] (rows) * Wuv, uvb = [s1*b1 + t1 | 0] ([2C], added to UV by the
+   * node-side GEMM's epilogue), Wc4f = s1 (rows) * Wc4, t2f = s2*b2 + t2:
+   *   h1 = relu(U'[dst] + V'[src] + Wc4f.attr),  message = relu(s2 * (W2.h1) + t2f)                        */
+  const float *Wuvf, *uvb, *Wc4f, *t2f;
 } yolat_conv_eval;
 
 typedef struct {
@@ -429,30 +456,6 @@ typedef struct {
   const float *Wc2, *bc2, *sc2, *tc2;         /* prediction_cls.1                                */
   const float *Wc3, *bc3;                     /* prediction_cls.2 (bare Linear)                  */
 } yolat_model_eval;
-
-/* One AttrRelativeEdgeConvGlobalPool2 layer in eval mode (torch_vertex.py:319-337, BatchNorm folded)
- * as ONE persistent kernel: gather -> edge MLP (2 MFMA GEMMs) -> mean aggregation -> + lin_r(x), and
- * the node branch mlp_node(xn).  No [E,*] intermediate is written to HBM.  C must be 64, Cin <= 64.
- * f_out / s_out: [N,C] destinations (ld = ldf / lds), e.g. column slots of the concat buffers.     */
-int yolat_conv_eval_fused(const float* x, int64_t ldx, const float* xn, int64_t ldxn, int64_t N,
-                          int64_t Cin, const int32_t* row_ptr, const int32_t* src_csr,
-                          const int32_t* dst_csr, const float* attr_csr, int64_t E,
-                          const yolat_conv_eval* w, int64_t C, float* f_out, int64_t ldf, float* s_out,
-                          int64_t lds, yolat_stream_t stream);
-
-/* Same contract, second implementation (conv_chain.hip): every wave owns 32 edges end to end, its features
- * stream from global memory straight into the MFMA B operand, the two edge-MLP GEMMs are chained through
- * the accumulator registers, and there is no workgroup barrier in the edge loop.  Cin in {5, 6, 64}.
- * `packed`: W1 / W2 re-ordered into MFMA fragment order by yolat_conv_pack_weights (once per weight
- * version; yolat_conv_pack_elems(Cin) floats, 16-byte aligned).                                      */
-size_t yolat_conv_pack_elems(int64_t Cin);
-int yolat_conv_pack_weights(const float* W1, const float* W2, int64_t Cin, float* packed,
-                            yolat_stream_t stream);
-int yolat_conv_eval_chain(const float* x, int64_t ldx, const float* xn, int64_t ldxn, int64_t N,
-                          int64_t Cin, const int32_t* row_ptr, const int32_t* src_csr,
-                          const int32_t* dst_csr, const float* attr_csr, int64_t E,
-                          const yolat_conv_eval* w, const float* packed, int64_t C, float* f_out,
-                          int64_t ldf, float* s_out, int64_t lds, yolat_stream_t stream);
 
 /* workspace (bytes) needed by yolat_forward_eval for a batch of N nodes / E edges / P proposals */
 size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, int64_t N, int64_t E, int64_t P);

@@ -389,20 +389,24 @@ def test_segment_mean_max_forward_backward(P, D):
     np.testing.assert_array_equal(dX.cpu().numpy(), Xr.grad.numpy())
 
 
-@pytest.mark.parametrize("impl", ["yolat_conv_eval_fused", "yolat_conv_eval_chain"])
+@pytest.mark.parametrize("fold", [False, True])
+@pytest.mark.parametrize("variant", [1, 2, 3])
 @pytest.mark.parametrize("N,E,Cin", [(6, 7, 5), (70, 300, 5), (70, 300, 64), (1000, 4000, 64), (33, 0, 64),
                                      (500, 9000, 64), (2500, 3000, 5), (300, 700, 6), (9000, 30000, 64)])
-def test_fused_conv_layer_eval_matches_oracle(N, E, Cin, impl):
-    """yolat_conv_eval_fused (gather -> MLP -> mean -> + root, node branch in one persistent kernel) against
-    the oracle's AttrRelativeEdgeConvGlobalPool2 in eval mode; outputs land in column slots of wider
-    buffers (ld = 128) like in the model."""
-    import ctypes
+def test_factorised_conv_layer_eval_matches_oracle(N, E, Cin, variant, fold):
+    """One whole eval conv layer through the factorised kernels — yolat_conv_split_w1 (+ the folded form of
+    ops.fold_factorised_layer), yolat_node_uv_eval (per-node products | root Linear | node branch) and
+    yolat_edge_uv_mlp2_mean_eval_variant (node tiles / persistent fp32 / persistent bf16x6-emulated) — against the
+    oracle's AttrRelativeEdgeConvGlobalPool2 in eval mode (torch_vertex.py:319-337); outputs land in column slots of
+    wider buffers (ld = 128) like in the model."""
     yv = _yv()
-    from yolat_vectorgraphicsrecognition_amd._lib import lib, check, ConvEval
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
     src, dst, xfull, attr = _edge_case(N, max(E, 1), Cin, 7 * N + E, ldx=Cin)
     src, dst, attr = src[:E], dst[:E], attr[:E]
     if E > 20:
-        dst[:15] = 3                                  # one high-degree node spanning chunks
+        dst[:15] = 3                                  # one high-degree node
+    if E > 200:
+        dst[20:170] = N // 2                          # a node spanning three 64-edge passes
     conv = orc.AttrRelativeEdgeConvGlobalPool2(Cin, 64)
     gu.fill_state_(conv, 11)
     conv.eval()
@@ -414,39 +418,39 @@ def test_fused_conv_layer_eval_matches_oracle(N, E, Cin, impl):
     g = yv.ops.build_graph(dev(np.stack([src, dst], 1)) if E else torch.zeros(0, 2, dtype=torch.int64).cuda(),
                            dev(attr) if E else torch.zeros(0, 4).cuda(), None, N, 1)
     cd = conv.cuda()
-    keep = []
 
-    def fold(bn):
+    def folded(bn):
         c = torch.empty(2, 64).cuda()
         yv.ops.bn_eval_coeffs(bn, c[0], c[1])
-        keep.append(c)
-        return c[0].data_ptr(), c[1].data_ptr()
+        return c[0], c[1]
 
-    w = ConvEval()
-    w.Cin = Cin
-    w.W1, w.b1 = cd.nn[0].weight.data_ptr(), cd.nn[0].bias.data_ptr()
-    w.s1, w.t1 = fold(cd.nn[1])
-    w.W2, w.b2 = cd.nn[3].weight.data_ptr(), cd.nn[3].bias.data_ptr()
-    w.s2, w.t2 = fold(cd.nn[4])
-    w.Wr, w.br = cd.lin_r.weight.data_ptr(), cd.lin_r.bias.data_ptr()
-    w.Wn, w.bn = cd.mlp_node[0].weight.data_ptr(), cd.mlp_node[0].bias.data_ptr()
-    w.sn, w.tn = fold(cd.mlp_node[1])
+    p1, p2, pn = folded(cd.nn[1]), folded(cd.nn[4]), folded(cd.mlp_node[1])
+    st = torch.cuda.current_stream().cuda_stream
+    wuv, wc4 = torch.empty(128, Cin).cuda(), torch.empty(64, 4).cuda()
+    check(lib.yolat_conv_split_w1(cd.nn[0].weight.data_ptr(), Cin, 64, wuv.data_ptr(), wc4.data_ptr(), st))
+    uvb = None
+    b1, b2 = cd.nn[0].bias, cd.nn[3].bias
+    if fold:
+        wuv, uvb, wc4, t2f = yv.ops.fold_factorised_layer(wuv, wc4, b1, p1[0], p1[1], b2, p2[0], p2[1])
+        b1, p1, b2, p2 = None, None, None, (p2[0], t2f)
     fbuf = torch.full((N, 128), float("nan")).cuda()
     sbuf = torch.full((N, 128), float("nan")).cuda()
+    UV = torch.empty(N, 128).cuda()
     xd, xnd = x.cuda(), xn.cuda()
-    st = torch.cuda.current_stream().cuda_stream
-    if impl == "yolat_conv_eval_chain":
-        pk = torch.empty(int(lib.yolat_conv_pack_elems(Cin))).cuda()
-        check(lib.yolat_conv_pack_weights(w.W1, w.W2, Cin, pk.data_ptr(), st))
-        check(lib.yolat_conv_eval_chain(xd.data_ptr(), Cin, xnd.data_ptr(), Cin, N, Cin, g.row_ptr.data_ptr(),
-                                        g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E, ctypes.byref(w),
-                                        pk.data_ptr(), 64, fbuf[:, 64:].data_ptr(), 128, sbuf[:, :64].data_ptr(), 128, st))
+    check(lib.yolat_node_uv_eval(xd.data_ptr(), Cin, xnd.data_ptr(), Cin, N, Cin, wuv.data_ptr(),
+                                 uvb.data_ptr() if uvb is not None else None, cd.lin_r.weight.data_ptr(),
+                                 cd.lin_r.bias.data_ptr(), cd.mlp_node[0].weight.data_ptr(),
+                                 cd.mlp_node[0].bias.data_ptr(), pn[0].data_ptr(), pn[1].data_ptr(), 64, UV.data_ptr(), 128,
+                                 fbuf[:, 64:].data_ptr(), 128, sbuf[:, :64].data_ptr(), 128, st))
+    if E >= 64 or variant == 1 or E == 0:
+        yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, b1, p1, cd.nn[3].weight, b2, p2, fbuf[:, 64:], variant=variant)
     else:
-        check(lib.yolat_conv_eval_fused(xd.data_ptr(), Cin, xnd.data_ptr(), Cin, N, Cin, g.row_ptr.data_ptr(),
-                                        g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E, ctypes.byref(w), 64,
-                                        fbuf[:, 64:].data_ptr(), 128, sbuf[:, :64].data_ptr(), 128, st))
-    close(fbuf[:, 64:], want_f, msg="fused conv out")
-    close(sbuf[:, :64], want_s, msg="fused conv node branch")
+        # the persistent variants need at least one full pass; the automatic choice never picks them there
+        with pytest.raises(RuntimeError):
+            yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, b1, p1, cd.nn[3].weight, b2, p2, fbuf[:, 64:], variant=variant)
+        yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, b1, p1, cd.nn[3].weight, b2, p2, fbuf[:, 64:], variant=0)
+    close(fbuf[:, 64:], want_f, msg="factorised conv out")
+    close(sbuf[:, :64], want_s, msg="factorised conv node branch")
     assert torch.isnan(fbuf[:, :64]).all() and torch.isnan(sbuf[:, 64:]).all()
 
 
@@ -748,7 +752,7 @@ def test_factorised_edge_layer_matches_unfactorised(N, E, Cin):
     assert torch.equal(wc4, W1[:, 2 * Cin:])
     UV = torch.empty(N, 128).cuda()
     f_out, s_out = torch.empty(N, 64).cuda(), torch.empty(N, 64).cuda()
-    check(lib.yolat_node_uv_eval(x.data_ptr(), Cin, s_in.data_ptr(), Cin, N, Cin, wuv.data_ptr(), Wr.data_ptr(),
+    check(lib.yolat_node_uv_eval(x.data_ptr(), Cin, s_in.data_ptr(), Cin, N, Cin, wuv.data_ptr(), None, Wr.data_ptr(),
                                  br.data_ptr(), Wn.data_ptr(), bn.data_ptr(), pn[0].data_ptr(), pn[1].data_ptr(), 64,
                                  UV.data_ptr(), 128, f_out.data_ptr(), 64, s_out.data_ptr(), 64, st))
     fa, sa = torch.empty(N, 64).cuda(), torch.empty(N, 64).cuda()
@@ -763,7 +767,8 @@ def test_factorised_edge_layer_matches_unfactorised(N, E, Cin):
     assert torch.isnan(got[:, 64:]).all()
 
 
-@pytest.mark.parametrize("N,E", [(6, 7), (70, 300), (1000, 4000), (500, 9001), (2500, 3000), (9000, 54000)])
+@pytest.mark.parametrize("N,E", [(6, 7), (70, 300), (1000, 4000), (500, 9001), (2500, 3000), (9000, 54000),
+                                 (40000, 9000), (30000, 140000)])
 def test_fused_edge_mean_is_bit_identical_to_edge_kernel_plus_csr_mean(N, E):
     """yolat_edge_uv_mlp2_mean_eval (node-tiled: edge MLP + mean aggregation, no [E,64] tensor) against
     yolat_edge_uv_mlp2_eval + yolat_csr_mean_fwd(accumulate); one node gets > 64 in-edges (multi-pass)."""
@@ -793,7 +798,41 @@ def test_fused_edge_mean_is_bit_identical_to_edge_kernel_plus_csr_mean(N, E):
                                            g.row_ptr.data_ptr(), N, E, wc4.data_ptr(), b1.data_ptr(), p1[0].data_ptr(),
                                            p1[1].data_ptr(), W2.data_ptr(), b2.data_ptr(), p2[0].data_ptr(),
                                            p2[1].data_ptr(), 64, got[:, 64:].data_ptr(), 128, st))
-    assert torch.equal(got, want)
+    if E < 131072:
+        assert torch.equal(got, want)                 # automatic choice = node tiles: bit-identical
+    else:                                             # automatic choice = bf16x6-emulated persistent kernel
+        assert float((got - want).abs().max()) <= 2e-6 * float((want[:, 64:] - base[:, 64:]).abs().max()) + 1e-7
+    # the node tiles explicitly, and the persistent wave-specialised kernel on fp32 MFMAs: same arithmetic, same order
+    for variant in (yv.ops.EDGE_TILES, yv.ops.EDGE_WS_F32):
+        if variant == yv.ops.EDGE_WS_F32 and E < 64:
+            continue
+        got = base.clone()
+        yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, b1, p1, W2, b2, p2, got[:, 64:], variant=variant)
+        assert torch.equal(got, want), "variant %d" % variant
+    if E >= 64:
+        # bf16x6-emulated layer 2: exact operand splits, exact products, fp32 accumulation in a different order
+        got = base.clone()
+        yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, b1, p1, W2, b2, p2, got[:, 64:], variant=yv.ops.EDGE_WS_X6)
+        agg = (want[:, 64:] - base[:, 64:]).abs().max()
+        assert float((got - want).abs().max()) <= 2e-6 * float(agg) + 1e-7
+        again = base.clone()
+        yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, b1, p1, W2, b2, p2, again[:, 64:], variant=yv.ops.EDGE_WS_X6)
+        assert torch.equal(got, again), "bf16x6 variant is not run-to-run deterministic"
+        # folded parameterisation (b1 = s1 = t1 = b2 = None): every variant against the unfused kernels
+        H2 = torch.empty(E, 64).cuda()
+        check(lib.yolat_edge_uv_mlp2_eval(UV.data_ptr(), 128, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), E,
+                                          wc4.data_ptr(), None, None, None, W2.data_ptr(), None, p2[0].data_ptr(),
+                                          p2[1].data_ptr(), 64, H2.data_ptr(), 64, st))
+        wantf = base.clone()
+        yv.ops.csr_mean_fwd(H2, g, wantf[:, 64:], accumulate=True)
+        for variant in (yv.ops.EDGE_TILES, yv.ops.EDGE_WS_F32, yv.ops.EDGE_WS_X6):
+            got = base.clone()
+            yv.ops.edge_uv_mlp2_mean_eval(UV, g, wc4, None, None, W2, None, p2, got[:, 64:], variant=variant)
+            if variant == yv.ops.EDGE_WS_X6:
+                aggf = (wantf[:, 64:] - base[:, 64:]).abs().max()
+                assert float((got - wantf).abs().max()) <= 2e-6 * float(aggf) + 1e-7
+            else:
+                assert torch.equal(got, wantf), "folded, variant %d" % variant
 
 
 @pytest.mark.parametrize("N,E", [(300, 1000), (50, 31), (2000, 9001), (64, 64), (1000, 4097)])

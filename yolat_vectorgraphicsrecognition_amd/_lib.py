@@ -23,7 +23,7 @@ class ConvEval(ctypes.Structure):
     """yolat_conv_eval (include/yolat_hip.h)"""
     _fields_ = [("Cin", c_i64)] + [(n, c_p) for n in
                                    ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn",
-                                    "packed", "Wuv", "Wc4")]
+                                    "Wuv", "Wc4", "Wuvf", "uvb", "Wc4f", "t2f")]
 
 
 class ModelEval(ctypes.Structure):
@@ -64,16 +64,18 @@ SIGNATURES = {
     "yolat_gather_rows_bytes": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_fixup_offsets": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_i64, c_p]),
     "yolat_conv_split_w1": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p]),
-    "yolat_node_uv_eval": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p,
-                                    c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_node_uv_eval": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64,
+                                    c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_edge_uv_mlp2_eval": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64,
                                          c_p, c_i64, c_p]),
     "yolat_edge_uv_mlp2_mean_eval": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p,
                                               c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_edge_uv_mlp2_mean_eval_variant": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
+                                                      c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_int, c_p]),
     "yolat_fusion_pair_eval": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
                                         c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "yolat_graph_prepare_node_uv": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64] + [c_p] * 9 +
-                                    [c_p, c_i64, c_i64] + [c_p] * 7 + [c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
+                                    [c_p, c_i64, c_i64] + [c_p] * 8 + [c_i64, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_csc_work_elems": (c_sz, [c_i64]),
     "yolat_csc_by_source": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_segment_ptr": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
@@ -120,12 +122,6 @@ SIGNATURES = {
     "yolat_profile_count": (c_int, []),
     "yolat_profile_get": (c_int, [c_int, ctypes.c_char_p, c_int, ctypes.POINTER(c_f), ctypes.POINTER(c_int),
                                   ctypes.POINTER(ctypes.c_double), ctypes.POINTER(ctypes.c_double)]),
-    "yolat_conv_eval_fused": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64,
-                                      ctypes.POINTER(ConvEval), c_i64, c_p, c_i64, c_p, c_i64, c_p]),
-    "yolat_conv_pack_elems": (c_sz, [c_i64]),
-    "yolat_conv_pack_weights": (c_int, [c_p, c_p, c_i64, c_p, c_p]),
-    "yolat_conv_eval_chain": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64,
-                                      ctypes.POINTER(ConvEval), c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_forward_eval_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEval), c_i64, c_i64, c_i64]),
     "yolat_forward_eval": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64,
                                    c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),

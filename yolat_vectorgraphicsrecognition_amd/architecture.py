@@ -122,8 +122,9 @@ class SparseCADGCN(nn.Module):
         forward on the same batch (predict, epochs over a cached batch) re-uses them; the device-side
         CSR / segment structure is added lazily for the training path (the eval plan builds its own)."""
         cache = getattr(data, "_yolat_stage", None)
-        key = (data.x.data_ptr(), data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
-               data.bbox_idx._version, data.e_attr.data_ptr(), tuple(data.x.shape), tuple(data.edge.shape))
+        key = (data.x.data_ptr(), data.x._version, data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
+               data.bbox_idx._version, data.e_attr.data_ptr(), data.e_attr._version, data.bbox.data_ptr(),
+               data.bbox._version, tuple(data.x.shape), tuple(data.edge.shape))
         if cache is None or cache[0] != key:
             x = data.x.cuda(non_blocking=True)
             if x.dtype != torch.float32:
@@ -143,6 +144,10 @@ class SparseCADGCN(nn.Module):
         return st
 
     def forward(self, data, slices=None):
+        """arch:106-137.  Preconditions the dataset guarantees (Datasets/graph_dict3.py:594-600,732):
+        `data.bbox_idx` non-decreasing, edge ids inside [0, N).  Violations are flagged in a device status word
+        (ops.STATUS_*) and the kernels stay memory-safe; `check_last_status()` (synchronising) raises on them —
+        `predict` and `Trainer.step`'s first call check it where the host synchronises anyway."""
         if not self.training and not torch.is_grad_enabled():
             # eval fast path: one call into libyolat_hip.so (plan.EvalPlan / yolat_forward_eval)
             st = self._stage(data, need_graph=False)
@@ -162,10 +167,16 @@ class SparseCADGCN(nn.Module):
             st["plan_status"] = plan
         else:
             st = self._stage(data)
+            self._yolat_plan = st["g"]       # ops.Graph carries the status word of the training path
             pred_cls = _ModelFn.apply(self, st["g"], st["x"], *list(self.parameters()))
         if self.classifier != "softmax":
             pred_cls = torch.sigmoid(pred_cls)
         return pred_cls, st["bbox"]
+
+    def check_last_status(self):
+        """Synchronising check of the most recent forward's input-validity flags (raises IndexError / ValueError)."""
+        last = self.__dict__.get("_yolat_plan")
+        return True if last is None else last.check_status()
 
     def predict(self, data, slices):
         """Two-pass root/children inference, arch:139-356: forward on the sub-batch of all root
@@ -188,6 +199,7 @@ class SparseCADGCN(nn.Module):
         has_object = (is_object == self.n_classes - 1).cpu().numpy()     # D2H sync, as in the reference
         if int(status1.item()) & ops.STATUS_EDGE_RANGE:
             raise KeyError("an edge of a root proposal references a node outside the selected sub-batch")
+        self.check_last_status()          # the host has just synchronised: the flags of pass 1 are free to read
         ps, pe, es, ee, slice_bbox_child, image_child = select_tree_ranges(data, slices, has_object)
         if int((pe - ps).sum()) == 0:
             slice_image_bbox, slice_bbox = image_root, slice_bbox_root
@@ -274,7 +286,14 @@ class DetectionLoss(nn.Module):
 
     def forward(self, out, data):
         pred_cls = out[0]
-        gt_cls = data.labels.cuda(non_blocking=True)
+        labels = data.labels
+        if not labels.is_cuda and labels.numel():
+            # host-side range check while the labels are still on the host (torch's CrossEntropyLoss raises
+            # "Target ... is out of bounds"); device-resident labels are guarded in the kernel (NaN loss)
+            lo, hi = int(labels.min()), int(labels.max())
+            if lo < 0 or hi >= pred_cls.shape[1]:
+                raise IndexError("Target %d is out of bounds." % (lo if lo < 0 else hi))
+        gt_cls = labels.cuda(non_blocking=True)
         if self.classifier == "softmax":
             l0 = _CEFn.apply(pred_cls.contiguous(), gt_cls)
         else:

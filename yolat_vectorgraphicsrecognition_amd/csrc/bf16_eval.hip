@@ -651,7 +651,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     const yolat_conv_eval& cv0 = m->conv[0];
     NodeUv a;
     // the fp32 destinations are placeholders for the builder's checks; UV and the node branch go to bf16
-    YL_TRY(yl_build_node_uv(&a, x, ldx, x, ldx, N, cv0.Cin, cv0.Wuv, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C,
+    YL_TRY(yl_build_node_uv(&a, x, ldx, x, ldx, N, cv0.Cin, cv0.Wuv, nullptr, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C,
                             p.root, 2 * C, p.root, C, p.root, C));
     a.euv.Y = nullptr; a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
     a.euv.scale = mh->uv_scale[0]; a.euv.shift = mh->uv_shift[0];

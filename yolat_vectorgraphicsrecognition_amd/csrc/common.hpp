@@ -605,9 +605,9 @@ struct NodeUv {
   int N, C, Cin;
 };
 int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
-                     int64_t Cin, const float* Wuv, const float* Wr, const float* br, const float* Wn,
-                     const float* bn, const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv,
-                     float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so);
+                     int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr, const float* br,
+                     const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
+                     int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so);
 // stage profiler hooks (forward_eval.hip): HIP-event pair around one stage of a whole-forward entry point
 bool yl_profile_on();
 void yl_stage_begin(const char* name, double flops, double bytes, yolat_stream_t stream);

@@ -136,9 +136,9 @@ extern "C" int yolat_conv_split_w1(const float* W1, int64_t Cin, int64_t C, floa
 }
 
 int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
-                     int64_t Cin, const float* Wuv, const float* Wr, const float* br, const float* Wn,
-                     const float* bn, const float* sn, const float* tn, int64_t C, float* UV, int64_t ld_uv,
-                     float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so) {
+                     int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr, const float* br,
+                     const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
+                     int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so) {
   if (N <= 0 || Cin <= 0 || !f_in || !s_in || !Wuv || !Wr || !Wn || !UV || !f_out || !s_out) return YOLAT_E_INVALID;
   if (C != 64) return YOLAT_E_UNSUPPORTED;
   if (N >= (1LL << 31) || ld_f < Cin || ld_s < Cin || ld_uv < 2 * C || ld_fo < C || ld_so < C) return YOLAT_E_INVALID;
@@ -148,7 +148,7 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
   Epilogue e;
   e.bias = nullptr; e.scale = nullptr; e.shift = nullptr; e.relu = 0;
   e.Y = UV; e.ldy = ld_uv; e.accumulate = 0; e.stats = nullptr; e.seg = nullptr; e.pool = nullptr; e.ldpool = 0;
-  a->euv = e;
+  a->euv = e; a->euv.bias = uv_bias;
   a->er = e; a->er.bias = br; a->er.Y = f_out; a->er.ldy = ld_fo;
   a->en = e; a->en.bias = bn; a->en.scale = sn; a->en.shift = tn; a->en.relu = 1; a->en.Y = s_out; a->en.ldy = ld_so;
   a->N = (int)N; a->C = (int)C; a->Cin = (int)Cin;
@@ -156,13 +156,13 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
 }
 
 extern "C" int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
-                                  int64_t Cin, const float* Wuv, const float* Wr, const float* br, const float* Wn,
-                                  const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
-                                  int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
-                                  yolat_stream_t stream) {
+                                  int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr,
+                                  const float* br, const float* Wn, const float* bn, const float* sn, const float* tn,
+                                  int64_t C, float* UV, int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out,
+                                  int64_t ld_so, yolat_stream_t stream) {
   NodeUv a;
-  const int rc = yl_build_node_uv(&a, f_in, ld_f, s_in, ld_s, N, Cin, Wuv, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv, f_out,
-                                  ld_fo, s_out, ld_so);
+  const int rc = yl_build_node_uv(&a, f_in, ld_f, s_in, ld_s, N, Cin, Wuv, uv_bias, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv,
+                                  f_out, ld_fo, s_out, ld_so);
   if (rc != 0) return rc;
   const dim3 grid(yl_cdiv(N, 64), 4);
   if (Cin <= 16) hipLaunchKernelGGL(k_gemm_nt_node3<16>, grid, dim3(256), 0, (hipStream_t)stream, a);

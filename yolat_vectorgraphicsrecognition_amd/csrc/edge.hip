@@ -213,7 +213,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2(const float* __restrict__ 
   float4 wc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
-  const float4 bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+  const float4 bb = b1 ? *reinterpret_cast<const float4*>(b1 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
   int di[4], si[4];
@@ -307,7 +307,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   float4 wc[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
-  const float4 bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+  const float4 bb = b1 ? *reinterpret_cast<const float4*>(b1 + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
   float4 sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
   if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
   const float bias2 = b2 ? b2[col] : 0.f, sc2 = s2 ? s2[col] : 1.f, sh2 = s2 ? t2[col] : 0.f;
@@ -399,20 +399,398 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   }
 }
 
-extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,
-                                            const int32_t* dst_csr, const float* attr_csr,
-                                            const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
-                                            const float* b1, const float* s1, const float* t1, const float* W2,
-                                            const float* b2, const float* s2, const float* t2, int64_t C,
-                                            float* f_out, int64_t ld_fo, yolat_stream_t stream) {
-  if (E < 0 || N <= 0 || !UV || !Wc4 || !b1 || !W2 || !row_ptr || !f_out) return YOLAT_E_INVALID;
+// ------------------------------------------------------------------------------------------------
+// Wave-specialised factorised edge MLP + mean aggregation (round 2) — the large-graph path.
+// Why (profiles/r02_base_fwd_cfg5_pmc_sq_*.txt and the phase ablation in profiles/r02_edge_ablation.txt, cfg 5): the
+// node-tiled kernel above runs its phases — gather, layer-1 VALU, layer-2 MFMA, aggregation — one after the other
+// in every wave, and because all resident workgroups start together and contend for the same pipes they stay in
+// lockstep: the phase times ADD (87 us without the MFMAs + 105 us of MFMA phase = 192 us) although the MFMA pipe
+// needs only ~75 us of it; its 64-row passes are also only 75 % full and W2 is re-staged for every 96 edges.
+// Here a 512-thread workgroup owns the edge range [w*chunk, (w+1)*chunk) moved to node boundaries (the node holding
+// edge w*chunk is dst[w*chunk]: no search) and walks it in FULL 64-edge passes with two kinds of waves:
+//   waves 0-3 "producers": per pass the row gathers U[dst] + V[src] + attr (issued one pass ahead of their use, the
+//              indices two passes ahead), layer 1 on the VALU -> LDS tile Hs[(p+1)&1], and the per-node mean of the
+//              messages of pass p-1 (segment table built from dst with one ballot per pass; the running sum of a
+//              node that straddles two passes travels through 65 floats of LDS);
+//   waves 4-7 "consumers": W2's MFMA B fragments in 32 registers for the whole kernel, per pass 8 ds_read_b128 (the
+//              tile is stored k-parity-interleaved, row stride 68: one conflict-free read feeds four MFMAs) +
+//              32 v_mfma_f32_32x32x2_f32 on Hs[p&1], BN+ReLU epilogue -> Ms[p&1].
+// One s_barrier per pass; every SIMD hosts one producer and one consumer wave of each of the two resident
+// workgroups.
+//
+// X6 = false: layer 2 on v_mfma_f32_32x32x2_f32 — the same arithmetic in the same order as k_edge_uv_mlp2 +
+//   k_csr_mean_fwd (bit-identical results).  Measured 180 us at cfg 5 against 213 us for the node tiles: on gfx950 the
+//   fp32-input MFMA executes on the SIMD's VECTOR ALUs (tools/exp/pipe_overlap.hip: the MFMA time and the VALU time
+//   of two waves on one SIMD ADD, 124 + 104 -> 222 us), so specialising waves cannot overlap the two, and a single
+//   VALU-heavy wave per SIMD issues one instruction per ~7 cycles (tools/exp/valu_rate.hip).
+// X6 = true (the product path for large graphs): layer 2 as an fp32 GEMM EMULATED on the bf16 matrix cores, which
+//   do run beside the vector ALUs: a = a_h + a_m + a_l with three bfloat16 terms (truncation splits, 8 + 8 + 8 = 24
+//   significand bits: the split is exact), a.b = a_h b_h + (a_h b_m + a_m b_h + a_h b_l + a_l b_h + a_m b_m) + O(2^-24):
+//   six v_mfma_f32_32x32x16_bf16 (32 cycles each) per 16 k instead of eight fp32 MFMAs (64 cycles each), exact
+//   products, fp32 accumulation.  The result differs from the fp32-MFMA kernels only by the summation order
+//   (measured ~1e-7 relative); tests/test_gpu_ops.py compares the two at 2e-6 of scale.
+// FOLD: layer 1's bias / BatchNorm live in UV and Wc4 (node-side epilogue; b1 = s1 = t1 = NULL) and layer 2's bias
+//   in t2 (b2 = NULL): h1 = relu(U + V + Wc4.attr), message = relu(s2 * (W2.h1) + t2) — 6 instead of 8 VALU
+//   operations per hidden activation (packed fp32 math) and 2 instead of 3 per message.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 yl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned yl_u32x4 __attribute__((ext_vector_type(4)));
+// exact 3-way bfloat16 split of 8 fp32 values (truncation: every term keeps the next 8 significand bits)
+__device__ __forceinline__ void yl_split8(const float x[8], yl_bf16x8& h, yl_bf16x8& m, yl_bf16x8& l) {
+  yl_u32x4 ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned x0 = __float_as_uint(x[2 * i]), x1 = __float_as_uint(x[2 * i + 1]);
+    // h = top 8 significand bits, hm = top 16: m = hm - h and l = x - hm are exact and need 8 bits each
+    const yl_f32x2 xv = {x[2 * i], x[2 * i + 1]};
+    const yl_f32x2 hv = {__uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1 & 0xffff0000u)};
+    const yl_f32x2 hmv = {__uint_as_float(x0 & 0xffffff00u), __uint_as_float(x1 & 0xffffff00u)};
+    const yl_f32x2 mv = hmv - hv, lv = xv - hmv;     // v_pk_add_f32 with negated operand
+    ph[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+    pm[i] = __builtin_amdgcn_perm(__float_as_uint(mv.y), __float_as_uint(mv.x), 0x07060302u);
+    pl[i] = __builtin_amdgcn_perm(__float_as_uint(lv.y), __float_as_uint(lv.x), 0x07060302u);
+  }
+  h = *reinterpret_cast<yl_bf16x8*>(&ph);
+  m = *reinterpret_cast<yl_bf16x8*>(&pm);
+  l = *reinterpret_cast<yl_bf16x8*>(&pl);
+}
+
+template <bool FOLD, bool X6>
+__global__ void __launch_bounds__(512, 4) k_edge_uv_mlp2_mean_ws(const float* __restrict__ UV, long ld_uv,
+                                                                 const int* __restrict__ src,
+                                                                 const int* __restrict__ dst,
+                                                                 const float* __restrict__ attr,
+                                                                 const int* __restrict__ row_ptr, int N, int E, int chunk,
+                                                                 const float* __restrict__ Wc4,
+                                                                 const float* __restrict__ b1,
+                                                                 const float* __restrict__ s1,
+                                                                 const float* __restrict__ t1,
+                                                                 const float* __restrict__ W2,
+                                                                 const float* __restrict__ b2,
+                                                                 const float* __restrict__ s2,
+                                                                 const float* __restrict__ t2, float* f_out, long ld_fo) {
+  constexpr int LDH = 68, TILE = 64 * LDH;
+  __shared__ __attribute__((aligned(16))) float Hs[2 * TILE];   // layer-1 activations, k-parity-interleaved
+  __shared__ __attribute__((aligned(16))) float Ms[2 * TILE];   // layer-2 messages, row-major
+  __shared__ int seg_start[2][66];                              // first row of the k-th node of the pass (+ end)
+  __shared__ int seg_node[2][64];
+  __shared__ int seg_info[2][4];                                // #nodes, first continues from / last continues into
+  __shared__ __attribute__((aligned(16))) float carry_s[2][64];
+  __shared__ int carry_cnt_s[2];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  // ---- this workgroup's edge range, moved to node boundaries (uniform)
+  const long c_lo = (long)blockIdx.x * chunk;
+  if (c_lo >= E) return;
+  const long c_hi = c_lo + chunk;
+  int eS = 0, eE = E;
+  if (c_lo > 0) {
+    const int n = dst[c_lo];
+    eS = (row_ptr[n] == (int)c_lo) ? (int)c_lo : row_ptr[n + 1];
+  }
+  if (c_hi < E) {
+    const int n = dst[c_hi];
+    eE = (row_ptr[n] == (int)c_hi) ? (int)c_hi : row_ptr[n + 1];
+  }
+  if (eS >= eE) return;
+  const int np = (eE - eS + 63) >> 6;
+
+  if (wave >= 4) {
+    // ================================ consumers: layer 2 on the matrix cores ================================
+    const int cw = wave - 4, wm = cw >> 1, wn = cw & 1, l31 = lane & 31, lhi = lane >> 5;
+    const int col = wn * 32 + l31;
+    const float bias2 = (!FOLD && b2) ? b2[col] : 0.f, sc2 = s2 ? s2[col] : 1.f, sh2 = s2 ? t2[col] : 0.f;
+    auto store_messages = [&](const f32x16& acc, int p) {
+      float* ms = Ms + (p & 1) * TILE;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        ms[row * LDH + col] = FOLD ? fmaxf(fmaf(acc[r], sc2, sh2), 0.f) : fmaxf(fmaf(acc[r] + bias2, sc2, sh2), 0.f);
+      }
+    };
+    if (X6) {
+      // W2[col][16 ks + 8 lhi + 0..7] as three bfloat16 fragments per k step, resident for the whole kernel.
+      // FOLD: the BatchNorm scale s2[col] is multiplied into W2's row before the split and the shift t2[col] is the
+      // accumulator's initial value, so the epilogue is one add (the two accumulators) and the ReLU.
+      yl_bf16x8 Bh[4], Bm[4], Bl[4];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const float4* wp = reinterpret_cast<const float4*>(W2 + (long)col * 64 + 16 * ks + 8 * lhi);
+        const float4 w0 = wp[0], w1 = wp[1];
+        float x[8] = {w0.x, w0.y, w0.z, w0.w, w1.x, w1.y, w1.z, w1.w};
+        if (FOLD) {
+#pragma unroll
+          for (int i = 0; i < 8; ++i) x[i] *= sc2;
+        }
+        yl_split8(x, Bh[ks], Bm[ks], Bl[ks]);
+      }
+      __syncthreads();                                // barrier 0: Hs[0] is complete
+      for (int p = 0; p < np; ++p) {
+        const float* arow = Hs + (p & 1) * TILE + (wm * 32 + l31) * LDH + 8 * lhi;
+        f32x16 accM, accS;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { accM[r] = FOLD ? sh2 : 0.f; accS[r] = 0.f; }
+#pragma unroll
+        for (int ks = 0; ks < 4; ++ks) {
+          const float4 a0 = *reinterpret_cast<const float4*>(arow + 16 * ks);
+          const float4 a1 = *reinterpret_cast<const float4*>(arow + 16 * ks + 4);
+          const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+          yl_bf16x8 Ah, Am, Al;
+          yl_split8(x, Ah, Am, Al);
+          // two accumulators, three products each, alternating: no MFMA waits on the one issued just before it
+          accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Al, Bh[ks], accS, 0, 0, 0);
+          accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bl[ks], accM, 0, 0, 0);
+          accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh[ks], accS, 0, 0, 0);
+          accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bm[ks], accM, 0, 0, 0);
+          accS = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm[ks], accS, 0, 0, 0);
+          accM = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh[ks], accM, 0, 0, 0);
+        }
+        float* ms = Ms + (p & 1) * TILE;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+          const float z = accM[r] + accS[r];
+          ms[row * LDH + col] = FOLD ? fmaxf(z, 0.f) : fmaxf(fmaf(z + bias2, sc2, sh2), 0.f);
+        }
+        __syncthreads();                              // barrier p+1: Ms[p&1] complete, Hs[p&1] free
+      }
+      return;
+    }
+    float bfrag[32];                                  // bfrag[m] = W2[col][2m + lhi]
+    {
+      const float4* wrow = reinterpret_cast<const float4*>(W2 + (long)col * 64);
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float4 f = wrow[j];
+        bfrag[2 * j] = lhi ? f.y : f.x;
+        bfrag[2 * j + 1] = lhi ? f.w : f.z;
+      }
+    }
+    __syncthreads();                                  // barrier 0: Hs[0] is complete
+    for (int p = 0; p < np; ++p) {
+      // fp32 path: Hs rows are k-parity-interleaved (position(k) = (k & 1) * 32 + (k >> 1)), so the A operands of four
+      // consecutive MFMAs (k = 2m + lhi) are one ds_read_b128
+      const float* arow = Hs + (p & 1) * TILE + (wm * 32 + l31) * LDH + lhi * 32;
+      f32x16 acc2;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
+#pragma unroll
+      for (int m4 = 0; m4 < 8; ++m4) {
+        const float4 av = *reinterpret_cast<const float4*>(arow + 4 * m4);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, bfrag[4 * m4 + 0], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, bfrag[4 * m4 + 1], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, bfrag[4 * m4 + 2], acc2, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, bfrag[4 * m4 + 3], acc2, 0, 0, 0);
+      }
+      store_messages(acc2, p);
+      __syncthreads();                                // barrier p+1: Ms[p&1] complete, Hs[p&1] free
+    }
+    return;
+  }
+
+  // ================================== producers: gathers, layer 1, mean ==================================
+  const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t;
+                                                      // aggregation role: nodes rb, rb+16, .. of the pass, same columns
+  float4 wc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) wc[j] = *reinterpret_cast<const float4*>(Wc4 + (4 * q + j) * 4);
+  float4 bb = make_float4(0.f, 0.f, 0.f, 0.f), sc = make_float4(1.f, 1.f, 1.f, 1.f), sh = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (!FOLD) {
+    if (b1) bb = *reinterpret_cast<const float4*>(b1 + 4 * q);
+    if (s1) { sc = *reinterpret_cast<const float4*>(s1 + 4 * q); sh = *reinterpret_cast<const float4*>(t1 + 4 * q); }
+  }
+  int di[4], si[4];
+  float4 u[4], v[4], a[4];
+  // every load below is unconditional (addresses clamped into the range), so the compiler can count the loads in
+  // flight: a pass beyond the range re-reads the last edge and its tile is never consumed
+  // (uniform base + 32-bit byte offset: one VALU operation per address; the host checks that UV / attr / the index
+  // arrays are smaller than 4 GiB)
+  const unsigned ldb = (unsigned)ld_uv * 4u, qb = 16u * q;
+  auto load_idx = [&](int c0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned eb = 4u * (unsigned)yl_min(c0 + rb + 16 * t, eE - 1);
+      di[t] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(dst) + eb);
+      si[t] = *reinterpret_cast<const int*>(reinterpret_cast<const char*>(src) + eb);
+    }
+  };
+  auto gather = [&](int c0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const unsigned e = (unsigned)yl_min(c0 + rb + 16 * t, eE - 1);
+      u[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(UV) + ((unsigned)di[t] * ldb + qb));
+      v[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(UV) + ((unsigned)si[t] * ldb + qb + 256u));
+      a[t] = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(attr) + 16u * e);
+    }
+  };
+  auto layer1 = [&](float* hs) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      auto one = [&](float uu, float vv, const float4& w, float b, float s, float h) {
+        float z = uu + vv;
+        z = fmaf(a[t].x, w.x, z); z = fmaf(a[t].y, w.y, z); z = fmaf(a[t].z, w.z, z); z = fmaf(a[t].w, w.w, z);
+        return fmaxf(fmaf(z + b, s, h), 0.f);
+      };
+      float h0, h1, h2, h3;
+      if (FOLD) {
+        // packed fp32 math (v_pk_add_f32 / v_pk_fma_f32: two IEEE operations per instruction, same roundings)
+        yl_f32x2 z02 = {u[t].x + v[t].x, u[t].z + v[t].z}, z13 = {u[t].y + v[t].y, u[t].w + v[t].w};
+        const yl_f32x2 ax = {a[t].x, a[t].x}, ay = {a[t].y, a[t].y}, az = {a[t].z, a[t].z}, aw = {a[t].w, a[t].w};
+        z02 = __builtin_elementwise_fma(ax, (yl_f32x2){wc[0].x, wc[2].x}, z02);
+        z13 = __builtin_elementwise_fma(ax, (yl_f32x2){wc[1].x, wc[3].x}, z13);
+        z02 = __builtin_elementwise_fma(ay, (yl_f32x2){wc[0].y, wc[2].y}, z02);
+        z13 = __builtin_elementwise_fma(ay, (yl_f32x2){wc[1].y, wc[3].y}, z13);
+        z02 = __builtin_elementwise_fma(az, (yl_f32x2){wc[0].z, wc[2].z}, z02);
+        z13 = __builtin_elementwise_fma(az, (yl_f32x2){wc[1].z, wc[3].z}, z13);
+        z02 = __builtin_elementwise_fma(aw, (yl_f32x2){wc[0].w, wc[2].w}, z02);
+        z13 = __builtin_elementwise_fma(aw, (yl_f32x2){wc[1].w, wc[3].w}, z13);
+        h0 = fmaxf(z02.x, 0.f); h2 = fmaxf(z02.y, 0.f); h1 = fmaxf(z13.x, 0.f); h3 = fmaxf(z13.y, 0.f);
+      } else {
+        h0 = one(u[t].x, v[t].x, wc[0], bb.x, sc.x, sh.x);
+        h1 = one(u[t].y, v[t].y, wc[1], bb.y, sc.y, sh.y);
+        h2 = one(u[t].z, v[t].z, wc[2], bb.z, sc.z, sh.z);
+        h3 = one(u[t].w, v[t].w, wc[3], bb.w, sc.w, sh.w);
+      }
+      if (X6) {                                       // natural k order: the consumers read 8 consecutive k per lane
+        *reinterpret_cast<float4*>(hs + (rb + 16 * t) * LDH + 4 * q) = make_float4(h0, h1, h2, h3);
+      } else {
+        float* hrow = hs + (rb + 16 * t) * LDH + 2 * q;
+        *reinterpret_cast<float2*>(hrow) = make_float2(h0, h2);
+        *reinterpret_cast<float2*>(hrow + 32) = make_float2(h1, h3);
+      }
+    }
+  };
+  // segment table of pass P from its 64 destination ids (lane = row); every producer wave writes the same values
+  int dm_cur = dst[yl_min(eS + lane, eE - 1)], dm_nxt = dst[yl_min(eS + 64 + lane, eE - 1)], prev_last = -1;
+  auto meta = [&](int P) {
+    const int c0 = eS + 64 * P, bsel = P & 1;
+    const int nrows = yl_min(64, eE - c0);
+    const int dprev = __shfl_up(dm_cur, 1);
+    const bool start = lane < nrows && (lane == 0 || dm_cur != dprev);
+    const unsigned long long mask = __ballot(start);
+    const int k = __popcll(mask & ((1ull << lane) - 1ull));
+    if (start) { seg_start[bsel][k] = lane; seg_node[bsel][k] = dm_cur; }
+    if (lane == 0) {
+      const int nseg = __popcll(mask);
+      seg_start[bsel][nseg] = nrows;
+      seg_info[bsel][0] = nseg;
+      seg_info[bsel][1] = (P > 0 && prev_last == dm_cur) ? 1 : 0;
+    }
+    const int first_next = __shfl(dm_nxt, 0);
+    if (lane == 63) seg_info[bsel][2] = (c0 + 64 < eE && first_next == dm_cur) ? 1 : 0;
+    prev_last = __shfl(dm_cur, 63);
+    dm_cur = dm_nxt;
+    dm_nxt = dst[yl_min(c0 + 128 + lane, eE - 1)];
+  };
+  // f_out row of this thread's FIRST node of pass P (the common case: <= 16 nodes per pass; further nodes load on
+  // demand).  Issued one whole interval before aggregate(P) adds to it, unconditionally and clamped so that the
+  // compiler can count the loads in flight: the wait in aggregate() then leaves the younger prefetches (next row
+  // gathers, indices) in flight instead of draining them.  seg_node was written by this wave itself in meta(P).
+  float4 fo0 = make_float4(0.f, 0.f, 0.f, 0.f);
+  auto fo_load = [&](int P) {
+    const int bsel = P & 1;
+    const int k = yl_min(rb, seg_info[bsel][0] - 1);
+    fo0 = *reinterpret_cast<const float4*>(f_out + (long)seg_node[bsel][k] * ld_fo + 4 * q);
+  };
+  auto aggregate = [&](int P) {
+    const int bsel = P & 1;
+    const float* ms = Ms + bsel * TILE + 4 * q;
+    const int nseg = seg_info[bsel][0], cont_in = seg_info[bsel][1], cont_out = seg_info[bsel][2];
+    for (int k = rb; k < nseg; k += 16) {
+      const int lo = seg_start[bsel][k], hi = seg_start[bsel][k + 1];
+      float4 sm = make_float4(0.f, 0.f, 0.f, 0.f);
+      int cn = 0;
+      if (k == 0 && cont_in) {
+        sm = *reinterpret_cast<const float4*>(&carry_s[bsel ^ 1][4 * q]);
+        cn = carry_cnt_s[bsel ^ 1];
+      }
+      for (int r = lo; r < hi; ++r) {
+        const float4 m = *reinterpret_cast<const float4*>(ms + r * LDH);
+        sm.x += m.x; sm.y += m.y; sm.z += m.z; sm.w += m.w;
+      }
+      cn += hi - lo;
+      if (k == nseg - 1 && cont_out) {                // the node continues in the next pass
+        *reinterpret_cast<float4*>(&carry_s[bsel][4 * q]) = sm;
+        if (q == 0) carry_cnt_s[bsel] = cn;
+      } else {
+        const float inv = 1.f / (float)cn;
+        float4* o = reinterpret_cast<float4*>(f_out + (long)seg_node[bsel][k] * ld_fo + 4 * q);
+        float4 d = fo0;
+        if (k != rb) d = *o;
+        // explicit mul then add (no fma contraction): the same two roundings as k_csr_mean_fwd*
+        d.x = yl_mul_rn(sm.x, inv) + d.x; d.y = yl_mul_rn(sm.y, inv) + d.y;
+        d.z = yl_mul_rn(sm.z, inv) + d.z; d.w = yl_mul_rn(sm.w, inv) + d.w;
+        *o = d;
+      }
+    }
+  };
+  load_idx(eS);
+  gather(eS);
+  load_idx(eS + 64);
+  layer1(Hs);
+  gather(eS + 64);
+  load_idx(eS + 128);
+  __syncthreads();                                    // barrier 0
+  for (int p = 0; p < np; ++p) {
+    layer1(Hs + ((p + 1) & 1) * TILE);                // pass p+1 (gathered during pass p-1 / the barrier)
+    gather(eS + 64 * (p + 2));
+    load_idx(eS + 64 * (p + 3));
+    meta(p);
+    if (p >= 1) aggregate(p - 1);                     // adds onto fo0 = rows loaded at the end of the last interval
+    fo_load(p);
+    __syncthreads();                                  // barrier p+1
+  }
+  aggregate(np - 1);
+}
+
+extern "C" int yolat_edge_uv_mlp2_mean_eval_variant(const float* UV, int64_t ld_uv, const int32_t* src_csr,
+                                                    const int32_t* dst_csr, const float* attr_csr,
+                                                    const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                                                    const float* b1, const float* s1, const float* t1, const float* W2,
+                                                    const float* b2, const float* s2, const float* t2, int64_t C,
+                                                    float* f_out, int64_t ld_fo, int variant, yolat_stream_t stream) {
+  if (E < 0 || N <= 0 || !UV || !Wc4 || !W2 || !row_ptr || !f_out) return YOLAT_E_INVALID;
+  if (variant < YOLAT_EDGE_AUTO || variant > YOLAT_EDGE_WS_X6) return YOLAT_E_INVALID;
   if (C != 64) return YOLAT_E_UNSUPPORTED;
   if (E == 0) return 0;
   if (!src_csr || !dst_csr || !attr_csr || E >= (1LL << 31) || ld_fo < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
   if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return YOLAT_E_INVALID;
   if (ld_uv % 4 != 0 || ld_fo % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) ||
-      !yl_aligned16(b1) || !yl_aligned16(f_out) || (s1 && (!yl_aligned16(s1) || !yl_aligned16(t1))))
+      (b1 && !yl_aligned16(b1)) || !yl_aligned16(f_out) || (s1 && (!yl_aligned16(s1) || !yl_aligned16(t1))))
     return YOLAT_E_UNSUPPORTED;
+  // folded form: layer 1's bias / BatchNorm already applied to UV and Wc4 by the caller, layer 2's bias inside t2
+  const bool fold = b1 == nullptr && s1 == nullptr && b2 == nullptr;
+  // YOLAT_EDGE_VARIANT (1..3) overrides the automatic choice, YOLAT_EDGE_WGS the number of persistent workgroups
+  // (bench A/B hooks; an explicit `variant` argument always wins)
+  static int env_variant = -1;
+  static long ws_wgs = 512;
+  if (env_variant < 0) {
+    const char* e = getenv("YOLAT_EDGE_VARIANT");
+    env_variant = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
+    if (const char* w = getenv("YOLAT_EDGE_WGS")) ws_wgs = atol(w) > 0 ? atol(w) : 512;
+  }
+  // the persistent kernel addresses UV / attr / the index arrays with 32-bit byte offsets
+  const bool ws_ok = yl_aligned16(W2) && E >= 64 && N * ld_uv * 4 < (1LL << 32) && E * 16 < (1LL << 32);
+  if (variant == YOLAT_EDGE_AUTO) {
+    variant = env_variant != 0 ? env_variant : (E >= 131072 ? YOLAT_EDGE_WS_X6 : YOLAT_EDGE_TILES);
+    if (!ws_ok) variant = YOLAT_EDGE_TILES;
+  } else if (variant != YOLAT_EDGE_TILES && !ws_ok) {
+    return YOLAT_E_UNSUPPORTED;
+  }
+  if (variant != YOLAT_EDGE_TILES) {
+    // 2 workgroups of 512 threads per CU, each walking a contiguous edge range in full 64-edge passes
+    long chunk = ((E + ws_wgs - 1) / ws_wgs + 63) / 64 * 64;
+    if (chunk < 64) chunk = 64;
+    const unsigned grid = (unsigned)((E + chunk - 1) / chunk);
+#define YL_WS_LAUNCH(F, X)                                                                                          \
+  hipLaunchKernelGGL((k_edge_uv_mlp2_mean_ws<F, X>), dim3(grid), dim3(512), 0, (hipStream_t)stream, UV, (long)ld_uv,   \
+                     src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)E, (int)chunk, Wc4, b1, s1, t1, W2, b2, s2, t2, \
+                     f_out, (long)ld_fo)
+    if (variant == YOLAT_EDGE_WS_X6) { if (fold) YL_WS_LAUNCH(true, true); else YL_WS_LAUNCH(false, true); }
+    else { if (fold) YL_WS_LAUNCH(true, false); else YL_WS_LAUNCH(false, false); }
+#undef YL_WS_LAUNCH
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   // nodes per workgroup: ~56 edges on average so that a single 64-edge pass is the common case
   // (measured at cfg 5: 9 nodes / one pass 208 us, 12 nodes / a second mostly-empty pass 242 us, 16 nodes /
   // two full passes 194 us — on big graphs two passes halve the per-workgroup W2 staging)
@@ -433,6 +811,16 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, cons
                        (long)ld_fo, (int)E);
   YL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,
+                                            const int32_t* dst_csr, const float* attr_csr,
+                                            const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                                            const float* b1, const float* s1, const float* t1, const float* W2,
+                                            const float* b2, const float* s2, const float* t2, int64_t C,
+                                            float* f_out, int64_t ld_fo, yolat_stream_t stream) {
+  return yolat_edge_uv_mlp2_mean_eval_variant(UV, ld_uv, src_csr, dst_csr, attr_csr, row_ptr, N, E, Wc4, b1, s1, t1, W2,
+                                              b2, s2, t2, C, f_out, ld_fo, YOLAT_EDGE_AUTO, stream);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -524,12 +912,12 @@ extern "C" int yolat_edge_uv_mlp2_eval(const float* UV, int64_t ld_uv, const int
                                        const float* b1, const float* s1, const float* t1, const float* W2,
                                        const float* b2, const float* s2, const float* t2, int64_t C, float* H2,
                                        int64_t ldh, yolat_stream_t stream) {
-  if (E < 0 || !UV || !Wc4 || !b1 || !W2) return YOLAT_E_INVALID;
+  if (E < 0 || !UV || !Wc4 || !W2) return YOLAT_E_INVALID;
   if (C != 64) return YOLAT_E_UNSUPPORTED;
   if (E == 0) return 0;
   if (!src_csr || !dst_csr || !attr_csr || !H2 || E >= (1LL << 31) || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
   if ((s1 == nullptr) != (t1 == nullptr) || (s2 == nullptr) != (t2 == nullptr)) return YOLAT_E_INVALID;
-  if (ld_uv % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) || !yl_aligned16(b1) ||
+  if (ld_uv % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) || (b1 && !yl_aligned16(b1)) ||
       (s1 && (!yl_aligned16(s1) || !yl_aligned16(t1))))
     return YOLAT_E_UNSUPPORTED;
   DenseOp w2 = yl_dense(W2, C, C, C);

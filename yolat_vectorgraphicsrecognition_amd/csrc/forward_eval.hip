@@ -57,11 +57,6 @@ struct StageRec { std::string name; double flops, bytes; std::vector<std::pair<h
 std::vector<StageRec> g_stages;
 std::vector<hipEvent_t> g_pool;
 bool g_profile = false;
-int g_conv_mode = -1;   // conv layer implementation: 0 (default) tile kernels: edge_mlp2 -> node_pair -> csr_mean;
-                        // 1 conv_fused.hip, 2 conv_chain.hip (whole-layer persistent kernels, kept for A/B:
-                        // measured on MI355X they lose at every size — cfg 2 block layer 46 us (mode 0) vs
-                        // 50-54 us; cfg 5 block layer 543 us vs 767 us).  env YOLAT_CONV_MODE overrides.
-
 hipEvent_t new_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
@@ -143,11 +138,6 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     return YOLAT_E_INVALID;
   Plan p = carve(m, N, E, P, workspace);
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
-  if (g_conv_mode < 0) {
-    const char* e = getenv("YOLAT_CONV_MODE");
-    g_conv_mode = (e && e[0] >= '0' && e[0] <= '2') ? (e[0] - '0') : 0;
-  }
-  const int conv_mode = g_conv_mode;
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
   const int lo = m->n_blocks - m->n_blocks_out;
 
@@ -156,7 +146,8 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   // The node side of layer 0 (UV products, root Linear, node-branch Linear) reads only x: its GEMM tiles are
   // co-scheduled with the last, latency-bound pre-processing launch instead of being a launch of their own.
   const yolat_conv_eval& cv0 = m->conv[0];
-  const bool node0_in_prep = (conv_mode == 0) && C == 64 && cv0.Wuv != nullptr && cv0.Wc4 != nullptr;
+  const bool node0_in_prep = C == 64 && cv0.Wuv != nullptr && cv0.Wc4 != nullptr;
+  const bool fold0 = cv0.Wuvf && cv0.uvb && cv0.Wc4f && cv0.t2f;
   if (node0_in_prep) {
     const int slot0 = 0 - lo;
     float* f0 = slot0 >= 0 ? p.feats + slot0 * C : p.f_tmp[0];
@@ -166,7 +157,8 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
              16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N + 4.0 * (2.0 * N * cv0.Cin + 4.0 * N * C),
              yolat_graph_prepare_node_uv(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
                                          p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, x, ldx, cv0.Cin,
-                                         cv0.Wuv, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C, p.UV, 2 * C, f0,
+                                         fold0 ? cv0.Wuvf : cv0.Wuv, fold0 ? cv0.uvb : nullptr, cv0.Wr, cv0.br, cv0.Wn,
+                                         cv0.bn, cv0.sn, cv0.tn, C, p.UV, 2 * C, f0,
                                          ld0, s0, ld0, stream));
   } else {
   YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N,
@@ -184,40 +176,32 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     float* s_out = slot >= 0 ? p.fsup + slot * C : p.s_tmp[l];
     const long ld_out = slot >= 0 ? D : C;
     const double K1 = 2.0 * cv.Cin + 4;
-    const bool chain_ok = C == 64 && cv.packed != nullptr && (cv.Cin == 64 || cv.Cin == 5 || cv.Cin == 6) &&
-                          (cv.Cin != 64 || ld_f % 4 == 0);
-    if (conv_mode == 2 && chain_ok) {
-      // register-chained persistent kernel (conv_chain.hip)
-      snprintf(nm, sizeof nm, "conv_chain[Cin=%ld: gather+MLP+mean+root+node]", (long)cv.Cin);
-      YL_STAGE(nm, 2.0 * E * (K1 * C + C * C) + 4.0 * N * cv.Cin * C,
-               E * (K1 * 4.0 + 8.0) + 4.0 * N * (2.0 * cv.Cin + 2.0 * C),
-               yolat_conv_eval_chain(f_in, ld_f, s_in, ld_s, N, cv.Cin, p.row_ptr, p.src, p.dst, p.attr, E, &cv,
-                                     cv.packed, C, f_out, ld_out, s_out, ld_out, stream));
-    } else if (conv_mode == 1 && C == 64 && (cv.Cin == 64 || cv.Cin <= 8)) {
-      // LDS-staged persistent kernel (conv_fused.hip)
-      snprintf(nm, sizeof nm, "conv_fused[Cin=%ld: gather+MLP+mean+root+node]", (long)cv.Cin);
-      YL_STAGE(nm, 2.0 * E * (K1 * C + C * C) + 4.0 * N * cv.Cin * C,
-               E * (K1 * 4.0 + 8.0) + 4.0 * N * (2.0 * cv.Cin + 2.0 * C),
-               yolat_conv_eval_fused(f_in, ld_f, s_in, ld_s, N, cv.Cin, p.row_ptr, p.src, p.dst, p.attr, E, &cv, C,
-                                     f_out, ld_out, s_out, ld_out, stream));
-    } else if (C == 64) {
+    if (C == 64) {
       if (cv.Wuv != nullptr && cv.Wc4 != nullptr) {
         // factorised layer, two launches: (1) node side — UV = f_in.[W1a-W1b | W1b]^T, root Linear and
         // node-branch Linear in one launch; (2) per destination-node tile: gather-add of U[dst] + V[src] +
         // W1c.attr, BN+ReLU, second edge Linear, BN+ReLU and the CSR mean, accumulated into the root output
         // (neither [E,64] activation reaches HBM).  The K = 2*Cin GEMM runs once per node instead of once
         // per edge (E = 4..6 N).
+        // folded form (yolat_conv_eval.{Wuvf, uvb, Wc4f, t2f}): layer 1's bias / BatchNorm ride in the node-side
+        // epilogue and the scaled weights, layer 2's bias in t2f
+        const bool fold = cv.Wuvf && cv.uvb && cv.Wc4f && cv.t2f;
         if (!(l == 0 && node0_in_prep)) {
           snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
           YL_STAGE(nm, 8.0 * N * cv.Cin * C, 4.0 * (2.0 * N * cv.Cin + 4.0 * N * C),
-                   yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, cv.Wuv, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn,
-                                      cv.tn, C, p.UV, 2 * C, f_out, ld_out, s_out, ld_out, stream));
+                   yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, fold ? cv.Wuvf : cv.Wuv,
+                                      fold ? cv.uvb : nullptr, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn, C, p.UV, 2 * C,
+                                      f_out, ld_out, s_out, ld_out, stream));
         }
         if (E > 0) {
           snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
           YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C,
-                   yolat_edge_uv_mlp2_mean_eval(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.b1,
-                                                cv.s1, cv.t1, cv.W2, cv.b2, cv.s2, cv.t2, C, f_out, ld_out, stream));
+                   fold ? yolat_edge_uv_mlp2_mean_eval(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4f,
+                                                       nullptr, nullptr, nullptr, cv.W2, nullptr, cv.s2, cv.t2f, C,
+                                                       f_out, ld_out, stream)
+                        : yolat_edge_uv_mlp2_mean_eval(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.b1,
+                                                       cv.s1, cv.t1, cv.W2, cv.b2, cv.s2, cv.t2, C, f_out, ld_out,
+                                                       stream));
         }
       } else {
       // three launches per layer: edge MLP (hidden activation in LDS); root Linear | node-branch Linear as one

@@ -463,13 +463,14 @@ extern "C" int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e
                                            int64_t P, int32_t* row_ptr, int32_t* perm, int32_t* src_csr,
                                            int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
                                            int32_t* work, int32_t* status, const float* x, int64_t ldx, int64_t Cin,
-                                           const float* Wuv, const float* Wr, const float* br, const float* Wn,
+                                           const float* Wuv, const float* uv_bias, const float* Wr, const float* br,
+                                           const float* Wn,
                                            const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
                                            int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
                                            yolat_stream_t stream) {
   NodeUv a;
-  const int rc = yl_build_node_uv(&a, x, ldx, x, ldx, N, Cin, Wuv, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv, f_out, ld_fo,
-                                  s_out, ld_so);
+  const int rc = yl_build_node_uv(&a, x, ldx, x, ldx, N, Cin, Wuv, uv_bias, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv, f_out,
+                                  ld_fo, s_out, ld_so);
   if (rc != 0) return rc;
   return yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
                             attr_csr, seg_ptr, node_seg, work, status, &a, stream);

@@ -17,8 +17,10 @@ __global__ void __launch_bounds__(1024) k_softmax_ce(const float* logits, long l
     float s = 0.f;
     for (int k = 0; k < K; ++k) s += expf(z[k] - m);
     const float lse = m + logf(s);
-    const int y = (int)labels[p];
-    acc += lse - z[y];
+    const int64_t yl = labels[p];
+    const bool bad = yl < 0 || yl >= K;          // no out-of-bounds read; the loss is poisoned (NaN) instead
+    const int y = bad ? 0 : (int)yl;
+    acc += bad ? __builtin_nanf("") : lse - z[y];
     if (dl != nullptr) {
       float* d = dl + (long)p * lddl;
       const float invs = 1.f / s;
@@ -62,8 +64,12 @@ __global__ void __launch_bounds__(256) k_softmax_ce_rows(const float* logits, lo
       v[k] = expf(v[k] - m);
       s += (k < K) ? v[k] : 0.f;
     }
-    const int y = (int)labels[p];
-    row_loss = m + logf(s) - z[y];
+    // a label outside [0, K) (torch raises "Target out of bounds"; ignore_index is not used by the reference,
+    // architecture3cc_rpn_gp_iter2.py:363) must not become an out-of-bounds read: the loss is poisoned with NaN
+    const int64_t yl = labels[p];
+    const bool bad = yl < 0 || yl >= K;
+    const int y = bad ? 0 : (int)yl;
+    row_loss = bad ? __builtin_nanf("") : m + logf(s) - z[y];
     if (dl != nullptr) {
       const float invs = 1.f / s, invP = 1.f / (float)P;
       float* d = dl + (long)p * lddl;

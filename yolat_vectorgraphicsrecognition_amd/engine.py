@@ -98,9 +98,10 @@ def flush_batch_counters():
 
 
 def _bn_eval(bn, dev):
-    """Folded eval coefficients, cached on the module until any of its tensors changes."""
+    """Folded eval coefficients, cached on the module until any of its tensors changes (torch-side edits show up
+    in `_version`, raw-pointer writes of the HIP kernels — Adam, running statistics — in ops.weight_epoch())."""
     key = (bn.weight._version, bn.bias._version, bn.running_mean._version, bn.running_var._version,
-           bn.weight.data_ptr(), bn.running_mean.data_ptr())
+           bn.weight.data_ptr(), bn.running_mean.data_ptr(), ops.weight_epoch())
     cache = getattr(bn, "_yolat_eval", None)
     if cache is not None and cache[0] == key:
         return cache[1]

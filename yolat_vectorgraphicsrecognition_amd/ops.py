@@ -11,6 +11,20 @@ from ._lib import lib, check
 STATS_ROWS = 32
 STATUS_EDGE_RANGE, STATUS_SEG_UNSORTED, STATUS_SEG_RANGE = 1, 2, 4
 
+# The HIP kernels write parameters and BatchNorm buffers through raw pointers, which torch's per-tensor `_version`
+# counters never see.  Every wrapper below that modifies model state (Adam step, running-statistic updates) bumps
+# this epoch; every cache derived from model state (folded eval BatchNorm coefficients in engine._bn_eval, the
+# eval plan's descriptor in plan.EvalPlan) carries it in its key.
+_WEIGHT_EPOCH = [0]
+
+
+def weight_epoch():
+    return _WEIGHT_EPOCH[0]
+
+
+def bump_weight_epoch():
+    _WEIGHT_EPOCH[0] += 1
+
 
 def _stream():
     return torch.cuda.current_stream().cuda_stream
@@ -109,8 +123,10 @@ def build_graph(edge, e_attr, bbox_idx, num_nodes, num_proposals):
     g.attr = torch.empty(max(E, 1), 4, dtype=torch.float32, device=dev)
     g.seg_ptr = g.node_seg = None
     if bbox_idx is not None:
-        g.seg_ptr = torch.empty(P + 1, dtype=torch.int32, device=dev)
-        g.node_seg = torch.empty(max(N, 1), dtype=torch.int32, device=dev)
+        # zero-initialised: with a malformed (unsorted) bbox_idx the kernels flag STATUS_SEG_UNSORTED and the
+        # pointers stay inside [0, N] whatever the write order, so every downstream kernel is memory-safe
+        g.seg_ptr = torch.zeros(P + 1, dtype=torch.int32, device=dev)
+        g.node_seg = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
     if E > 0:
         if e_attr.shape[0] != E or e_attr.shape[1] != 4:
             raise ValueError("e_attr must be [E,4]")
@@ -177,6 +193,8 @@ def bn_finalize(stats, M, bn, scale, shift, save_mean, save_invstd, update_runni
     rm = bn.running_mean if (update_running and bn.track_running_stats) else None
     rv = bn.running_var if (update_running and bn.track_running_stats) else None
     mom = 0.1 if bn.momentum is None else float(bn.momentum)
+    if rm is not None:
+        bump_weight_epoch()
     check(lib.yolat_bn_finalize(_f(stats), M, C, _f(bn.weight), _f(bn.bias), _f(rm, "rm", True),
                                 _f(rv, "rv", True), mom, float(bn.eps), _f(save_mean),
                                 _f(save_invstd), _f(scale), _f(shift), _stream()), "yolat_bn_finalize")
@@ -239,6 +257,38 @@ def edge_lin1_fwd_factorised(x, g, W1, b1, H1, stats=None):
                                      wc4.data_ptr(), _f(b1, "b1", True), C, _f(H1), _ld(H1),
                                      _f(stats, "stats", True), _stream()), "yolat_edge_uv_lin1_fwd")
     return H1
+
+
+def fold_factorised_layer(wuv, wc4, b1, s1, t1, b2, s2, t2):
+    """Folded form of a factorised eval conv layer (include/yolat_hip.h, yolat_conv_eval.{Wuvf, uvb, Wc4f, t2f}):
+    nn.1's folded BatchNorm (s1, t1) and the bias b1 move into the per-node products and the attr weights, b2 into the
+    shift of nn.4, so the per-edge arithmetic is  h1 = relu(U'[dst] + V'[src] + Wc4f.attr),
+    message = relu(s2 * (W2.h1) + t2f).  Elementwise work on [C]- / weight-sized tensors, once per weight version."""
+    zeros = torch.zeros_like(s1)
+    b1 = zeros if b1 is None else b1.detach()
+    b2 = zeros if b2 is None else b2.detach()
+    wuvf = (wuv * torch.cat([s1, s1]).unsqueeze(1)).contiguous()
+    uvb = torch.cat([s1 * b1 + t1, zeros]).contiguous()
+    wc4f = (wc4 * s1.unsqueeze(1)).contiguous()
+    t2f = (s2 * b2 + t2).contiguous()
+    return wuvf, uvb, wc4f, t2f
+
+
+EDGE_AUTO, EDGE_TILES, EDGE_WS_F32, EDGE_WS_X6 = 0, 1, 2, 3
+
+
+def edge_uv_mlp2_mean_eval(UV, g, wc4, b1, pro1, W2, b2, pro2, f_out, variant=EDGE_AUTO):
+    """f_out[n] += mean over the CSR row of n of relu(s2*(W2.relu(s1*(U[dst]+V[src]+wc4.attr+b1)+t1)+b2)+t2)
+    (yolat_edge_uv_mlp2_mean_eval_variant; b1 / pro1 / b2 may be None)."""
+    s1, t1 = pro1 if pro1 is not None else (None, None)
+    s2, t2 = pro2 if pro2 is not None else (None, None)
+    check(lib.yolat_edge_uv_mlp2_mean_eval_variant(_f(UV, "UV"), _ld(UV), g.src.data_ptr(), g.dst.data_ptr(),
+                                                   g.attr.data_ptr(), g.row_ptr.data_ptr(), g.N, g.E, _f(wc4),
+                                                   _f(b1, "b1", True), _f(s1, "s1", True), _f(t1, "t1", True), _f(W2),
+                                                   _f(b2, "b2", True), _f(s2, "s2", True), _f(t2, "t2", True),
+                                                   W2.shape[0], _f(f_out), _ld(f_out), int(variant), _stream()),
+          "yolat_edge_uv_mlp2_mean_eval_variant")
+    return f_out
 
 
 def edge_mlp2_eval(x, g, W1, b1, pro1, W2, b2, pro2, H2):
@@ -415,6 +465,8 @@ def fusion_pool_train_fwd(A, lin, bn, g, Z):
     W = lin.weight
     if not W.is_contiguous():
         raise ValueError("fusion_block weight must be contiguous")
+    if track:
+        bump_weight_epoch()
     check(lib.yolat_fusion_pool_train_fwd(_f(A, "A"), _ld(A), N, K, _f(W), _f(lin.bias, "bias", True), F,
                                           _f(bn.weight), _f(bn.bias), _f(bn.running_mean if track else None, "rm", True),
                                           _f(bn.running_var if track else None, "rv", True), mom, float(bn.eps),
@@ -450,6 +502,7 @@ def softmax_ce(logits, labels, loss, dlogits=None):
 
 def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_decay, step,
               grad_scale=1.0):
+    bump_weight_epoch()
     check(lib.yolat_adam_step(_f(param), _f(grad), _f(exp_avg), _f(exp_avg_sq), param.numel(),
                               float(lr), float(beta1), float(beta2), float(eps), float(weight_decay),
                               int(step), float(grad_scale), _stream()), "yolat_adam_step")

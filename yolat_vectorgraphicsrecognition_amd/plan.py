@@ -39,7 +39,7 @@ class EvalPlan(object):
         self.use_graph = os.environ.get("YOLAT_HIP_GRAPH", "0") == "1"
 
     def _version_key(self):
-        return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(),)
+        return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(), ops.weight_epoch())
 
     def _build(self):
         from .engine import model_convs
@@ -74,17 +74,11 @@ class EvalPlan(object):
             folds1.append((keep[-1][0], keep[-1][1]))
             c.W2, c.b2 = ptr(cv.nn[3].weight), ptr(cv.nn[3].bias)
             c.s2, c.t2 = folded(cv.nn[4])
+            fold2 = keep[-1]
             c.Wr, c.br = ptr(cv.lin_r.weight), ptr(cv.lin_r.bias)
             c.Wn, c.bn = ptr(cv.mlp_node[0].weight), ptr(cv.mlp_node[0].bias)
             c.sn, c.tn = folded(cv.mlp_node[1])
             C = cv.nn[0].out_features
-            if C == 64:
-                # W1 / W2 in MFMA fragment order for the register-chained conv kernel (conv_chain.hip, C = 64 only)
-                pk = torch.empty(int(lib.yolat_conv_pack_elems(cv.in_channels)), dtype=torch.float32, device=dev)
-                check(lib.yolat_conv_pack_weights(c.W1, c.W2, cv.in_channels, pk.data_ptr(), ops._stream()),
-                      "yolat_conv_pack_weights")
-                keep.append(pk)
-                c.packed = pk.data_ptr()
             # factorised first edge Linear: per-node weights [W1a - W1b | W1b] and the 4 attr columns
             wuv = torch.empty(2 * C, cv.in_channels, dtype=torch.float32, device=dev)
             wc4 = torch.empty(C, 4, dtype=torch.float32, device=dev)
@@ -94,6 +88,16 @@ class EvalPlan(object):
             wuvs.append(wuv)
             if self.precision == "bf16" or os.environ.get("YOLAT_EDGE_FACTORISED", "1") != "0":
                 c.Wuv, c.Wc4 = wuv.data_ptr(), wc4.data_ptr()
+                if self.precision == "fp32" and os.environ.get("YOLAT_EDGE_FOLD", "1") != "0":
+                    # folded form of the layer (once per weight version; elementwise on [C]-sized tensors): nn.1's
+                    # folded BatchNorm (s1, t1) and the bias b1 move into the per-node products and the attr weights,
+                    # b2 into the shift of nn.4 — the per-edge arithmetic shrinks to
+                    #   h1 = relu(U'[dst] + V'[src] + Wc4f.attr),  message = relu(s2 * (W2.h1) + t2f)
+                    s1, t1 = folds1[l]
+                    wuvf, uvb, wc4f, t2f = ops.fold_factorised_layer(wuv, wc4, cv.nn[0].bias, s1, t1, cv.nn[3].bias,
+                                                                     fold2[0], fold2[1])
+                    keep += [wuvf, uvb, wc4f, t2f]
+                    c.Wuvf, c.uvb, c.Wc4f, c.t2f = wuvf.data_ptr(), uvb.data_ptr(), wc4f.data_ptr(), t2f.data_ptr()
         fb, fs = net.fusion_block, net.fusion_block_super
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
