@@ -130,3 +130,68 @@ def test_named_configs_have_the_stated_sizes():
     d, s, kw, n = yv.config("2")
     assert (d.x.shape[0], d.edge.shape[0], d.bbox.shape[0], n) == (10000, 40000, 400, 1)
     assert kw["n_blocks"] == 2
+
+
+def test_dropin_shims_resolve_the_reference_imports(golden_dir):
+    """dropin/ first on sys.path: the reference's own import statements (architecture3cc_rpn_gp_iter2.py:6-9,
+    train.py:16-18,30) resolve to the MI355X implementation, and the model built through them has the reference's
+    state_dict keys."""
+    import subprocess
+    import sys
+    repo = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    dropin = os.path.join(repo, "yolat_vectorgraphicsrecognition_amd", "dropin")
+    code = r"""
+import torch_geometric as tg
+from gcn_lib.sparse import MultiSeq, MLP, GraphConv, PlainDynBlock, ResBlock, DenseDynBlock, DilatedKnnGraph
+from torch_scatter import scatter
+from torch_geometric.data import Data
+import torch_geometric.transforms as T
+from torch_geometric.nn.data_parallel import DataParallel
+from torch_geometric.data import InMemoryDataset
+from architecture3cc_rpn_gp_iter2 import SparseCADGCN, DetectionLoss
+import yolat_vectorgraphicsrecognition_amd as yv
+assert SparseCADGCN is yv.SparseCADGCN and GraphConv is yv.GraphConv and Data is yv.Data and scatter is yv.scatter
+m = SparseCADGCN(yv.Opt())
+print("\n".join(m.state_dict().keys()))
+for cls in (PlainDynBlock, DenseDynBlock, DilatedKnnGraph, DataParallel, InMemoryDataset):
+    try:
+        cls()
+    except NotImplementedError:
+        pass
+    else:
+        raise SystemExit("%s must not be instantiable" % cls.__name__)
+d = Data(x=1)
+assert d.x == 1 and "x" in d.keys
+"""
+    env = dict(os.environ)
+    env["PYTHONPATH"] = os.pathsep.join([dropin, repo, env.get("PYTHONPATH", "")])
+    out = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    want = [l.split()[0] for l in open(os.path.join(golden_dir, "state_dict_keys.txt")) if l.strip()]
+    assert out.stdout.split() == want
+
+
+@pytest.mark.parametrize("prefix", ["", "module."])
+def test_reference_format_checkpoint_loads(tmp_path, prefix):
+    """A checkpoint shaped like the reference's (train.py:313-321), with and without the `module.` prefix that
+    utils/ckpt_util.py:51-64 strips, loads into SparseCADGCN and reproduces every tensor."""
+    import sys
+    import yolat_vectorgraphicsrecognition_amd as yv
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import golden_util as gu
+    from oracle import oracle_torch as orc
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt()), 5)
+    sd = {prefix + k: v.clone() for k, v in ref.state_dict().items()}
+    path = str(tmp_path / "ckpt_3.pth")
+    torch.save({"epoch": 3, "state_dict": sd, "best_value": 0.5}, path)
+    model = yv.SparseCADGCN(yv.Opt())
+    epoch, best = yv.load_reference_checkpoint(model, path)
+    assert epoch == 3 and best == 0.5
+    own = model.state_dict()
+    assert list(own.keys()) == list(ref.state_dict().keys())
+    for k, v in ref.state_dict().items():
+        assert torch.equal(own[k], v), k
+    with pytest.raises(RuntimeError):
+        bad = dict(sd)
+        bad.pop(next(iter(bad)))
+        yv.load_reference_checkpoint(yv.SparseCADGCN(yv.Opt()), {"state_dict": bad})

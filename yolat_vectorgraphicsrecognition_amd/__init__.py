@@ -20,6 +20,7 @@ from .data import (Data, collate, collate_to_device, fixup_offsets, synth_graph,
                    select_tree_nodes, build_subset)
 from .postprocess import non_max_suppression, get_batch_statistics, ap_per_class, compute_ap, bbox_iou  # noqa: F401
 from .evaluation import evaluate_batch, test as evaluate  # noqa: F401
-from .trainer import FlatParams, FlatAdam, Trainer, shard_graph_ids, allreduce_mean_, broadcast_parameters  # noqa: F401
+from .trainer import (FlatParams, FlatAdam, Trainer, shard_graph_ids, allreduce_mean_, broadcast_parameters,  # noqa: F401
+                      load_reference_checkpoint)
 
 __version__ = "0.1.0"

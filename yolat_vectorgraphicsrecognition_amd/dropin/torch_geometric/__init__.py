@@ -1,2 +1,2 @@
 """Minimal torch_geometric surface used by the YOLaT model file and collate (Data only)."""
-from . import data  # noqa: F401
+from . import data, nn, transforms  # noqa: F401

@@ -58,32 +58,130 @@ class FlatParams(object):
         model._yolat_flat = self
 
 
-class FlatAdam(object):
+class FlatAdam(torch.optim.Optimizer):
+    """``torch.optim.Adam(model.parameters(), lr, weight_decay)`` of cad_recognition/train.py:212 as ONE kernel over
+    the flat buffers.  It is a ``torch.optim.Optimizer`` (one param group holding the model's parameters), so the
+    reference's ``StepLR(optimizer, lr_adjust_freq, lr_decay_rate)`` (train.py:214) drives its learning rate, and
+    ``state_dict()`` / ``load_state_dict()`` speak ``torch.optim.Adam``'s format — per-parameter ``step`` /
+    ``exp_avg`` / ``exp_avg_sq`` in ``model.parameters()`` order — so ``optimizer_state_dict`` entries of reference
+    checkpoints (utils/ckpt_util.py:86-104) load."""
+
     def __init__(self, flat, lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0):
         self.flat = flat
-        self.lr, self.betas, self.eps, self.weight_decay = lr, betas, eps, weight_decay
         self.exp_avg = torch.zeros_like(flat.param)
         self.exp_avg_sq = torch.zeros_like(flat.param)
         self.step_count = 0
+        super(FlatAdam, self).__init__(list(flat.params), dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay))
+        if len(self.param_groups) != 1:
+            raise ValueError("FlatAdam keeps one param group (the whole flat buffer)")
 
-    def zero_grad(self):
+    # hyper-parameters live in the param group (that is what LR schedulers edit)
+    lr = property(lambda self: self.param_groups[0]["lr"])
+    betas = property(lambda self: self.param_groups[0]["betas"])
+    eps = property(lambda self: self.param_groups[0]["eps"])
+    weight_decay = property(lambda self: self.param_groups[0]["weight_decay"])
+
+    def set_lr(self, lr):
+        self.param_groups[0]["lr"] = float(lr)
+
+    def zero_grad(self, set_to_none=False):
         # every gradient is overwritten (not accumulated) by the next backward; nothing to clear
         self.flat.grads_ready = False
 
-    def step(self, grad_scale=1.0):
+    @torch.no_grad()
+    def step(self, closure=None, grad_scale=1.0):
+        loss = closure() if closure is not None else None
+        g = self.param_groups[0]
         self.step_count += 1
-        ops.adam_step(self.flat.param, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr,
-                      self.betas[0], self.betas[1], self.eps, self.weight_decay, self.step_count,
-                      grad_scale)
+        ops.adam_step(self.flat.param, self.flat.grad, self.exp_avg, self.exp_avg_sq, g["lr"], g["betas"][0],
+                      g["betas"][1], g["eps"], g["weight_decay"], self.step_count, grad_scale)
+        return loss
+
+    def _slices(self):
+        off = 0
+        for i, p in enumerate(self.flat.params):
+            yield i, p, off, off + p.numel()
+            off += p.numel()
 
     def state_dict(self):
-        return {"step": self.step_count, "exp_avg": self.exp_avg, "exp_avg_sq": self.exp_avg_sq,
-                "lr": self.lr, "betas": self.betas, "eps": self.eps, "weight_decay": self.weight_decay}
+        """torch.optim.Adam layout: {'state': {i: {'step', 'exp_avg', 'exp_avg_sq'}}, 'param_groups': [...]}."""
+        state = {}
+        if self.step_count > 0:
+            for i, p, lo, hi in self._slices():
+                state[i] = {"step": torch.tensor(float(self.step_count)),
+                            "exp_avg": self.exp_avg[lo:hi].view(p.shape).clone(),
+                            "exp_avg_sq": self.exp_avg_sq[lo:hi].view(p.shape).clone()}
+        group = {k: v for k, v in self.param_groups[0].items() if k != "params"}
+        group["params"] = list(range(len(self.flat.params)))
+        return {"state": state, "param_groups": [group]}
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.exp_avg.copy_(sd["exp_avg"])
-        self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+        if "param_groups" not in sd:          # round-1 format: flat tensors
+            self.step_count = int(sd["step"])
+            self.exp_avg.copy_(sd["exp_avg"])
+            self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+            for k in ("lr", "betas", "eps", "weight_decay"):
+                if k in sd:
+                    self.param_groups[0][k] = sd[k]
+            return
+        groups = sd["param_groups"]
+        if len(groups) != 1 or len(groups[0]["params"]) != len(self.flat.params):
+            raise ValueError("optimizer state_dict does not match the model: expected one param group with %d "
+                             "parameters" % len(self.flat.params))
+        for k, v in groups[0].items():
+            if k != "params":
+                self.param_groups[0][k] = v
+        ids = groups[0]["params"]
+        state = sd["state"]
+        steps = set()
+        self.exp_avg.zero_()
+        self.exp_avg_sq.zero_()
+        for (i, p, lo, hi), pid in zip(self._slices(), ids):
+            st = state.get(pid, state.get(str(pid)))
+            if st is None:
+                continue
+            if tuple(st["exp_avg"].shape) != tuple(p.shape):
+                raise ValueError("optimizer state of parameter %d has shape %s, expected %s"
+                                 % (i, tuple(st["exp_avg"].shape), tuple(p.shape)))
+            self.exp_avg[lo:hi].copy_(st["exp_avg"].reshape(-1))
+            self.exp_avg_sq[lo:hi].copy_(st["exp_avg_sq"].reshape(-1))
+            steps.add(int(float(st["step"])))
+        if len(steps) > 1:
+            raise ValueError("per-parameter step counts differ (%s): not an Adam state FlatAdam can represent" % steps)
+        self.step_count = steps.pop() if steps else 0
+
+
+def load_reference_checkpoint(model, checkpoint, optimizer=None, strict=True):
+    """Load a checkpoint in the reference's format (cad_recognition/train.py:313-321: {'epoch', 'state_dict',
+    'optimizer_state_dict', 'scheduler_state_dict', 'best_value'}) into the HIP modules: the same `module.` prefix
+    fix-up as utils/ckpt_util.py:51-64 (checkpoints saved from a multi-GPU wrapper), then load_state_dict — the
+    parameter / buffer names are the reference's.  `checkpoint`: a path or the loaded dict.
+    Returns (epoch, best_value)."""
+    if not isinstance(checkpoint, dict):
+        checkpoint = torch.load(checkpoint, map_location="cpu")
+    sd = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
+    own_multi = next(iter(model.state_dict())).startswith("module.")
+    ckpt_multi = next(iter(sd)).startswith("module.")
+    if own_multi != ckpt_multi:
+        sd = {(k[7:] if ckpt_multi else "module." + k): v for k, v in sd.items()}
+    flat = getattr(model, "_yolat_flat", None)
+    if flat is not None:
+        # parameters are views of the flat buffer: copy in place so the views stay views
+        own = model.state_dict()
+        missing = [k for k in own if k not in sd]
+        unexpected = [k for k in sd if k not in own]
+        if strict and (missing or unexpected):
+            raise RuntimeError("checkpoint does not match the model: missing %s, unexpected %s" % (missing, unexpected))
+        with torch.no_grad():
+            for k, v in sd.items():
+                if k in own:
+                    own[k].copy_(v)
+        ops.bump_weight_epoch()
+    else:
+        model.load_state_dict(sd, strict=strict)
+    if optimizer is not None and "optimizer_state_dict" in checkpoint:
+        optimizer.load_state_dict(checkpoint["optimizer_state_dict"])
+    return checkpoint.get("epoch", -1), checkpoint.get("best_value", None)
 
 
 def shard_graph_ids(num_graphs, rank, world_size):
@@ -118,6 +216,7 @@ class Trainer(object):
         broadcast_parameters(self.flat, model)
         self.optimizer = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.criterion = DetectionLoss(opt)
+        self._checked_inputs = False
 
     def step(self, data, slices=None):
         """One training step on this rank's batch.  Returns the (device) loss tensor."""
@@ -144,4 +243,8 @@ class Trainer(object):
             loss.backward()
             scale = allreduce_mean_(self.flat.grad)
         self.optimizer.step(grad_scale=scale)
+        if not self._checked_inputs:
+            # first batch only (synchronises): edge ids inside [0, N), bbox_idx sorted — see SparseCADGCN.forward
+            self._checked_inputs = True
+            self.model.check_last_status()
         return loss.detach()
