@@ -39,6 +39,8 @@ def parse():
     ap.add_argument("--config", default=None, help="cfg id 1..5 (default: 2 for fwd, 3 for train)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true",
+                    help="skip the sub-records (multi_stream, floorplans_sized, train_dp)")
     ap.add_argument("--keep-csr", action="store_true", help="re-use the CSR across steps (fwd mode)")
     ap.add_argument("--graphs", action="store_true",
                     help="fwd mode: replay a captured hipGraph per stream instead of launching every kernel "
@@ -154,19 +156,39 @@ def plan_profile(step, n):
     return out
 
 
-# HBM/fabric bytes per launch from the committed PMC passes (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE
-# runs of this same command: profiles/r01_fwd_cfg2_pmc_{fetch,write}_v7.txt; FETCH_SIZE doubled per the gfx950
-# note in MI355X_MICROARCH.md §HBM, KiB -> bytes).  Only valid for the default cfg-2 workload.
-PMC_TRAFFIC_CFG2 = {
-    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": 2 * 5974.7 * 1024 + 7980.3 * 1024,
-}
+# HBM/fabric bytes per launch of the roofline kernel: read from profiles/pmc_traffic.json, which tools/pmc_traffic.sh
+# regenerates on the GPU box from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of this same command
+# (FETCH_SIZE doubled per the gfx950 note in MI355X_MICROARCH.md section HBM).  Every entry records the sha256 of the
+# kernel sources it was measured on; when the sources have changed since, the entry is STALE and `traffic` is null.
+def _source_digest(files):
+    import hashlib
+    h = hashlib.sha256()
+    for f in files:
+        with open(os.path.join(REPO, f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic(stage_label, cfg):
+    path = os.path.join(REPO, "profiles", "pmc_traffic.json")
+    if not os.path.exists(path):
+        return None, "no profiles/pmc_traffic.json"
+    try:
+        table = json.load(open(path))
+    except ValueError:
+        return None, "profiles/pmc_traffic.json unreadable"
+    ent = table.get("cfg%s" % cfg, {}).get(stage_label)
+    if ent is None:
+        return None, "no PMC pass recorded for this stage at cfg %s" % cfg
+    if ent.get("source_digest") != _source_digest(ent.get("sources", [])):
+        return None, "STALE: %s changed since %s was measured" % (", ".join(ent.get("sources", [])), ent.get("file"))
+    return 2.0 * ent["fetch_kib"] * 1024 + ent["write_kib"] * 1024, ent.get("file")
 
 
 def roofline_entry(summary, cfg=None):
     r = _roofline_entry(summary)
-    if cfg == "2" and r["kernel"] in PMC_TRAFFIC_CFG2:
-        r["traffic"] = PMC_TRAFFIC_CFG2[r["kernel"]]
-        r["traffic_source"] = "profiles/r01_fwd_cfg2_pmc_fetch_v7.txt (x2, gfx950) + r01_fwd_cfg2_pmc_write_v7.txt"
+    if cfg is not None:
+        r["traffic"], r["traffic_source"] = pmc_traffic(r["kernel"], cfg)
         r["algorithmic_bytes"] = summary[r["kernel"]]["bytes"]
     return r
 
@@ -257,12 +279,25 @@ def edge_layer_roofline(cfg_name="5", reps=10):
     b_agg = E * ((2 * Cin + 4) * 4.0 + 8) + N * C * 4.0
     f_edge = 2.0 * E * ((2 * Cin + 4) * C + C * C)
     t_bytes, t_flops = b_agg / (PEAK_HBM_GBS * 1e9), f_edge / (PEAK_MFMA_F32_TFLOPS * 1e12)
+    # what the kernel really executes (factorised first Linear; at this size layer 2 runs as an fp32 GEMM emulated with
+    # six bf16 MFMA products): compulsory HBM bytes = UV once + attr + indices + f_out read-modify-write
+    x_bytes = N * 2 * C * 4.0 + E * (16.0 + 8.0) + 2.0 * N * C * 4.0 + 4.0 * N
+    x_flops_f32 = 2.0 * E * (4 * C + C * C)
+    x_flops_bf16 = 6.0 * 2.0 * E * C * C
+    x_bound = max(x_bytes / (PEAK_HBM_GBS * 1e9), x_flops_bf16 / (PEAK_MFMA_BF16_TFLOPS * 1e12))
     out = {"kernel": "edge_uv_mlp2_mean[E=%d, N=%d, C=%d] (factorised edge MLP + mean aggregation, one kernel)" % (E, N, C),
            "traffic": None, "avg_launch_us": t * 1e6, "algorithmic_bytes": b_agg, "algorithmic_flops": f_edge,
            "hbm_equivalent_GBs": b_agg / t / 1e9, "frac": max(t_bytes, t_flops) / t,
-           "note": "bytes / flops are those of the UNFACTORISED layer (SURVEY 8d: B_agg, F_edge), i.e. what a per-edge "
-                   "gathered GEMM has to move / compute; the kernel itself gathers 2*C*4 B per edge and executes "
-                   "2*E*(4*C + C*C) flop because the K = 2*Cin part of the first Linear runs once per node"}
+           "note": "frac / achieved: SURVEY 8(d) pricing of a fused kernel, max(bytes/BW, flops/peak)/t with the bytes / "
+                   "flops of the UNFACTORISED layer (B_agg, F_edge) — credit for the algebra, not pipe utilisation; "
+                   "`executed` prices the work the kernel really does",
+           "executed": {"compulsory_bytes": x_bytes, "hbm_GBs": x_bytes / t / 1e9,
+                        "hbm_frac": x_bytes / t / 1e9 / PEAK_HBM_GBS,
+                        "fp32_equivalent_flops": x_flops_f32, "fp32_equivalent_TFLOPs": x_flops_f32 / t / 1e12,
+                        "bf16_mfma_flops": x_flops_bf16, "bf16_mfma_frac": x_flops_bf16 / t / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                        "frac_of_executed_bound": x_bound / t,
+                        "limiter": "VALU issue (PMC: profiles/r02_edge_x6_pmc_sq.txt, VALU busy ~60 % of the kernel; "
+                                   "operand splits + gather-add + epilogue), not HBM or the matrix cores"}}
     if t_flops > t_bytes:
         out.update(bound="mfma", achieved=f_edge / t / 1e12, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s")
     else:
@@ -273,7 +308,7 @@ def edge_layer_roofline(cfg_name="5", reps=10):
 # ---------------------------------------------------------------------------------------------
 # CPU baseline: the op-for-op torch oracle on the host cores (bounded sample)
 # ---------------------------------------------------------------------------------------------
-def cpu_baseline(cfg_name, optkw, mode):
+def cpu_baseline(cfg_name, optkw, mode, budget_s=25):
     from oracle import oracle_torch as orc
     import yolat_vectorgraphicsrecognition_amd as yv
     sys.path.insert(0, os.path.join(REPO, "tests"))
@@ -311,13 +346,128 @@ def cpu_baseline(cfg_name, optkw, mode):
         med = ts[len(ts) // 2]
         if best is None or med < best[0]:
             best = (med, threads, reps)
-        if time.time() - budget_t0 > 25:
+        if time.time() - budget_t0 > budget_s:
             break
     med, threads, reps = best
     return {"value": n_graphs / med, "unit": "graphs/s", "cores": threads, "kind": "port",
             "ms_per_step": med * 1e3, "host_cpus": ncpu,
             "sample": "cfg %s, %s, median of %d steps of the op-for-op torch oracle (fp32), best of "
                       "thread counts {8,16,32,64}<=cpu_count" % (cfg_name, mode, reps)}
+
+
+# ---------------------------------------------------------------------------------------------
+# sub-records of the N = 1 line / the N > 1 line
+# ---------------------------------------------------------------------------------------------
+def multi_stream_throughput(model, data, slices, n_graphs, n_streams=32, forwards=1024, keep_csr=False):
+    """graphs/s with `n_streams` independent forwards in flight (round-robin over HIP streams), measured over
+    `forwards` (>= 512) complete forwards regardless of --steps: the serving-style throughput of one GPU."""
+    streams = [torch.cuda.Stream() for _ in range(n_streams)]
+
+    def one(i):
+        if not keep_csr:
+            data._yolat_stage = None
+        with torch.cuda.stream(streams[i % n_streams]), torch.no_grad():
+            model(data, slices)
+
+    for i in range(3 * n_streams):          # per-stream plans: fold / split weights, workspaces
+        one(i)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(forwards):
+        one(i)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": n_graphs * forwards / dt, "unit": "graphs/s", "streams": n_streams, "forwards": forwards,
+            "us_per_forward": dt / forwards * 1e6}
+
+
+def floorplans_sized_record(yv, gu, cpu=True):
+    """cfg 1 (BASELINE.json configs[0]: one Floorplans-sized graph, P = 2000 proposals, N ~ 44k, E ~ 53k) on this GPU
+    next to the CPU oracle on the same graph — north_star's ">= 10x the CPU-reference graphs/s on Floorplans-sized
+    graphs at 1 GPU" as a measured pair."""
+    data, slices, optkw, n_graphs = yv.config("1")
+    N, E, P = data.x.shape[0], data.edge.shape[0], data.bbox.shape[0]
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 0).cuda().eval()
+    to_device(data)
+
+    def one():
+        data._yolat_stage = None
+        with torch.no_grad():
+            return model(data, slices)[0]
+
+    for _ in range(5):
+        one()
+    torch.cuda.synchronize()
+    n = 100
+    t0 = time.perf_counter()
+    for _ in range(n):
+        one()
+    torch.cuda.synchronize()
+    lat = (time.perf_counter() - t0) / n
+    ms = multi_stream_throughput(model, data, slices, n_graphs, n_streams=16, forwards=512)
+    rec = {"workload": "cfg1 eval forward: Floorplans-sized synthetic Bezier graph", "nodes": N, "edges": E,
+           "proposals": P, "ms_per_forward": lat * 1e3, "graphs_per_sec_one_at_a_time": n_graphs / lat,
+           "graphs_per_sec_16_streams": ms["value"]}
+    if cpu:
+        c = cpu_baseline("1", optkw, "fwd", budget_s=12)
+        rec["cpu_baseline"] = c
+        rec["speedup_vs_cpu_one_at_a_time"] = rec["graphs_per_sec_one_at_a_time"] / c["value"]
+        rec["speedup_vs_cpu_16_streams"] = rec["graphs_per_sec_16_streams"] / c["value"]
+    return rec
+
+
+def train_dp_record(yv, gu, rank, world, steps, warmup):
+    """BASELINE.json configs[3]: Diagrams-style batches of 32 graphs per rank (K = 22), one training step = forward +
+    CE + backward + RCCL all-reduce of the flat gradient (two async buckets overlapping the conv backward) + Adam.
+    Every rank runs `steps` timed steps between barriers; time = max over ranks.  Also timed: the same step with the
+    collective switched off (what the exchange costs after overlap) and the all-reduce of the flat buffer alone."""
+    import torch.distributed as dist
+    data, slices, optkw, n_graphs = yv.config("4", rank=rank)
+    opt = yv.Opt(**optkw)
+    model = gu.fill_state_(yv.SparseCADGCN(opt), 0).cuda()
+    to_device(data)
+    trainer = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5)
+
+    def timed(fn, n):
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(n):
+            fn()
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / n
+
+    def step():
+        data._yolat_stage = None
+        return trainer.step(data, slices)
+
+    for _ in range(max(warmup, 3)):
+        step()
+    t_step = timed(step, steps)
+    trainer.exchange_gradients = False
+    for _ in range(2):
+        step()
+    t_local = timed(step, steps)
+    trainer.exchange_gradients = True
+    broadcast = getattr(yv, "broadcast_parameters")
+    broadcast(trainer.flat, model)              # the replicas diverged while the exchange was off
+    g = trainer.flat.grad
+    for _ in range(3):
+        dist.all_reduce(g, op=dist.ReduceOp.SUM)
+    t_ar = timed(lambda: dist.all_reduce(g, op=dist.ReduceOp.SUM), max(steps, 20))
+    nbytes = g.numel() * 4
+    return {"workload": "cfg4 train step (fwd+CE+bwd+all-reduce+Adam), %d Diagrams-style graphs/rank/step, K=%d" %
+                        (n_graphs, optkw["n_classes"]),
+            "nodes_rank0": int(data.x.shape[0]), "edges_rank0": int(data.edge.shape[0]),
+            "proposals_rank0": int(data.bbox.shape[0]), "ms_per_step": t_step * 1e3,
+            "graphs_per_sec": n_graphs * world / t_step, "ms_per_step_without_exchange": t_local * 1e3,
+            "exchange_cost_ms_after_overlap": (t_step - t_local) * 1e3, "allreduce_bytes": nbytes,
+            "allreduce_alone_ms": t_ar * 1e3, "allreduce_alone_GBs": nbytes / t_ar / 1e9, "steps": steps,
+            "collective": "2 async SUM all-reduces per step (fusion+classifier bucket during the conv backward, conv "
+                          "bucket after it) over %s" % dist.get_backend()}
 
 
 def main():
@@ -472,6 +622,17 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
         cpu = cpu_baseline(cfg, optkw, args.mode)
 
+    multi = floor = train_dp = None
+    if args.mode == "fwd" and rank == 0 and not args.no_extras:
+        # serving-style throughput with many forwards in flight, over >= 512 forwards whatever --steps is
+        multi = multi_stream_throughput(model, data, slices, n_graphs, n_streams=max(args.streams, 1),
+                                        forwards=1024 if (N < 50000) else 256, keep_csr=args.keep_csr)
+        if world == 1 and str(cfg) == "2" and args.precision == "fp32":
+            floor = floorplans_sized_record(yv, gu, cpu=not args.no_cpu_baseline)
+    if world > 1 and not args.no_extras:
+        # the data-parallel training step (north_star: RCCL all-reduce of gradients over xGMI) next to the replicas
+        train_dp = train_dp_record(yv, gu, rank, world, steps=max(min(args.steps, 50), 10), warmup=args.warmup)
+
     if world > 1:
         torch.distributed.barrier()
     if rank == 0:
@@ -500,6 +661,9 @@ def main():
                        "csr_rebuilt_each_step": not args.keep_csr, "precision": args.precision,
                        "streams_in_flight": n_streams, "hip_graph_replay": bool(args.mode == "fwd" and args.graphs),
                        "parallelism": "replicas (graph-id sharding)" if args.mode == "fwd" else "dp%d" % world},
+            "multi_stream": multi,
+            "floorplans_sized": floor,
+            "train_dp": train_dp,
             "roofline": roof,
             "roofline_aggregation": agg,
             "roofline_edge_layer": edge_roof,

@@ -217,6 +217,7 @@ class Trainer(object):
         self.optimizer = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.criterion = DetectionLoss(opt)
         self._checked_inputs = False
+        self.exchange_gradients = True      # False: skip the all-reduce (bench.py: cost of the exchange after overlap)
 
     def step(self, data, slices=None):
         """One training step on this rank's batch.  Returns the (device) loss tensor."""
@@ -225,6 +226,8 @@ class Trainer(object):
         out = self.model(data, slices)
         loss = self.criterion(out, data)["loss"]
         world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+        if not self.exchange_gradients:
+            world = 1
         if world > 1 and self.flat.conv_end > 0:
             # bucket 1 (fusion blocks + classifier, 93 % of the bytes) is all-reduced while the conv layers'
             # backward still runs; bucket 2 (conv layers) after the backward
@@ -241,7 +244,7 @@ class Trainer(object):
             scale = 1.0 / world
         else:
             loss.backward()
-            scale = allreduce_mean_(self.flat.grad)
+            scale = allreduce_mean_(self.flat.grad) if world > 1 else 1.0
         self.optimizer.step(grad_scale=scale)
         if not self._checked_inputs:
             # first batch only (synchronises): edge ids inside [0, N), bbox_idx sorted — see SparseCADGCN.forward
