@@ -526,6 +526,34 @@ int yolat_profile_count(void);
 int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms, int* calls,
                       double* flops, double* bytes);
 
+/* ------------------------------------------------------------------------------------------
+ * Box-proposal generation (dataset side): the integer core of
+ * SESYDFloorPlan._get_proposal, /root/reference/Datasets/graph_dict3.py:309-789 — HOST code (proposals.hip), it
+ * runs in DataLoader workers and its result is cached per SVG (:924-929).
+ *   pos [n_nodes,2] float64: positions of the non-control nodes; (cc_ptr, cc_idx): the connected components as
+ *   CSR lists of node ids (graph_dict['cc'] after the control-point renumbering :329-345); edge / edge_super
+ *   [.,2] int64 node ids; bbox_sampling_step as in the dataset (10 Floorplans / 5 Diagrams).
+ * For every component: distinct-coordinate grid (:392-404), sampling-grid windows with the reference's endpoint
+ * scans (:471-528), point set of every window (:541-549), de-duplication (:557), then per sub-cluster the edges
+ * with both end points inside in the reference's pick-up order (:582-613) and the rejection tests
+ * (no edge :597, box thinner than 1e-4 :621, no node with two neighbours :681).
+ * Proposals are emitted component by component, inside a component in lexicographic order of the sorted node-id
+ * tuple (the reference iterates a Python set: hash order).
+ * Errors: YOLAT_E_UNSUPPORTED for a component of zero width or height (numpy.arange raises ZeroDivisionError
+ * there, :462-463).                                                                                           */
+typedef struct yolat_proposals yolat_proposals;
+int yolat_proposals_build(const double* pos, int64_t n_nodes, const int64_t* cc_ptr, const int64_t* cc_idx,
+                          int64_t n_cc, const int64_t* edge, int64_t n_edge, const int64_t* edge_super,
+                          int64_t n_edge_super, double bbox_sampling_step, yolat_proposals** out);
+int64_t yolat_proposals_count(const yolat_proposals* p);
+int64_t yolat_proposals_total(const yolat_proposals* p, int what);   /* 0 nodes, 1 edges, 2 super edges */
+/* node_ptr / edge_ptr / sedge_ptr [count+1]; node_idx / edge_idx / sedge_idx [totals]; cc_of [count];
+ * bbox [count,4] = min_x, min_y, max_x, max_y of the member points (index arrays may be NULL to skip them)   */
+int yolat_proposals_get(const yolat_proposals* p, int64_t* node_ptr, int64_t* node_idx, int64_t* edge_ptr,
+                        int64_t* edge_idx, int64_t* sedge_ptr, int64_t* sedge_idx, int64_t* cc_of, double* bbox);
+int yolat_proposals_window_counts(const yolat_proposals* p, int64_t* windows, int64_t* distinct);   /* [n_cc] each */
+void yolat_proposals_free(yolat_proposals* p);
+
 #ifdef __cplusplus
 }
 #endif

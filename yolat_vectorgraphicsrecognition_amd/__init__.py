@@ -10,6 +10,7 @@ Layout
     architecture.py  cad_recognition/architecture3cc_rpn_gp_iter2 mirror: SparseCADGCN, ...
     trainer.py       flat-buffer Adam + data-parallel step (RCCL all-reduce of one gradient bucket)
     data.py          Data bag, collate / offset fix-up, synthetic Bezier-graph generators
+    proposals.py     box-proposal generation (graph_dict3._get_proposal) over the native window / edge pick-up op
     dropin/          import shims so the reference's own scripts resolve gcn_lib / torch_scatter / ...
 """
 from . import _lib  # noqa: F401  (raises if libyolat_hip.so is missing)
@@ -23,4 +24,6 @@ from .evaluation import evaluate_batch, test as evaluate  # noqa: F401
 from .trainer import (FlatParams, FlatAdam, Trainer, shard_graph_ids, allreduce_mean_, broadcast_parameters,  # noqa: F401
                       load_reference_checkpoint)
 
-__version__ = "0.1.0"
+from .proposals import get_proposal, proposal_windows  # noqa: F401
+
+__version__ = "0.2.0"

@@ -129,6 +129,12 @@ SIGNATURES = {
     "yolat_nms_work_bytes": (c_sz, [c_i64]),
     "yolat_nms": (c_int, [c_p, c_p, c_i64, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "yolat_f32_to_bf16": (c_int, [c_p, c_i64, c_p, c_p]),
+    "yolat_proposals_build": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, ctypes.c_double, c_p]),
+    "yolat_proposals_count": (c_i64, [c_p]),
+    "yolat_proposals_total": (c_i64, [c_p, c_int]),
+    "yolat_proposals_get": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_proposals_window_counts": (c_int, [c_p, c_p, c_p]),
+    "yolat_proposals_free": (None, [c_p]),
     "yolat_forward_eval_bf16_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEvalBf16), c_i64, c_i64, c_i64]),
     "yolat_forward_eval_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),

@@ -1,0 +1,227 @@
+"""Box-proposal generation — the dataset-side producer of the hot path's input.
+
+``get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step, n_classes)`` mirrors
+``SESYDFloorPlan._get_proposal`` (/root/reference/Datasets/graph_dict3.py:309-789, without the random ``mixup``
+augmentation of :364-365): same arguments, same 14-tuple
+
+    pos, is_super, is_control, edge, edge_super, e_attr, e_attr_super, labels, bbox_idx, bbox, bbox_targets,
+    stat_feats, has_obj, roots
+
+The combinatorial core — distinct-coordinate grid, sampling-grid windows, point set per window, de-duplication, edge
+pick-up, the rejection tests — is native host code behind the C ABI (csrc/proposals.hip, ``yolat_proposals_build``);
+what is left here is per-proposal float64 numpy arithmetic written exactly as the reference writes it (IoU labels
+:624-640, angle statistics :644-705, box normalisation :714-722) and the bookkeeping of the proposal tree (:756-781).
+
+ORDER.  The reference walks ``list(set(sub_clusters))`` (:557): CPython hash order, not reproducible across runs of
+different interpreters.  Here the proposals of a component come in lexicographic order of their sorted node-id
+tuples.  Everything per proposal is identical; ``bbox_idx``, the edge offsets and the root (first largest-area
+proposal) follow that order.  tests/test_proposals.py compares against fixtures produced by the reference's own method
+as canonically ordered sets.
+"""
+import ctypes
+
+import numpy as np
+
+from ._lib import lib, check, YolatLibraryError
+from .data import idxTree
+
+
+def bbox_iou_ios_cpu(box1, box2):
+    """utils/det_util.py:311-341 (x1y1x2y2)."""
+    b1_x1, b1_y1, b1_x2, b1_y2 = box1[:, 0], box1[:, 1], box1[:, 2], box1[:, 3]
+    b2_x1, b2_y1, b2_x2, b2_y2 = box2[:, 0], box2[:, 1], box2[:, 2], box2[:, 3]
+    ix1, iy1 = np.maximum(b1_x1, b2_x1), np.maximum(b1_y1, b2_y1)
+    ix2, iy2 = np.minimum(b1_x2, b2_x2), np.minimum(b1_y2, b2_y2)
+    inter = np.maximum(ix2 - ix1, 0) * np.maximum(iy2 - iy1, 0)
+    a1 = (b1_x2 - b1_x1) * (b1_y2 - b1_y1)
+    a2 = (b2_x2 - b2_x1) * (b2_y2 - b2_y1)
+    return inter / (a1 + a2 - inter + 1e-16), inter / a2
+
+
+def intersect_bb_idx(box1, box2):
+    """utils/det_util.py:343-362."""
+    ix1, iy1 = np.maximum(box1[:, 0], box2[:, 0]), np.maximum(box1[:, 1], box2[:, 1])
+    ix2, iy2 = np.minimum(box1[:, 2], box2[:, 2]), np.minimum(box1[:, 3], box2[:, 3])
+    return np.where((ix2 > ix1) & (iy2 > iy1))[0]
+
+
+def _i64(a):
+    return np.ascontiguousarray(a, dtype=np.int64)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
+
+
+def proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step):
+    """The native core on already renumbered inputs.  pos [n,2] float64; cc: list of lists of node ids;
+    edge / edge_super [.,2] int64.  Returns a dict of int64 CSR arrays (node / edge / super-edge members of every
+    proposal), `cc_of`, `bbox` [count,4] float64 and the per-component window statistics."""
+    pos = np.ascontiguousarray(pos, dtype=np.float64)
+    edge = _i64(np.asarray(edge).reshape(-1, 2))
+    edge_super = _i64(np.asarray(edge_super).reshape(-1, 2))
+    cc_ptr = np.zeros(len(cc) + 1, dtype=np.int64)
+    np.cumsum([len(c) for c in cc], out=cc_ptr[1:])
+    cc_idx = _i64(np.concatenate([np.asarray(c, dtype=np.int64) for c in cc])) if len(cc) else np.zeros(0, np.int64)
+    handle = ctypes.c_void_p()
+    rc = lib.yolat_proposals_build(_ptr(pos), pos.shape[0], _ptr(cc_ptr), _ptr(cc_idx), len(cc), _ptr(edge),
+                                   edge.shape[0], _ptr(edge_super), edge_super.shape[0], float(bbox_sampling_step),
+                                   ctypes.byref(handle))
+    if rc == -2:        # YOLAT_E_UNSUPPORTED: numpy.arange(min, max, 0) in the reference
+        raise ZeroDivisionError("a connected component has zero width or height (graph_dict3.py:462-463)")
+    check(rc, "yolat_proposals_build")
+    try:
+        n = int(lib.yolat_proposals_count(handle))
+        tot = [int(lib.yolat_proposals_total(handle, w)) for w in range(3)]
+        out = {"node_ptr": np.zeros(n + 1, np.int64), "node_idx": np.zeros(tot[0], np.int64),
+               "edge_ptr": np.zeros(n + 1, np.int64), "edge_idx": np.zeros(tot[1], np.int64),
+               "sedge_ptr": np.zeros(n + 1, np.int64), "sedge_idx": np.zeros(tot[2], np.int64),
+               "cc_of": np.zeros(n, np.int64), "bbox": np.zeros((n, 4), np.float64),
+               "windows_per_cc": np.zeros(len(cc), np.int64), "distinct_per_cc": np.zeros(len(cc), np.int64)}
+        check(lib.yolat_proposals_get(handle, _ptr(out["node_ptr"]), _ptr(out["node_idx"]), _ptr(out["edge_ptr"]),
+                                      _ptr(out["edge_idx"]), _ptr(out["sedge_ptr"]), _ptr(out["sedge_idx"]),
+                                      _ptr(out["cc_of"]), _ptr(out["bbox"])), "yolat_proposals_get")
+        check(lib.yolat_proposals_window_counts(handle, _ptr(out["windows_per_cc"]), _ptr(out["distinct_per_cc"])),
+              "yolat_proposals_window_counts")
+    finally:
+        lib.yolat_proposals_free(handle)
+    return out
+
+
+def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classes=17, normalize_bbox=True):
+    """graph_dict3.py:309-789 (do_mixup = False).  graph_dict: the pickled per-SVG dict of
+    utils/svg_utils/build_graph_bbox.py:351-370 ('cc', 'pos'/'spatial', 'edge'/{'shape','super'},
+    'edge_attr'/{'shape','super'}, 'attr'/{'is_super','is_control'}, 'img_width', 'img_height')."""
+    cc = graph_dict["cc"]
+    pos = np.asarray(graph_dict["pos"]["spatial"])
+    edge = np.asarray(graph_dict["edge"]["shape"])
+    edge_super = np.asarray(graph_dict["edge"]["super"])
+    e_attr = np.asarray(graph_dict["edge_attr"]["shape"])
+    e_attr_super = np.asarray(graph_dict["edge_attr"]["super"])
+    is_super = np.asarray(graph_dict["attr"]["is_super"])
+    is_control = np.asarray(graph_dict["attr"]["is_control"])
+    gt_bbox = np.asarray(gt_bbox)
+    # :329-356 — control points are dropped, everything is renumbered
+    not_control = (is_control == 0)[:, 0]
+    o2n = np.cumsum(not_control) - 1
+    if edge.size and (~not_control[edge.reshape(-1)]).any():
+        raise KeyError("an edge references a control point")          # o2n[e[0]] in the reference
+    edge = o2n[edge.reshape(-1, 2)] if edge.size else np.zeros((0, 2), np.int64)
+    edge_super = o2n[edge_super.reshape(-1, 2)] if edge_super.size else np.zeros((0, 2), np.int64)
+    cc = [[int(o2n[i]) for i in cluster] for cluster in cc]
+    pos = pos[not_control]
+    is_super = is_super[not_control]
+
+    w = proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step)
+    count = w["cc_of"].shape[0]
+    # :573-577 — every component must overlap a ground-truth box
+    valid_of_cc = []
+    for c, cluster in enumerate(cc):
+        pc = pos[cluster, :]
+        bbox_cc = np.array([pc[:, 0].min(0), pc[:, 1].min(0), pc[:, 0].max(0), pc[:, 1].max(0)])[None, :]
+        valid = intersect_bb_idx(bbox_cc, gt_bbox)
+        if valid.shape[0] == 0:
+            raise SystemExit("cc has no intersect gt bbox")
+        valid_of_cc.append(valid)
+
+    new_pos, new_is_super, new_edge, new_edge_super, new_e_attr, new_e_attr_super = [], [], [], [], [], []
+    labels, has_objs, bbox_idx, new_bbox, bbox_targets, stat_feats = [], [], [], [], [], []
+    slice_pos, slice_edge, slice_super = [0], [0], [0]
+    offset = 0
+    for p in range(count):
+        idxs = w["node_idx"][w["node_ptr"][p]:w["node_ptr"][p + 1]]
+        eids = w["edge_idx"][w["edge_ptr"][p]:w["edge_ptr"][p + 1]]
+        sids = w["sedge_idx"][w["sedge_ptr"][p]:w["sedge_ptr"][p + 1]]
+        local = {int(g): i for i, g in enumerate(idxs)}
+        pos_bbox = pos[idxs, :]
+        edge_bbox = np.array([[local[int(a)] + offset, local[int(b)] + offset] for a, b in edge[eids]])
+        e_attr_bbox = e_attr[eids]
+        edge_super_bbox = np.array([[local[int(a)] + offset, local[int(b)] + offset] for a, b in edge_super[sids]])
+        e_attr_super_bbox = e_attr_super[sids]
+        min_x, min_y, max_x, max_y = w["bbox"][p]
+        # :624-640
+        valid = valid_of_cc[int(w["cc_of"][p])]
+        proposal = np.array([min_x, min_y, max_x, max_y])[None, :]
+        iou, ios = bbox_iou_ios_cpu(proposal, gt_bbox[valid, :])
+        idx_gt = np.argmax(iou)
+        if iou[idx_gt] > 0.7:
+            label = gt_labels[valid[idx_gt]]
+            bbox_target = gt_bbox[valid[idx_gt]][None, :]
+        else:
+            label = n_classes - 1
+            bbox_target = np.zeros((1, 4))
+        has_obj = 1 if ios[idx_gt] > 0.7 else 0
+        # :644-705 — angle statistics over pairs of neighbours of every node
+        k = pos_bbox.shape[0]
+        adj = [set() for _ in range(k)]
+        for a, b in edge_bbox:
+            adj[a - offset].add(b - offset)
+            adj[b - offset].add(a - offset)
+        n_less, n_90, n_more, angles = 0, 0, 0, []
+        for anchor, neighbors in enumerate(adj):
+            neighbors = list(neighbors)
+            for i in range(len(neighbors)):
+                for j in range(i + 1, len(neighbors)):
+                    v0 = pos_bbox[neighbors[i]] - pos_bbox[anchor]
+                    v1 = pos_bbox[neighbors[j]] - pos_bbox[anchor]
+                    dot = v0[0] * v1[0] + v0[1] * v1[1]
+                    if dot <= -1e-2:
+                        n_more += 1
+                    elif dot >= 1e-2:
+                        n_less += 1
+                    elif np.abs(dot) < 1e-2:
+                        n_90 += 1
+                    angles.append(dot)
+        assert angles, "the native rejection test keeps only proposals with an angle pair"
+        angles = np.array(angles)
+        width, height = max_x - min_x, max_y - min_y
+        stat_feat = np.array([k, edge_bbox.shape[0], n_90, n_less, n_more, width, height, np.mean(angles),
+                              np.max(angles), np.min(angles), np.std(angles), np.mean(e_attr_bbox[:, -1]),
+                              np.std(e_attr_bbox[:, -1])])[None, :]
+        if normalize_bbox:
+            pos_bbox = (pos_bbox - [min_x, min_y]) / [max_x - min_x, max_y - min_y]
+        slice_pos.append(slice_pos[-1] + k)
+        slice_edge.append(slice_edge[-1] + edge_bbox.shape[0])
+        slice_super.append(slice_super[-1] + edge_super_bbox.shape[0])
+        new_pos.append(pos_bbox)
+        new_is_super.append(is_super[idxs, :])
+        new_edge.append(edge_bbox)
+        if edge_super_bbox.shape[0] > 0:
+            new_edge_super.append(edge_super_bbox)
+        new_e_attr.append(e_attr_bbox)
+        new_e_attr_super.append(e_attr_super_bbox)
+        labels.append(label)
+        has_objs.append(has_obj)
+        bbox_idx += [p] * k
+        offset += k
+        new_bbox.append([min_x, min_y, max_x, max_y])
+        bbox_targets.append(bbox_target)
+        stat_feats.append(stat_feat)
+
+    # :756-781 — per component: the largest-area proposal is the root, the others its children
+    roots = []
+    bb = np.array(new_bbox).reshape(-1, 4)
+    for c in range(len(cc)):
+        members = np.where(w["cc_of"] == c)[0]
+        if members.size == 0:
+            raise ValueError("component %d produced no proposal (np.argmax of an empty array in the reference)" % c)
+        area = (bb[members, 2] - bb[members, 0]) * (bb[members, 3] - bb[members, 1])
+        top = int(np.argmax(area))
+        nodes = []
+        for m in members:
+            t = idxTree()
+            t.value["idx_pos"] = (slice_pos[m], slice_pos[m + 1])
+            t.value["idx_edge"] = (slice_edge[m], slice_edge[m + 1])
+            t.value["idx_edge_super"] = (slice_super[m], slice_super[m + 1])
+            t.value["idx_bbox"] = int(m)
+            nodes.append(t)
+        root = nodes[top]
+        root.children = [t for i, t in enumerate(nodes) if i != top]
+        roots.append(root)
+
+    pos_out = np.concatenate(new_pos, axis=0)
+    return (pos_out, np.concatenate(new_is_super, axis=0), np.zeros((pos_out.shape[0], 1)),
+            np.concatenate(new_edge, axis=0), np.concatenate(new_edge_super, axis=0),
+            np.concatenate(new_e_attr, axis=0), np.concatenate(new_e_attr_super, axis=0), labels,
+            np.array(bbox_idx), bb, np.concatenate(bbox_targets, axis=0), np.concatenate(stat_feats, axis=0),
+            has_objs, roots)
