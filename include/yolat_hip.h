@@ -286,6 +286,17 @@ int yolat_edge_uv_lin1_fwd(const float* UV, int64_t ld_uv, const int32_t* src_cs
                            const float* attr_csr, int64_t E, const float* Wc4, const float* b1, int64_t C,
                            float* H1, int64_t ldh, float* stats, yolat_stream_t stream);
 
+/* Backward of the factorised first edge Linear (training; replaces yolat_edge_lin1_bwd_w / _bwd_x /
+ * yolat_edge_scatter_bwd when E >> N):  dUV[n, 0:C] = sum of dH1 over the CSR row of n (edges INTO n),
+ * dUV[n, C:2C] = sum of dH1 over the CSC column of n (edges OUT OF n; col_ptr / slots of yolat_csc_by_source).
+ * Then dWuv = dUV^T.x and dx += dUV.Wuv are N-row dense calls, dWc4 = dH1^T.attr, db1 = column sums of dH1
+ * (yolat_linear_bwd_w), and yolat_conv_merge_dw1 maps (dWuv, dWc4) back onto dW1 (inverse of yolat_conv_split_w1).
+ * C = 64; deterministic (ascending slot order).                                                               */
+int yolat_edge_uv_sums(const float* dH1, int64_t ldh, const int32_t* row_ptr, const int32_t* col_ptr,
+                       const int32_t* slots, int64_t N, int64_t C, float* dUV, int64_t ld_uv, yolat_stream_t stream);
+int yolat_conv_merge_dw1(const float* dWuv, const float* dWc4, int64_t Cin, int64_t C, float* dW1, int64_t lddw,
+                         int accumulate, yolat_stream_t stream);
+
 /* yolat_edge_uv_mlp2_mean_eval: the same edge MLP with the mean aggregation fused in:
  *   f_out[n] += mean_{q in CSR row n} H2[q]       (H2 is never written; f_out already holds lin_r(f_in))
  * b1, (s1, t1), b2, (s2, t2) are each nullable (0 / identity); b1 = s1 = t1 = b2 = NULL is the folded form of

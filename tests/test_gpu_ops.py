@@ -865,3 +865,47 @@ def test_factorised_training_edge_lin1_matches_gathered_gemm(N, E):
     yv.ops.bn_finalize(stats, E, bn, coef[0], coef[1], coef[2], coef[3])
     close(coef[2], want.mean(0), msg="edge batch mean (factorised)")
     close(coef[3], 1 / torch.sqrt(want.var(0, unbiased=False) + 1e-5), msg="edge invstd (factorised)")
+
+
+@pytest.mark.parametrize("N,E,Cin", [(300, 1000, 64), (50, 31, 64), (2000, 9001, 64), (700, 5000, 5), (4000, 30000, 64)])
+def test_factorised_edge_lin1_backward_matches_gathered_gemms(N, E, Cin):
+    """ops.edge_lin1_bwd_factorised (per-node sums of dH1 + N-row dense algebra, csrc/edge.hip yolat_edge_uv_sums)
+    against the gathered path yolat_edge_lin1_bwd_w / _bwd_x / yolat_edge_scatter_bwd and against float64 autograd of
+    the reference formulation cat[x_i, x_j - x_i, attr] @ W1^T (torch_vertex.py:331,335)."""
+    yv = _yv()
+    src, dst, xfull, attr = _edge_case(N, E, Cin, 17 * N + E, ldx=Cin)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    tg = torch.Generator().manual_seed(N + E)
+    K1 = 2 * Cin + 4
+    W1 = (torch.randn(64, K1, generator=tg) / K1 ** 0.5).cuda()
+    dH = torch.randn(E, 64, generator=tg).cuda()          # CSR (destination-sorted) edge order, like every [E,*] tensor
+    x = dev(xfull)
+    base = torch.randn(N, Cin, generator=tg).cuda()
+    # gathered path
+    dW_a, db_a = torch.empty(64, K1).cuda(), torch.empty(64).cuda()
+    yv.ops.edge_lin1_bwd_w(dH, x, g, dW_a, db_a)
+    dx_a = base.clone()
+    dG = torch.empty(E, 2 * Cin).cuda()
+    yv.ops.edge_lin1_bwd_x(dH, W1, Cin, dG)
+    yv.ops.edge_scatter_bwd(dG, Cin, g, dx_a, accumulate=True)
+    # factorised path
+    dW_b, db_b = torch.empty(64, K1).cuda(), torch.empty(64).cuda()
+    dx_b = base.clone()
+    yv.ops.edge_lin1_bwd_factorised(dH, x, g, W1, dW_b, db_b, dx=dx_b, dx_accumulate=True)
+    # float64 autograd of the reference formulation, on the CSR-ordered edge list
+    xs = x.double().cpu().requires_grad_(True)
+    Wd = W1.double().cpu().requires_grad_(True)
+    bd = torch.zeros(64, dtype=torch.float64, requires_grad=True)
+    s, d = g.src.cpu().long()[:E], g.dst.cpu().long()[:E]
+    F = torch.cat([xs[d], xs[s] - xs[d], g.attr.cpu().double()[:E]], 1)
+    ((F @ Wd.t() + bd) * dH.double().cpu()).sum().backward()
+    for name, got, want in (("dW1", dW_b, Wd.grad), ("db1", db_b, bd.grad), ("dx", dx_b - base, xs.grad)):
+        scale = float(want.abs().max())
+        assert float((got.double().cpu() - want).abs().max()) <= 2e-5 * scale, name
+    for name, a, b in (("dW1", dW_a, dW_b), ("db1", db_a, db_b), ("dx", dx_a, dx_b)):
+        assert float((a - b).abs().max()) <= 5e-5 * float(a.abs().max()), name
+    # deterministic
+    dW_c, db_c = torch.empty(64, K1).cuda(), torch.empty(64).cuda()
+    dx_c = base.clone()
+    yv.ops.edge_lin1_bwd_factorised(dH, x, g, W1, dW_c, db_c, dx=dx_c, dx_accumulate=True)
+    assert torch.equal(dW_b, dW_c) and torch.equal(db_b, db_c) and torch.equal(dx_b, dx_c)

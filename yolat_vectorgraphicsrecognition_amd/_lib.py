@@ -72,6 +72,8 @@ SIGNATURES = {
                                               c_p, c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_edge_uv_mlp2_mean_eval_variant": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p,
                                                       c_p, c_p, c_p, c_p, c_i64, c_p, c_i64, c_int, c_p]),
+    "yolat_edge_uv_sums": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+    "yolat_conv_merge_dw1": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_i64, c_int, c_p]),
     "yolat_fusion_pair_eval": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64,
                                         c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "yolat_graph_prepare_node_uv": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64] + [c_p] * 9 +

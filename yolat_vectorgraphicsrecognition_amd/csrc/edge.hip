@@ -1191,6 +1191,101 @@ __global__ void __launch_bounds__(256) k_edge_scatter_bwd_v4(const float* __rest
   *o = s;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Backward of the FACTORISED first edge Linear (training, E >> N).  Forward:  H1[q] = U[dst_q] + V[src_q] + W1c.attr_q + b1
+// with UV = x.[W1a - W1b | W1b]^T, so the gradients w.r.t. the per-node products are two per-node sums of dH1 rows,
+//   dU[n] = sum_{q in CSR row n} dH1[q]   (contiguous rows)      dV[n] = sum_{t in CSC col n} dH1[slots[t]]   (gathered)
+// and everything else is N-row dense algebra (dWuv = dUV^T.x, dx += dUV.Wuv) plus dW1c = dH1^T.attr, db1 = colsum(dH1).
+// Replaces the gathered K = 2Cin+4 TN GEMM (dW1), the E x 64 -> E x 2Cin NT GEMM (dG) and the gather-scatter of dG:
+// at cfg 5 (E = 1.2 M, N = 200 k) 595 + 347 + 145 us per block layer.  One 16-lane group per node, one float4 of
+// columns per lane, 8 rows in flight; ascending slot order -> deterministic.  C = 64.
+// ------------------------------------------------------------------------------------------------
+__global__ void __launch_bounds__(256) k_edge_uv_sums(const float* __restrict__ dH, long ldh,
+                                                      const int* __restrict__ row_ptr, const int* __restrict__ col_ptr,
+                                                      const int* __restrict__ slots, int N, float* __restrict__ dUV,
+                                                      long ldo) {
+  const int sub = threadIdx.x & 15;
+  const int n = blockIdx.x * 16 + (threadIdx.x >> 4);
+  if (n >= N) return;
+  const float* hp = dH + 4 * sub;
+  auto acc = [](float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
+  // ---- dU: the node's own CSR rows
+  const int q0 = row_ptr[n], q1 = row_ptr[n + 1];
+  float4 su = make_float4(0.f, 0.f, 0.f, 0.f);
+  int q = q0;
+  for (; q + 8 <= q1; q += 8) {
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)(q + j) * ldh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc(su, v[j]);
+  }
+  if (q < q1) {
+    float4 v[7];
+#pragma unroll
+    for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)yl_min(q + j, q1 - 1) * ldh);
+#pragma unroll
+    for (int j = 0; j < 7; ++j)
+      if (q + j < q1) acc(su, v[j]);
+  }
+  // ---- dV: rows of the edges that leave this node (CSC by source; slot list ascending)
+  const int t0 = col_ptr[n], t1 = col_ptr[n + 1];
+  float4 sv = make_float4(0.f, 0.f, 0.f, 0.f);
+  for (int t = t0; t < t1; t += 8) {
+    int sl[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) sl[j] = slots[yl_min(t + j, t1 - 1)];
+    float4 v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)sl[j] * ldh);
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      if (t + j < t1) acc(sv, v[j]);
+  }
+  float* o = dUV + (long)n * ldo + 4 * sub;
+  *reinterpret_cast<float4*>(o) = su;
+  *reinterpret_cast<float4*>(o + 64) = sv;
+}
+
+extern "C" int yolat_edge_uv_sums(const float* dH1, int64_t ldh, const int32_t* row_ptr, const int32_t* col_ptr,
+                                  const int32_t* slots, int64_t N, int64_t C, float* dUV, int64_t ld_uv,
+                                  yolat_stream_t stream) {
+  if (N <= 0 || !dH1 || !row_ptr || !col_ptr || !slots || !dUV || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if (C != 64 || ldh % 4 != 0 || ld_uv % 4 != 0 || !yl_aligned16(dH1) || !yl_aligned16(dUV)) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_edge_uv_sums, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dH1, (long)ldh, row_ptr,
+                     col_ptr, slots, (int)N, dUV, (long)ld_uv);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// dW1 [C, 2Cin+4] from the gradients of the split weights (inverse of yolat_conv_split_w1):
+//   dW1[:, 0:Cin] = dWuv[0:C],  dW1[:, Cin:2Cin] = dWuv[C:2C] - dWuv[0:C],  dW1[:, 2Cin:] = dWc4
+static __global__ void k_conv_merge_dw1(const float* __restrict__ dWuv, const float* __restrict__ dWc4, int Cin, int C,
+                                        float* dW1, long ld, int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < C * Cin) {
+    const int c = i / Cin, k = i % Cin;
+    const float a = dWuv[(long)c * Cin + k], b = dWuv[(long)(C + c) * Cin + k] - a;
+    float* row = dW1 + (long)c * ld;
+    row[k] = accumulate ? row[k] + a : a;
+    row[Cin + k] = accumulate ? row[Cin + k] + b : b;
+  }
+  if (i < C * 4) {
+    float* d = dW1 + (long)(i / 4) * ld + 2 * Cin + (i % 4);
+    *d = accumulate ? *d + dWc4[i] : dWc4[i];
+  }
+}
+
+extern "C" int yolat_conv_merge_dw1(const float* dWuv, const float* dWc4, int64_t Cin, int64_t C, float* dW1,
+                                    int64_t lddw, int accumulate, yolat_stream_t stream) {
+  if (!dWuv || !dWc4 || !dW1 || Cin <= 0 || C <= 0 || lddw < 2 * Cin + 4) return YOLAT_E_INVALID;
+  const long n = C * (Cin > 4 ? Cin : 4);
+  hipLaunchKernelGGL(k_conv_merge_dw1, dim3(yl_cdiv(n, 256)), dim3(256), 0, (hipStream_t)stream, dWuv, dWc4, (int)Cin,
+                     (int)C, dW1, (long)lddw, accumulate);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_edge_scatter_bwd(const float* dG, int64_t lddg, int64_t Cin,
                                       const int32_t* row_ptr, const int32_t* col_ptr,
                                       const int32_t* slots, int64_t N, float* dX, int64_t lddx,

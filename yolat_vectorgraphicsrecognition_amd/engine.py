@@ -231,11 +231,16 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         ops.linear_fwd_wt(dM, nn3.weight, dA1)
         ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
                         sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
-        ops.edge_lin1_bwd_w(dA1, x, g, sink.get(nn0.weight), sink.get(nn0.bias))
-        if need_dx:
-            dG = _empty(E, 2 * Cin, dev)
-            ops.edge_lin1_bwd_x(dA1, nn0.weight, Cin, dG)
-            ops.edge_scatter_bwd(dG, Cin, g, dx, accumulate=True)
+        if FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous() and nn0.bias is not None:
+            # per-node sums of dH1 + N-row dense algebra instead of the gathered E-row GEMMs (pays when E >> N)
+            ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), sink.get(nn0.bias),
+                                         dx=dx if need_dx else None, dx_accumulate=True)
+        else:
+            ops.edge_lin1_bwd_w(dA1, x, g, sink.get(nn0.weight), sink.get(nn0.bias))
+            if need_dx:
+                dG = _empty(E, 2 * Cin, dev)
+                ops.edge_lin1_bwd_x(dA1, nn0.weight, Cin, dG)
+                ops.edge_scatter_bwd(dG, Cin, g, dx, accumulate=True)
     else:
         for p in (nn0.weight, nn0.bias, bn1.weight, bn1.bias, nn3.weight, nn3.bias, bn4.weight, bn4.bias):
             sink.get(p).zero_()

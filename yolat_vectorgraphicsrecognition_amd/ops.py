@@ -240,17 +240,46 @@ def edge_lin1_fwd(x, g, W1, b1, H1, o_pro=None, o_relu=False, stats=None):
     return H1
 
 
+def split_w1(W1, Cin):
+    """yolat_conv_split_w1: Wuv [2C,Cin] = [W1a - W1b | W1b] (rows), Wc4 [C,4] = the attr columns."""
+    C = W1.shape[0]
+    if not W1.is_contiguous():
+        raise ValueError("W1 must be contiguous")
+    wuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=W1.device)
+    wc4 = torch.empty(C, 4, dtype=torch.float32, device=W1.device)
+    check(lib.yolat_conv_split_w1(_f(W1), Cin, C, wuv.data_ptr(), wc4.data_ptr(), _stream()), "yolat_conv_split_w1")
+    return wuv, wc4
+
+
+def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=False, wuv=None):
+    """Backward of the first edge Linear through the per-node products (see yolat_edge_uv_sums): writes dW1, db1 and,
+    when `dx` is given, (accumulates) the gradient w.r.t. the node features.  C = 64; pays when E >> N."""
+    N, Cin = x.shape
+    C = W1.shape[0]
+    g.ensure_csc()
+    if wuv is None:
+        wuv, _ = split_w1(W1, Cin)
+    dUV = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
+    check(lib.yolat_edge_uv_sums(_f(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(), g.slots.data_ptr(), N, C,
+                                 dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums")
+    dwuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
+    linear_bwd_w(dUV, x, dwuv)
+    dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
+    linear_bwd_w(dH1, g.attr, dwc4, db1)
+    check(lib.yolat_conv_merge_dw1(dwuv.data_ptr(), dwc4.data_ptr(), Cin, C, _f(dW1), _ld(dW1), 0, _stream()),
+          "yolat_conv_merge_dw1")
+    if dx is not None:
+        linear_fwd_wt(dUV, wuv, dx, accumulate=dx_accumulate)
+    return dW1
+
+
 def edge_lin1_fwd_factorised(x, g, W1, b1, H1, stats=None):
     """Same result as edge_lin1_fwd (to fp32 rounding) through the per-node products: UV = x.[W1a-W1b | W1b]^T by a
     dense GEMM over the N nodes, then a gather-add over the E edges (csrc/edge.hip, yolat_edge_uv_lin1_fwd).  Pays
     when E >> N; Cin == C == 64 only."""
     N, Cin = x.shape
     C = W1.shape[0]
-    if not W1.is_contiguous():
-        raise ValueError("W1 must be contiguous")
-    wuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
-    wc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
-    check(lib.yolat_conv_split_w1(_f(W1), Cin, C, wuv.data_ptr(), wc4.data_ptr(), _stream()), "yolat_conv_split_w1")
+    wuv, wc4 = split_w1(W1, Cin)
     uv = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
     linear_fwd(x, wuv, None, uv)
     check(lib.yolat_edge_uv_lin1_fwd(uv.data_ptr(), 2 * C, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), g.E,
