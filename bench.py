@@ -46,9 +46,10 @@ def parse():
                     help="fwd mode: replay a captured hipGraph per stream instead of launching every kernel "
                          "(measured: no gain at cfg 2 — with 8 streams the GPU, not the host, is the limit)")
     ap.add_argument("--precision", default="fp32", choices=["fp32", "bf16"],
-                    help="fwd mode: storage precision of the eval forward.  fp32 (default) is the parity mode the "
-                         "headline metric is quoted in; bf16 = bf16 node activations / weights with fp32 accumulation "
-                         "(csrc/bf16_eval.hip), the mode BASELINE.json's configs[4] names — use with --config 5")
+                    help="storage precision.  fp32 (default) is the parity mode the headline metric is quoted in; bf16 = "
+                         "the mode BASELINE.json's configs[4] names — fwd: bf16 node activations / weights with fp32 "
+                         "accumulation (csrc/bf16_eval.hip); train: bf16 storage of the per-edge activations and "
+                         "their gradients — use with --config 5")
     ap.add_argument("--streams", type=int, default=32,
                     help="fwd mode: independent forwards are issued round-robin on this many HIP streams "
                          "(1 = strictly one forward at a time)")
@@ -525,7 +526,7 @@ def main():
         def step_single():
             return step_on(streams[0])
     else:
-        trainer = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5)
+        trainer = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5, precision=args.precision)
 
         def step():
             data._yolat_stage = None
@@ -651,7 +652,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32" if (args.mode != "fwd" or args.precision == "fp32") else "bf16 storage / f32 accumulate",
+            "dtype": "f32" if args.precision == "fp32" else "bf16 storage / f32 accumulate",
             "data": "synthetic",
             "config": {"workload": "cfg%s %s: synthetic Bezier graph(s), in_channels=5, n_blocks=%d, "
                                    "%d graph(s)/rank/step" % (cfg, "eval forward" if args.mode == "fwd"

@@ -538,6 +538,45 @@ int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms,
                       double* flops, double* bytes);
 
 /* ------------------------------------------------------------------------------------------
+ * Training with bfloat16 STORAGE of the [E,*] tensors (the precision mode BASELINE.json configs[4] names, applied to
+ * the train step: cad_recognition/train.py:263-284): the per-edge activations H1, H2 and their gradients cross HBM
+ * as bfloat16 (round-to-nearest-even on store, exact widening on load); every accumulation, the BatchNorm
+ * statistics, the parameters, their gradients and the optimizer state stay fp32.  `uint16_t*` = bfloat16 bits.
+ * Same contracts as the fp32 entry points they shadow; rows 8-byte aligned, leading dimensions multiples of 4.
+ *   yolat_edge_uv_lin1_fwd_h   H1 (bf16) + BatchNorm partial statistics of the fp32 values   (yolat_edge_uv_lin1_fwd)
+ *   yolat_linear_fwd_h         Y (bf16) = pro(A bf16).W^T + bias, + statistics, on v_mfma_f32_32x32x16_bf16 (K % 64
+ *                              == 0; W converted to bf16 into w_work [Nout*K] first)          (yolat_linear_fwd)
+ *   yolat_csr_mean_fwd_h       out (fp32) (+)= mean over CSR rows of pro(H bf16)              (yolat_csr_mean_fwd)
+ *   yolat_csr_mean_bwd_h       dM (bf16)[q] = dOut[dst_q] / deg                               (yolat_csr_mean_bwd)
+ *   yolat_bn_relu_bwd_h        dY (bf16) from dZ, Y (bf16); dgamma / dbeta fp32                (yolat_bn_relu_bwd)
+ *   yolat_linear_bwd_w_h       dW, db (fp32) = dY(bf16)^T . pro(A), A bf16 or fp32            (yolat_linear_bwd_w)
+ *   yolat_linear_fwd_wt_h      Y (bf16) = A (bf16) . Wt, bf16 MFMAs, w_work as above          (yolat_linear_fwd_wt)
+ *   yolat_edge_uv_sums_h       dUV (fp32) = per-node CSR / CSC sums of dH1 (bf16)             (yolat_edge_uv_sums)
+ * ------------------------------------------------------------------------------------------ */
+int yolat_edge_uv_lin1_fwd_h(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                             const float* attr_csr, int64_t E, const float* Wc4, const float* b1, int64_t C,
+                             uint16_t* H1, int64_t ldh, float* stats, yolat_stream_t stream);
+int yolat_linear_fwd_h(const uint16_t* A, int64_t lda, int64_t M, int64_t K, const float* a_scale,
+                       const float* a_shift, int a_relu, const float* W, int64_t ldw, const float* bias, int64_t Nout,
+                       uint16_t* Y, int64_t ldy, float* stats, uint16_t* w_work, yolat_stream_t stream);
+int yolat_csr_mean_fwd_h(const uint16_t* H, int64_t ldh, int64_t C, const float* h_scale, const float* h_shift,
+                         int h_relu, const int32_t* row_ptr, int64_t N, float* out, int64_t ldo, int accumulate,
+                         yolat_stream_t stream);
+int yolat_csr_mean_bwd_h(const float* dOut, int64_t lddo, int64_t C, const int32_t* row_ptr, const int32_t* dst_csr,
+                         int64_t E, uint16_t* dM, int64_t lddm, yolat_stream_t stream);
+int yolat_bn_relu_bwd_h(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, int64_t M, int64_t C,
+                        const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
+                        int relu, float* dgamma, float* dbeta, int accumulate, uint16_t* dY, int64_t lddy, float* work,
+                        yolat_stream_t stream);
+int yolat_linear_bwd_w_h(const uint16_t* dY, int64_t lddy, int64_t M, int64_t Nout, const void* A, int a_is_half,
+                         int64_t lda, int64_t K, const float* a_scale, const float* a_shift, int a_relu, float* dW,
+                         int64_t lddw, float* db, int accumulate, float* partial, yolat_stream_t stream);
+int yolat_linear_fwd_wt_h(const uint16_t* A, int64_t lda, int64_t M, int64_t K, const float* Wt, int64_t ldw,
+                          int64_t Nout, uint16_t* Y, int64_t ldy, uint16_t* w_work, yolat_stream_t stream);
+int yolat_edge_uv_sums_h(const uint16_t* dH1, int64_t ldh, const int32_t* row_ptr, const int32_t* col_ptr,
+                         const int32_t* slots, int64_t N, int64_t C, float* dUV, int64_t ld_uv, yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Box-proposal generation (dataset side): the integer core of
  * SESYDFloorPlan._get_proposal, /root/reference/Datasets/graph_dict3.py:309-789 — HOST code (proposals.hip), it
  * runs in DataLoader workers and its result is cached per SVG (:924-929).

@@ -228,3 +228,169 @@ def test_bf16_hip_graph_replay_and_concurrent_streams_match_direct_launches():
     torch.cuda.synchronize()
     for o in res:
         assert torch.equal(o, want)
+
+
+# ---------------------------------------------------------------------------------------------
+# bf16-storage TRAINING step (BASELINE.json configs[4]; SURVEY.md section 8 row g)
+# ---------------------------------------------------------------------------------------------
+def _train_once(yv, optkw, data, seed, precision, slices=None):
+    opt = yv.Opt(**optkw)
+    model = gu.fill_state_(yv.SparseCADGCN(opt), seed).cuda()
+    tr = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5, precision=precision)
+    if hasattr(data, "_yolat_stage"):
+        data._yolat_stage = None
+    loss = tr.step(data, slices)
+    grads = {n: tr.flat.grad_views[id(p)].detach().clone() for n, p in model.named_parameters()}
+    bufs = {n: b.detach().clone() for n, b in model.named_buffers() if b.is_floating_point()}
+    return float(loss), grads, bufs
+
+
+def _rms(t):
+    return float(t.double().pow(2).mean().sqrt())
+
+
+def _perturbed_fp32(yv, optkw, data, seed, slices=None):
+    """Sensitivity baseline: the fp32 step on node features carrying bf16-sized relative noise (uniform in
+    +-2^-9).  A freshly initialised YOLaT network is discontinuous in its activations (per-proposal max pooling picks
+    rows, ReLUs gate), so ANY 0.2 % perturbation moves the gradients by ~10 %; the bf16-storage step is held to the
+    same scale, not to the rounding unit."""
+    x0 = data.x
+    g = torch.Generator().manual_seed(1)
+    data.x = x0 * (1 + (torch.rand(x0.shape, generator=g) - 0.5) * 2 ** -8)
+    try:
+        return _train_once(yv, optkw, data, seed, "fp32", slices)
+    finally:
+        data.x = x0
+
+
+def _cos(ga, gb):
+    a = torch.cat([ga[n].flatten().double() for n in ga])
+    b = torch.cat([gb[n].flatten().double() for n in ga])
+    return float(a @ b / (a.norm() * b.norm()))
+
+
+def _check_bf16_step(yv, optkw, data, seed, slices=None, loss_tol=1e-3):
+    l32, g32, b32 = _train_once(yv, optkw, data, seed, "fp32", slices)
+    l16, g16, b16 = _train_once(yv, optkw, data, seed, "bf16", slices)
+    lp, gp, _ = _perturbed_fp32(yv, optkw, data, seed, slices)
+    assert np.isfinite(l16) and abs(l16 - l32) <= loss_tol * abs(l32), (l16, l32)
+    assert any(not torch.equal(g16[n], g32[n]) for n in g32)          # the bf16 path really ran
+    cos16, cosp = _cos(g32, g16), _cos(g32, gp)
+    assert cos16 >= 0.99 and (1 - cos16) <= 2.5 * (1 - cosp) + 1e-4, (cos16, cosp)
+    gscale = max(_rms(v) for v in g32.values())
+    for n in g32:
+        assert bool(torch.isfinite(g16[n]).all()), n
+        err16, errp = _rms(g16[n] - g32[n]), _rms(gp[n] - g32[n])
+        # per tensor: within 2.5x of what the bf16-sized input perturbation does to the fp32 step, + a floor for the
+        # mathematically-zero gradients (biases in front of a BatchNorm): there the sum over E rounded rows is a random
+        # walk of rounding errors, sqrt(E) * 2^-9 * rms — a few percent of the largest gradient at E = 1.2 M
+        assert err16 <= 2.5 * errp + 2e-2 * _rms(g32[n]) + 4e-2 * gscale, \
+            "%s: rms err %.3e (perturbed fp32: %.3e) vs rms %.3e" % (n, err16, errp, _rms(g32[n]))
+    for n in b32:
+        assert float((b16[n] - b32[n]).abs().max()) <= 1e-2 * float(b32[n].abs().max()) + 1e-6, n
+    return l16, g16, cos16, cosp
+
+
+@pytest.mark.parametrize("kind", ["medium", "deep"])
+def test_bf16_storage_train_step_matches_fp32_step(kind):
+    """The [E,64] activations of the edge MLP and their gradients stored as bfloat16 (fp32 accumulation, statistics,
+    parameters): loss within 1e-3 (2 blocks) / 5e-3 (4-block fixture) of the fp32 HIP step; gradients as close to it as the fp32 step itself is under a
+    bf16-sized perturbation of its input (see _perturbed_fp32); BatchNorm running statistics within 1e-2; deterministic."""
+    yv = _yv()
+    arrs, optkw = gu.graph_case(kind)
+    data = gu.to_data(arrs, yv.Data)
+    assert arrs["edge"].shape[0] >= 2 * arrs["x"].shape[0]          # the factorised / bf16 path applies
+    # loss: <= 1e-3 for the 2-block case; the 4-block fixture (few hundred rows per BatchNorm) moves by 2e-3
+    l16, g16, _, _ = _check_bf16_step(yv, optkw, data, 3, loss_tol=1e-3 if kind == "medium" else 5e-3)
+    l16b, g16b, _ = _train_once(yv, optkw, data, 3, "bf16")
+    assert l16b == l16 and all(torch.equal(g16[n], g16b[n]) for n in g16)
+
+
+def test_bf16_storage_train_step_cfg5():
+    """configs[4] at full size (N = 200k, E = 1.2M, n_blocks = 4): the bf16-storage step against the fp32 step."""
+    yv = _yv()
+    data, slices, optkw, _ = yv.config("5")
+    l16, _, cos16, cosp = _check_bf16_step(yv, optkw, data, 5, slices, loss_tol=2e-3)
+    print("cfg 5 bf16-storage step: loss %.6f, gradient cosine vs fp32 %.5f (fp32 under 2^-9 input noise: %.5f)" %
+          (l16, cos16, cosp))
+
+
+def test_bf16_storage_ops_match_fp32_ops_on_the_same_values():
+    """Every bf16-storage op against its fp32 twin fed the widened bf16 values: the arithmetic is the same, only the
+    final store rounds (bf16 MFMA GEMMs: products exact, fp32 accumulation in a different order)."""
+    yv = _yv()
+    N, E = 500, 6000
+    rng = np.random.default_rng(3)
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    g = yv.ops.build_graph(torch.from_numpy(np.stack([src, dst], 1)).cuda(),
+                           torch.from_numpy(rng.standard_normal((E, 4)).astype(np.float32)).cuda(), None, N, 1)
+    tg = torch.Generator().manual_seed(0)
+    bf = torch.bfloat16
+    H = torch.randn(E, 64, generator=tg).cuda().to(bf)
+    G = torch.randn(E, 64, generator=tg).cuda().to(bf)
+    W = (torch.randn(64, 64, generator=tg) / 8).cuda()
+    b = torch.randn(64, generator=tg).cuda() * 0.1
+    sc, sh = (torch.rand(64, generator=tg) + 0.5).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda()
+    # Linear + statistics
+    Y16, Y32 = torch.empty(E, 64, device="cuda", dtype=bf), torch.empty(E, 64, device="cuda")
+    st16, st32 = yv.ops.stats_buffer(E, 64, "cuda"), yv.ops.stats_buffer(E, 64, "cuda")
+    yv.ops.linear_fwd(H, W, b, Y16, a_pro=(sc, sh), a_relu=True, stats=st16)
+    A32 = torch.relu(H.float() * sc + sh).to(bf).float()              # the prologue result is re-rounded to bf16
+    yv.ops.linear_fwd(A32, W.to(bf).float(), b, Y32, stats=st32)
+    assert float((Y16.float() - Y32).abs().max()) <= 2 ** -7 * float(Y32.abs().max())
+    # (sum, M2) per 32-row group: the kernel's prologue is an fma, torch's a mul + add, so now and then one element
+    # rounds to the neighbouring bf16 value
+    nst = 2 * ((E + 31) // 32) * 64                                   # the written part of the (padded) buffer
+    assert float((st16[:nst] - st32[:nst]).abs().max()) <= 2e-2 * float(st32[:nst].abs().max())
+    # dX = dY . W
+    X16, X32 = torch.empty(E, 64, device="cuda", dtype=bf), torch.empty(E, 64, device="cuda")
+    yv.ops.linear_fwd_wt(G, W, X16)
+    yv.ops.linear_fwd_wt(G.float(), W.to(bf).float(), X32)
+    assert float((X16.float() - X32).abs().max()) <= 2 ** -7 * float(X32.abs().max())
+    # dW = dY^T . pro(A)  (fp32 accumulation of exact widened values: agrees to fp32 round-off)
+    dW16, db16, dW32, db32 = (torch.empty(64, 64, device="cuda"), torch.empty(64, device="cuda"),
+                              torch.empty(64, 64, device="cuda"), torch.empty(64, device="cuda"))
+    yv.ops.linear_bwd_w(G, H, dW16, db16, a_pro=(sc, sh), a_relu=True)
+    yv.ops.linear_bwd_w(G.float(), H.float(), dW32, db32, a_pro=(sc, sh), a_relu=True)
+    assert float((dW16 - dW32).abs().max()) <= 1e-5 * float(dW32.abs().max())
+    assert float((db16 - db32).abs().max()) <= 1e-5 * float(db32.abs().max())
+    # BatchNorm + ReLU backward
+    mean, invstd = H.float().mean(0), 1.0 / (H.float().var(0, unbiased=False) + 1e-5).sqrt()
+    dg16, dbt16, dg32, dbt32 = [torch.empty(64, device="cuda") for _ in range(4)]
+    D16, D32 = torch.empty(E, 64, device="cuda", dtype=bf), torch.empty(E, 64, device="cuda")
+    yv.ops.bn_relu_bwd(G, H, sc, mean, invstd, sc, sh, True, dg16, dbt16, D16)
+    yv.ops.bn_relu_bwd(G.float(), H.float(), sc, mean, invstd, sc, sh, True, dg32, dbt32, D32)
+    assert float((dg16 - dg32).abs().max()) <= 1e-4 * float(dg32.abs().max())
+    assert float((dbt16 - dbt32).abs().max()) <= 1e-4 * float(dbt32.abs().max())
+    assert torch.equal(D16, D32.to(bf)) or float((D16.float() - D32).abs().max()) <= 2 ** -7 * float(D32.abs().max())
+    # per-node sums for the factorised backward
+    x = torch.randn(N, 64, generator=tg).cuda()
+    W1 = (torch.randn(64, 132, generator=tg) / 11).cuda()
+    outs = []
+    for dH in (G, G.float()):
+        dW1, db1, dx = torch.empty(64, 132, device="cuda"), torch.empty(64, device="cuda"), torch.zeros(N, 64, device="cuda")
+        yv.ops.edge_lin1_bwd_factorised(dH, x, g, W1, dW1, db1, dx=dx, dx_accumulate=True)
+        outs.append((dW1, db1, dx))
+    for a, b_ in zip(outs[0], outs[1]):
+        assert float((a - b_).abs().max()) <= 1e-5 * float(b_.abs().max())
+
+
+def test_bf16_storage_ops_round_to_nearest_even_and_reject_fp32_mixups():
+    yv = _yv()
+    N, E = 300, 1500
+    rng = np.random.default_rng(0)
+    src, dst = rng.integers(0, N, E), rng.integers(0, N, E)
+    g = yv.ops.build_graph(torch.from_numpy(np.stack([src, dst], 1)).cuda(),
+                           torch.from_numpy(rng.standard_normal((E, 4)).astype(np.float32)).cuda(), None, N, 1)
+    d_f = torch.randn(N, 64, device="cuda")
+    dm32 = torch.empty(E, 64, device="cuda")
+    dm16 = torch.empty(E, 64, device="cuda", dtype=torch.bfloat16)
+    yv.ops.csr_mean_bwd(d_f, g, dm32)
+    yv.ops.csr_mean_bwd(d_f, g, dm16)
+    assert torch.equal(dm16, dm32.to(torch.bfloat16))                  # same rounding as torch's conversion
+    out32, out16 = torch.zeros(N, 64, device="cuda"), torch.zeros(N, 64, device="cuda")
+    yv.ops.csr_mean_fwd(dm16.float(), g, out32)
+    yv.ops.csr_mean_fwd(dm16, g, out16)
+    assert torch.equal(out32, out16)                                   # exact widening, same summation order
+    with pytest.raises(ValueError):
+        yv.ops.linear_fwd(dm16, torch.randn(64, 64, device="cuda"), None, torch.empty(E, 64, device="cuda"))

@@ -131,6 +131,17 @@ SIGNATURES = {
     "yolat_nms_work_bytes": (c_sz, [c_i64]),
     "yolat_nms": (c_int, [c_p, c_p, c_i64, c_f, c_p, c_p, c_p, c_sz, c_p]),
     "yolat_f32_to_bf16": (c_int, [c_p, c_i64, c_p, c_p]),
+    "yolat_edge_uv_lin1_fwd_h": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
+    "yolat_linear_fwd_h": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p,
+                                   c_p, c_p]),
+    "yolat_csr_mean_fwd_h": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64, c_int, c_p]),
+    "yolat_csr_mean_bwd_h": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p]),
+    "yolat_bn_relu_bwd_h": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_int,
+                                    c_p, c_i64, c_p, c_p]),
+    "yolat_linear_bwd_w_h": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_int, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64,
+                                     c_p, c_int, c_p, c_p]),
+    "yolat_linear_fwd_wt_h": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p]),
+    "yolat_edge_uv_sums_h": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_proposals_build": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, ctypes.c_double, c_p]),
     "yolat_proposals_count": (c_i64, [c_p]),
     "yolat_proposals_total": (c_i64, [c_p, c_int]),

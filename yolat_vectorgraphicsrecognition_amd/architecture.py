@@ -233,6 +233,16 @@ class SparseCADGCN(nn.Module):
             self.__dict__.pop("_yolat_plans", None)
         return self
 
+    def set_train_precision(self, precision="fp32"):
+        """Storage precision of the training step's per-edge tensors: "fp32" (default, the parity mode) or "bf16" —
+        the [E,64] activations of the edge MLP and their gradients are stored as bfloat16 (fp32 accumulation,
+        statistics, parameters, optimizer); used where the factorised edge layer applies (E >= 2 N).  Gradients agree
+        with the fp32 step to ~1e-2 (tests/test_gpu_bf16.py)."""
+        if precision not in ("fp32", "bf16"):
+            raise ValueError("precision must be 'fp32' or 'bf16'")
+        self.__dict__["_yolat_train_precision"] = precision
+        return self
+
     def use_hip_graphs(self, on=True):
         """Eval forwards replay a captured hipGraph when they are called again with the same input buffers
         (plan.EvalPlan._run_graph): one graph launch instead of a memset + 12 kernel launches."""

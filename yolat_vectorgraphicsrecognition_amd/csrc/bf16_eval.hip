@@ -74,6 +74,26 @@ struct FOp {
   }
 };
 
+// bf16 rows with the producer's BatchNorm + ReLU applied while staging (training with bf16 storage: the consumer of
+// a lazily normalised activation): widen, fma with the per-column (scale, shift), floor, round back to bf16.
+struct HProOp {
+  const u16* p; long ld; int rows;
+  const float* scale; const float* shift; float floor;
+  static constexpr int NR = 1;
+  __device__ __forceinline__ void load(int r, int k, u32x4* raw) const {
+    const u32x4 v = *reinterpret_cast<const u32x4*>(p + (long)yl_min(r, rows - 1) * ld + k);
+    const float4 s0 = *reinterpret_cast<const float4*>(scale + k), s1 = *reinterpret_cast<const float4*>(scale + k + 4);
+    const float4 h0 = *reinterpret_cast<const float4*>(shift + k), h1 = *reinterpret_cast<const float4*>(shift + k + 4);
+    u32x4 o;
+    o.x = yl_pack_bf16(fmaxf(fmaf(yl_bf16_lo(v.x), s0.x, h0.x), floor), fmaxf(fmaf(yl_bf16_hi(v.x), s0.y, h0.y), floor));
+    o.y = yl_pack_bf16(fmaxf(fmaf(yl_bf16_lo(v.y), s0.z, h0.z), floor), fmaxf(fmaf(yl_bf16_hi(v.y), s0.w, h0.w), floor));
+    o.z = yl_pack_bf16(fmaxf(fmaf(yl_bf16_lo(v.z), s1.x, h1.x), floor), fmaxf(fmaf(yl_bf16_hi(v.z), s1.y, h1.y), floor));
+    o.w = yl_pack_bf16(fmaxf(fmaf(yl_bf16_lo(v.w), s1.z, h1.z), floor), fmaxf(fmaf(yl_bf16_hi(v.w), s1.w, h1.w), floor));
+    raw[0] = o;
+  }
+  static __device__ __forceinline__ u32x4 pack(const u32x4* raw) { return raw[0]; }
+};
+
 constexpr int YL_HRS = 72;   // LDS row stride in bf16 elements (144 B)
 template <int TM, int TN> struct HTileSmem { static constexpr int elems = 64 * (TM + TN) * YL_HRS; };
 
@@ -768,4 +788,64 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     });
   }
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Training with bf16 storage: the two [E,64] x [64,64] Linears of the edge MLP on the bf16 matrix cores.
+//   yolat_linear_fwd_h     Y (bf16) = pro(A bf16) . W^T + bias, BatchNorm partial statistics from the fp32 accumulators
+//   yolat_linear_fwd_wt_h  Y (bf16) = A (bf16) . Wt          (dX = dY . W)
+// W / Wt are fp32 parameters: converted (and, for Wt, transposed) into `w_work` ([Nout*K] bf16) on the stream first.
+// K % 64 == 0 (the edge MLP: K = 64).
+// ------------------------------------------------------------------------------------------------
+static __global__ void k_f32_to_bf16_t(const float* __restrict__ Wt, long ldw, int K, int Nout, u16* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // dst[n][k] = Wt[k][n]
+  if (i >= K * Nout) return;
+  const int n = i / K, k = i % K;
+  dst[i] = (u16)(yl_pack_bf16(Wt[(long)k * ldw + n], 0.f) & 0xFFFFu);
+}
+static __global__ void k_f32_to_bf16_rows(const float* __restrict__ W, long ldw, int K, int Nout, u16* __restrict__ dst) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= K * Nout) return;
+  dst[i] = (u16)(yl_pack_bf16(W[(long)(i / K) * ldw + (i % K)], 0.f) & 0xFFFFu);
+}
+
+extern "C" int yolat_linear_fwd_h(const uint16_t* A, int64_t lda, int64_t M, int64_t K, const float* a_scale,
+                                  const float* a_shift, int a_relu, const float* W, int64_t ldw, const float* bias,
+                                  int64_t Nout, uint16_t* Y, int64_t ldy, float* stats, uint16_t* w_work,
+                                  yolat_stream_t stream) {
+  if (M <= 0 || K <= 0 || Nout <= 0 || !A || !Y || !W || !w_work) return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lda < K || ldw < K || ldy < Nout || (ldy & 1) || (((uintptr_t)Y) & 3)) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
+  if (K % 64 != 0 || lda % 8 != 0 || (((uintptr_t)A) & 15) || (((uintptr_t)w_work) & 15) ||
+      (a_scale && (!yl_aligned16(a_scale) || !yl_aligned16(a_shift))))
+    return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(yl_cdiv(K * Nout, 256)), dim3(256), 0, st, W, (long)ldw, (int)K, (int)Nout,
+                     w_work);
+  YL_LAUNCH_CHECK();
+  Epilogue ep = plain_epilogue();
+  ep.bias = bias; ep.Yh = Y; ep.ldy = ldy; ep.stats = stats;
+  HOp b{w_work, K, (int)Nout};
+  if (a_scale != nullptr) {
+    HProOp a{A, lda, (int)M, a_scale, a_shift, a_relu ? 0.f : -INFINITY};
+    return launch_hgemm(a, b, ep, M, Nout, K, st);
+  }
+  HOp a{A, lda, (int)M};
+  return launch_hgemm(a, b, ep, M, Nout, K, st);
+}
+
+extern "C" int yolat_linear_fwd_wt_h(const uint16_t* A, int64_t lda, int64_t M, int64_t K, const float* Wt,
+                                     int64_t ldw, int64_t Nout, uint16_t* Y, int64_t ldy, uint16_t* w_work,
+                                     yolat_stream_t stream) {
+  if (M <= 0 || K <= 0 || Nout <= 0 || !A || !Y || !Wt || !w_work) return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lda < K || ldw < Nout || ldy < Nout || (ldy & 1) || (((uintptr_t)Y) & 3)) return YOLAT_E_INVALID;
+  if (K % 64 != 0 || lda % 8 != 0 || (((uintptr_t)A) & 15) || (((uintptr_t)w_work) & 15)) return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(k_f32_to_bf16_t, dim3(yl_cdiv(K * Nout, 256)), dim3(256), 0, st, Wt, (long)ldw, (int)K, (int)Nout,
+                     w_work);
+  YL_LAUNCH_CHECK();
+  Epilogue ep = plain_epilogue();
+  ep.Yh = Y; ep.ldy = ldy;
+  HOp a{A, lda, (int)M}, b{w_work, K, (int)Nout};
+  return launch_hgemm(a, b, ep, M, Nout, K, st);
 }

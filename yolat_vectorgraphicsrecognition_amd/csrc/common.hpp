@@ -97,6 +97,61 @@ struct DenseOpT {
 typedef DenseOpT<false> DenseOp;
 typedef DenseOpT<true> DenseProOp;
 
+// bfloat16-STORED dense operand (training with bf16 storage of the [E,*] tensors, train_bf16.hip): the same loader
+// contract, elements converted to fp32 while loading (bf16 -> fp32 is a 16-bit shift: exact), prologue in fp32.
+typedef unsigned short yl_bf16_t;
+__device__ __forceinline__ float4 yl_ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 yl_ld4(const yl_bf16_t* p) {
+  const uint2 u = *reinterpret_cast<const uint2*>(p);
+  return make_float4(yl_bf16_lo(u.x), yl_bf16_hi(u.x), yl_bf16_lo(u.y), yl_bf16_hi(u.y));
+}
+__device__ __forceinline__ void yl_st4(float* p, const float4& v) { *reinterpret_cast<float4*>(p) = v; }
+__device__ __forceinline__ void yl_st4(yl_bf16_t* p, const float4& v) {       // round-to-nearest-even
+  uint2 u;
+  u.x = yl_pack_bf16(v.x, v.y); u.y = yl_pack_bf16(v.z, v.w);
+  *reinterpret_cast<uint2*>(p) = u;
+}
+__device__ __forceinline__ float yl_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float yl_ld1(const yl_bf16_t* p) { return __uint_as_float(((unsigned)*p) << 16); }
+
+template <bool PRO>
+struct HalfOpT {
+  const yl_bf16_t* p;
+  long ld;
+  int rows, cols;
+  const float* scale;
+  const float* shift;
+  float floor;
+  int vec;  // ld % 4 == 0, base 8-byte aligned (and scale/shift 16-byte aligned)
+
+  template <bool FAST>
+  __device__ __forceinline__ void load4(int r, int k, float v[4]) const {
+    const yl_bf16_t* q = p + (long)yl_min(r, rows - 1) * ld;
+    if (FAST) {
+      const float4 t = yl_ld4(q + k);
+      v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+      if (PRO) {
+        const float4 s = *reinterpret_cast<const float4*>(scale + k);
+        const float4 h = *reinterpret_cast<const float4*>(shift + k);
+        v[0] = fmaxf(fmaf(v[0], s.x, h.x), floor);
+        v[1] = fmaxf(fmaf(v[1], s.y, h.y), floor);
+        v[2] = fmaxf(fmaf(v[2], s.z, h.z), floor);
+        v[3] = fmaxf(fmaf(v[3], s.w, h.w), floor);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kc = yl_min(k + j, cols - 1);
+        float t = yl_ld1(q + kc);
+        if (PRO) t = fmaxf(fmaf(t, scale[kc], shift[kc]), floor);
+        v[j] = (k + j < cols) ? t : 0.f;
+      }
+    }
+  }
+};
+typedef HalfOpT<false> HalfOp;
+typedef HalfOpT<true> HalfProOp;
+
 // Dense operand used transposed: logical element (r, k) = p[k*ld + r]  (r fast in memory).
 struct TransOp {
   const float* p;
@@ -911,6 +966,21 @@ static inline DenseProOp yl_dense_pro(const float* p, long ld, long rows, long c
   d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
   d.scale = scale; d.shift = shift; d.floor = relu ? 0.f : -INFINITY;
   d.vec = (ld % 4 == 0) && yl_aligned16(p) && yl_aligned16(scale) && yl_aligned16(shift);
+  return d;
+}
+static inline HalfOp yl_half(const yl_bf16_t* p, long ld, long rows, long cols) {
+  HalfOp d;
+  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
+  d.scale = nullptr; d.shift = nullptr; d.floor = -INFINITY;
+  d.vec = (ld % 4 == 0) && ((((uintptr_t)p) & 7) == 0);
+  return d;
+}
+static inline HalfProOp yl_half_pro(const yl_bf16_t* p, long ld, long rows, long cols, const float* scale,
+                                    const float* shift, int relu) {
+  HalfProOp d;
+  d.p = p; d.ld = ld; d.rows = (int)rows; d.cols = (int)cols;
+  d.scale = scale; d.shift = shift; d.floor = relu ? 0.f : -INFINITY;
+  d.vec = (ld % 4 == 0) && ((((uintptr_t)p) & 7) == 0) && yl_aligned16(scale) && yl_aligned16(shift);
   return d;
 }
 static inline EdgeOp yl_edge(const float* x, long ldx, long Cin, const int* src, const int* dst,

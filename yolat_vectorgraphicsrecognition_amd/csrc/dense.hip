@@ -256,6 +256,51 @@ extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int6
 }
 
 // ------------------------------------------------------------------------------------------------
+// bfloat16-STORED operands (training with bf16 storage of the [E,*] activations and their gradients, the mode
+// BASELINE.json configs[4] names): the same fp32-accumulating tile kernels, elements converted while loading /
+// rounded (nearest-even) while storing; BatchNorm statistics are taken from the fp32 accumulators.
+// ------------------------------------------------------------------------------------------------
+// dW [Nout,K] (+= when accumulate) = dY^T . pro(A),  db = column sums of dY;  dY bf16 [M,Nout];  A bf16 (a_is_half,
+// optional BatchNorm+ReLU prologue) or fp32 [M,K].  `partial`: yolat_linear_bwd_w_work_elems(M, Nout, K) floats.
+extern "C" int yolat_linear_bwd_w_h(const uint16_t* dY, int64_t lddy, int64_t M, int64_t Nout, const void* A,
+                                    int a_is_half, int64_t lda, int64_t K, const float* a_scale, const float* a_shift,
+                                    int a_relu, float* dW, int64_t lddw, float* db, int accumulate, float* partial,
+                                    yolat_stream_t stream) {
+  if (M <= 0 || K <= 0 || Nout <= 0 || !dW || !partial || !dY || !A) return YOLAT_E_INVALID;
+  if (M >= (1LL << 31) || lddy < Nout || lda < K || lddw < K) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale) || (a_scale && !a_is_half)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  TnPlan p = yl_tn_plan(M, Nout, K);
+  HalfOp y = yl_half(dY, lddy, M, Nout);
+  float* dbpart = db ? partial + (size_t)p.S * Nout * K : nullptr;
+  dim3 grid(yl_cdiv(Nout, 64), yl_cdiv(K, 64), p.S);
+  if (a_is_half && a_scale != nullptr) {
+    HalfProOp a = yl_half_pro(reinterpret_cast<const yl_bf16_t*>(A), lda, M, K, a_scale, a_shift, a_relu);
+    hipLaunchKernelGGL((k_gemm_tn<HalfOp, HalfProOp>), grid, dim3(256), 0, st, y, a, partial, dbpart, (int)M, (int)Nout,
+                       (int)K, p.rows_per_split);
+  } else if (a_is_half) {
+    HalfOp a = yl_half(reinterpret_cast<const yl_bf16_t*>(A), lda, M, K);
+    hipLaunchKernelGGL((k_gemm_tn<HalfOp, HalfOp>), grid, dim3(256), 0, st, y, a, partial, dbpart, (int)M, (int)Nout,
+                       (int)K, p.rows_per_split);
+  } else {
+    DenseOp a = yl_dense(reinterpret_cast<const float*>(A), lda, M, K);
+    hipLaunchKernelGGL((k_gemm_tn<HalfOp, DenseOp>), grid, dim3(256), 0, st, y, a, partial, dbpart, (int)M, (int)Nout,
+                       (int)K, p.rows_per_split);
+  }
+  YL_LAUNCH_CHECK();
+  const long elems = Nout * K;
+  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 32)), dim3(256), 0, st, partial, elems, p.S, dW, (long)lddw,
+                     (int)K, accumulate);
+  YL_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(Nout, 32)), dim3(256), 0, st, dbpart, (long)Nout, p.S, db,
+                       (long)Nout, (int)Nout, accumulate);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // BatchNorm1d statistics (training mode): Chan merge of the 32-row (sum, M2) partials in fp64.
 // Level 1: workgroup g merges a contiguous range of row groups (64 columns x 16 partitions per
 // workgroup) into one (n, mean, M2) triple per column.  Level 2: one workgroup merges the level-1
@@ -459,8 +504,9 @@ __global__ void __launch_bounds__(256) k_bn_bwd_partial(const float* dZ, long ld
 // 4 rows = 1 KiB per load), 4 independent row loads in flight per thread, 512-row blocks (half the partials for
 // the finalize kernel).  The one-float-per-lane kernel above ran at 3 TB/s (36 us for 2 x 54 MB at E = 212k).
 #define BNB_ROWS_V4 512
-__global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const float* __restrict__ dZ, long lddz,
-                                                           const float* __restrict__ Y, long ldy, long M, int C,
+template <class T>
+__global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const T* __restrict__ dZ, long lddz,
+                                                           const T* __restrict__ Y, long ldy, long M, int C,
                                                            const float* __restrict__ mean,
                                                            const float* __restrict__ invstd,
                                                            const float* __restrict__ scale,
@@ -485,8 +531,8 @@ __global__ void __launch_bounds__(256) k_bn_bwd_partial_v4(const float* __restri
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
         const long rr = (r + 16 * k < r1) ? r + 16 * k : r1 - 1;
-        y[k] = *reinterpret_cast<const float4*>(Y + rr * ldy + c);
-        g[k] = *reinterpret_cast<const float4*>(dZ + rr * lddz + c);
+        y[k] = yl_ld4(Y + rr * ldy + c);
+        g[k] = yl_ld4(dZ + rr * lddz + c);
       }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
@@ -556,6 +602,44 @@ __global__ void k_bn_bwd_apply(const float* dZ, long lddz, const float* Y, long 
   }
 }
 
+// dY = scale*(dyh - c1 - xhat*c2) with 4 columns per lane and 4 rows in flight per thread (bf16-stored tensors:
+// 8-byte accesses; also used for fp32 when the rows are 16-byte aligned)
+template <class T>
+__global__ void __launch_bounds__(256) k_bn_bwd_apply_v4(const T* __restrict__ dZ, long lddz, const T* __restrict__ Y,
+                                                         long ldy, long M, int C, const float* __restrict__ mean,
+                                                         const float* __restrict__ invstd, const float* __restrict__ scale,
+                                                         const float* __restrict__ shift, int relu,
+                                                         const float* __restrict__ coef, T* dY, long lddy) {
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * q;
+  if (c >= C) return;
+  const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+  const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+  const float4 c1 = *reinterpret_cast<const float4*>(coef + c), c2 = *reinterpret_cast<const float4*>(coef + C + c);
+  auto one = [&](float y, float g, float m, float i, float a, float b, float k1, float k2) {
+    if (relu && !(fmaf(y, a, b) > 0.f)) g = 0.f;
+    return a * (g - k1 - ((y - m) * i) * k2);
+  };
+  for (long r = (long)blockIdx.y * 64 + rg; r < M; r += (long)gridDim.y * 64) {
+    float4 y[4], g[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const long rr = (r + 16 * k < M) ? r + 16 * k : M - 1;
+      y[k] = yl_ld4(Y + rr * ldy + c);
+      g[k] = yl_ld4(dZ + rr * lddz + c);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      if (r + 16 * k < M)
+        yl_st4(dY + (r + 16 * k) * lddy + c,
+               make_float4(one(y[k].x, g[k].x, mu.x, is.x, sc.x, sh.x, c1.x, c2.x),
+                           one(y[k].y, g[k].y, mu.y, is.y, sc.y, sh.y, c1.y, c2.y),
+                           one(y[k].z, g[k].z, mu.z, is.z, sc.z, sh.z, c1.z, c2.z),
+                           one(y[k].w, g[k].w, mu.w, is.w, sc.w, sh.w, c1.w, c2.w)));
+    }
+  }
+}
+
 extern "C" size_t yolat_bn_bwd_work_elems(int64_t M, int64_t C) {
   return (size_t)(2 * yl_cdiv(M, BNB_ROWS) * C + 2 * C);
 }
@@ -576,7 +660,7 @@ extern "C" int yolat_bn_relu_bwd(const float* dZ, int64_t lddz, const float* Y, 
   float2* part = reinterpret_cast<float2*>(work);
   float* coef = work + 2 * (long)yl_cdiv(M, BNB_ROWS) * C;          // after the (larger) scalar-layout partial area
   if (v4)
-    hipLaunchKernelGGL(k_bn_bwd_partial_v4, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, dZ, (long)lddz, Y,
+    hipLaunchKernelGGL(k_bn_bwd_partial_v4<float>, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, dZ, (long)lddz, Y,
                        (long)ldy, (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, part);
   else
   hipLaunchKernelGGL(k_bn_bwd_partial, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, dZ,
@@ -591,6 +675,35 @@ extern "C" int yolat_bn_relu_bwd(const float* dZ, int64_t lddz, const float* Y, 
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st, dZ, (long)lddz, Y,
                      (long)ldy, (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, coef,
                      dY, (long)lddy);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same backward on bfloat16-stored dZ / Y / dY ([M,C], C % 4 == 0, 8-byte aligned rows); sums in fp32 / fp64.
+extern "C" int yolat_bn_relu_bwd_h(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, int64_t M,
+                                   int64_t C, const float* save_mean, const float* save_invstd, const float* scale,
+                                   const float* shift, int relu, float* dgamma, float* dbeta, int accumulate,
+                                   uint16_t* dY, int64_t lddy, float* work, yolat_stream_t stream) {
+  if (M <= 0 || C <= 0 || !dZ || !Y || !save_mean || !save_invstd || !scale || !shift || !dgamma || !dbeta || !dY || !work)
+    return YOLAT_E_INVALID;
+  if (C % 4 != 0 || lddz % 4 != 0 || ldy % 4 != 0 || lddy % 4 != 0 || (((uintptr_t)dZ | (uintptr_t)Y | (uintptr_t)dY) & 7) ||
+      !yl_aligned16(save_mean) || !yl_aligned16(save_invstd) || !yl_aligned16(scale) || !yl_aligned16(shift))
+    return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const long nb = yl_cdiv(M, BNB_ROWS_V4);
+  float2* part = reinterpret_cast<float2*>(work);
+  float* coef = work + 2 * (long)yl_cdiv(M, BNB_ROWS) * C;
+  if ((((uintptr_t)coef) & 15) != 0) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_bn_bwd_partial_v4<yl_bf16_t>, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, dZ, (long)lddz,
+                     Y, (long)ldy, (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, part);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, part, nb, (long)M, (int)C, dgamma, dbeta,
+                     accumulate, coef);
+  YL_LAUNCH_CHECK();
+  int gy = yl_cdiv(M, 64);
+  if (gy > 4096) gy = 4096;
+  hipLaunchKernelGGL(k_bn_bwd_apply_v4<yl_bf16_t>, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st, dZ, (long)lddz, Y, (long)ldy,
+                     (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, coef, dY, (long)lddy);
   YL_LAUNCH_CHECK();
   return 0;
 }

@@ -831,11 +831,12 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, cons
 // its A operand is two random 256-B row gathers per edge.  One workgroup = 64 edges: thread (row rb + 16 t,
 // columns 4q..) writes its 16 bytes of H1 and parks them in LDS; 128 threads then reduce the two 32-row groups.
 // ------------------------------------------------------------------------------------------------
+template <class TO>
 __global__ void __launch_bounds__(256) k_edge_uv_lin1(const float* __restrict__ UV, long ld_uv,
                                                       const int* __restrict__ src, const int* __restrict__ dst,
                                                       const float* __restrict__ attr, int E,
                                                       const float* __restrict__ Wc4, const float* __restrict__ b1,
-                                                      float* __restrict__ H1, long ldh, float2* __restrict__ stats) {
+                                                      TO* __restrict__ H1, long ldh, float2* __restrict__ stats) {
   constexpr int LDT = 65;
   __shared__ float T[64 * LDT];
   const int tid = threadIdx.x, q = tid & 15, rb = tid >> 4;
@@ -869,7 +870,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_lin1(const float* __restrict__ 
     const float4 h = make_float4(one(u[t].x, v[t].x, wc[0], bb.x), one(u[t].y, v[t].y, wc[1], bb.y),
                                  one(u[t].z, v[t].z, wc[2], bb.z), one(u[t].w, v[t].w, wc[3], bb.w));
     const int r = rb + 16 * t;
-    if (row0 + r < E) *reinterpret_cast<float4*>(H1 + (long)(row0 + r) * ldh + 4 * q) = h;
+    if (row0 + r < E) yl_st4(H1 + (long)(row0 + r) * ldh + 4 * q, h);
     float* tr = T + r * LDT + 4 * q;
     tr[0] = h.x; tr[1] = h.y; tr[2] = h.z; tr[3] = h.w;
   }
@@ -901,8 +902,26 @@ extern "C" int yolat_edge_uv_lin1_fwd(const float* UV, int64_t ld_uv, const int3
   if (ld_uv % 4 != 0 || ldh % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) ||
       !yl_aligned16(H1) || (b1 && !yl_aligned16(b1)) || (stats && (((uintptr_t)stats) & 7) != 0))
     return YOLAT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(k_edge_uv_lin1, dim3(yl_cdiv(E, 64)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv, src_csr,
+  hipLaunchKernelGGL(k_edge_uv_lin1<float>, dim3(yl_cdiv(E, 64)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv, src_csr,
                      dst_csr, attr_csr, (int)E, Wc4, b1, H1, (long)ldh, reinterpret_cast<float2*>(stats));
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// The same with H1 stored as bfloat16 (round-to-nearest-even); the BatchNorm partial statistics are those of the
+// fp32 values before rounding.
+extern "C" int yolat_edge_uv_lin1_fwd_h(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                                        const float* attr_csr, int64_t E, const float* Wc4, const float* b1, int64_t C,
+                                        uint16_t* H1, int64_t ldh, float* stats, yolat_stream_t stream) {
+  if (E < 0 || !UV || !Wc4) return YOLAT_E_INVALID;
+  if (C != 64) return YOLAT_E_UNSUPPORTED;
+  if (E == 0) return 0;
+  if (!src_csr || !dst_csr || !attr_csr || !H1 || E >= (1LL << 31) || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if (ld_uv % 4 != 0 || ldh % 4 != 0 || !yl_aligned16(UV) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) ||
+      (((uintptr_t)H1) & 7) != 0 || (b1 && !yl_aligned16(b1)) || (stats && (((uintptr_t)stats) & 7) != 0))
+    return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_edge_uv_lin1<yl_bf16_t>, dim3(yl_cdiv(E, 64)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
+                     src_csr, dst_csr, attr_csr, (int)E, Wc4, b1, H1, (long)ldh, reinterpret_cast<float2*>(stats));
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -1017,8 +1036,8 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd(const float* H, long ldh, 
 // C == 4*LPN, 16-byte aligned rows: LPN lanes own one node (one float4 of columns each), 64/LPN nodes per
 // wave, up to 8 rows (8 x 16 B per lane) in flight per lane.  Per-column summation order is unchanged
 // (ascending CSR slot), so results are bit-identical to the scalar kernel above.
-template <int LPN>
-__global__ void __launch_bounds__(256) k_csr_mean_fwd_v4(const float* __restrict__ H, long ldh,
+template <int LPN, class T = float>
+__global__ void __launch_bounds__(256) k_csr_mean_fwd_v4(const T* __restrict__ H, long ldh,
                                                          const float* hs, const float* hb, int relu,
                                                          const int* __restrict__ row_ptr, int N,
                                                          float* out, long ldo, int accumulate) {
@@ -1033,7 +1052,7 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd_v4(const float* __restrict
     sh = *reinterpret_cast<const float4*>(hb + 4 * sub);
   }
   const float floor = relu ? 0.f : -INFINITY;
-  const float* hp = H + 4 * sub;
+  const T* hp = H + 4 * sub;
   float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
   auto add = [&](const float4& v) {
     s.x += fmaxf(fmaf(v.x, sc.x, sh.x), floor);
@@ -1045,14 +1064,14 @@ __global__ void __launch_bounds__(256) k_csr_mean_fwd_v4(const float* __restrict
   for (; q + 8 <= q1; q += 8) {
     float4 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)(q + j) * ldh);
+    for (int j = 0; j < 8; ++j) v[j] = yl_ld4(hp + (long)(q + j) * ldh);
 #pragma unroll
     for (int j = 0; j < 8; ++j) add(v[j]);
   }
   if (q < q1) {   // 1..7 remaining rows: clamped (re-read) addresses keep the loads unconditional
     float4 v[7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)yl_min(q + j, q1 - 1) * ldh);
+    for (int j = 0; j < 7; ++j) v[j] = yl_ld4(hp + (long)yl_min(q + j, q1 - 1) * ldh);
 #pragma unroll
     for (int j = 0; j < 7; ++j)
       if (q + j < q1) add(v[j]);
@@ -1087,6 +1106,21 @@ extern "C" int yolat_csr_mean_fwd(const float* H, int64_t ldh, int64_t C, const 
   return 0;
 }
 
+// bfloat16-stored message matrix (training with bf16 storage): C = 64, 8-byte aligned rows
+extern "C" int yolat_csr_mean_fwd_h(const uint16_t* H, int64_t ldh, int64_t C, const float* h_scale,
+                                    const float* h_shift, int h_relu, const int32_t* row_ptr, int64_t N, float* out,
+                                    int64_t ldo, int accumulate, yolat_stream_t stream) {
+  if (N <= 0 || !H || !row_ptr || !out || ldo < C || ldh < C) return YOLAT_E_INVALID;
+  if ((h_scale == nullptr) != (h_shift == nullptr)) return YOLAT_E_INVALID;
+  if (C != 64 || ldh % 4 != 0 || ldo % 4 != 0 || (((uintptr_t)H) & 7) != 0 || !yl_aligned16(out) ||
+      (h_scale && (!yl_aligned16(h_scale) || !yl_aligned16(h_shift))))
+    return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL((k_csr_mean_fwd_v4<16, yl_bf16_t>), dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, H,
+                     (long)ldh, h_scale, h_shift, h_relu, row_ptr, (int)N, out, (long)ldo, accumulate);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 __global__ void __launch_bounds__(256) k_csr_mean_bwd(const float* dOut, long lddo, int C,
                                                       const int* row_ptr, const int* dst, int E,
                                                       float* dM, long lddm) {
@@ -1100,9 +1134,10 @@ __global__ void __launch_bounds__(256) k_csr_mean_bwd(const float* dOut, long ld
 }
 
 // C == 64, aligned rows: 16 lanes x float4 per edge, a wave writes 4 rows (1 KiB) per store instead of 256 B
+template <class T>
 __global__ void __launch_bounds__(256) k_csr_mean_bwd_v4(const float* __restrict__ dOut, long lddo,
                                                          const int* __restrict__ row_ptr, const int* __restrict__ dst,
-                                                         int E, float* __restrict__ dM, long lddm) {
+                                                         int E, T* __restrict__ dM, long lddm) {
   const int l16 = threadIdx.x & 15;
   const int q = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (q >= E) return;
@@ -1110,7 +1145,7 @@ __global__ void __launch_bounds__(256) k_csr_mean_bwd_v4(const float* __restrict
   const int deg = row_ptr[n + 1] - row_ptr[n];
   const float inv = 1.f / (float)(deg > 1 ? deg : 1);
   const float4 g = *reinterpret_cast<const float4*>(dOut + (long)n * lddo + 4 * l16);
-  *reinterpret_cast<float4*>(dM + (long)q * lddm + 4 * l16) = make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv);
+  yl_st4(dM + (long)q * lddm + 4 * l16, make_float4(g.x * inv, g.y * inv, g.z * inv, g.w * inv));
 }
 
 extern "C" int yolat_csr_mean_bwd(const float* dOut, int64_t lddo, int64_t C,
@@ -1120,11 +1155,25 @@ extern "C" int yolat_csr_mean_bwd(const float* dOut, int64_t lddo, int64_t C,
   if (E == 0) return 0;
   if (!dst_csr || !dM || lddm < C) return YOLAT_E_INVALID;
   if (C == 64 && lddo % 4 == 0 && lddm % 4 == 0 && yl_aligned16(dOut) && yl_aligned16(dM))
-    hipLaunchKernelGGL(k_csr_mean_bwd_v4, dim3(yl_cdiv(E, 16)), dim3(256), 0, (hipStream_t)stream, dOut, (long)lddo,
+    hipLaunchKernelGGL(k_csr_mean_bwd_v4<float>, dim3(yl_cdiv(E, 16)), dim3(256), 0, (hipStream_t)stream, dOut, (long)lddo,
                        row_ptr, dst_csr, (int)E, dM, (long)lddm);
   else
   hipLaunchKernelGGL(k_csr_mean_bwd, dim3(yl_cdiv(E, 4)), dim3(256), 0, (hipStream_t)stream, dOut,
                      (long)lddo, (int)C, row_ptr, dst_csr, (int)E, dM, (long)lddm);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_csr_mean_bwd_h(const float* dOut, int64_t lddo, int64_t C, const int32_t* row_ptr,
+                                    const int32_t* dst_csr, int64_t E, uint16_t* dM, int64_t lddm,
+                                    yolat_stream_t stream) {
+  if (E < 0 || !dOut || !row_ptr) return YOLAT_E_INVALID;
+  if (E == 0) return 0;
+  if (!dst_csr || !dM || lddm < C) return YOLAT_E_INVALID;
+  if (C != 64 || lddo % 4 != 0 || lddm % 4 != 0 || !yl_aligned16(dOut) || (((uintptr_t)dM) & 7) != 0)
+    return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_csr_mean_bwd_v4<yl_bf16_t>, dim3(yl_cdiv(E, 16)), dim3(256), 0, (hipStream_t)stream, dOut,
+                     (long)lddo, row_ptr, dst_csr, (int)E, dM, (long)lddm);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -1200,14 +1249,15 @@ __global__ void __launch_bounds__(256) k_edge_scatter_bwd_v4(const float* __rest
 // at cfg 5 (E = 1.2 M, N = 200 k) 595 + 347 + 145 us per block layer.  One 16-lane group per node, one float4 of
 // columns per lane, 8 rows in flight; ascending slot order -> deterministic.  C = 64.
 // ------------------------------------------------------------------------------------------------
-__global__ void __launch_bounds__(256) k_edge_uv_sums(const float* __restrict__ dH, long ldh,
+template <class T>
+__global__ void __launch_bounds__(256) k_edge_uv_sums(const T* __restrict__ dH, long ldh,
                                                       const int* __restrict__ row_ptr, const int* __restrict__ col_ptr,
                                                       const int* __restrict__ slots, int N, float* __restrict__ dUV,
                                                       long ldo) {
   const int sub = threadIdx.x & 15;
   const int n = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (n >= N) return;
-  const float* hp = dH + 4 * sub;
+  const T* hp = dH + 4 * sub;
   auto acc = [](float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
   // ---- dU: the node's own CSR rows
   const int q0 = row_ptr[n], q1 = row_ptr[n + 1];
@@ -1216,14 +1266,14 @@ __global__ void __launch_bounds__(256) k_edge_uv_sums(const float* __restrict__ 
   for (; q + 8 <= q1; q += 8) {
     float4 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)(q + j) * ldh);
+    for (int j = 0; j < 8; ++j) v[j] = yl_ld4(hp + (long)(q + j) * ldh);
 #pragma unroll
     for (int j = 0; j < 8; ++j) acc(su, v[j]);
   }
   if (q < q1) {
     float4 v[7];
 #pragma unroll
-    for (int j = 0; j < 7; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)yl_min(q + j, q1 - 1) * ldh);
+    for (int j = 0; j < 7; ++j) v[j] = yl_ld4(hp + (long)yl_min(q + j, q1 - 1) * ldh);
 #pragma unroll
     for (int j = 0; j < 7; ++j)
       if (q + j < q1) acc(su, v[j]);
@@ -1237,7 +1287,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_sums(const float* __restrict__ 
     for (int j = 0; j < 8; ++j) sl[j] = slots[yl_min(t + j, t1 - 1)];
     float4 v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = *reinterpret_cast<const float4*>(hp + (long)sl[j] * ldh);
+    for (int j = 0; j < 8; ++j) v[j] = yl_ld4(hp + (long)sl[j] * ldh);
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       if (t + j < t1) acc(sv, v[j]);
@@ -1252,8 +1302,20 @@ extern "C" int yolat_edge_uv_sums(const float* dH1, int64_t ldh, const int32_t* 
                                   yolat_stream_t stream) {
   if (N <= 0 || !dH1 || !row_ptr || !col_ptr || !slots || !dUV || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
   if (C != 64 || ldh % 4 != 0 || ld_uv % 4 != 0 || !yl_aligned16(dH1) || !yl_aligned16(dUV)) return YOLAT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(k_edge_uv_sums, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dH1, (long)ldh, row_ptr,
+  hipLaunchKernelGGL(k_edge_uv_sums<float>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dH1, (long)ldh, row_ptr,
                      col_ptr, slots, (int)N, dUV, (long)ld_uv);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_edge_uv_sums_h(const uint16_t* dH1, int64_t ldh, const int32_t* row_ptr, const int32_t* col_ptr,
+                                    const int32_t* slots, int64_t N, int64_t C, float* dUV, int64_t ld_uv,
+                                    yolat_stream_t stream) {
+  if (N <= 0 || !dH1 || !row_ptr || !col_ptr || !slots || !dUV || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if (C != 64 || ldh % 4 != 0 || ld_uv % 4 != 0 || (((uintptr_t)dH1) & 7) != 0 || !yl_aligned16(dUV))
+    return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_edge_uv_sums<yl_bf16_t>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dH1, (long)ldh,
+                     row_ptr, col_ptr, slots, (int)N, dUV, (long)ld_uv);
   YL_LAUNCH_CHECK();
   return 0;
 }

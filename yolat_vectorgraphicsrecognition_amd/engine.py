@@ -168,7 +168,7 @@ def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inp
 # AttrRelativeEdgeConvGlobalPool2
 # ---------------------------------------------------------------------------------------------
 
-def conv_fwd(conv, g, x, xn, out_f, out_s, training):
+def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False):
     """x [N,Cin] materialised; xn Lazy [N,Cin]; out_f / out_s: [N,C] destinations (or None).
     Returns (f tensor, s Lazy, saved)."""
     nn0, bn1, nn3, bn4 = conv.nn[0], conv.nn[1], conv.nn[3], conv.nn[4]
@@ -180,10 +180,16 @@ def conv_fwd(conv, g, x, xn, out_f, out_s, training):
     # root term first, the aggregation accumulates onto it:  out = lin_r(x) + mean_e(m_e)   (:325)
     ops.linear_fwd(x, conv.lin_r.weight, conv.lin_r.bias, out_f)
     if E > 0:
-        H1, H2 = _empty(E, C, dev), _empty(E, C, dev)
+        factorised = (training and FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous()
+                      and nn0.bias is not None)
+        # bf16 STORAGE of the two [E,C] activations (and, in conv_bwd, of their gradients): halves the traffic of the
+        # bandwidth-bound part of the step; accumulation, statistics, parameters and node tensors stay fp32
+        hdt = torch.bfloat16 if (half and factorised) else torch.float32
+        H1 = torch.empty(E, C, dtype=hdt, device=dev)
+        H2 = torch.empty(E, C, dtype=hdt, device=dev)
         if training:
             st1 = ops.stats_buffer(E, C, dev)
-            if FACTORISED_TRAIN and C == 64 and x.shape[1] == 64 and E >= 2 * N and nn0.weight.is_contiguous():
+            if factorised:
                 # per-node products + gather-add instead of the gathered K = 132 GEMM (pays when E >> N)
                 ops.edge_lin1_fwd_factorised(x, g, nn0.weight, nn0.bias, H1, stats=st1)
             else:
@@ -222,16 +228,18 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         ops.linear_fwd_wt(d_f, conv.lin_r.weight, dx, accumulate=dx_acc)
     if E > 0:
         H1, H2, c1, c2 = sv["H1"], sv["H2"], sv["c1"], sv["c2"]
-        dM = _empty(E, C, dev)
+        dM = torch.empty(E, C, dtype=H1.dtype, device=dev)
         ops.csr_mean_bwd(d_f, g, dM)
         ops.bn_relu_bwd(dM, H2, bn4.weight, c2[2], c2[3], c2[0], c2[1], True,
                         sink.get(bn4.weight), sink.get(bn4.bias), dM)            # dM -> dH2 in place
         ops.linear_bwd_w(dM, H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
-        dA1 = _empty(E, C, dev)
+        dA1 = torch.empty(E, C, dtype=H1.dtype, device=dev)
         ops.linear_fwd_wt(dM, nn3.weight, dA1)
         ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
                         sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
-        if FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous() and nn0.bias is not None:
+        hdt = H1.dtype
+        if hdt == torch.bfloat16 or (FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous()
+                                     and nn0.bias is not None):
             # per-node sums of dH1 + N-row dense algebra instead of the gathered E-row GEMMs (pays when E >> N)
             ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), sink.get(nn0.bias),
                                          dx=dx if need_dx else None, dx_accumulate=True)
@@ -266,6 +274,7 @@ def model_fwd(model, g, x, training):
     P = g.P
     C = convs[0].nn[0].out_features
     F = net.fusion_block[0].out_features
+    half = model.__dict__.get("_yolat_train_precision", "fp32") == "bf16"
     D = C * n_out                       # fusion_dims
     if training and model.prediction_cls[1][-1].__class__.__name__.startswith("Dropout"):
         raise NotImplementedError("training with dropout > 0 is not implemented (README recipe uses 0.0)")
@@ -279,7 +288,7 @@ def model_fwd(model, g, x, training):
         slot = l - lo
         of = feats[:, slot * C:(slot + 1) * C] if slot >= 0 else None
         os_ = fsup[:, slot * C:(slot + 1) * C] if slot >= 0 else None
-        f, s, sv_c = conv_fwd(conv, g, f, s, of, os_, training)
+        f, s, sv_c = conv_fwd(conv, g, f, s, of, os_, training, half=training and half)
         if training and slot >= 0:
             sup_coef[0, slot * C:(slot + 1) * C].copy_(s.scale)
             sup_coef[1, slot * C:(slot + 1) * C].copy_(s.shift)

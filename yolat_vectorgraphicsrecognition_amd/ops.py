@@ -45,6 +45,19 @@ def _f(t, name="tensor", allow_none=False):
     return t.data_ptr()
 
 
+def _h(t, name="tensor"):
+    """data_ptr of a bfloat16 CUDA tensor whose last dim is dense (bf16-storage training tensors)."""
+    if not t.is_cuda or t.dtype != torch.bfloat16:
+        raise TypeError("%s must be a bfloat16 CUDA tensor" % name)
+    if t.dim() >= 1 and t.shape[-1] > 1 and t.stride(-1) != 1:
+        raise ValueError("%s must be dense along its last dimension" % name)
+    return t.data_ptr()
+
+
+def _is_h(t):
+    return t is not None and t.dtype == torch.bfloat16
+
+
 def _i(t, dtype, name="index"):
     if t is None:
         return None
@@ -158,6 +171,14 @@ def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False
     Nout = W.shape[0]
     asc, ash = (a_pro if a_pro is not None else (None, None))
     osc, osh = (o_pro if o_pro is not None else (None, None))
+    if _is_h(A) or _is_h(Y):
+        if not (_is_h(A) and _is_h(Y)) or o_pro is not None or o_relu or accumulate:
+            raise ValueError("bf16-storage linear_fwd: A and Y bfloat16, no output epilogue / accumulation")
+        wwork = torch.empty(Nout * K, dtype=torch.bfloat16, device=A.device)
+        check(lib.yolat_linear_fwd_h(_h(A, "A"), _ld(A), M, K, _f(asc, "a_scale", True), _f(ash, "a_shift", True),
+                                     int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias", True), Nout, _h(Y, "Y"), _ld(Y),
+                                     _f(stats, "stats", True), wwork.data_ptr(), _stream()), "yolat_linear_fwd_h")
+        return Y
     check(lib.yolat_linear_fwd(_f(A, "A"), _ld(A), M, K, _f(asc, "a_scale", True), _f(ash, "a_shift", True),
                                int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias", True), Nout,
                                _f(osc, "o_scale", True), _f(osh, "o_shift", True), int(o_relu),
@@ -170,6 +191,13 @@ def linear_fwd_wt(A, Wt, Y, accumulate=False):
     """Y = A @ Wt   (Wt: [K, Nout] row-major, e.g. dX = dY @ W)."""
     M, K = A.shape
     Nout = Wt.shape[1]
+    if _is_h(A) or _is_h(Y):
+        if not (_is_h(A) and _is_h(Y)) or accumulate:
+            raise ValueError("bf16-storage linear_fwd_wt: A and Y bfloat16, no accumulation")
+        wwork = torch.empty(Nout * K, dtype=torch.bfloat16, device=A.device)
+        check(lib.yolat_linear_fwd_wt_h(_h(A, "A"), _ld(A), M, K, _f(Wt, "Wt"), _ld(Wt), Nout, _h(Y, "Y"), _ld(Y),
+                                        wwork.data_ptr(), _stream()), "yolat_linear_fwd_wt_h")
+        return Y
     check(lib.yolat_linear_fwd_wt(_f(A, "A"), _ld(A), M, K, _f(Wt, "Wt"), _ld(Wt), Nout, _f(Y, "Y"),
                                   _ld(Y), int(accumulate), _stream()), "yolat_linear_fwd_wt")
     return Y
@@ -181,6 +209,12 @@ def linear_bwd_w(dY, A, dW, db=None, a_pro=None, a_relu=False, accumulate=False)
     asc, ash = (a_pro if a_pro is not None else (None, None))
     work = torch.empty(int(lib.yolat_linear_bwd_w_work_elems(M, Nout, K)), dtype=torch.float32,
                        device=dY.device)
+    if _is_h(dY):
+        check(lib.yolat_linear_bwd_w_h(_h(dY, "dY"), _ld(dY), M, Nout, _h(A, "A") if _is_h(A) else _f(A, "A"),
+                                       int(_is_h(A)), _ld(A), K, _f(asc, "a_scale", True), _f(ash, "a_shift", True),
+                                       int(a_relu), _f(dW, "dW"), _ld(dW), _f(db, "db", True), int(accumulate),
+                                       work.data_ptr(), _stream()), "yolat_linear_bwd_w_h")
+        return dW
     check(lib.yolat_linear_bwd_w(_f(dY, "dY"), _ld(dY), M, Nout, _f(A, "A"), _ld(A), K,
                                  _f(asc, "a_scale", True), _f(ash, "a_shift", True), int(a_relu),
                                  _f(dW, "dW"), _ld(dW), _f(db, "db", True), int(accumulate),
@@ -217,6 +251,11 @@ def bn_relu_bwd(dZ, Y, gamma, save_mean, save_invstd, scale, shift, relu, dgamma
                 accumulate=False):
     M, C = Y.shape
     work = torch.empty(int(lib.yolat_bn_bwd_work_elems(M, C)), dtype=torch.float32, device=Y.device)
+    if _is_h(Y):
+        check(lib.yolat_bn_relu_bwd_h(_h(dZ, "dZ"), _ld(dZ), _h(Y, "Y"), _ld(Y), M, C, _f(save_mean), _f(save_invstd),
+                                      _f(scale), _f(shift), int(relu), _f(dgamma), _f(dbeta), int(accumulate),
+                                      _h(dY, "dY"), _ld(dY), work.data_ptr(), _stream()), "yolat_bn_relu_bwd_h")
+        return dY
     check(lib.yolat_bn_relu_bwd(_f(dZ), _ld(dZ), _f(Y), _ld(Y), M, C, _f(gamma), _f(save_mean),
                                 _f(save_invstd), _f(scale), _f(shift), int(relu), _f(dgamma),
                                 _f(dbeta), int(accumulate), _f(dY), _ld(dY), work.data_ptr(),
@@ -260,8 +299,13 @@ def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=Fal
     if wuv is None:
         wuv, _ = split_w1(W1, Cin)
     dUV = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
-    check(lib.yolat_edge_uv_sums(_f(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(), g.slots.data_ptr(), N, C,
-                                 dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums")
+    if _is_h(dH1):
+        check(lib.yolat_edge_uv_sums_h(_h(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
+                                       g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()),
+              "yolat_edge_uv_sums_h")
+    else:
+        check(lib.yolat_edge_uv_sums(_f(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
+                                     g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums")
     dwuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
     linear_bwd_w(dUV, x, dwuv)
     dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
@@ -282,6 +326,11 @@ def edge_lin1_fwd_factorised(x, g, W1, b1, H1, stats=None):
     wuv, wc4 = split_w1(W1, Cin)
     uv = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
     linear_fwd(x, wuv, None, uv)
+    if _is_h(H1):
+        check(lib.yolat_edge_uv_lin1_fwd_h(uv.data_ptr(), 2 * C, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(),
+                                           g.E, wc4.data_ptr(), _f(b1, "b1", True), C, _h(H1, "H1"), _ld(H1),
+                                           _f(stats, "stats", True), _stream()), "yolat_edge_uv_lin1_fwd_h")
+        return H1
     check(lib.yolat_edge_uv_lin1_fwd(uv.data_ptr(), 2 * C, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), g.E,
                                      wc4.data_ptr(), _f(b1, "b1", True), C, _f(H1), _ld(H1),
                                      _f(stats, "stats", True), _stream()), "yolat_edge_uv_lin1_fwd")
@@ -362,6 +411,11 @@ def edge_scatter_bwd(dG, Cin, g, dX, accumulate=False):
 def csr_mean_fwd(H, g, out, h_pro=None, h_relu=False, accumulate=False):
     C = out.shape[1]
     hs, hb = (h_pro if h_pro is not None else (None, None))
+    if _is_h(H):
+        check(lib.yolat_csr_mean_fwd_h(_h(H, "H"), _ld(H), C, _f(hs, "h_scale", True), _f(hb, "h_shift", True),
+                                       int(h_relu), g.row_ptr.data_ptr(), g.N, _f(out), _ld(out), int(accumulate),
+                                       _stream()), "yolat_csr_mean_fwd_h")
+        return out
     check(lib.yolat_csr_mean_fwd(_f(H, "H", g.E == 0), _ld(H) if H is not None else C, C,
                                  _f(hs, "h_scale", True), _f(hb, "h_shift", True), int(h_relu),
                                  g.row_ptr.data_ptr(), g.N, _f(out), _ld(out), int(accumulate),
@@ -371,6 +425,10 @@ def csr_mean_fwd(H, g, out, h_pro=None, h_relu=False, accumulate=False):
 
 def csr_mean_bwd(dOut, g, dM):
     C = dOut.shape[1]
+    if _is_h(dM):
+        check(lib.yolat_csr_mean_bwd_h(_f(dOut), _ld(dOut), C, g.row_ptr.data_ptr(), g.dst.data_ptr(), g.E, _h(dM, "dM"),
+                                       _ld(dM), _stream()), "yolat_csr_mean_bwd_h")
+        return dM
     check(lib.yolat_csr_mean_bwd(_f(dOut), _ld(dOut), C, g.row_ptr.data_ptr(), g.dst.data_ptr(), g.E,
                                  _f(dM), _ld(dM), _stream()), "yolat_csr_mean_bwd")
     return dM

@@ -210,8 +210,10 @@ def allreduce_mean_(flat_grad):
 
 
 class Trainer(object):
-    def __init__(self, model, opt, lr=2.5e-4, weight_decay=1e-5):
+    def __init__(self, model, opt, lr=2.5e-4, weight_decay=1e-5, precision=None):
         self.model = model
+        if precision is not None:
+            model.set_train_precision(precision)
         self.flat = FlatParams(model)
         broadcast_parameters(self.flat, model)
         self.optimizer = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay)
