@@ -537,6 +537,16 @@ int yolat_profile_count(void);
 int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms, int* calls,
                       double* flops, double* bytes);
 
+/* nn.Dropout2d(p) of MLP in training mode (gcn_lib/sparse/torch_nn.py:67-68; only prediction_cls.1 can carry it,
+ * architecture3cc_rpn_gp_iter2.py:92) on a [M,C] activation, with the producer's lazy BatchNorm + ReLU applied on the
+ * way:  Z = relu?(Y*scale + shift) * keep / (1-p),  keep ~ Bernoulli(1-p) per ELEMENT (what torch 1.7.1's
+ * feature_dropout does for a 2-D input), a pure function of (seed, element index); `mask` (uint8 [M*C]) is written
+ * for yolat_dropout_bwd:  dX = dZ * keep / (1-p).                                                            */
+int yolat_dropout_fwd(const float* Y, int64_t ldy, int64_t M, int64_t C, const float* scale, const float* shift,
+                      int relu, float p, uint64_t seed, uint8_t* mask, float* Z, int64_t ldz, yolat_stream_t stream);
+int yolat_dropout_bwd(const float* dZ, int64_t lddz, int64_t M, int64_t C, const uint8_t* mask, float p, float* dX,
+                      int64_t lddx, yolat_stream_t stream);
+
 /* ------------------------------------------------------------------------------------------
  * Training with bfloat16 STORAGE of the [E,*] tensors (the precision mode BASELINE.json configs[4] names, applied to
  * the train step: cad_recognition/train.py:263-284): the per-edge activations H1, H2 and their gradients cross HBM

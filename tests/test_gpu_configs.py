@@ -310,3 +310,62 @@ def test_cross_entropy_rejects_out_of_range_labels():
     loss = torch.empty(1, device="cuda")
     yv.ops.softmax_ce(logits, labels, loss)
     assert bool(torch.isnan(loss).all())
+
+
+def test_training_mode_dropout2d_matches_oracle_with_the_same_mask():
+    """`--dropout p` puts nn.Dropout2d(p) behind prediction_cls.1 (torch_nn.py:67-68, arch:92).  The kernel draws an
+    element-wise Bernoulli(1-p) mask (torch 1.7.1's behaviour for a 2-D input); with that very mask injected into the
+    oracle, loss and gradients agree; eval mode ignores dropout; the mask follows torch.manual_seed."""
+    yv = _yv()
+    arrs, optkw = gu.graph_case("medium")
+    optkw = dict(optkw, dropout=0.4)
+    opt = yv.Opt(**optkw)
+    data = gu.to_data(arrs, yv.Data)
+    model = _model(yv, optkw, 8).train()
+    assert any(m.__class__.__name__ == "Dropout2d" for m in model.prediction_cls[1])
+    captured = {}
+    real = yv.ops.dropout_fwd
+
+    def spy(Y, scale, shift, relu, p, seed, Z):
+        mask = real(Y, scale, shift, relu, p, seed, Z)
+        want = Y * scale + shift if scale is not None else Y
+        want = torch.relu(want) if relu else want
+        assert torch.equal(Z, want * mask.view(Y.shape).float() * yv.ops.torch.tensor(1.0 / (1.0 - p), device="cuda").float()) \
+            or float((Z - want * mask.view(Y.shape).float() / (1 - p)).abs().max()) <= 1e-6 * float(want.abs().max())
+        captured["mask"], captured["p"] = mask.view(Y.shape).clone(), p
+        return mask
+
+    yv.ops.dropout_fwd = spy
+    try:
+        torch.manual_seed(123)
+        out = model(data, None)
+        loss = yv.DetectionLoss(opt)(out, data)["loss"]
+        loss.backward()
+    finally:
+        yv.ops.dropout_fwd = real
+    mask, p = captured["mask"], captured["p"]
+    frac = float(mask.float().mean())
+    assert abs(p - 0.4) < 1e-7 and abs(frac - 0.6) < 0.05, frac
+    # the oracle with the same mask
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 8).train()
+
+    class FixedMask(torch.nn.Module):
+        def forward(self, x):
+            return x * mask.cpu().float() / (1 - p)
+
+    seq = ref.prediction_cls[1]
+    idx = [i for i, m in enumerate(seq) if isinstance(m, torch.nn.Dropout2d)]
+    assert len(idx) == 1
+    seq[idx[0]] = FixedMask()
+    rlogits, rloss = _oracle_train(ref, optkw, data)
+    assert abs(float(loss) - float(rloss)) <= RTOL_FWD * abs(float(rloss))
+    _grad_check({n: q.grad for n, q in model.named_parameters()}, ref, 2e-3, "dropout")
+    # same seed -> same mask; eval mode: no dropout, equals the p = 0 model
+    m2 = _model(yv, optkw, 8).train()
+    torch.manual_seed(123)
+    l2 = yv.DetectionLoss(opt)(m2(data, None), data)["loss"]
+    assert torch.equal(l2.detach(), loss.detach())
+    fresh = _model(yv, optkw, 8).eval()                   # (the training forward above moved `model`'s running stats)
+    plain = _model(yv, dict(optkw, dropout=0.0), 8).eval()
+    with torch.no_grad():
+        assert torch.equal(fresh(data, None)[0], plain(data, None)[0])

@@ -142,6 +142,8 @@ SIGNATURES = {
                                      c_p, c_int, c_p, c_p]),
     "yolat_linear_fwd_wt_h": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_edge_uv_sums_h": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
+    "yolat_dropout_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_f, ctypes.c_uint64, c_p, c_p, c_i64, c_p]),
+    "yolat_dropout_bwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_f, c_p, c_i64, c_p]),
     "yolat_proposals_build": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, ctypes.c_double, c_p]),
     "yolat_proposals_count": (c_i64, [c_p]),
     "yolat_proposals_total": (c_i64, [c_p, c_int]),

@@ -162,7 +162,72 @@ extern "C" int yolat_adam_step(float* param, const float* grad, float* exp_avg, 
   return 0;
 }
 
-extern "C" int yolat_abi_version(void) { return 1; }
+// ------------------------------------------------------------------------------------------------
+// nn.Dropout2d(p) of MLP (gcn_lib/sparse/torch_nn.py:67-68), training mode, on a [M,C] activation.  With the
+// reference's torch 1.7.1 a 2-D input gets ELEMENT-wise Bernoulli(1-p) noise scaled by 1/(1-p) (feature_dropout's
+// noise has the shape of a 2-D input); that is what this does.  The producer's lazy BatchNorm + ReLU is applied on
+// the way: Z = relu?(Y*scale + shift) * keep / (1-p).  keep[r,c] = 1 iff hash(seed, r*C + c) >= p * 2^32 — a
+// counter-based generator (splitmix64 finaliser), so the mask is a pure function of (seed, position): deterministic,
+// independent of the launch geometry; the mask is stored (uint8) for the backward.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned yl_hash32(unsigned long long seed, unsigned long long idx) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (idx + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  z = z ^ (z >> 31);
+  return (unsigned)(z >> 32);
+}
+
+__global__ void k_dropout_fwd(const float* __restrict__ Y, long ldy, long M, int C, const float* __restrict__ scale,
+                              const float* __restrict__ shift, int relu, unsigned thresh, float inv_keep,
+                              unsigned long long seed, unsigned char* __restrict__ mask, float* __restrict__ Z, long ldz) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const long r = i / C;
+  const int c = (int)(i % C);
+  float v = Y[r * ldy + c];
+  if (scale != nullptr) v = fmaf(v, scale[c], shift[c]);
+  if (relu) v = fmaxf(v, 0.f);
+  const unsigned char keep = yl_hash32(seed, (unsigned long long)i) >= thresh ? 1 : 0;
+  mask[i] = keep;
+  Z[r * ldz + c] = keep ? v * inv_keep : 0.f;
+}
+
+__global__ void k_dropout_bwd(const float* __restrict__ dZ, long lddz, long M, int C,
+                              const unsigned char* __restrict__ mask, float inv_keep, float* __restrict__ dX, long lddx) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= M * C) return;
+  const long r = i / C;
+  const int c = (int)(i % C);
+  dX[r * lddx + c] = mask[i] ? dZ[r * lddz + c] * inv_keep : 0.f;
+}
+
+extern "C" int yolat_dropout_fwd(const float* Y, int64_t ldy, int64_t M, int64_t C, const float* scale,
+                                 const float* shift, int relu, float p, uint64_t seed, uint8_t* mask, float* Z,
+                                 int64_t ldz, yolat_stream_t stream) {
+  if (M < 0 || C <= 0 || !(p >= 0.f && p < 1.f) || (scale == nullptr) != (shift == nullptr)) return YOLAT_E_INVALID;
+  if (M == 0) return 0;
+  if (!Y || !mask || !Z || ldy < C || ldz < C) return YOLAT_E_INVALID;
+  const double t = (double)p * 4294967296.0;
+  const unsigned thresh = t >= 4294967295.0 ? 0xFFFFFFFFu : (unsigned)t;
+  hipLaunchKernelGGL(k_dropout_fwd, dim3(yl_cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, Y, (long)ldy, (long)M,
+                     (int)C, scale, shift, relu, thresh, 1.f / (1.f - p), (unsigned long long)seed, mask, Z, (long)ldz);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_dropout_bwd(const float* dZ, int64_t lddz, int64_t M, int64_t C, const uint8_t* mask, float p,
+                                 float* dX, int64_t lddx, yolat_stream_t stream) {
+  if (M < 0 || C <= 0 || !(p >= 0.f && p < 1.f)) return YOLAT_E_INVALID;
+  if (M == 0) return 0;
+  if (!dZ || !mask || !dX || lddz < C || lddx < C) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_dropout_bwd, dim3(yl_cdiv(M * C, 256)), dim3(256), 0, (hipStream_t)stream, dZ, (long)lddz, (long)M,
+                     (int)C, mask, 1.f / (1.f - p), dX, (long)lddx);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_abi_version(void) { return 2; }
 
 extern "C" const char* yolat_strerror(int code) {
   if (code == 0) return "ok";

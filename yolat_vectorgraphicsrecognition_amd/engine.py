@@ -140,6 +140,29 @@ def lbr_fwd(a, lin, bn, relu, training, out=None):
     return Lazy(y), sv
 
 
+def dropout_fwd(a, p):
+    """Training-mode nn.Dropout2d(p) behind a Linear+BN+ReLU block (torch_nn.py:67-68): materialises the lazy
+    activation with the element-wise mask applied.  Returns (Lazy output, saved (mask, p))."""
+    M, C = a.t.shape
+    z = _empty(M, C, a.t.device)
+    seed = int(torch.randint(0, 2 ** 62, (1,)).item())          # host generator: follows torch.manual_seed
+    mask = ops.dropout_fwd(a.t, a.scale, a.shift, a.relu, p, seed, z)
+    return Lazy(z), (mask, p)
+
+
+def dropout_bwd(saved, dz):
+    """dz (gradient w.r.t. the dropped-out activation) -> gradient w.r.t. the block's post-activation output,
+    in place."""
+    mask, p = saved
+    return ops.dropout_bwd(dz, mask, p, dz)
+
+
+def _drop_p(mlp):
+    """p of the nn.Dropout2d a gcn_lib MLP ends with (0 when there is none)."""
+    last = list(mlp.children())[-1]
+    return float(last.p) if last.__class__.__name__.startswith("Dropout") else 0.0
+
+
 def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inplace=True):
     """dz: gradient w.r.t. the block's (post-activation) output [M,C].  Writes parameter gradients
     into ``sink``; returns the gradient w.r.t. the block's *post-prologue* input (i.e. w.r.t. the
@@ -276,8 +299,6 @@ def model_fwd(model, g, x, training):
     F = net.fusion_block[0].out_features
     half = model.__dict__.get("_yolat_train_precision", "fp32") == "bf16"
     D = C * n_out                       # fusion_dims
-    if training and model.prediction_cls[1][-1].__class__.__name__.startswith("Dropout"):
-        raise NotImplementedError("training with dropout > 0 is not implemented (README recipe uses 0.0)")
 
     feats = _empty(N, D, dev)           # cat of the last n_out conv outputs          (arch:60)
     fsup = _empty(N, D, dev)            # cat of the last n_out node-branch outputs   (arch:65)
@@ -324,12 +345,16 @@ def model_fwd(model, g, x, training):
     m1, m2, m3 = model.prediction_cls[0], model.prediction_cls[1], model.prediction_cls[2]
     c1, sv1 = lbr_fwd(Lazy(Z), m1[0], m1[1], True, training)
     c2, sv2 = lbr_fwd(c1, m2[0], m2[1], True, training)
+    p_drop = _drop_p(m2) if training else 0.0                     # arch:92: only prediction_cls.1 carries dropout
+    sv_drop = None
+    if p_drop > 0:
+        c2, sv_drop = dropout_fwd(c2, p_drop)
     logits, sv3 = lbr_fwd(c2, m3[0], None, False, training)
     if not training:
         return logits.t, None
     flush_batch_counters()
     sv.update(feats=feats, fsup=fsup, Z=Z, fus=sv_fus, fs=sv_fs, arg_fus=arg_fus, arg_feat=arg_feat,
-              cls=(sv1, sv2, sv3), dims=(N, P, C, F, D, L, lo))
+              cls=(sv1, sv2, sv3), drop=sv_drop, dims=(N, P, C, F, D, L, lo))
     return logits.t, sv
 
 
@@ -340,6 +365,8 @@ def model_bwd(model, g, sv, dlogits, sink):
     dev = dlogits.device
     sv1, sv2, sv3 = sv["cls"]
     d2 = lbr_bwd(sv3, dlogits, sink)
+    if sv.get("drop") is not None:
+        d2 = dropout_bwd(sv["drop"], d2)
     d1 = lbr_bwd(sv2, d2, sink)
     dZ = lbr_bwd(sv1, d1, sink)                                      # [P, 2(F+D)]
     # fusion_block_super: input = sup (Z[:, 2F+D:]), output post-activation = Z[:, F+D:2F+D]

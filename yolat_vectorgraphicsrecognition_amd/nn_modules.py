@@ -81,9 +81,9 @@ class _MLPFn(torch.autograd.Function):
         a = Lazy(x)
         saved = []
         for lin, bn, relu, drop in _groups(mlp):
-            if drop > 0 and training:
-                raise NotImplementedError("training-mode Dropout2d has no MI355X kernel (recipe uses dropout 0.0)")
             a, sv = engine.lbr_fwd(a, lin, bn, relu, training)
+            if drop > 0 and training:
+                a, sv["drop"] = engine.dropout_fwd(a, drop)
             saved.append(sv)
         engine.flush_batch_counters()
         ctx.mlp, ctx.saved_blocks, ctx.params = mlp, saved, params
@@ -99,6 +99,8 @@ class _MLPFn(torch.autograd.Function):
         d = dz.contiguous().clone()
         blocks = ctx.saved_blocks
         for i in range(len(blocks) - 1, -1, -1):
+            if blocks[i].get("drop") is not None:
+                d = engine.dropout_bwd(blocks[i]["drop"], d)
             d = engine.lbr_bwd(blocks[i], d, sink, need_dx=(i > 0 or ctx.needs_input_grad[1]))
         return (None, d if ctx.needs_input_grad[1] else None) + tuple(sink.out.get(id(p)) for p in ctx.params)
 

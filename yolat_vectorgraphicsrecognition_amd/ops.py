@@ -595,6 +595,23 @@ def adam_step(param, grad, exp_avg, exp_avg_sq, lr, beta1, beta2, eps, weight_de
                               int(step), float(grad_scale), _stream()), "yolat_adam_step")
 
 
+def dropout_fwd(Y, scale, shift, relu, p, seed, Z):
+    """Z = relu?(Y*scale+shift) * keep/(1-p) with an element-wise Bernoulli(1-p) mask (yolat_dropout_fwd); returns the
+    uint8 mask for dropout_bwd."""
+    M, C = Y.shape
+    mask = torch.empty(M * C, dtype=torch.uint8, device=Y.device)
+    check(lib.yolat_dropout_fwd(_f(Y), _ld(Y), M, C, _f(scale, "scale", True), _f(shift, "shift", True), int(relu),
+                                float(p), int(seed), mask.data_ptr(), _f(Z), _ld(Z), _stream()), "yolat_dropout_fwd")
+    return mask
+
+
+def dropout_bwd(dZ, mask, p, dX):
+    M, C = dZ.shape
+    check(lib.yolat_dropout_bwd(_f(dZ), _ld(dZ), M, C, mask.data_ptr(), float(p), _f(dX), _ld(dX), _stream()),
+          "yolat_dropout_bwd")
+    return dX
+
+
 def nms(boxes, scores, iou_threshold):
     """torchvision.ops.nms(boxes, scores, iou_threshold) on the HIP path (csrc/nms.hip, yolat_nms): indices of the
     kept boxes in descending score order.  boxes [n,4] (x1,y1,x2,y2), scores [n]; both CUDA tensors."""
