@@ -462,6 +462,13 @@ typedef struct {
   int64_t H1, H2;                             /* classifier hidden widths (512, 256)             */
   yolat_conv_eval conv[YOLAT_MAX_LAYERS];     /* head, then backbone[i].body                     */
   const float *Wf, *bf, *sf, *tf;             /* cls_net.fusion_block                            */
+  /* nullable (all eight or none): both fusion blocks prepared for the bf16x6-emulated kernel (yolat_fusion_pair_eval_x6) —
+   * Wf_hi + Wf_mid + Wf_lo == fl(sf (rows) * Wf) exactly, three bfloat16 [F, D] matrices (yolat_split_bf16x3);
+   * tf_fold = sf*bf + tf                                                                                     */
+  const uint16_t *Wf_hi, *Wf_mid, *Wf_lo;
+  const float *tf_fold;
+  const uint16_t *Wfs_hi, *Wfs_mid, *Wfs_lo;  /* the same for fusion_block_super                              */
+  const float *tfs_fold;
   const float *Wfs, *bfs, *sfs, *tfs;         /* cls_net.fusion_block_super                      */
   const float *Wc1, *bc1, *sc1, *tc1;         /* prediction_cls.0                                */
   const float *Wc2, *bc2, *sc2, *tc2;         /* prediction_cls.1                                */
@@ -536,6 +543,20 @@ int yolat_profile_reset(void);
 int yolat_profile_count(void);
 int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms, int* calls,
                       double* flops, double* bytes);
+
+/* Eval fusion block + per-proposal max with the [N,D] x [D,F] GEMM emulated on the bf16 matrix cores (fusion_x6.hip):
+ * both operands split exactly into three bfloat16 terms, six v_mfma_f32_32x32x16_bf16 products per 16 k, fp32
+ * accumulation — the fp32 result up to the summation order (~1e-7 relative) at 2.7x the fp32-MFMA rate.
+ *   yolat_split_bf16x3         hi + mid + lo == fl(row_scale[r] * W[r, c]) exactly (row_scale nullable)
+ *   yolat_fusion_pair_eval_x6  same contract as yolat_fusion_pair_eval with both fusion blocks given as (hi, mid,
+ *                              lo) = split of s (.) W and the folded shift s*b + t;  D in {64, 128}, F % 64 == 0   */
+int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int64_t cols, const float* row_scale, uint16_t* hi,
+                       uint16_t* mid, uint16_t* lo, yolat_stream_t stream);
+int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
+                              const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,
+                              int64_t ldpool, const float* S, int64_t lds, int64_t P, const uint16_t* Wsh,
+                              const uint16_t* Wsm, const uint16_t* Wsl, const float* tsfold, float* Ys, int64_t ldys,
+                              yolat_stream_t stream);
 
 /* nn.Dropout2d(p) of MLP in training mode (gcn_lib/sparse/torch_nn.py:67-68; only prediction_cls.1 can carry it,
  * architecture3cc_rpn_gp_iter2.py:92) on a [M,C] activation, with the producer's lazy BatchNorm + ReLU applied on the

@@ -909,3 +909,56 @@ def test_factorised_edge_lin1_backward_matches_gathered_gemms(N, E, Cin):
     dx_c = base.clone()
     yv.ops.edge_lin1_bwd_factorised(dH, x, g, W1, dW_c, db_c, dx=dx_c, dx_accumulate=True)
     assert torch.equal(dW_b, dW_c) and torch.equal(db_b, db_c) and torch.equal(dx_b, dx_c)
+
+
+@pytest.mark.parametrize("N,P,D", [(700, 30, 128), (10000, 400, 128), (257, 5, 64), (5000, 4999, 128)])
+def test_fusion_x6_matches_fp32_fusion_kernel(N, P, D):
+    """yolat_fusion_pair_eval_x6 (fusion GEMM emulated with six bf16 MFMA products on exactly split operands, BatchNorm
+    scale folded into the weights) against yolat_fusion_pair_eval (fp32 MFMAs): pooled maxima and the super branch."""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    F = 1024
+    tg = torch.Generator().manual_seed(N + P)
+    A = torch.randn(N, D, generator=tg).cuda()
+    S = torch.randn(P, D, generator=tg).cuda()
+    Wf, Wfs = (torch.randn(F, D, generator=tg) / D ** 0.5).cuda(), (torch.randn(F, D, generator=tg) / D ** 0.5).cuda()
+    bf, bfs = (torch.randn(F, generator=tg) * 0.1).cuda(), (torch.randn(F, generator=tg) * 0.1).cuda()
+    sf, sfs = (torch.rand(F, generator=tg) - 0.3).cuda(), (torch.rand(F, generator=tg) + 0.5).cuda()    # some negative scales
+    tf, tfs = (torch.randn(F, generator=tg) * 0.2).cuda(), (torch.randn(F, generator=tg) * 0.2).cuda()
+    seg = torch.sort(torch.randint(0, P, (N,), generator=tg))[0].int().cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    ZW = 2 * (F + D)
+    Za, Zb = torch.zeros(P, ZW).cuda(), torch.zeros(P, ZW).cuda()
+    check(lib.yolat_fusion_pair_eval(A.data_ptr(), D, N, D, Wf.data_ptr(), bf.data_ptr(), sf.data_ptr(), tf.data_ptr(), F,
+                                     seg.data_ptr(), Za.data_ptr(), ZW, S.data_ptr(), D, P, Wfs.data_ptr(), bfs.data_ptr(),
+                                     sfs.data_ptr(), tfs.data_ptr(), Za[:, F + D:].data_ptr(), ZW, st))
+    parts = [torch.empty(F * D, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    check(lib.yolat_split_bf16x3(Wf.data_ptr(), D, F, D, sf.data_ptr(), parts[0].data_ptr(), parts[1].data_ptr(),
+                                 parts[2].data_ptr(), st))
+    scaled = (Wf * sf[:, None]).flatten()
+    assert torch.equal(parts[0].float() + parts[1].float() + parts[2].float(), scaled)      # the split is exact
+    tfold = sf * bf + tf
+    sparts = [torch.empty(F * D, dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+    check(lib.yolat_split_bf16x3(Wfs.data_ptr(), D, F, D, sfs.data_ptr(), sparts[0].data_ptr(), sparts[1].data_ptr(),
+                                 sparts[2].data_ptr(), st))
+    tsfold = sfs * bfs + tfs
+
+    def x6(Z):
+        check(lib.yolat_fusion_pair_eval_x6(A.data_ptr(), D, N, D, parts[0].data_ptr(), parts[1].data_ptr(),
+                                            parts[2].data_ptr(), tfold.data_ptr(), F, seg.data_ptr(), Z.data_ptr(), ZW,
+                                            S.data_ptr(), D, P, sparts[0].data_ptr(), sparts[1].data_ptr(),
+                                            sparts[2].data_ptr(), tsfold.data_ptr(), Z[:, F + D:].data_ptr(), ZW, st))
+
+    x6(Zb)
+    sup_a, sup_b = Za[:, F + D:2 * F + D], Zb[:, F + D:2 * F + D]
+    assert float((sup_a - sup_b).abs().max()) <= 3e-6 * float(sup_a.abs().max())            # super branch
+    scale = float(Za[:, :F].abs().max())
+    assert float((Za[:, :F] - Zb[:, :F]).abs().max()) <= 3e-6 * scale
+    # against float64
+    want = torch.zeros(P, F, dtype=torch.float64)
+    act = torch.relu((A.double().cpu() @ Wf.double().cpu().t() + bf.double().cpu()) * sf.double().cpu() + tf.double().cpu())
+    want.index_reduce_(0, seg.cpu().long(), act, "amax", include_self=True)
+    assert float((Zb[:, :F].double().cpu() - want).abs().max()) <= 2e-6 * scale
+    Zc = torch.zeros(P, ZW).cuda()
+    x6(Zc)
+    assert torch.equal(Zb, Zc)

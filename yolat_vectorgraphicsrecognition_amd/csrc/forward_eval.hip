@@ -255,9 +255,14 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   // fusion block over the nodes + per-proposal max, and fusion_block_super over the per-proposal means
   // (arch:61-63,65-69,122): two independent GEMMs in one flattened launch
   snprintf(nm, sizeof nm, "fusion_gemm+segmax[N x %ld -> %ld -> P] | super[P x %ld -> %ld]", D, F, D, F);
+  const bool fusion_x6 = m->Wf_hi && m->Wf_mid && m->Wf_lo && m->tf_fold && m->Wfs_hi && m->Wfs_mid && m->Wfs_lo &&
+                         m->tfs_fold && (D == 64 || D == 128) && F % 64 == 0 && (long)P * ZW < (1LL << 32);
   YL_STAGE(nm, 2.0 * (N + P) * D * F, 4.0 * (N * D + 2.0 * D * F + 2.0 * P * F + N + P * D),
-           yolat_fusion_pair_eval(p.feats, D, N, D, m->Wf, m->bf, m->sf, m->tf, F, p.node_seg, p.Z, ZW, sup, ZW, P,
-                                  m->Wfs, m->bfs, m->sfs, m->tfs, p.Z + F + D, ZW, stream));
+           fusion_x6 ? yolat_fusion_pair_eval_x6(p.feats, D, N, D, m->Wf_hi, m->Wf_mid, m->Wf_lo, m->tf_fold, F, p.node_seg,
+                                                 p.Z, ZW, sup, ZW, P, m->Wfs_hi, m->Wfs_mid, m->Wfs_lo, m->tfs_fold,
+                                                 p.Z + F + D, ZW, stream)
+                     : yolat_fusion_pair_eval(p.feats, D, N, D, m->Wf, m->bf, m->sf, m->tf, F, p.node_seg, p.Z, ZW, sup,
+                                              ZW, P, m->Wfs, m->bfs, m->sfs, m->tfs, p.Z + F + D, ZW, stream));
   // ---- classifier (arch:91-93,127-128)
   snprintf(nm, sizeof nm, "cls1[P x %ld -> %ld]", ZW, (long)m->H1);
   YL_STAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + ZW * m->H1 + P * m->H1),

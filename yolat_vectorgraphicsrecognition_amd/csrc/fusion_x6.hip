@@ -1,0 +1,337 @@
+// fusion_x6.hip — eval-mode fusion block + per-proposal max pooling (architecture3cc_rpn_gp_iter2.py:61-63,122) with
+// the [N,128] x [128,1024] GEMM as an fp32 GEMM EMULATED on the bf16 matrix cores (round 2).
+//
+// Why: the fp32-input MFMA of gfx950 executes on the SIMD's vector ALUs at the fp32 vector rate ("fp32 MFMA
+// and the vector ALU"): the round-1 kernel (k_gemm_nt_two, 64x64 tiles) sits at 0.48 of that peak at cfg 2 and its
+// epilogue VALU work adds to, not under, its MFMA time.  Both operands split exactly into three bfloat16 terms
+// (truncation: 8 + 8 + 8 significand bits) and six products per 16 k — a_h b_l, a_l b_h, a_m b_m, a_m b_h, a_h b_m,
+// a_h b_h, the three O(2^-24) ones dropped — give the fp32 result up to the summation order at 16/6 = 2.7x the
+// fp32-MFMA rate, on a pipe that runs beside the VALU.
+//
+// Structure: a 512-thread workgroup (8 waves) owns 256 rows.  Every wave splits ITS 32 rows x K of A once into
+// registers (3 x K/16 fragments = 96 VGPRs at K = 128) and keeps them for all the column tiles it walks; the weights —
+// split once per weight version by yolat_split_bf16x3, BatchNorm scale folded into their rows — stream through a
+// double-buffered LDS tile (3 x 64 columns x K bf16 = 48 KB, row stride K+8: conflict-free ds_read_b128), the next
+// tile's 16-byte pieces loaded into registers while the current tile's 96 MFMAs per wave and its pooling epilogue
+// run; one barrier per column tile.  W is re-streamed once per 256 rows (4x less L2 -> LDS traffic than 64-row
+// tiles: at N = 200 k, 0.65 GB instead of 2.6 GB).  Pooling epilogue: the run-length integer atomicMax of
+// bf16_eval.hip's rows kernel (values >= 0: int order == float order, exact, order-independent).
+// fusion_block_super (P rows, its own weights, plain relu store) is a second problem of the same launch.
+#include "common.hpp"
+
+typedef __bf16 fx_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned fx_u32x4 __attribute__((ext_vector_type(4)));
+
+namespace {
+// exact 3-way bfloat16 split of 8 fp32 values (h = top 8 significand bits, hm = top 16: m = hm - h and l = x - hm are
+// exact and need 8 bits each)
+__device__ __forceinline__ void fx_split8(const float x[8], fx_bf16x8& h, fx_bf16x8& m, fx_bf16x8& l) {
+  fx_u32x4 ph, pm, pl;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const unsigned x0 = __float_as_uint(x[2 * i]), x1 = __float_as_uint(x[2 * i + 1]);
+    const yl_f32x2 xv = {x[2 * i], x[2 * i + 1]};
+    const yl_f32x2 hv = {__uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1 & 0xffff0000u)};
+    const yl_f32x2 hmv = {__uint_as_float(x0 & 0xffffff00u), __uint_as_float(x1 & 0xffffff00u)};
+    const yl_f32x2 mv = hmv - hv, lv = xv - hmv;
+    ph[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
+    pm[i] = __builtin_amdgcn_perm(__float_as_uint(mv.y), __float_as_uint(mv.x), 0x07060302u);
+    pl[i] = __builtin_amdgcn_perm(__float_as_uint(lv.y), __float_as_uint(lv.x), 0x07060302u);
+  }
+  h = *reinterpret_cast<fx_bf16x8*>(&ph);
+  m = *reinterpret_cast<fx_bf16x8*>(&pm);
+  l = *reinterpret_cast<fx_bf16x8*>(&pl);
+}
+
+// Run structure of a lane's 16 rows (C/D layout of a 32x32 MFMA tile) from their proposal ids — the same for every
+// column tile: keep[r] = 1 when row r continues the run of row r-1, flush bit r = a run ends at row r (uflush: in
+// some lane of the wave).  The proposal id of a flushed row is re-read from LDS (segs: the wave's 32 ids) — rare,
+// and 16 registers cheaper than keeping the offsets.
+struct FxRuns { float keep[16]; unsigned flush_bits, uflush; };
+__device__ __forceinline__ void fx_seg_runs(int segv, int lhi, FxRuns& sr) {
+  int sgs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);
+  unsigned fb = 0, uf = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    sr.keep[r] = (r > 0 && sgs[r] == sgs[r - 1]) ? 1.f : 0.f;
+    const bool fl = sgs[r] >= 0 && (r == 15 || sgs[r] != sgs[r + 1]);
+    fb |= fl ? (1u << r) : 0u;
+    uf |= (__builtin_amdgcn_ballot_w64(fl) != 0ull) ? (1u << r) : 0u;
+  }
+  sr.flush_bits = fb; sr.uflush = uf;
+}
+// values = relu(acc) (the shift is the accumulator's initial value, the scale is inside the weights).  Both column
+// blocks in one pass: two independent running-max chains (the chain is latency bound) and one test per row.
+__device__ __forceinline__ void fx_segmax2(const f32x16& acc0, const f32x16& acc1, float* pool, unsigned ldpool,
+                                           const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, const FxRuns& sr) {
+  float cur0 = 0.f, cur1 = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cur0 = fmaxf(fmaxf(cur0 * sr.keep[r], acc0[r]), 0.f);
+    cur1 = fmaxf(fmaxf(cur1 * sr.keep[r], acc1[r]), 0.f);
+    if ((sr.uflush >> r) & 1u) {
+      if ((sr.flush_bits >> r) & 1u) {
+        int* o = reinterpret_cast<int*>(pool) + ((unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldpool + c0);
+        if (ok0 && cur0 > 0.f) atomicMax(o, __float_as_int(cur0));
+        if (ok1 && cur1 > 0.f) atomicMax(o + 32, __float_as_int(cur1));
+      }
+    }
+  }
+}
+}  // namespace
+
+// One GEMM problem of the launch: rows of A against the pre-split weights; seg != NULL -> pooling epilogue into `out`
+// (pool), else plain store of relu(.) into out [rows, F] (fusion_block_super).
+struct FxProb {
+  const float* A; long lda; int N;
+  const yl_bf16_t *Wh, *Wm, *Wl;
+  const float* tfold;
+  const int* seg;
+  float* out; long ldo;
+  int tm, groups, ng;
+};
+
+template <int KD>
+__global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1, int F) {
+  constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
+  constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / 512;   // 16-byte chunks of one W tile, per thread
+  static_assert(CHUNKS % 512 == 0, "W tile / thread mismatch");
+  __shared__ __attribute__((aligned(16))) yl_bf16_t Ws[2][3 * 64 * RS];
+  __shared__ int seg_s[256];
+  const int tid = threadIdx.x;
+  // the small problem's workgroups come first (padded to a multiple of 8 so that the big problem keeps its
+  // id % 8 = XCD alignment): they start with the first round of workgroups instead of forming a tail
+  const int n1 = p1.tm * p1.groups, n1p = (n1 + 7) & ~7;
+  const int id = blockIdx.x;
+  int logical;
+  if (id < n1p) {
+    if (id >= n1) return;
+    logical = id;
+  } else {
+    // (row tile, column group) pairs, column group fastest, dealt to the XCDs in contiguous ranges
+    const int n0 = p0.tm * p0.groups, j0 = id - n1p;
+    const int chunk = n0 >> 3, rem = n0 & 7;
+    const int xcd = j0 & 7, slot = j0 >> 3;
+    logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
+  }
+  // the problem's fields as wave-uniform scalars (a reference to "p0 or p1" would make the compiler index the
+  // kernel arguments through memory)
+  const bool small = id < n1p;
+  struct { const float* A; long lda; int N; const float* tfold; const int* seg; float* out; long ldo; int groups, ng; } P;
+  P.A = small ? p1.A : p0.A;
+  P.lda = small ? p1.lda : p0.lda;
+  P.N = small ? p1.N : p0.N;
+  P.tfold = small ? p1.tfold : p0.tfold;
+  P.seg = small ? p1.seg : p0.seg;
+  P.out = small ? p1.out : p0.out;
+  P.ldo = small ? p1.ldo : p0.ldo;
+  P.groups = small ? p1.groups : p0.groups;
+  P.ng = small ? p1.ng : p0.ng;
+  const float* __restrict__ A = P.A;
+  const int N = P.N;
+  const int rt = logical / P.groups, cg = logical % P.groups;
+  const int tn = (F + 63) >> 6;
+  const int ct0 = cg * P.ng;
+  const int ngl = yl_min(P.ng, tn - ct0);
+  if (ngl <= 0) return;
+
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = rt * 256 + wave * 32;
+  // ---- this wave's 32 rows of A, split once
+  fx_bf16x8 Ah[KS], Am[KS], Al[KS];
+  {
+    const float* ap = A + (long)yl_min(row0 + l31, N - 1) * P.lda + 8 * lhi;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * ks);
+      const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
+      const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      fx_split8(x, Ah[ks], Am[ks], Al[ks]);
+    }
+  }
+  const bool pooling = P.seg != nullptr;
+  FxRuns runs;
+  {
+    const int sv = (pooling && row0 + l31 < N) ? P.seg[row0 + l31] : -1;
+    if (lhi == 0) seg_s[wave * 32 + l31] = sv;          // read back by the same wave only, after the barrier below
+    fx_seg_runs(sv, lhi, runs);
+  }
+  const int* segs = seg_s + wave * 32;
+  const yl_bf16_t* const wparts[3] = {small ? p1.Wh : p0.Wh, small ? p1.Wm : p0.Wm, small ? p1.Wl : p0.Wl};
+  // W tile pieces: thread tid moves 16-byte piece (tid + 512 t) of the [3][64][KD] tile; 64 * CPR is a multiple of
+  // 512, so the part (hi / mid / lo) of piece t is a compile-time constant
+  constexpr int PER = 64 * CPR / 512;                       // pieces per thread and part
+  static_assert((64 * CPR) % 512 == 0, "part boundary inside a thread's pieces");
+  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
+  auto load_w = [&](int ct, fx_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int part = t / PER;
+      const unsigned r = wr0 + (unsigned)(t % PER) * (512 / CPR);
+      rw[t] = *reinterpret_cast<const fx_u32x4*>(wparts[part] + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
+    }
+  };
+  auto store_w = [&](int buf, const fx_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int part = t / PER;
+      const unsigned r = wr0 + (unsigned)(t % PER) * (512 / CPR);
+      *reinterpret_cast<fx_u32x4*>(&Ws[buf][part * 64 * RS + r * RS + wk]) = rw[t];
+    }
+  };
+  fx_u32x4 rw[NW];
+  load_w(ct0, rw);
+  // shifts of the first tile; later tiles: fetched one tile ahead, BEFORE that tile's W loads, so that no wait on
+  // them ever sits behind younger loads or the epilogue's atomics (vmcnt retires in order)
+  float t0 = P.tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = P.tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
+  store_w(0, rw);
+  __syncthreads();
+  for (int j = 0; j < ngl; ++j) {
+    const int ct = ct0 + j, buf = j & 1;
+    const int c0 = ct * 64 + l31, c1 = c0 + 32;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = t0; acc1[r] = t1; }
+    if (j + 1 < ngl) {
+      t0 = P.tfold[yl_min(c0 + 64, F - 1)];
+      t1 = P.tfold[yl_min(c1 + 64, F - 1)];
+      load_w(ct + 1, rw);                              // in flight while the MFMAs below run
+    }
+    const yl_bf16_t* wb = &Ws[buf][l31 * RS + 8 * lhi];
+    // B fragments: column block 0 / 1 x hi / mid / lo; the compiler issues the next k step's reads as registers free up
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      fx_bf16x8 bf[6];                                 // [0] b0h [1] b1h [2] b0m [3] b1m [4] b0l [5] b1l
+#pragma unroll
+      for (int q = 0; q < 6; ++q) {
+        bf[q] = *reinterpret_cast<const fx_bf16x8*>(wb + q * 32 * RS + 16 * ks);
+      }
+      // small terms first.  The empty asm ties both accumulators after every MFMA: it pins the MFMAs' program order
+      // (instruction selection otherwise pairs up MFMAs on the same accumulator) and emits nothing
+#define FX_MFMA(acc, a, b)                                         \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); \
+  asm volatile("" : "+v"(acc0), "+v"(acc1))
+      FX_MFMA(acc0, Al[ks], bf[0]);
+      FX_MFMA(acc1, Al[ks], bf[1]);
+      FX_MFMA(acc0, Ah[ks], bf[4]);
+      FX_MFMA(acc1, Ah[ks], bf[5]);
+      FX_MFMA(acc0, Am[ks], bf[2]);
+      FX_MFMA(acc1, Am[ks], bf[3]);
+      FX_MFMA(acc0, Am[ks], bf[0]);
+      FX_MFMA(acc1, Am[ks], bf[1]);
+      FX_MFMA(acc0, Ah[ks], bf[2]);
+      FX_MFMA(acc1, Ah[ks], bf[3]);
+      FX_MFMA(acc0, Ah[ks], bf[0]);
+      FX_MFMA(acc1, Ah[ks], bf[1]);
+#undef FX_MFMA
+    }
+    // next W tile into the other buffer (its readers finished before the last barrier) BEFORE the epilogue: the
+    // wait for its loads then never includes the epilogue's atomics / stores
+    if (j + 1 < ngl) store_w(buf ^ 1, rw);
+    // everything still in flight here (next tile's shifts and W pieces, the previous tile's atomics) was issued a
+    // whole MFMA phase ago: waiting now costs nothing and keeps the compiler from waiting on the shifts at the top
+    // of the next tile, where the wait would also cover this tile's atomics (vmcnt retires in order)
+    __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
+    if (pooling) {
+      fx_segmax2(acc0, acc1, P.out, (unsigned)P.ldo, segs, lhi, (unsigned)c0, c0 < F, c1 < F, runs);
+    } else {
+      // the row base goes through an opaque asm so that the 16 row addresses are recomputed here instead of being
+      // kept in 32 registers across the MFMA loop
+      unsigned rb = (unsigned)(row0 + 4 * lhi);
+      asm volatile("" : "+v"(rb));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = rb + (r & 3) + 8 * (r >> 2);
+        if ((int)row < N) {
+          float* o = P.out + (unsigned long)row * (unsigned long)P.ldo;
+          if (c0 < F) o[c0] = fmaxf(acc0[r], 0.f);
+          if (c1 < F) o[c1] = fmaxf(acc1[r], 0.f);
+        }
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// W [rows, cols] fp32 (optionally scaled per row) -> three bfloat16 matrices hi / mid / lo [rows, cols] with
+// hi + mid + lo == fl(row_scale * W) exactly.
+static __global__ void k_split_bf16x3(const float* __restrict__ W, long ldw, long rows, int cols,
+                                      const float* __restrict__ row_scale, yl_bf16_t* __restrict__ hi,
+                                      yl_bf16_t* __restrict__ mid, yl_bf16_t* __restrict__ lo) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= rows * cols) return;
+  const long r = i / cols;
+  float x = W[r * ldw + (i % cols)];
+  if (row_scale != nullptr) x *= row_scale[r];
+  const unsigned u = __float_as_uint(x);
+  const float h = __uint_as_float(u & 0xffff0000u), hm = __uint_as_float(u & 0xffffff00u);
+  const float m = hm - h, l = x - hm;
+  hi[i] = (yl_bf16_t)(u >> 16);
+  mid[i] = (yl_bf16_t)(__float_as_uint(m) >> 16);
+  lo[i] = (yl_bf16_t)(__float_as_uint(l) >> 16);
+}
+
+extern "C" int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int64_t cols, const float* row_scale,
+                                  uint16_t* hi, uint16_t* mid, uint16_t* lo, yolat_stream_t stream) {
+  if (rows <= 0 || cols <= 0 || !W || !hi || !mid || !lo || ldw < cols) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_split_bf16x3, dim3(yl_cdiv(rows * cols, 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
+                     (long)rows, (int)cols, row_scale, hi, mid, lo);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// pool[p, 0:F] = max over the rows of proposal p of relu(A . (sf (.) Wf)^T + tfold),  Ys = relu(S . (sfs (.) Wfs)^T
+// + tsfold): both fusion blocks with pre-split weights (yolat_split_bf16x3 of the scaled rows) and folded shifts
+// (s*b + t).  `pool` must be zero-filled first (yolat_pool_prepare).  D in {64, 128}, F % 64 == 0.
+extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh,
+                                         const uint16_t* Wm, const uint16_t* Wl, const float* tfold, int64_t F,
+                                         const int32_t* node_seg, float* pool, int64_t ldpool, const float* S,
+                                         int64_t lds, int64_t P, const uint16_t* Wsh, const uint16_t* Wsm,
+                                         const uint16_t* Wsl, const float* tsfold, float* Ys, int64_t ldys,
+                                         yolat_stream_t stream) {
+  if (N <= 0 || P <= 0 || F <= 0 || !A || !Wh || !Wm || !Wl || !tfold || !node_seg || !pool || !S || !Wsh || !Wsm || !Wsl ||
+      !tsfold || !Ys)
+    return YOLAT_E_INVALID;
+  if (N >= (1LL << 31) - 256 || lda < D || lds < D || ldpool < F || ldys < F) return YOLAT_E_INVALID;
+  if ((D != 64 && D != 128) || F % 64 != 0 || lda % 4 != 0 || lds % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(S) ||
+      !yl_aligned16(Wh) || !yl_aligned16(Wm) || !yl_aligned16(Wl) || !yl_aligned16(Wsh) || !yl_aligned16(Wsm) ||
+      !yl_aligned16(Wsl) || (int64_t)P * ldpool >= (1LL << 32))
+    return YOLAT_E_UNSUPPORTED;
+  const int tn = (int)(F / 64);
+  // Column groups.  One workgroup per CU is resident (8 waves x ~240 VGPRs), so the launch runs in rounds of 256
+  // workgroups; a workgroup costs one prologue (load + split of its 256 rows of A, measured ~ one column tile's time)
+  // plus its column tiles.  Pick the power-of-two split with the fewest (rounds x workgroup cost); the small problem
+  // always gets the finest split (its few row tiles must not become the longest workgroups).
+  // YOLAT_FUSION_X6_GROUPS=g forces the split of the pooled problem (experiments).
+  static int forced = -1;
+  if (forced < 0) { const char* e = getenv("YOLAT_FUSION_X6_GROUPS"); forced = e ? atoi(e) : 0; }
+  FxProb p0, p1;
+  p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = Wh; p0.Wm = Wm; p0.Wl = Wl; p0.tfold = tfold; p0.seg = node_seg;
+  p0.out = pool; p0.ldo = ldpool;
+  p1.A = S; p1.lda = lds; p1.N = (int)P; p1.Wh = Wsh; p1.Wm = Wsm; p1.Wl = Wsl; p1.tfold = tsfold; p1.seg = nullptr;
+  p1.out = Ys; p1.ldo = ldys;
+  p0.tm = yl_cdiv(N, 256);
+  p1.tm = yl_cdiv(P, 256);
+  p1.groups = tn; p1.ng = 1;
+  const long n1 = (((long)p1.tm * tn + 7) & ~7L);
+  int best_g = 1;
+  double best = 1e300;
+  for (int g = 1; g <= tn; g *= 2) {
+    const int ng = yl_cdiv(tn, g);
+    const long wgs = (long)p0.tm * yl_cdiv(tn, ng) + n1;
+    const double cost = (double)((wgs + 255) / 256) * (1.0 + ng);
+    if (cost < best) { best = cost; best_g = g; }
+  }
+  if (forced > 0) best_g = forced < tn ? forced : tn;
+  p0.ng = yl_cdiv(tn, best_g);
+  p0.groups = yl_cdiv(tn, p0.ng);
+  const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L);
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, (int)F);
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, (int)F);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

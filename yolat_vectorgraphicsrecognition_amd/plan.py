@@ -101,8 +101,28 @@ class EvalPlan(object):
         fb, fs = net.fusion_block, net.fusion_block_super
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
+        Dk = fb[0].in_features
+        x6 = (self.precision == "fp32" and os.environ.get("YOLAT_FUSION_X6", "1") != "0" and Dk in (64, 128)
+              and d.F % 64 == 0)
+
+        def split3(lin, fold):
+            # fusion block for the bf16x6-emulated kernel: BatchNorm scale folded into the weight rows, exact 3-way
+            # bfloat16 split of the result, shift = s*b + t
+            s_t, t_t = fold[0], fold[1]
+            parts = [torch.empty(d.F * Dk, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+            check(lib.yolat_split_bf16x3(ptr(lin.weight), Dk, d.F, Dk, s_t.data_ptr(), parts[0].data_ptr(),
+                                         parts[1].data_ptr(), parts[2].data_ptr(), ops._stream()), "yolat_split_bf16x3")
+            bias = lin.bias.detach() if lin.bias is not None else torch.zeros_like(s_t)
+            tfold = (s_t * bias + t_t).contiguous()
+            keep.extend(parts + [tfold])
+            return parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), tfold.data_ptr()
+
+        if x6:
+            d.Wf_hi, d.Wf_mid, d.Wf_lo, d.tf_fold = split3(fb[0], keep[-1])
         d.Wfs, d.bfs = ptr(fs[0].weight), ptr(fs[0].bias)
         d.sfs, d.tfs = folded(fs[1])
+        if x6:
+            d.Wfs_hi, d.Wfs_mid, d.Wfs_lo, d.tfs_fold = split3(fs[0], keep[-1])
         m1, m2, m3 = m.prediction_cls[0], m.prediction_cls[1], m.prediction_cls[2]
         d.H1, d.H2 = m1[0].out_features, m2[0].out_features
         d.Wc1, d.bc1 = ptr(m1[0].weight), ptr(m1[0].bias)
