@@ -455,6 +455,7 @@ typedef struct {
   const float *Wuvf, *uvb, *Wc4f, *t2f;
 } yolat_conv_eval;
 
+#define YOLAT_CLS_X6_MAX_ROWS 2048
 typedef struct {
   int32_t n_blocks, n_blocks_out, n_classes, reserved;
   int64_t C;                                  /* n_filters (64)                                  */
@@ -473,6 +474,11 @@ typedef struct {
   const float *Wc1, *bc1, *sc1, *tc1;         /* prediction_cls.0                                */
   const float *Wc2, *bc2, *sc2, *tc2;         /* prediction_cls.1                                */
   const float *Wc3, *bc3;                     /* prediction_cls.2 (bare Linear)                  */
+  /* nullable (all six or none): the three classifier layers prepared for yolat_linear_x6 — Wc_x6[i] =
+   * yolat_split_bf16x3_packed of (scale (rows) * Wc{i+1}) (scale = 1 for the bare last layer), tc_fold[i] =
+   * scale*b + shift (= b for the last layer).  Used while P <= YOLAT_CLS_X6_MAX_ROWS.                          */
+  const uint16_t *Wc_x6[3];
+  const float *tc_fold[3];
 } yolat_model_eval;
 
 /* workspace (bytes) needed by yolat_forward_eval for a batch of N nodes / E edges / P proposals */
@@ -552,6 +558,19 @@ int yolat_profile_get(int index, char* name, int name_capacity, float* total_ms,
  *                              lo) = split of s (.) W and the folded shift s*b + t;  D in {64, 128}, F % 64 == 0   */
 int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int64_t cols, const float* row_scale, uint16_t* hi,
                        uint16_t* mid, uint16_t* lo, yolat_stream_t stream);
+/* out [M, N] = act(A [M, K] . W^T + shift) with W given as its exact 3-way bfloat16 split, packed in MFMA operand
+ * order by yolat_split_bf16x3_packed (any row scale already inside): the skinny, long-K classifier layers as a
+ * bf16x6-emulated fp32 GEMM (fp32 accumulate, ~3e-7 relative to the fp32 product; deterministic).  shift NULL: none;
+ * relu != 0: ReLU.  K % 16 == 0, lda % 4 == 0, A and Wp 16-byte aligned.  Replaces nn.Linear + BatchNorm1d(eval) +
+ * ReLU of prediction_cls (architecture3cc_rpn_gp_iter2.py:91-93,127-128) for a few hundred rows.               */
+size_t yolat_split_bf16x3_packed_elems(int64_t N, int64_t K);
+int yolat_split_bf16x3_packed(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale,
+                              uint16_t* packed, yolat_stream_t stream);
+int yolat_linear_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
+                    int64_t N, float* out, int64_t ldo, yolat_stream_t stream);
+/* the same with A given pre-split: Ap = yolat_split_bf16x3_packed(A, lda, M, K, NULL) — for long K                */
+int yolat_linear_x6_pre(const uint16_t* Ap, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
+                        int64_t N, float* out, int64_t ldo, yolat_stream_t stream);
 int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
                               const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,
                               int64_t ldpool, const float* S, int64_t lds, int64_t P, const uint16_t* Wsh,

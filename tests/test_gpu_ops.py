@@ -962,3 +962,49 @@ def test_fusion_x6_matches_fp32_fusion_kernel(N, P, D):
     Zc = torch.zeros(P, ZW).cuda()
     x6(Zc)
     assert torch.equal(Zb, Zc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,relu", [(400, 2304, 512, 1), (400, 512, 256, 1), (400, 256, 10, 0), (1, 64, 33, 0),
+                                         (8000, 2304, 512, 1), (37, 48, 70, 1)])
+def test_linear_x6_matches_fp64(M, K, N, relu):
+    """yolat_linear_x6 (bf16x6-emulated skinny Linear with folded BatchNorm + ReLU) against the fp64 product of the
+    same operands: fp32-class accuracy (5e-6 of the output scale; the fp32 MFMA kernel sits at ~1e-6), deterministic,
+    and edge sizes (one row, N not a multiple of 32, K = 48)."""
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=gen).cuda()
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    s = (torch.rand(N, generator=gen) + 0.5).cuda()
+    shift = torch.randn(N, generator=gen).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    packed = torch.empty(lib.yolat_split_bf16x3_packed_elems(N, K), dtype=torch.bfloat16, device="cuda")
+    check(lib.yolat_split_bf16x3_packed(W.data_ptr(), K, N, K, s.data_ptr(), packed.data_ptr(), st))
+    # the split is exact and the packing is the documented one: [ct][ks][part][lane][8]
+    pk = packed.view((N + 31) // 32, K // 16, 3, 2, 32, 8).double().sum(2)       # [ct, ks, lhi, j, e]
+    rec = pk.permute(0, 3, 1, 2, 4).reshape(-1, K)[:N]                           # [ct*32 + j, ks*16 + lhi*8 + e]
+    assert torch.equal(rec, (s[:, None] * W).double())
+    out = torch.full((M, N + 3), -7.0, device="cuda")
+
+    def run(o, k=K):
+        return lib.yolat_linear_x6(A.data_ptr(), K, M, k, packed.data_ptr(), shift.data_ptr(), relu, N, o.data_ptr(),
+                                   N + 3, st)
+    check(run(out))
+    ref = A.double() @ (s[:, None] * W).double().t() + shift.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = float(ref.abs().max())
+    assert float((out[:, :N].double() - ref).abs().max()) <= 5e-6 * scale
+    assert torch.all(out[:, N:] == -7.0)                                   # nothing written past N
+    out2 = torch.full((M, N + 3), -7.0, device="cuda")
+    check(run(out2))
+    assert torch.equal(out, out2)
+    assert run(out, K - 1) != 0                                            # contract: K % 16 == 0
+    # A pre-split and packed (the long-K path): same accuracy class, deterministic
+    apk = torch.empty(lib.yolat_split_bf16x3_packed_elems(M, K), dtype=torch.bfloat16, device="cuda")
+    check(lib.yolat_split_bf16x3_packed(A.data_ptr(), K, M, K, None, apk.data_ptr(), st))
+    out3 = torch.full((M, N + 3), -7.0, device="cuda")
+    check(lib.yolat_linear_x6_pre(apk.data_ptr(), M, K, packed.data_ptr(), shift.data_ptr(), relu, N, out3.data_ptr(),
+                                  N + 3, st))
+    assert float((out3[:, :N].double() - ref).abs().max()) <= 5e-6 * scale
+    assert torch.all(out3[:, N:] == -7.0)

@@ -32,7 +32,9 @@ class ModelEval(ctypes.Structure):
                  ("reserved", ctypes.c_int32), ("C", c_i64), ("F", c_i64), ("H1", c_i64), ("H2", c_i64),
                  ("conv", ConvEval * YOLAT_MAX_LAYERS)] +
                 [(n, c_p) for n in ("Wf", "bf", "sf", "tf", "Wf_hi", "Wf_mid", "Wf_lo", "tf_fold", "Wfs_hi", "Wfs_mid",
-                                    "Wfs_lo", "tfs_fold", "Wfs", "bfs", "sfs", "tfs", "Wc1", "bc1", "sc1", "tc1", "Wc2", "bc2", "sc2", "tc2", "Wc3", "bc3")])
+                                    "Wfs_lo", "tfs_fold", "Wfs", "bfs", "sfs", "tfs", "Wc1", "bc1", "sc1", "tc1", "Wc2",
+                                    "bc2", "sc2", "tc2", "Wc3", "bc3")] +
+                [("Wc_x6", c_p * 3), ("tc_fold", c_p * 3)])
 
 
 class ModelEvalBf16(ctypes.Structure):
@@ -145,6 +147,10 @@ SIGNATURES = {
     "yolat_split_bf16x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "yolat_fusion_pair_eval_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p,
                                           c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "yolat_split_bf16x3_packed_elems": (c_sz, [c_i64, c_i64]),
+    "yolat_split_bf16x3_packed": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "yolat_linear_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p]),
+    "yolat_linear_x6_pre": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p]),
     "yolat_dropout_fwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_f, ctypes.c_uint64, c_p, c_p, c_i64, c_p]),
     "yolat_dropout_bwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_f, c_p, c_i64, c_p]),
     "yolat_proposals_build": (c_int, [c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_i64, ctypes.c_double, c_p]),

@@ -19,6 +19,7 @@ struct Plan {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
   float* H1; float* H2; float* UV; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
   float* feats; float* fsup; float* Z; float* c1; float* c2;
+  uint16_t* Zs;                                        // Z pre-split for the skinny bf16x6 classifier (few proposals)
   size_t bytes;
 };
 
@@ -37,6 +38,8 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   }
   p.feats = c.take<float>(N * D); p.fsup = c.take<float>(N * D);
   p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
+  p.Zs = (P <= YOLAT_CLS_X6_MAX_ROWS && m->Wc_x6[0] && (2 * (F + D)) % 16 == 0)
+             ? c.take<uint16_t>((long)yolat_split_bf16x3_packed_elems(P, 2 * (F + D))) : nullptr;
   p.bytes = c.off + 256;
   return p;
 }
@@ -118,6 +121,14 @@ extern "C" int yolat_profile_get(int index, char* name, int cap, float* total_ms
   if (flops) *flops = s.flops;
   if (bytes) *bytes = s.bytes;
   return 0;
+}
+
+// cls1 on the skinny bf16x6 kernel: K = 2304 is long enough that splitting Z once (a small launch) beats splitting it
+// on the fly in each of the H1/32 column tiles
+static int cls1_x6(const float* Z, long ZW, long P, uint16_t* Zs, const uint16_t* Wp, const float* shift, long H1,
+                   float* c1, yolat_stream_t stream) {
+  YL_TRY(yolat_split_bf16x3_packed(Z, ZW, P, ZW, nullptr, Zs, stream));
+  return yolat_linear_x6_pre(Zs, P, ZW, Wp, shift, 1, H1, c1, H1, stream);
 }
 
 extern "C" size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, int64_t N, int64_t E,
@@ -264,17 +275,24 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
                      : yolat_fusion_pair_eval(p.feats, D, N, D, m->Wf, m->bf, m->sf, m->tf, F, p.node_seg, p.Z, ZW, sup,
                                               ZW, P, m->Wfs, m->bfs, m->sfs, m->tfs, p.Z + F + D, ZW, stream));
   // ---- classifier (arch:91-93,127-128)
+  // few proposals: the skinny bf16x6 kernel (one workgroup per 32 x 32 outputs, weights re-read per 32 rows)
+  bool cls_x6 = p.Zs != nullptr && m->H1 % 16 == 0 && m->H2 % 16 == 0;
+  for (int i = 0; i < 3; ++i) cls_x6 = cls_x6 && m->Wc_x6[i] != nullptr && m->tc_fold[i] != nullptr;
   snprintf(nm, sizeof nm, "cls1[P x %ld -> %ld]", ZW, (long)m->H1);
   YL_STAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + ZW * m->H1 + P * m->H1),
-           yolat_linear_fwd(p.Z, ZW, P, ZW, nullptr, nullptr, 0, m->Wc1, ZW, m->bc1, m->H1, m->sc1, m->tc1, 1,
-                            p.c1, m->H1, 0, nullptr, stream));
+           cls_x6 ? cls1_x6(p.Z, ZW, P, p.Zs, m->Wc_x6[0], m->tc_fold[0], m->H1, p.c1, stream)
+                  : yolat_linear_fwd(p.Z, ZW, P, ZW, nullptr, nullptr, 0, m->Wc1, ZW, m->bc1, m->H1, m->sc1, m->tc1, 1,
+                                     p.c1, m->H1, 0, nullptr, stream));
   snprintf(nm, sizeof nm, "cls2[P x %ld -> %ld]", (long)m->H1, (long)m->H2);
   YL_STAGE(nm, 2.0 * P * m->H1 * m->H2, 4.0 * (P * m->H1 + m->H1 * m->H2 + P * m->H2),
-           yolat_linear_fwd(p.c1, m->H1, P, m->H1, nullptr, nullptr, 0, m->Wc2, m->H1, m->bc2, m->H2, m->sc2,
-                            m->tc2, 1, p.c2, m->H2, 0, nullptr, stream));
+           cls_x6 ? yolat_linear_x6(p.c1, m->H1, P, m->H1, m->Wc_x6[1], m->tc_fold[1], 1, m->H2, p.c2, m->H2, stream)
+                  : yolat_linear_fwd(p.c1, m->H1, P, m->H1, nullptr, nullptr, 0, m->Wc2, m->H1, m->bc2, m->H2, m->sc2,
+                                     m->tc2, 1, p.c2, m->H2, 0, nullptr, stream));
   snprintf(nm, sizeof nm, "cls3[P x %ld -> %d]", (long)m->H2, (int)m->n_classes);
   YL_STAGE(nm, 2.0 * P * m->H2 * m->n_classes, 4.0 * (P * m->H2 + m->H2 * m->n_classes + P * m->n_classes),
-           yolat_linear_fwd(p.c2, m->H2, P, m->H2, nullptr, nullptr, 0, m->Wc3, m->H2, m->bc3, m->n_classes,
-                            nullptr, nullptr, 0, logits, ld_logits, 0, nullptr, stream));
+           cls_x6 ? yolat_linear_x6(p.c2, m->H2, P, m->H2, m->Wc_x6[2], m->tc_fold[2], 0, m->n_classes, logits,
+                                    ld_logits, stream)
+                  : yolat_linear_fwd(p.c2, m->H2, P, m->H2, nullptr, nullptr, 0, m->Wc3, m->H2, m->bc3, m->n_classes,
+                                     nullptr, nullptr, 0, logits, ld_logits, 0, nullptr, stream));
   return 0;
 }

@@ -335,3 +335,177 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   YL_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------------------------
+// Skinny Linear (+ folded BatchNorm + ReLU) with long K as a bf16x6-emulated fp32 GEMM — the per-proposal classifier
+// layers (architecture3cc_rpn_gp_iter2.py:91-93,127-128: P x 2304 -> 512 -> 256 -> n_classes).  Few rows, long K:
+// one 512-thread workgroup owns a 32 x 32 output tile and its 8 waves split K (wave w takes the 16-wide k steps w,
+// w+8, ...), everything in registers: the wave's A values are loaded as fp32 and split on the fly (VALU, beside the
+// matrix pipe); the weights are pre-split AND pre-packed in MFMA operand order (yolat_split_bf16x3_packed: one k
+// step of one 32-column tile = 3 x 1 KB, each a fully coalesced wave load); four k steps in flight per wave.
+// Column tiles are dealt to the XCDs (blockIdx % 8), so each XCD's L2 holds only its own eighth of the weights.
+// The partial accumulators are summed through LDS by wave 0 in a fixed order (no atomics: deterministic), which
+// applies shift (+ ReLU) and stores.  vs k_gemm_nt_sk (fp32 MFMA, 64 cycles per 2 k): 6 x 32 cycles per 16 k.
+// ------------------------------------------------------------------------------------------------------------------
+#define FX_SK_WAVES 8
+// APRE: A is given pre-split and packed like the weights (yolat_split_bf16x3_packed of its rows) — no VALU in the loop;
+// otherwise fp32 A [M, lda], split on the fly (36+ VALU per k step: the VALU then bounds the kernel, fine for short K).
+template <bool APRE>
+__global__ void __launch_bounds__(64 * FX_SK_WAVES) k_linear_x6_sk(const void* __restrict__ Av, long lda, int M, int K,
+                                                                   const yl_bf16_t* __restrict__ Wp,
+                                                                   const float* __restrict__ shift, int relu, int N,
+                                                                   float* __restrict__ out, long ldo, int tm, int tn) {
+  constexpr int NW = FX_SK_WAVES, DEPTH = 4;                  // k steps in flight per wave (the loads are latency bound)
+  __shared__ float red[NW - 1][16][64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  // column tile ct = xcd + 8 * (slot / tm), row tile = slot % tm
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int ct = xcd + 8 * (slot / tm), rt = slot % tm;
+  if (ct >= tn) return;
+  const int row0 = rt * 32, col0 = ct * 32;
+  const int nks = K >> 4;
+  const float* ap = APRE ? nullptr : reinterpret_cast<const float*>(Av) + (long)yl_min(row0 + l31, M - 1) * lda + 8 * lhi;
+  const yl_bf16_t* app = APRE ? reinterpret_cast<const yl_bf16_t*>(Av) + (long)rt * nks * (3 * 512) + lane * 8 : nullptr;
+  const yl_bf16_t* wp = Wp + (long)ct * nks * (3 * 512) + lane * 8;
+  // two accumulators: the six products of a k step alternate between them (no MFMA waits on the one before it)
+  f32x16 acc, acc2;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+  struct Stage { float4 a0, a1; fx_bf16x8 a[3]; fx_bf16x8 w[3]; };
+  // unconditional, clamped loads (a wave past its last k step re-reads that step; its products are zeroed): the
+  // number of loads in flight is static
+  auto load = [&](int ks, Stage& s) {
+    const int kc = yl_min(ks, nks - 1);
+    if (APRE) {
+#pragma unroll
+      for (int q = 0; q < 3; ++q) s.a[q] = *reinterpret_cast<const fx_bf16x8*>(app + (long)kc * (3 * 512) + q * 512);
+    } else {
+      s.a0 = *reinterpret_cast<const float4*>(ap + 16 * kc);
+      s.a1 = *reinterpret_cast<const float4*>(ap + 16 * kc + 4);
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q) s.w[q] = *reinterpret_cast<const fx_bf16x8*>(wp + (long)kc * (3 * 512) + q * 512);
+  };
+  // branch-free: a step past the end contributes zeros (a branch here would make the compiler's vmcnt bookkeeping
+  // give up and wait for ALL loads at the loop top)
+  auto compute = [&](const Stage& s, bool valid) {
+    fx_bf16x8 ah, am, al;
+    if (APRE) {
+      fx_u32x4 z = {0u, 0u, 0u, 0u};
+      const fx_bf16x8 zero = *reinterpret_cast<fx_bf16x8*>(&z);
+      ah = valid ? s.a[0] : zero; am = valid ? s.a[1] : zero; al = valid ? s.a[2] : zero;
+    } else {
+      const float g = valid ? 1.f : 0.f;
+      const float x[8] = {s.a0.x * g, s.a0.y * g, s.a0.z * g, s.a0.w * g, s.a1.x * g, s.a1.y * g, s.a1.z * g, s.a1.w * g};
+      fx_split8(x, ah, am, al);
+    }
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, s.w[0], acc, 0, 0, 0);      // small terms first
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, s.w[2], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, s.w[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am, s.w[0], acc2, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, s.w[1], acc, 0, 0, 0);
+    acc2 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, s.w[0], acc2, 0, 0, 0);
+  };
+  Stage st[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(wave + NW * d, st[d]);
+  for (int ks = wave; ks < nks; ks += NW * DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      compute(st[d], ks + NW * d < nks);
+      __builtin_amdgcn_sched_barrier(0);               // keep the refill HERE (the scheduler would sink it to its use)
+      load(ks + NW * (d + DEPTH), st[d]);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave - 1][r][lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+    const int col = col0 + l31;
+    const float sh = (shift && col < N) ? shift[col] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      float v = acc[r];
+#pragma unroll
+      for (int w = 0; w < NW - 1; ++w) v += red[w][r][lane];               // fixed order
+      v += sh;
+      if (relu) v = fmaxf(v, 0.f);
+      const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row < M && col < N) out[(long)row * ldo + col] = v;
+    }
+  }
+}
+
+// W [rows = N, cols = K] fp32 (optionally scaled per row) -> its exact 3-way bfloat16 split in the operand order of
+// k_linear_x6_sk: packed[ct][ks][part][lane][8] with ct = n / 32, ks = k / 16, lane = n % 32 + 32 * ((k % 16) / 8),
+// element k % 8; rows beyond N are zero.  One thread per 8 consecutive k.
+static __global__ void k_split_bf16x3_packed(const float* __restrict__ W, long ldw, int N, int K,
+                                             const float* __restrict__ row_scale, yl_bf16_t* __restrict__ packed) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;         // (ct, ks, lane)
+  const int nks = K >> 4, tn = (N + 31) >> 5;
+  if (i >= (long)tn * nks * 64) return;
+  const int lane = (int)(i & 63), ks = (int)((i >> 6) % nks), ct = (int)((i >> 6) / nks);
+  const int n = ct * 32 + (lane & 31), k0 = ks * 16 + 8 * (lane >> 5);
+  float x[8];
+#pragma unroll
+  for (int e = 0; e < 8; ++e) x[e] = n < N ? W[(long)n * ldw + k0 + e] * (row_scale ? row_scale[n] : 1.f) : 0.f;
+  fx_bf16x8 h, m, l;
+  fx_split8(x, h, m, l);
+  yl_bf16_t* o = packed + (((long)ct * nks + ks) * 3) * 512 + lane * 8;
+  *reinterpret_cast<fx_bf16x8*>(o) = h;
+  *reinterpret_cast<fx_bf16x8*>(o + 512) = m;
+  *reinterpret_cast<fx_bf16x8*>(o + 1024) = l;
+}
+
+extern "C" size_t yolat_split_bf16x3_packed_elems(int64_t N, int64_t K) {
+  return (N <= 0 || K <= 0) ? 0 : (size_t)yl_cdiv(N, 32) * (size_t)(K / 16) * 3 * 512;
+}
+// packed: yolat_split_bf16x3_packed_elems(N, K) bfloat16 values, 16-byte aligned.  K % 16 == 0.
+extern "C" int yolat_split_bf16x3_packed(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale,
+                                         uint16_t* packed, yolat_stream_t stream) {
+  if (N <= 0 || K <= 0 || !W || !packed || ldw < K || N >= (1LL << 31) - 32 || K >= (1LL << 31)) return YOLAT_E_INVALID;
+  if (K % 16 != 0 || !yl_aligned16(packed)) return YOLAT_E_UNSUPPORTED;
+  const long items = (long)yl_cdiv(N, 32) * (K / 16) * 64;
+  hipLaunchKernelGGL(k_split_bf16x3_packed, dim3((unsigned)yl_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, W,
+                     (long)ldw, (int)N, (int)K, row_scale, reinterpret_cast<yl_bf16_t*>(packed));
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// out [M, N] = act(A [M, K] . (s (.) W)^T + shift),  W given pre-split and packed (yolat_split_bf16x3_packed of the
+// scaled rows), shift = s*b + t folded (NULL: none), act = ReLU when relu != 0.  K % 16 == 0, lda % 4 == 0, A and Wp
+// 16-byte aligned.  Meant for few rows (the launch has cdiv(M,32) * cdiv(N,32) workgroups and re-reads the weights
+// once per 32 rows).  yolat_linear_x6_pre: A given as yolat_split_bf16x3_packed(A, lda, M, K, NULL) — the choice for
+// long K (on-the-fly splitting of A costs more VALU time than the products cost matrix-pipe time).
+static int linear_x6_launch(const void* A, bool pre, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp,
+                            const float* shift, int relu, int64_t N, float* out, int64_t ldo, yolat_stream_t stream) {
+  if (M <= 0 || N <= 0 || K <= 0 || !A || !Wp || !out) return YOLAT_E_INVALID;
+  if ((!pre && lda < K) || ldo < N || M >= (1LL << 31) - 32 || N >= (1LL << 31) - 64) return YOLAT_E_INVALID;
+  if (K % 16 != 0 || (!pre && lda % 4 != 0) || !yl_aligned16(A) || !yl_aligned16(Wp)) return YOLAT_E_UNSUPPORTED;
+  const long tm = yl_cdiv(M, 32), tn = yl_cdiv(N, 32);
+  const long total = 8 * yl_cdiv(tn, 8) * tm;
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  const dim3 grid((unsigned)total), block(64 * FX_SK_WAVES);
+  const yl_bf16_t* wp = reinterpret_cast<const yl_bf16_t*>(Wp);
+  if (pre)
+    hipLaunchKernelGGL(k_linear_x6_sk<true>, grid, block, 0, (hipStream_t)stream, A, (long)lda, (int)M, (int)K, wp, shift,
+                       relu, (int)N, out, (long)ldo, (int)tm, (int)tn);
+  else
+    hipLaunchKernelGGL(k_linear_x6_sk<false>, grid, block, 0, (hipStream_t)stream, A, (long)lda, (int)M, (int)K, wp, shift,
+                       relu, (int)N, out, (long)ldo, (int)tm, (int)tn);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+extern "C" int yolat_linear_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift,
+                               int relu, int64_t N, float* out, int64_t ldo, yolat_stream_t stream) {
+  return linear_x6_launch(A, false, lda, M, K, Wp, shift, relu, N, out, ldo, stream);
+}
+extern "C" int yolat_linear_x6_pre(const uint16_t* Ap, int64_t M, int64_t K, const uint16_t* Wp, const float* shift,
+                                   int relu, int64_t N, float* out, int64_t ldo, yolat_stream_t stream) {
+  return linear_x6_launch(Ap, true, K, M, K, Wp, shift, relu, N, out, ldo, stream);
+}

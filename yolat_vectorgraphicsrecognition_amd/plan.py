@@ -106,14 +106,15 @@ class EvalPlan(object):
               and d.F % 64 == 0)
 
         def split3(lin, fold):
-            # fusion block for the bf16x6-emulated kernel: BatchNorm scale folded into the weight rows, exact 3-way
-            # bfloat16 split of the result, shift = s*b + t
-            s_t, t_t = fold[0], fold[1]
-            parts = [torch.empty(d.F * Dk, dtype=torch.bfloat16, device=dev) for _ in range(3)]
-            check(lib.yolat_split_bf16x3(ptr(lin.weight), Dk, d.F, Dk, s_t.data_ptr(), parts[0].data_ptr(),
-                                         parts[1].data_ptr(), parts[2].data_ptr(), ops._stream()), "yolat_split_bf16x3")
-            bias = lin.bias.detach() if lin.bias is not None else torch.zeros_like(s_t)
-            tfold = (s_t * bias + t_t).contiguous()
+            # Linear (+ BatchNorm) for a bf16x6-emulated kernel: BatchNorm scale folded into the weight rows, exact
+            # 3-way bfloat16 split of the result, shift = s*b + t (no BatchNorm: fold is None, shift = b)
+            rows, cols = lin.out_features, lin.in_features
+            parts = [torch.empty(rows * cols, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+            check(lib.yolat_split_bf16x3(ptr(lin.weight), cols, rows, cols, fold[0].data_ptr() if fold is not None else None,
+                                         parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), ops._stream()),
+                  "yolat_split_bf16x3")
+            bias = lin.bias.detach() if lin.bias is not None else torch.zeros(rows, device=dev)
+            tfold = (fold[0] * bias + fold[1]).contiguous() if fold is not None else bias.float().contiguous()
             keep.extend(parts + [tfold])
             return parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(), tfold.data_ptr()
 
@@ -127,9 +128,27 @@ class EvalPlan(object):
         d.H1, d.H2 = m1[0].out_features, m2[0].out_features
         d.Wc1, d.bc1 = ptr(m1[0].weight), ptr(m1[0].bias)
         d.sc1, d.tc1 = folded(m1[1])
+        c1fold = keep[-1]
         d.Wc2, d.bc2 = ptr(m2[0].weight), ptr(m2[0].bias)
         d.sc2, d.tc2 = folded(m2[1])
+        c2fold = keep[-1]
         d.Wc3, d.bc3 = ptr(m3[0].weight), ptr(m3[0].bias)
+        # classifier layers for the skinny bf16x6 kernel (yolat_linear_x6): all three or none.  Off by default: measured
+        # equal to the fp32 split-K kernel at P = 400 (20.8 vs 21.2 us for cls1; operands streamed from L2 straight
+        # into registers make it L1-bandwidth bound, profiles/r02_linear_x6_skinny.txt) and slower beyond.
+        if (self.precision == "fp32" and os.environ.get("YOLAT_CLS_X6", "0") == "1"
+                and all(l[0].in_features % 16 == 0 for l in (m1, m2, m3))):
+            for i, (l, fold) in enumerate(((m1, c1fold), (m2, c2fold), (m3, None))):
+                lin = l[0]
+                rows, cols = lin.out_features, lin.in_features
+                packed = torch.empty(lib.yolat_split_bf16x3_packed_elems(rows, cols), dtype=torch.bfloat16, device=dev)
+                check(lib.yolat_split_bf16x3_packed(ptr(lin.weight), cols, rows, cols,
+                                                    fold[0].data_ptr() if fold is not None else None,
+                                                    packed.data_ptr(), ops._stream()), "yolat_split_bf16x3_packed")
+                bias = lin.bias.detach() if lin.bias is not None else torch.zeros(rows, device=dev)
+                tfold = (fold[0] * bias + fold[1]).contiguous() if fold is not None else bias.float().contiguous()
+                keep += [packed, tfold]
+                d.Wc_x6[i], d.tc_fold[i] = packed.data_ptr(), tfold.data_ptr()
         self._desc, self._keep = d, keep
         self._desc_h = None
         if self.precision == "bf16":
