@@ -456,6 +456,7 @@ typedef struct {
 } yolat_conv_eval;
 
 #define YOLAT_CLS_X6_MAX_ROWS 2048
+#define YOLAT_CLS1_X6_MIN_ROWS 1024
 typedef struct {
   int32_t n_blocks, n_blocks_out, n_classes, reserved;
   int64_t C;                                  /* n_filters (64)                                  */
@@ -479,6 +480,10 @@ typedef struct {
    * scale*b + shift (= b for the last layer).  Used while P <= YOLAT_CLS_X6_MAX_ROWS.                          */
   const uint16_t *Wc_x6[3];
   const float *tc_fold[3];
+  /* nullable (both or none): prediction_cls.0 prepared for yolat_gemm_x6 — Wc1_gx = yolat_gemm_x6_pack of
+   * (sc1 (rows) * Wc1), tc1_gx = sc1*bc1 + tc1.  Used when P >= YOLAT_CLS1_X6_MIN_ROWS.                          */
+  const uint16_t *Wc1_gx;
+  const float *tc1_gx;
 } yolat_model_eval;
 
 /* workspace (bytes) needed by yolat_forward_eval for a batch of N nodes / E edges / P proposals */
@@ -563,6 +568,18 @@ int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int64_t cols, 
  * bf16x6-emulated fp32 GEMM (fp32 accumulate, ~3e-7 relative to the fp32 product; deterministic).  shift NULL: none;
  * relu != 0: ReLU.  K % 16 == 0, lda % 4 == 0, A and Wp 16-byte aligned.  Replaces nn.Linear + BatchNorm1d(eval) +
  * ReLU of prediction_cls (architecture3cc_rpn_gp_iter2.py:91-93,127-128) for a few hundred rows.               */
+/* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
+ * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).
+ * ~3e-7 relative to the fp32 product, deterministic (few rows: K is split over workgroups and the fp32 partials are
+ * summed in a fixed order; `work`: yolat_gemm_x6_work_elems(M, N, K) floats, NULL allowed when that is 0).
+ * K % 16 == 0, lda % 4 == 0, A / packed 16-byte aligned.  Replaces nn.Linear + BatchNorm1d(eval) + ReLU of
+ * prediction_cls.0 (architecture3cc_rpn_gp_iter2.py:91,127).                                                  */
+size_t yolat_gemm_x6_packed_elems(int64_t N, int64_t K);
+int yolat_gemm_x6_pack(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale, uint16_t* packed,
+                       yolat_stream_t stream);
+size_t yolat_gemm_x6_work_elems(int64_t M, int64_t N, int64_t K);
+int yolat_gemm_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
+                  int64_t N, float* out, int64_t ldo, float* work, yolat_stream_t stream);
 size_t yolat_split_bf16x3_packed_elems(int64_t N, int64_t K);
 int yolat_split_bf16x3_packed(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale,
                               uint16_t* packed, yolat_stream_t stream);

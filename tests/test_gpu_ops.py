@@ -1008,3 +1008,37 @@ def test_linear_x6_matches_fp64(M, K, N, relu):
                                   N + 3, st))
     assert float((out3[:, :N].double() - ref).abs().max()) <= 5e-6 * scale
     assert torch.all(out3[:, N:] == -7.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N,relu", [(400, 2304, 512, 1), (2000, 2304, 512, 1), (8000, 2304, 512, 1), (1, 64, 33, 0),
+                                         (37, 48, 70, 1), (129, 256, 129, 0), (20000, 64, 256, 1)])
+def test_gemm_x6_matches_fp64(M, K, N, relu):
+    """yolat_gemm_x6 (LDS-tiled bf16x6-emulated Linear with folded BatchNorm + ReLU, split-K for few rows) against the
+    fp64 product of the same operands: fp32-class accuracy (5e-6 of the output scale), deterministic, nothing written
+    past N, and the edge sizes (one row, ragged M / N, K = 48, both the split-K and the direct path)."""
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(M + K + N)
+    A = torch.randn(M, K, generator=gen).cuda()
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    s = (torch.rand(N, generator=gen) + 0.5).cuda()
+    shift = torch.randn(N, generator=gen).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+    packed = torch.empty(lib.yolat_gemm_x6_packed_elems(N, K), dtype=torch.bfloat16, device="cuda")
+    check(lib.yolat_gemm_x6_pack(W.data_ptr(), K, N, K, s.data_ptr(), packed.data_ptr(), st))
+    work = torch.empty(max(1, lib.yolat_gemm_x6_work_elems(M, N, K)), device="cuda")
+    ref = A.double() @ (s[:, None] * W).double().t() + shift.double()
+    if relu:
+        ref = ref.clamp_min(0)
+    scale = float(ref.abs().max())
+    outs = []
+    for _ in range(2):
+        out = torch.full((M, N + 3), -7.0, device="cuda")
+        check(lib.yolat_gemm_x6(A.data_ptr(), K, M, K, packed.data_ptr(), shift.data_ptr(), relu, N, out.data_ptr(), N + 3,
+                                work.data_ptr(), st))
+        outs.append(out)
+    assert float((outs[0][:, :N].double() - ref).abs().max()) <= 5e-6 * scale
+    assert torch.all(outs[0][:, N:] == -7.0)
+    assert torch.equal(outs[0], outs[1])
+    assert lib.yolat_gemm_x6(A.data_ptr(), K, M, K - 1, packed.data_ptr(), None, 0, N, outs[0].data_ptr(), N + 3,
+                             work.data_ptr(), st) != 0

@@ -8,12 +8,21 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 template <int CH>
-__global__ void __launch_bounds__(512) k(float* out, long long* cyc, int n) {
+__global__ void __launch_bounds__(512) k(float* out, long long* cyc, int n, int rnd) {
   f32x16 acc[CH];
   for (int c = 0; c < CH; ++c)
     for (int i = 0; i < 16; ++i) acc[c][i] = 0.f;
   bf16x8 a, b;
-  for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 1e-3f); b[i] = (__bf16)1.0f; }
+  if (rnd) {
+    // pseudo-random operands (every lane and element different, full-entropy significands): data-dependent power
+    unsigned h = threadIdx.x * 2654435761u + blockIdx.x * 40503u + 12345u;
+    for (int i = 0; i < 8; ++i) {
+      h = h * 1664525u + 1013904223u; a[i] = (__bf16)(((int)(h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f);
+      h = h * 1664525u + 1013904223u; b[i] = (__bf16)(((int)(h >> 8) & 0xffff) * (1.f / 32768.f) - 1.f);
+    }
+  } else {
+    for (int i = 0; i < 8; ++i) { a[i] = (__bf16)(threadIdx.x * 1e-3f); b[i] = (__bf16)1.0f; }
+  }
   const long long t0 = clock64();
   for (int i = 0; i < n; ++i) {
 #pragma unroll
@@ -31,27 +40,29 @@ __global__ void __launch_bounds__(512) k(float* out, long long* cyc, int n) {
 }
 
 template <int CH>
-void run(float* out, long long* cyc, int threads, int total) {
+void run(float* out, long long* cyc, int threads, int total, int rnd) {
   const int n = total / CH;
   hipEvent_t a, b; hipEventCreate(&a); hipEventCreate(&b);
-  hipLaunchKernelGGL(k<CH>, dim3(256), dim3(threads), 0, 0, out, cyc, n);
+  hipLaunchKernelGGL(k<CH>, dim3(256), dim3(threads), 0, 0, out, cyc, n, rnd);
   hipDeviceSynchronize();
   hipEventRecord(a);
-  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k<CH>, dim3(256), dim3(threads), 0, 0, out, cyc, n);
+  for (int i = 0; i < 5; ++i) hipLaunchKernelGGL(k<CH>, dim3(256), dim3(threads), 0, 0, out, cyc, n, rnd);
   hipEventRecord(b); hipEventSynchronize(b);
   float ms; hipEventElapsedTime(&ms, a, b);
   long long c; hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost);
   const int wps = threads / 256;
   const double ns = ms * 1e6 / 5 / ((double)total * wps);
-  printf("chains %d, waves/SIMD %d: %.2f ns per MFMA per SIMD, %.1f clock64 ticks per MFMA per SIMD (kernel %.1f us)\n", CH, wps, ns,
+  printf("%s operands, chains %d, waves/SIMD %d: %.2f ns per MFMA per SIMD, %.1f clock64 ticks per MFMA per SIMD (kernel %.1f us)\n", rnd ? "random" : "constant", CH, wps, ns,
          (double)c / ((double)total * wps), ms * 1e3 / 5);
 }
 
 int main() {
   float* out; long long* cyc;
   hipMalloc(&out, 4096); hipMalloc(&cyc, 8);
-  const int total = 8192;
-  run<1>(out, cyc, 256, total); run<2>(out, cyc, 256, total); run<4>(out, cyc, 256, total);
-  run<1>(out, cyc, 512, total); run<2>(out, cyc, 512, total); run<4>(out, cyc, 512, total);
+  const int total = 32768;
+  for (int rnd = 0; rnd < 2; ++rnd) {
+    run<1>(out, cyc, 256, total, rnd); run<2>(out, cyc, 256, total, rnd); run<4>(out, cyc, 256, total, rnd);
+    run<1>(out, cyc, 512, total, rnd); run<2>(out, cyc, 512, total, rnd); run<4>(out, cyc, 512, total, rnd);
+  }
   return 0;
 }

@@ -34,7 +34,7 @@ class ModelEval(ctypes.Structure):
                 [(n, c_p) for n in ("Wf", "bf", "sf", "tf", "Wf_hi", "Wf_mid", "Wf_lo", "tf_fold", "Wfs_hi", "Wfs_mid",
                                     "Wfs_lo", "tfs_fold", "Wfs", "bfs", "sfs", "tfs", "Wc1", "bc1", "sc1", "tc1", "Wc2",
                                     "bc2", "sc2", "tc2", "Wc3", "bc3")] +
-                [("Wc_x6", c_p * 3), ("tc_fold", c_p * 3)])
+                [("Wc_x6", c_p * 3), ("tc_fold", c_p * 3), ("Wc1_gx", c_p), ("tc1_gx", c_p)])
 
 
 class ModelEvalBf16(ctypes.Structure):
@@ -147,6 +147,10 @@ SIGNATURES = {
     "yolat_split_bf16x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "yolat_fusion_pair_eval_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p,
                                           c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "yolat_gemm_x6_packed_elems": (c_sz, [c_i64, c_i64]),
+    "yolat_gemm_x6_pack": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
+    "yolat_gemm_x6_work_elems": (c_sz, [c_i64, c_i64, c_i64]),
+    "yolat_gemm_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_split_bf16x3_packed_elems": (c_sz, [c_i64, c_i64]),
     "yolat_split_bf16x3_packed": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "yolat_linear_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p]),

@@ -19,6 +19,7 @@ struct Plan {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
   float* H1; float* H2; float* UV; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
   float* feats; float* fsup; float* Z; float* c1; float* c2;
+  float* gx_work;                                      // split-K partials of cls1 on yolat_gemm_x6 (few proposals)
   uint16_t* Zs;                                        // Z pre-split for the skinny bf16x6 classifier (few proposals)
   size_t bytes;
 };
@@ -38,6 +39,8 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   }
   p.feats = c.take<float>(N * D); p.fsup = c.take<float>(N * D);
   p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
+  const size_t gxw = (m->Wc1_gx && (2 * (F + D)) % 16 == 0) ? yolat_gemm_x6_work_elems(P, m->H1, 2 * (F + D)) : 0;
+  p.gx_work = gxw ? c.take<float>((long)gxw) : nullptr;
   p.Zs = (P <= YOLAT_CLS_X6_MAX_ROWS && m->Wc_x6[0] && (2 * (F + D)) % 16 == 0)
              ? c.take<uint16_t>((long)yolat_split_bf16x3_packed_elems(P, 2 * (F + D))) : nullptr;
   p.bytes = c.off + 256;
@@ -278,9 +281,13 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   // few proposals: the skinny bf16x6 kernel (one workgroup per 32 x 32 outputs, weights re-read per 32 rows)
   bool cls_x6 = p.Zs != nullptr && m->H1 % 16 == 0 && m->H2 % 16 == 0;
   for (int i = 0; i < 3; ++i) cls_x6 = cls_x6 && m->Wc_x6[i] != nullptr && m->tc_fold[i] != nullptr;
+  // the bf16x6 GEMM wins once there are enough 128-row tiles to run without a deep K split (measured: P = 2000
+  // 41 vs 58 us, P = 8000 129 vs 187 us; P = 400: 21 us either way — profiles/r02_gemm_x6_cls1.txt)
+  const bool cls1_gx = m->Wc1_gx && m->tc1_gx && ZW % 16 == 0 && P >= YOLAT_CLS1_X6_MIN_ROWS;
   snprintf(nm, sizeof nm, "cls1[P x %ld -> %ld]", ZW, (long)m->H1);
   YL_STAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + ZW * m->H1 + P * m->H1),
-           cls_x6 ? cls1_x6(p.Z, ZW, P, p.Zs, m->Wc_x6[0], m->tc_fold[0], m->H1, p.c1, stream)
+           cls1_gx ? yolat_gemm_x6(p.Z, ZW, P, ZW, m->Wc1_gx, m->tc1_gx, 1, m->H1, p.c1, m->H1, p.gx_work, stream)
+           : cls_x6 ? cls1_x6(p.Z, ZW, P, p.Zs, m->Wc_x6[0], m->tc_fold[0], m->H1, p.c1, stream)
                   : yolat_linear_fwd(p.Z, ZW, P, ZW, nullptr, nullptr, 0, m->Wc1, ZW, m->bc1, m->H1, m->sc1, m->tc1, 1,
                                      p.c1, m->H1, 0, nullptr, stream));
   snprintf(nm, sizeof nm, "cls2[P x %ld -> %ld]", (long)m->H1, (long)m->H2);

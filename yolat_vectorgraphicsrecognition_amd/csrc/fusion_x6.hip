@@ -17,32 +17,9 @@
 // tiles: at N = 200 k, 0.65 GB instead of 2.6 GB).  Pooling epilogue: the run-length integer atomicMax of
 // bf16_eval.hip's rows kernel (values >= 0: int order == float order, exact, order-independent).
 // fusion_block_super (P rows, its own weights, plain relu store) is a second problem of the same launch.
-#include "common.hpp"
-
-typedef __bf16 fx_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned fx_u32x4 __attribute__((ext_vector_type(4)));
+#include "x6.hpp"
 
 namespace {
-// exact 3-way bfloat16 split of 8 fp32 values (h = top 8 significand bits, hm = top 16: m = hm - h and l = x - hm are
-// exact and need 8 bits each)
-__device__ __forceinline__ void fx_split8(const float x[8], fx_bf16x8& h, fx_bf16x8& m, fx_bf16x8& l) {
-  fx_u32x4 ph, pm, pl;
-#pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    const unsigned x0 = __float_as_uint(x[2 * i]), x1 = __float_as_uint(x[2 * i + 1]);
-    const yl_f32x2 xv = {x[2 * i], x[2 * i + 1]};
-    const yl_f32x2 hv = {__uint_as_float(x0 & 0xffff0000u), __uint_as_float(x1 & 0xffff0000u)};
-    const yl_f32x2 hmv = {__uint_as_float(x0 & 0xffffff00u), __uint_as_float(x1 & 0xffffff00u)};
-    const yl_f32x2 mv = hmv - hv, lv = xv - hmv;
-    ph[i] = __builtin_amdgcn_perm(x1, x0, 0x07060302u);
-    pm[i] = __builtin_amdgcn_perm(__float_as_uint(mv.y), __float_as_uint(mv.x), 0x07060302u);
-    pl[i] = __builtin_amdgcn_perm(__float_as_uint(lv.y), __float_as_uint(lv.x), 0x07060302u);
-  }
-  h = *reinterpret_cast<fx_bf16x8*>(&ph);
-  m = *reinterpret_cast<fx_bf16x8*>(&pm);
-  l = *reinterpret_cast<fx_bf16x8*>(&pl);
-}
-
 // Run structure of a lane's 16 rows (C/D layout of a 32x32 MFMA tile) from their proposal ids — the same for every
 // column tile: keep[r] = 1 when row r continues the run of row r-1, flush bit r = a run ends at row r (uflush: in
 // some lane of the wave).  The proposal id of a flushed row is re-read from LDS (segs: the wave's 32 ids) — rare,

@@ -133,6 +133,17 @@ class EvalPlan(object):
         d.sc2, d.tc2 = folded(m2[1])
         c2fold = keep[-1]
         d.Wc3, d.bc3 = ptr(m3[0].weight), ptr(m3[0].bias)
+        # prediction_cls.0 (P x 2304 -> 512) on the LDS-tiled bf16x6 GEMM (yolat_gemm_x6)
+        if (self.precision == "fp32" and os.environ.get("YOLAT_CLS1_X6", "1") != "0" and m1[0].in_features % 16 == 0):
+            lin = m1[0]
+            rows, cols = lin.out_features, lin.in_features
+            packed = torch.empty(lib.yolat_gemm_x6_packed_elems(rows, cols), dtype=torch.bfloat16, device=dev)
+            check(lib.yolat_gemm_x6_pack(ptr(lin.weight), cols, rows, cols, c1fold[0].data_ptr(), packed.data_ptr(),
+                                         ops._stream()), "yolat_gemm_x6_pack")
+            bias = lin.bias.detach() if lin.bias is not None else torch.zeros(rows, device=dev)
+            tfold = (c1fold[0] * bias + c1fold[1]).contiguous()
+            keep += [packed, tfold]
+            d.Wc1_gx, d.tc1_gx = packed.data_ptr(), tfold.data_ptr()
         # classifier layers for the skinny bf16x6 kernel (yolat_linear_x6): all three or none.  Off by default: measured
         # equal to the fp32 split-K kernel at P = 400 (20.8 vs 21.2 us for cls1; operands streamed from L2 straight
         # into registers make it L1-bandwidth bound, profiles/r02_linear_x6_skinny.txt) and slower beyond.
