@@ -213,6 +213,37 @@ def _roofline_entry(summary):
             "frac": ach / PEAK_HBM_GBS, "traffic": None, "avg_launch_us": rec["ms_avg"] * 1e3}
 
 
+PEAK_MFMA_BF16_RANDOM_TFLOPS = 1870.0   # measured: v_mfma_f32_32x32x16_bf16 every 17.5 ns per SIMD on full-entropy
+                                        # operands, all 256 CUs busy (tools/exp/mfma_rate.hip; 13.6 ns on constants)
+
+
+def fusion_stage_roofline(summary, cfg, precision):
+    """The fusion stage of the eval plan (fusion_block + per-proposal max | fusion_block_super, one launch): the stage
+    that led the cfg-2 profile until round 2.  `frac` prices the ALGORITHMIC fp32 flops (2 (N+P) D F) against the
+    fp32-input MFMA peak, as SURVEY 8(d) prescribes for the reference's op; on the default fp32 path the kernel executes
+    them as six bf16 MFMA products per k (`executed`: 6x the flops against the dense bf16 peak and against the measured
+    random-operand issue rate)."""
+    label = next((k for k in summary if k.startswith("fusion_gemm+segmax")), None)
+    if label is None:
+        return None
+    rec = summary[label]
+    t = rec["ms_avg"] * 1e-3
+    ach = rec["flops"] / t / 1e12
+    out = {"kernel": label, "bound": "mfma", "achieved": ach, "peak": PEAK_MFMA_F32_TFLOPS, "unit": "TFLOP/s",
+           "frac": ach / PEAK_MFMA_F32_TFLOPS, "avg_launch_us": rec["ms_avg"] * 1e3,
+           "algorithmic_flops": rec["flops"], "algorithmic_bytes": rec["bytes"]}
+    out["traffic"], out["traffic_source"] = pmc_traffic(label, cfg)
+    if precision == "fp32" and os.environ.get("YOLAT_FUSION_X6", "1") != "0":
+        x = 6.0 * rec["flops"]
+        out["executed"] = {"bf16_mfma_flops": x, "bf16_TFLOPs": x / t / 1e12,
+                           "frac_of_dense_bf16_peak": x / t / 1e12 / PEAK_MFMA_BF16_TFLOPS,
+                           "frac_of_measured_random_operand_rate": x / t / 1e12 / PEAK_MFMA_BF16_RANDOM_TFLOPS,
+                           "note": "fp32 GEMM emulated with six exact-split bf16 products per k, fp32 accumulate "
+                                   "(fusion_x6.hip); frac above 1 against the fp32-MFMA peak would be credit for the "
+                                   "emulation, not pipe utilisation"}
+    return out
+
+
 def aggregation_roofline(cfg_name="5", C=64, reps=20):
     """HBM roofline of the sparse aggregation kernel (csr_mean: per-node mean over the CSR edge range,
     torch_vertex.py:333-335 'mean' aggr) on a cfg-5-sized graph, where the E x C message matrix (307 MB)
@@ -614,10 +645,12 @@ def main():
                         "DESIGN.md; traffic: from the committed separate --pmc passes (null when none exists for "
                         "this workload)")
 
-    agg = edge_roof = None
+    agg = edge_roof = fusion_roof = None
     if rank == 0 and not args.no_roofline:
         agg = aggregation_roofline()
         edge_roof = edge_layer_roofline()
+        if op_table is not None and args.mode == "fwd":
+            fusion_roof = fusion_stage_roofline(op_table, str(cfg), args.precision)
 
     cpu = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:      # reported at N=1 only
@@ -668,6 +701,7 @@ def main():
             "roofline": roof,
             "roofline_aggregation": agg,
             "roofline_edge_layer": edge_roof,
+            "roofline_fusion": fusion_roof,
             "cpu_baseline": cpu,
         }
         if op_table is not None:

@@ -1,6 +1,6 @@
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
-for args in "400 2304 512" "2000 2304 512" "8000 2304 512" "400 512 256"; do
+for args in "200000 64 192" "200000 64 64" "200000 64 256" "43520 64 192"; do
 n=linx6
 rm -rf $R/gpurun_out/$n
 timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$n --output-format rocpd -- python $R/tools/exp/linear_x6_bench.py $args > $R/gpurun_out/$n.log 2>&1

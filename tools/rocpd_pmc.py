@@ -9,7 +9,7 @@ c = sqlite3.connect(sys.argv[1])
 grid = {r[0]: (r[1], r[2]) for r in c.execute("select dispatch_id, grid_x, grid_y from kernels")}
 agg = {}
 for name, did, cn, v in c.execute("select name, dispatch_id, counter_name, counter_value from pmc_events"):
-    name = re.sub(r"\(.*$", "", str(name)).replace("void ", "")[:80]
+    name = re.sub(r"\(.*$", "", str(name).replace("(anonymous namespace)::", "")).replace("void ", "")[:80]
     gx, gy = grid.get(did, (0, 0))
     a = agg.setdefault((name, gx, gy, cn), [0.0, 0])
     a[0] += float(v)

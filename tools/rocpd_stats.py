@@ -6,7 +6,7 @@ import sys
 
 
 def short(name):
-    name = re.sub(r"\(.*$", "", name)
+    name = re.sub(r"\(.*$", "", name.replace("(anonymous namespace)::", ""))
     name = name.replace("void ", "")
     return name[:110]
 
