@@ -347,17 +347,29 @@ __global__ void __launch_bounds__(1024) k_bn_merge_l1(const float2* stats, long 
   }
 }
 
-__global__ void k_bn_finalize_l2(const double* l1, int G, int C, const float* gamma,
-                                 const float* beta, float* running_mean, float* running_var,
-                                 float momentum, float eps, float* save_mean, float* save_invstd,
-                                 float* scale, float* shift) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// 64 columns x 16 partitions per workgroup: partition p merges a contiguous range of the level-1 triples in order,
+// partition 0 then merges the 16 partials in order (a single thread per column walked up to 128 triples, two fp64
+// divisions each: 35 us of pure latency per BatchNorm at E = 1.2 M)
+__global__ void __launch_bounds__(1024) k_bn_finalize_l2(const double* l1, int G, int C, const float* gamma,
+                                                         const float* beta, float* running_mean, float* running_var,
+                                                         float momentum, float eps, float* save_mean,
+                                                         float* save_invstd, float* scale, float* shift) {
+  __shared__ double s_n[16][64], s_mean[16][64], s_m2[16][64];
+  const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const int per = (G + 15) / 16;
+  const int g0 = part * per, g1 = yl_min(G, g0 + per);
   Chan a; a.n = 0.0; a.mean = 0.0; a.m2 = 0.0;
-  for (int g = 0; g < G; ++g) {
-    const double* o = l1 + ((long)g * C + c) * 3;
-    chan_merge(a, o[0], o[1], o[2]);
+  if (c < C) {
+    for (int g = g0; g < g1; ++g) {
+      const double* o = l1 + ((long)g * C + c) * 3;
+      chan_merge(a, o[0], o[1], o[2]);
+    }
   }
+  s_n[part][cl] = a.n; s_mean[part][cl] = a.mean; s_m2[part][cl] = a.m2;
+  __syncthreads();
+  if (part != 0 || c >= C) return;
+  for (int p = 1; p < 16; ++p) chan_merge(a, s_n[p][cl], s_mean[p][cl], s_m2[p][cl]);
   const double var_b = a.n > 0.0 ? a.m2 / a.n : 0.0;                 // biased: used to normalise
   const double var_u = a.n > 1.0 ? a.m2 / (a.n - 1.0) : var_b;       // unbiased: running update
   const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
@@ -405,7 +417,7 @@ extern "C" int yolat_bn_finalize(const float* stats, int64_t M, int64_t C, const
   hipLaunchKernelGGL(k_bn_merge_l1, dim3(yl_cdiv(C, 64), (unsigned)G), dim3(1024), 0, st,
                      reinterpret_cast<const float2*>(stats), (long)M, (int)C, nb, per, l1);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_finalize_l2, dim3(yl_cdiv(C, 64)), dim3(64), 0, st, l1, (int)G, (int)C,
+  hipLaunchKernelGGL(k_bn_finalize_l2, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, l1, (int)G, (int)C,
                      gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
                      scale, shift);
   YL_LAUNCH_CHECK();
@@ -569,9 +581,13 @@ __global__ void __launch_bounds__(1024) k_bn_bwd_finalize(const float2* part, lo
   if (b1 > nb) b1 = nb;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (long i = b0; i < b1; ++i) {
-      const float2 t = part[i * C + c];
-      a += (double)t.x; b += (double)t.y;
+    for (long i = b0; i < b1; i += 8) {                    // 8 independent loads per step, summed in order
+      float2 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = part[(i + k < b1 ? i + k : b1 - 1) * C + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i + k < b1) { a += (double)t[k].x; b += (double)t[k].y; }
     }
   s1s[p][cl] = a; s2s[p][cl] = b;
   __syncthreads();
@@ -670,6 +686,15 @@ extern "C" int yolat_bn_relu_bwd(const float* dZ, int64_t lddz, const float* Y, 
   hipLaunchKernelGGL(k_bn_bwd_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, part, nb, (long)M,
                      (int)C, dgamma, dbeta, accumulate, coef);
   YL_LAUNCH_CHECK();
+  if (v4 && lddy % 4 == 0 && yl_aligned16(dY) && yl_aligned16(coef)) {
+    // float4 columns, 4 rows in flight per thread (the one-float-per-lane kernel below ran at ~3 TB/s)
+    int gy = yl_cdiv(M, 64);
+    if (gy > 4096) gy = 4096;
+    hipLaunchKernelGGL(k_bn_bwd_apply_v4<float>, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st, dZ, (long)lddz, Y, (long)ldy,
+                       (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, coef, dY, (long)lddy);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   int gy = yl_cdiv(M, 4);
   if (gy > 2048) gy = 2048;
   hipLaunchKernelGGL(k_bn_bwd_apply, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st, dZ, (long)lddz, Y,
