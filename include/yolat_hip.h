@@ -568,6 +568,30 @@ int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int64_t cols, 
  * bf16x6-emulated fp32 GEMM (fp32 accumulate, ~3e-7 relative to the fp32 product; deterministic).  shift NULL: none;
  * relu != 0: ReLU.  K % 16 == 0, lda % 4 == 0, A and Wp 16-byte aligned.  Replaces nn.Linear + BatchNorm1d(eval) +
  * ReLU of prediction_cls (architecture3cc_rpn_gp_iter2.py:91-93,127-128) for a few hundred rows.               */
+/* Backward of  out[n] += mean_{e in CSR row n} relu(BatchNorm_train(Y[e]))  without materialising the [E, C] gradients
+ * (bn_csr.hip; the aggregation of AttrRelativeEdgeConvGlobalPool2 on top of nn.4 / nn.5, torch_vertex.py:308,324,
+ * 333-335): the gradient w.r.t. Y,  dY[e] = scale * (g - c1 - xhat * c2),  g = relu'(.) * d_out[dst[e]] * inv_deg[dst[e]],
+ * is formed in the loaders of its consumers.  Call order per layer: yolat_bn_csr_bwd_stats (fills coef), then
+ * yolat_linear_bwd_w_csr and yolat_linear_fwd_wt_csr with g->coef pointing at that buffer.                        */
+typedef struct {
+  const float* d_out; int64_t ld_out;   /* [N, C] gradient w.r.t. the aggregated output                        */
+  const int32_t* dst;                   /* [E] destination node of every CSR slot                              */
+  const float* inv_deg;                 /* [N] 1 / max(in-degree, 1)                                           */
+  const float* Y; int64_t ldy;          /* [E, C] BatchNorm input (the second edge Linear's pre-activation)    */
+  const float *mean, *invstd;           /* [C] saved batch statistics                                          */
+  const float *scale, *shift;           /* [C] gamma * invstd, beta - mean * scale                             */
+  const float* coef;                    /* [2C] (c1 | c2) written by yolat_bn_csr_bwd_stats                    */
+  int32_t relu, reserved;
+} yolat_bn_csr_grad;
+size_t yolat_bn_csr_work_elems(int64_t E, int64_t C);
+int yolat_bn_csr_bwd_stats(const yolat_bn_csr_grad* g, int64_t E, int64_t C, float* dgamma, float* dbeta, int accumulate,
+                           float* coef_out, float* work, yolat_stream_t stream);
+int yolat_linear_bwd_w_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, const float* A, int64_t lda, int64_t K,
+                           const float* a_scale, const float* a_shift, int a_relu, float* dW, int64_t lddw, float* db,
+                           int accumulate, float* partial, yolat_stream_t stream);
+int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, const float* W, int64_t ldw, int64_t Nout,
+                            float* dA, int64_t ldda, yolat_stream_t stream);
+
 /* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
  * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).
  * ~3e-7 relative to the fp32 product, deterministic (few rows: K is split over workgroups and the fp32 partials are

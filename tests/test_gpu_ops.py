@@ -911,6 +911,71 @@ def test_factorised_edge_lin1_backward_matches_gathered_gemms(N, E, Cin):
     assert torch.equal(dW_b, dW_c) and torch.equal(db_b, db_c) and torch.equal(dx_b, dx_c)
 
 
+@pytest.mark.parametrize("N,E", [(300, 1000), (50, 31), (2000, 9001), (700, 5000), (4000, 30000), (64, 513)])
+def test_fused_bn_csr_backward_matches_materialised_path(N, E):
+    """ops.BnCsrGrad (bn_csr.hip: the gradient w.r.t. the second edge Linear's output formed inside the loaders of its
+    consumers) against the materialising sequence csr_mean_bwd -> bn_relu_bwd -> linear_bwd_w / linear_fwd_wt, and
+    against float64 autograd of mean-aggregate(relu(batchnorm(Y))) (torch_vertex.py:308,324 + torch_nn.py:58-66)."""
+    yv = _yv()
+    C = 64
+    src, dst, xfull, attr = _edge_case(N, E, 64, 3 * N + E, ldx=64)
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), dev(attr), None, N, 1)
+    tg = torch.Generator().manual_seed(N + 7 * E)
+    d_f = torch.randn(N, C, generator=tg).cuda()
+    H2 = torch.randn(E, C, generator=tg).cuda()
+    H1 = torch.randn(E, C, generator=tg).cuda()
+    W = (torch.randn(C, C, generator=tg) / 8).cuda()
+    c1 = torch.stack([torch.rand(C, generator=tg) + 0.5, torch.randn(C, generator=tg)]).cuda()     # prologue of H1
+    gamma = (torch.rand(C, generator=tg) + 0.5).cuda()
+    beta = torch.randn(C, generator=tg).cuda()
+    mean, var = H2.mean(0), H2.var(0, unbiased=False)
+    invstd = 1 / torch.sqrt(var + 1e-5)
+    scale = gamma * invstd
+    shift = beta - mean * scale
+    coefs = torch.stack([scale, shift, mean, invstd]).contiguous()
+    # materialising path
+    dM = torch.empty(E, C).cuda()
+    yv.ops.csr_mean_bwd(d_f, g, dM)
+    dg_a, db_a = torch.empty(C).cuda(), torch.empty(C).cuda()
+    yv.ops.bn_relu_bwd(dM, H2, gamma, coefs[2], coefs[3], coefs[0], coefs[1], True, dg_a, db_a, dM)
+    dW_a, dbias_a = torch.empty(C, C).cuda(), torch.empty(C).cuda()
+    yv.ops.linear_bwd_w(dM, H1, dW_a, dbias_a, a_pro=(c1[0], c1[1]), a_relu=True)
+    dA_a = torch.empty(E, C).cuda()
+    yv.ops.linear_fwd_wt(dM, W, dA_a)
+
+    def fused():
+        dg, db = torch.empty(C).cuda(), torch.empty(C).cuda()
+        dW, dbias, dA = torch.empty(C, C).cuda(), torch.empty(C).cuda(), torch.empty(E, C).cuda()
+        h = yv.ops.BnCsrGrad(d_f, g, H2, coefs[2], coefs[3], coefs[0], coefs[1], relu=True)
+        h.stats(dg, db)
+        h.bwd_w(H1, dW, dbias, a_pro=(c1[0], c1[1]), a_relu=True)
+        h.fwd_wt(W, dA)
+        return dg, db, dW, dbias, dA
+    got = fused()
+    for name, a, b in zip(("dgamma", "dbeta", "dW", "db", "dA"), (dg_a, db_a, dW_a, dbias_a, dA_a), got):
+        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-6), name
+    again = fused()
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)                                             # deterministic
+    # float64 autograd of the reference formulation (CSR edge order)
+    Y = H2.double().cpu().requires_grad_(True)
+    gam = gamma.double().cpu().requires_grad_(True)
+    bet = beta.double().cpu().requires_grad_(True)
+    d = g.dst.cpu().long()[:E]
+    z = torch.relu(torch.nn.functional.batch_norm(Y, None, None, gam, bet, True, 0.0, 1e-5))
+    deg = torch.bincount(d, minlength=N).clamp_min(1).double()
+    out = torch.zeros(N, C, dtype=torch.float64).index_add_(0, d, z) / deg[:, None]
+    (out * d_f.double().cpu()).sum().backward()
+    dY = Y.grad
+    a1 = torch.relu(H1.double().cpu() * c1[0].double().cpu() + c1[1].double().cpu())
+    want = (gam.grad, bet.grad, dY.t() @ a1, dY.sum(0), dY @ W.double().cpu())
+    for name, b, w in zip(("dgamma", "dbeta", "dW", "db", "dA"), got, want):
+        # db = column sums of dY is exactly 0 in exact arithmetic (BatchNorm's backward): measure it against the column
+        # sums of |dY|
+        ref = float(dY.abs().sum(0).max()) if name == "db" else max(float(w.abs().max()), 1e-6)
+        assert float((b.double().cpu() - w).abs().max()) <= 5e-5 * ref, name
+
+
 @pytest.mark.parametrize("N,P,D", [(700, 30, 128), (10000, 400, 128), (257, 5, 64), (5000, 4999, 128)])
 def test_fusion_x6_matches_fp32_fusion_kernel(N, P, D):
     """yolat_fusion_pair_eval_x6 (fusion GEMM emulated with six bf16 MFMA products on exactly split operands, BatchNorm

@@ -37,6 +37,13 @@ class ModelEval(ctypes.Structure):
                 [("Wc_x6", c_p * 3), ("tc_fold", c_p * 3), ("Wc1_gx", c_p), ("tc1_gx", c_p)])
 
 
+class BnCsrGrad(ctypes.Structure):
+    """yolat_bn_csr_grad (include/yolat_hip.h)"""
+    _fields_ = [("d_out", c_p), ("ld_out", c_i64), ("dst", c_p), ("inv_deg", c_p), ("Y", c_p), ("ldy", c_i64),
+                ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p),
+                ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+
+
 class ModelEvalBf16(ctypes.Structure):
     """yolat_model_eval_bf16 (include/yolat_hip.h)"""
     _fields_ = ([("base", ctypes.POINTER(ModelEval))] +
@@ -147,6 +154,11 @@ SIGNATURES = {
     "yolat_split_bf16x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
     "yolat_fusion_pair_eval_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p,
                                           c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "yolat_bn_csr_work_elems": (c_sz, [c_i64, c_i64]),
+    "yolat_bn_csr_bwd_stats": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_i64, c_p, c_p, c_int, c_p, c_p, c_p]),
+    "yolat_linear_bwd_w_csr": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_int, c_p,
+                                       c_i64, c_p, c_int, c_p, c_p]),
+    "yolat_linear_fwd_wt_csr": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_gemm_x6_packed_elems": (c_sz, [c_i64, c_i64]),
     "yolat_gemm_x6_pack": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "yolat_gemm_x6_work_elems": (c_sz, [c_i64, c_i64, c_i64]),

@@ -1,0 +1,247 @@
+// bn_csr.hip — backward of  out[n] += mean_{e in row n} relu(BN_train(Y[e]))  (the aggregation of
+// AttrRelativeEdgeConvGlobalPool2 on top of nn.4 / nn.5, torch_vertex.py:308,324,333-335 + torch_nn.py:58-66) WITHOUT
+// materialising either [E,C] gradient (round 2, the fp32 training path).
+//
+// The gradient w.r.t. the message of edge e is a broadcast:  dM[e] = d_out[dst[e]] / deg[dst[e]]; the gradient w.r.t.
+// the BatchNorm input is  dY[e] = scale * (g - c1 - xhat * c2)  with  g = relu'(.) dM[e],  xhat = (Y[e] - mean) invstd,
+// (c1, c2) = (sum g, sum g xhat) / E.  round 1 wrote dM, read it twice with Y for the sums and the apply pass, wrote dY
+// and read it in the two consumers (dW = dY^T A, dA = dY W): 11 passes over [E,C] per layer.  Here:
+//   yolat_bn_csr_bwd_stats   one pass over Y (+ the L2-resident rows of d_out): dgamma, dbeta, (c1, c2)
+//   yolat_linear_bwd_w_csr   dW (+)= dY^T . pro(A), db (+)= column sums of dY    — dY formed in the TN GEMM's loader
+//   yolat_linear_fwd_wt_csr  dA = dY . W                                          — dY formed in the NT GEMM's loader
+// = 5 passes.  The arithmetic per element is the one of k_csr_mean_bwd_v4 + k_bn_bwd_partial_v4 + k_bn_bwd_apply_v4
+// (same operations in the same order).
+#include "common.hpp"
+
+// dY rows formed on the fly (loader contract of the GEMM tile kernels, common.hpp)
+struct BnCsrOp {
+  const float* dout; long ldo;           // [N, C]
+  const int* dst; const float* inv_deg;  // [E], [N]
+  const float* Y; long ldy;              // [E, C]
+  const float *mean, *invstd, *scale, *shift, *coef;   // [C] each, coef [2C]
+  int C, relu;
+  int rows, cols, vec;
+
+  __device__ __forceinline__ float one(float g, float w, float y, float mu, float is, float sc, float sh, float k1,
+                                       float k2) const {
+    g = g * w;
+    if (relu && !(fmaf(y, sc, sh) > 0.f)) g = 0.f;
+    return sc * (g - k1 - ((y - mu) * is) * k2);
+  }
+  template <bool FAST>
+  __device__ __forceinline__ void load4(int r, int k, float v[4]) const {
+    const int rr = yl_min(r, rows - 1);
+    const int n = dst[rr];
+    const float w = inv_deg[n];
+    if (FAST) {
+      const float4 g = *reinterpret_cast<const float4*>(dout + (long)n * ldo + k);
+      const float4 y = *reinterpret_cast<const float4*>(Y + (long)rr * ldy + k);
+      const float4 mu = *reinterpret_cast<const float4*>(mean + k), is = *reinterpret_cast<const float4*>(invstd + k);
+      const float4 sc = *reinterpret_cast<const float4*>(scale + k), sh = *reinterpret_cast<const float4*>(shift + k);
+      const float4 k1 = *reinterpret_cast<const float4*>(coef + k), k2 = *reinterpret_cast<const float4*>(coef + C + k);
+      v[0] = one(g.x, w, y.x, mu.x, is.x, sc.x, sh.x, k1.x, k2.x);
+      v[1] = one(g.y, w, y.y, mu.y, is.y, sc.y, sh.y, k1.y, k2.y);
+      v[2] = one(g.z, w, y.z, mu.z, is.z, sc.z, sh.z, k1.z, k2.z);
+      v[3] = one(g.w, w, y.w, mu.w, is.w, sc.w, sh.w, k1.w, k2.w);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int kc = yl_min(k + j, cols - 1);
+        const float t = one(dout[(long)n * ldo + kc], w, Y[(long)rr * ldy + kc], mean[kc], invstd[kc], scale[kc], shift[kc],
+                            coef[kc], coef[C + kc]);
+        v[j] = (k + j < cols) ? t : 0.f;
+      }
+    }
+  }
+};
+
+namespace {
+#define BCS_ROWS 512
+// per 512-row block and column: (sum g, sum g*xhat), g = relu'(.) * d_out[dst] / deg — k_bn_bwd_partial_v4 with the
+// gradient gathered instead of read
+__global__ void __launch_bounds__(256) k_bn_csr_partial(const float* __restrict__ dout, long ldo,
+                                                        const int* __restrict__ dst, const float* __restrict__ inv_deg,
+                                                        const float* __restrict__ Y, long ldy, long M, int C,
+                                                        const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                        const float* __restrict__ scale, const float* __restrict__ shift,
+                                                        int relu, float2* part) {
+  __shared__ float4 red1[16][16], red2[16][16];
+  const int q = threadIdx.x & 15, rg = threadIdx.x >> 4;
+  const int c = blockIdx.x * 64 + 4 * q;
+  const long r0 = (long)blockIdx.y * BCS_ROWS;
+  long r1 = r0 + BCS_ROWS;
+  if (r1 > M) r1 = M;
+  float4 s1 = make_float4(0.f, 0.f, 0.f, 0.f), s2 = s1;
+  if (c < C) {
+    const float4 mu = *reinterpret_cast<const float4*>(mean + c), is = *reinterpret_cast<const float4*>(invstd + c);
+    const float4 sc = *reinterpret_cast<const float4*>(scale + c), sh = *reinterpret_cast<const float4*>(shift + c);
+    auto acc1 = [&](float y, float g, float m, float i, float a, float b, float& t1, float& t2) {
+      if (relu && !(fmaf(y, a, b) > 0.f)) g = 0.f;
+      t1 += g;
+      t2 += g * ((y - m) * i);
+    };
+    for (long r = r0 + rg; r < r1; r += 64) {                 // rows r, r+16, r+32, r+48 in flight together
+      float4 y[4], g[4];
+      float w[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const long rr = (r + 16 * k < r1) ? r + 16 * k : r1 - 1;
+        const int n = dst[rr];
+        w[k] = inv_deg[n];
+        y[k] = *reinterpret_cast<const float4*>(Y + rr * ldy + c);
+        g[k] = *reinterpret_cast<const float4*>(dout + (long)n * ldo + c);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        if (r + 16 * k < r1) {
+          acc1(y[k].x, g[k].x * w[k], mu.x, is.x, sc.x, sh.x, s1.x, s2.x);
+          acc1(y[k].y, g[k].y * w[k], mu.y, is.y, sc.y, sh.y, s1.y, s2.y);
+          acc1(y[k].z, g[k].z * w[k], mu.z, is.z, sc.z, sh.z, s1.z, s2.z);
+          acc1(y[k].w, g[k].w * w[k], mu.w, is.w, sc.w, sh.w, s1.w, s2.w);
+        }
+      }
+    }
+  }
+  red1[rg][q] = s1; red2[rg][q] = s2;
+  __syncthreads();
+  if (rg == 0 && c < C) {
+    float4 a = red1[0][q], b = red2[0][q];
+    for (int t = 1; t < 16; ++t) {
+      a.x += red1[t][q].x; a.y += red1[t][q].y; a.z += red1[t][q].z; a.w += red1[t][q].w;
+      b.x += red2[t][q].x; b.y += red2[t][q].y; b.z += red2[t][q].z; b.w += red2[t][q].w;
+    }
+    float2* o = part + (long)blockIdx.y * C + c;
+    o[0] = make_float2(a.x, b.x); o[1] = make_float2(a.y, b.y); o[2] = make_float2(a.z, b.z); o[3] = make_float2(a.w, b.w);
+  }
+}
+
+// fp64 ordered sum over the blocks (16 partitions, 8 loads in flight) -> dgamma, dbeta, coef = (s1/M, s2/M)
+__global__ void __launch_bounds__(1024) k_bn_csr_finalize(const float2* part, long nb, long M, int C, float* dgamma,
+                                                          float* dbeta, int accumulate, float* coef) {
+  __shared__ double s1s[16][64], s2s[16][64];
+  const int cl = threadIdx.x & 63, p = threadIdx.x >> 6;
+  const int c = blockIdx.x * 64 + cl;
+  const long per = (nb + 15) / 16;
+  long b0 = p * per, b1 = b0 + per;
+  if (b1 > nb) b1 = nb;
+  double a = 0.0, b = 0.0;
+  if (c < C)
+    for (long i = b0; i < b1; i += 8) {
+      float2 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = part[(i + k < b1 ? i + k : b1 - 1) * C + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k)
+        if (i + k < b1) { a += (double)t[k].x; b += (double)t[k].y; }
+    }
+  s1s[p][cl] = a; s2s[p][cl] = b;
+  __syncthreads();
+  if (p == 0 && c < C) {
+    for (int t = 1; t < 16; ++t) { a += s1s[t][cl]; b += s2s[t][cl]; }
+    float dg = (float)b, dbt = (float)a;
+    if (accumulate) { dg += dgamma[c]; dbt += dbeta[c]; }
+    dgamma[c] = dg; dbeta[c] = dbt;
+    coef[c] = (float)(a / (double)M);
+    coef[C + c] = (float)(b / (double)M);
+  }
+}
+
+int check_grad(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
+  if (!g || E <= 0 || C <= 0 || E >= (1LL << 31)) return YOLAT_E_INVALID;
+  if (!g->d_out || !g->dst || !g->inv_deg || !g->Y || !g->mean || !g->invstd || !g->scale || !g->shift || !g->coef)
+    return YOLAT_E_INVALID;
+  if (g->ld_out < C || g->ldy < C) return YOLAT_E_INVALID;
+  return 0;
+}
+BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
+  BnCsrOp o;
+  o.dout = g->d_out; o.ldo = g->ld_out; o.dst = g->dst; o.inv_deg = g->inv_deg; o.Y = g->Y; o.ldy = g->ldy;
+  o.mean = g->mean; o.invstd = g->invstd; o.scale = g->scale; o.shift = g->shift; o.coef = g->coef;
+  o.C = (int)C; o.relu = g->relu; o.rows = (int)E; o.cols = (int)C;
+  o.vec = (C % 4 == 0) && (g->ld_out % 4 == 0) && (g->ldy % 4 == 0) && yl_aligned16(g->d_out) && yl_aligned16(g->Y) &&
+          yl_aligned16(g->mean) && yl_aligned16(g->invstd) && yl_aligned16(g->scale) && yl_aligned16(g->shift) &&
+          yl_aligned16(g->coef);
+  return o;
+}
+}  // namespace
+
+extern "C" size_t yolat_bn_csr_work_elems(int64_t E, int64_t C) { return (size_t)(2 * yl_cdiv(E, BCS_ROWS) * C + 4); }
+
+// dgamma / dbeta (+= when accumulate) of the BatchNorm and g->coef = (c1 | c2) [2C] for the two consumers below.
+// C % 4 == 0 and 16-byte aligned rows / vectors required.  work: yolat_bn_csr_work_elems(E, C) floats.
+extern "C" int yolat_bn_csr_bwd_stats(const yolat_bn_csr_grad* g, int64_t E, int64_t C, float* dgamma, float* dbeta,
+                                      int accumulate, float* coef_out, float* work, yolat_stream_t stream) {
+  if (!g || E <= 0 || C <= 0 || E >= (1LL << 31) || !dgamma || !dbeta || !coef_out || !work) return YOLAT_E_INVALID;
+  if (!g->d_out || !g->dst || !g->inv_deg || !g->Y || !g->mean || !g->invstd || !g->scale || !g->shift)
+    return YOLAT_E_INVALID;
+  if (g->ld_out < C || g->ldy < C) return YOLAT_E_INVALID;
+  if (C % 4 != 0 || g->ld_out % 4 != 0 || g->ldy % 4 != 0 || !yl_aligned16(g->d_out) || !yl_aligned16(g->Y) ||
+      !yl_aligned16(g->mean) || !yl_aligned16(g->invstd) || !yl_aligned16(g->scale) || !yl_aligned16(g->shift))
+    return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const long nb = yl_cdiv(E, BCS_ROWS);
+  float2* part = reinterpret_cast<float2*>(work);
+  hipLaunchKernelGGL(k_bn_csr_partial, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, g->d_out, (long)g->ld_out,
+                     g->dst, g->inv_deg, g->Y, (long)g->ldy, (long)E, (int)C, g->mean, g->invstd, g->scale, g->shift,
+                     g->relu, part);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_bn_csr_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, part, nb, (long)E, (int)C, dgamma, dbeta,
+                     accumulate, coef_out);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// dW [C, K] (+= when accumulate) = dY^T . pro(A),  db [C] = column sums of dY;  A [E, K] fp32 with the optional
+// BatchNorm+ReLU prologue.  partial: yolat_linear_bwd_w_work_elems(E, C, K) floats.
+extern "C" int yolat_linear_bwd_w_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, const float* A, int64_t lda,
+                                      int64_t K, const float* a_scale, const float* a_shift, int a_relu, float* dW,
+                                      int64_t lddw, float* db, int accumulate, float* partial, yolat_stream_t stream) {
+  const int rc = check_grad(g, E, C);
+  if (rc) return rc;
+  if (K <= 0 || !A || !dW || !partial || lda < K || lddw < K) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  TnPlan p = yl_tn_plan(E, C, K);
+  BnCsrOp y = make_op(g, E, C);
+  float* dbpart = db ? partial + (size_t)p.S * C * K : nullptr;
+  dim3 grid(yl_cdiv(C, 64), yl_cdiv(K, 64), p.S);
+  if (a_scale != nullptr) {
+    DenseProOp a = yl_dense_pro(A, lda, E, K, a_scale, a_shift, a_relu);
+    hipLaunchKernelGGL((k_gemm_tn<BnCsrOp, DenseProOp>), grid, dim3(256), 0, st, y, a, partial, dbpart, (int)E, (int)C,
+                       (int)K, p.rows_per_split);
+  } else {
+    DenseOp a = yl_dense(A, lda, E, K);
+    hipLaunchKernelGGL((k_gemm_tn<BnCsrOp, DenseOp>), grid, dim3(256), 0, st, y, a, partial, dbpart, (int)E, (int)C, (int)K,
+                       p.rows_per_split);
+  }
+  YL_LAUNCH_CHECK();
+  const long elems = C * K;
+  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 32)), dim3(256), 0, st, partial, elems, p.S, dW, (long)lddw,
+                     (int)K, accumulate);
+  YL_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(C, 32)), dim3(256), 0, st, dbpart, (long)C, p.S, db, (long)C, (int)C,
+                       accumulate);
+    YL_LAUNCH_CHECK();
+  }
+  return 0;
+}
+
+// dA [E, Nout] = dY [E, C] . W,  W given as the Linear's weight [C, Nout] (row-major, ldw)
+extern "C" int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, const float* W, int64_t ldw,
+                                       int64_t Nout, float* dA, int64_t ldda, yolat_stream_t stream) {
+  const int rc = check_grad(g, E, C);
+  if (rc) return rc;
+  if (Nout <= 0 || !W || !dA || ldw < Nout || ldda < Nout) return YOLAT_E_INVALID;
+  BnCsrOp a = make_op(g, E, C);
+  TransOp b;
+  b.p = W; b.ld = ldw; b.rows = (int)Nout; b.cols = (int)C; b.vec = 1;
+  Epilogue ep;
+  ep.bias = nullptr; ep.scale = nullptr; ep.shift = nullptr; ep.relu = 0;
+  ep.Y = dA; ep.ldy = ldda; ep.accumulate = 0; ep.stats = nullptr; ep.seg = nullptr; ep.pool = nullptr; ep.ldpool = 0;
+  dim3 grid(yl_cdiv(E, 64), yl_cdiv(Nout, 64));
+  hipLaunchKernelGGL((k_gemm_nt<64, 64, 32, BnCsrOp, TransOp, true>), grid, dim3(256), 0, (hipStream_t)stream, a, b, ep,
+                     (int)E, (int)Nout, (int)C);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

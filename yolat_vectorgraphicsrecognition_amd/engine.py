@@ -191,6 +191,9 @@ def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inp
 # AttrRelativeEdgeConvGlobalPool2
 # ---------------------------------------------------------------------------------------------
 
+FUSED_BN_CSR_BWD = os.environ.get("YOLAT_FUSED_BN_CSR_BWD", "1") != "0"
+
+
 def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False):
     """x [N,Cin] materialised; xn Lazy [N,Cin]; out_f / out_s: [N,C] destinations (or None).
     Returns (f tensor, s Lazy, saved)."""
@@ -251,13 +254,21 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         ops.linear_fwd_wt(d_f, conv.lin_r.weight, dx, accumulate=dx_acc)
     if E > 0:
         H1, H2, c1, c2 = sv["H1"], sv["H2"], sv["c1"], sv["c2"]
-        dM = torch.empty(E, C, dtype=H1.dtype, device=dev)
-        ops.csr_mean_bwd(d_f, g, dM)
-        ops.bn_relu_bwd(dM, H2, bn4.weight, c2[2], c2[3], c2[0], c2[1], True,
-                        sink.get(bn4.weight), sink.get(bn4.bias), dM)            # dM -> dH2 in place
-        ops.linear_bwd_w(dM, H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
         dA1 = torch.empty(E, C, dtype=H1.dtype, device=dev)
-        ops.linear_fwd_wt(dM, nn3.weight, dA1)
+        if FUSED_BN_CSR_BWD and H1.dtype == torch.float32 and C % 4 == 0 and d_f.stride(0) % 4 == 0:
+            # the gradient w.r.t. H2 (mean aggregation -> ReLU -> BatchNorm backward) is formed inside its two consumers
+            # instead of being written and re-read: 5 instead of 11 passes over [E,C] (bn_csr.hip)
+            dh2 = ops.BnCsrGrad(d_f, g, H2, c2[2], c2[3], c2[0], c2[1], relu=True)
+            dh2.stats(sink.get(bn4.weight), sink.get(bn4.bias))
+            dh2.bwd_w(H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
+            dh2.fwd_wt(nn3.weight, dA1)
+        else:
+            dM = torch.empty(E, C, dtype=H1.dtype, device=dev)
+            ops.csr_mean_bwd(d_f, g, dM)
+            ops.bn_relu_bwd(dM, H2, bn4.weight, c2[2], c2[3], c2[0], c2[1], True,
+                            sink.get(bn4.weight), sink.get(bn4.bias), dM)            # dM -> dH2 in place
+            ops.linear_bwd_w(dM, H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
+            ops.linear_fwd_wt(dM, nn3.weight, dA1)
         ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
                         sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
         hdt = H1.dtype

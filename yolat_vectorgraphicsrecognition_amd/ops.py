@@ -4,6 +4,8 @@ Every function takes torch CUDA tensors, checks dtype / device / inner stride, a
 kernel(s) on torch's current stream.  torch is used for device memory and streams only — the
 arithmetic is in libyolat_hip.so.  There is no CPU path: a non-CUDA tensor raises.
 """
+import ctypes
+
 import torch
 
 from ._lib import lib, check
@@ -83,7 +85,14 @@ class Graph(object):
     proposal segments).  Owned by the caller / cached on the batch object."""
 
     __slots__ = ("N", "E", "P", "row_ptr", "perm", "src", "dst", "attr", "col_ptr", "slots",
-                 "seg_ptr", "node_seg", "status", "_work")
+                 "seg_ptr", "node_seg", "status", "_work", "_inv_deg")
+
+    def inv_deg(self):
+        """[N] fp32 1 / max(in-degree, 1) (the factor of the mean aggregation's backward), built once per graph."""
+        if getattr(self, "_inv_deg", None) is None:
+            deg = (self.row_ptr[1:] - self.row_ptr[:-1]).clamp_min(1).to(torch.float32)
+            self._inv_deg = torch.ones_like(deg) / deg
+        return self._inv_deg
 
     def ensure_csc(self):
         if self.col_ptr is None:
@@ -126,6 +135,7 @@ def build_graph(edge, e_attr, bbox_idx, num_nodes, num_proposals):
     dev = edge.device
     N, P = int(num_nodes), int(num_proposals)
     g = Graph()
+    g._inv_deg = None
     g.N, g.E, g.P = N, E, P
     g.col_ptr = g.slots = None
     g.row_ptr = torch.empty(N + 1, dtype=torch.int32, device=dev)
@@ -220,6 +230,47 @@ def linear_bwd_w(dY, A, dW, db=None, a_pro=None, a_relu=False, accumulate=False)
                                  _f(dW, "dW"), _ld(dW), _f(db, "db", True), int(accumulate),
                                  work.data_ptr(), _stream()), "yolat_linear_bwd_w")
     return dW
+
+
+class BnCsrGrad(object):
+    """The gradient w.r.t. the input Y [E,C] of BatchNorm(train)+ReLU followed by the CSR mean aggregation, never
+    materialised (bn_csr.hip): built from d_out [N,C] (gradient w.r.t. the aggregated output), the graph and the saved
+    BatchNorm coefficients; `stats()` reduces dgamma / dbeta and the two coefficients the consumers need, then
+    `bwd_w()` (dW = dY^T.pro(A), db) and `fwd_wt()` (dA = dY.W) form dY rows in their GEMM loaders."""
+
+    def __init__(self, d_out, g, Y, save_mean, save_invstd, scale, shift, relu=True):
+        from ._lib import BnCsrGrad as _S
+        self.E, self.C, self.dev = Y.shape[0], Y.shape[1], Y.device
+        self.coef = torch.empty(2 * self.C, dtype=torch.float32, device=self.dev)
+        self._keep = (d_out, g, Y, save_mean, save_invstd, scale, shift, g.inv_deg())
+        d = _S()
+        d.d_out, d.ld_out = _f(d_out, "d_out"), _ld(d_out)
+        d.dst, d.inv_deg = g.dst.data_ptr(), g.inv_deg().data_ptr()
+        d.Y, d.ldy = _f(Y, "Y"), _ld(Y)
+        d.mean, d.invstd, d.scale, d.shift = _f(save_mean), _f(save_invstd), _f(scale), _f(shift)
+        d.coef, d.relu = self.coef.data_ptr(), int(relu)
+        self._d = d
+
+    def stats(self, dgamma, dbeta, accumulate=False):
+        work = torch.empty(int(lib.yolat_bn_csr_work_elems(self.E, self.C)), dtype=torch.float32, device=self.dev)
+        check(lib.yolat_bn_csr_bwd_stats(ctypes.byref(self._d), self.E, self.C, _f(dgamma), _f(dbeta), int(accumulate),
+                                         self.coef.data_ptr(), work.data_ptr(), _stream()), "yolat_bn_csr_bwd_stats")
+        return self
+
+    def bwd_w(self, A, dW, db=None, a_pro=None, a_relu=False, accumulate=False):
+        K = A.shape[1]
+        asc, ash = (a_pro if a_pro is not None else (None, None))
+        work = torch.empty(int(lib.yolat_linear_bwd_w_work_elems(self.E, self.C, K)), dtype=torch.float32, device=self.dev)
+        check(lib.yolat_linear_bwd_w_csr(ctypes.byref(self._d), self.E, self.C, _f(A, "A"), _ld(A), K,
+                                         _f(asc, "a_scale", True), _f(ash, "a_shift", True), int(a_relu), _f(dW, "dW"),
+                                         _ld(dW), _f(db, "db", True), int(accumulate), work.data_ptr(), _stream()),
+              "yolat_linear_bwd_w_csr")
+        return dW
+
+    def fwd_wt(self, W, dA):
+        check(lib.yolat_linear_fwd_wt_csr(ctypes.byref(self._d), self.E, self.C, _f(W, "W"), _ld(W), W.shape[1],
+                                          _f(dA, "dA"), _ld(dA), _stream()), "yolat_linear_fwd_wt_csr")
+        return dA
 
 
 def bn_finalize(stats, M, bn, scale, shift, save_mean, save_invstd, update_running=True):
