@@ -453,10 +453,18 @@ typedef struct {
    * node-side GEMM's epilogue), Wc4f = s1 (rows) * Wc4, t2f = s2*b2 + t2:
    *   h1 = relu(U'[dst] + V'[src] + Wc4f.attr),  message = relu(s2 * (W2.h1) + t2f)                        */
   const float *Wuvf, *uvb, *Wc4f, *t2f;
+  /* nullable (all eight or none; Cin == C == 64): the node side prepared for yolat_node_uv_eval_x6 — Wfr_x6 = hi / mid
+   * / lo bfloat16 split (yolat_split_bf16x3) of the stacked [Wuvf ; Wr] [192, 64], tfr = [uvb ; br] [192]; Wn_x6 = split
+   * of sn (rows) * Wn [64, 64], tn_fold = sn*bn + tn.  Used when N >= YOLAT_NODE_X6_MIN_ROWS.                  */
+  const uint16_t *Wfr_x6[3];
+  const float *tfr;
+  const uint16_t *Wn_x6[3];
+  const float *tn_fold;
 } yolat_conv_eval;
 
 #define YOLAT_CLS_X6_MAX_ROWS 2048
 #define YOLAT_CLS1_X6_MIN_ROWS 1024
+#define YOLAT_NODE_X6_MIN_ROWS 65536
 typedef struct {
   int32_t n_blocks, n_blocks_out, n_classes, reserved;
   int64_t C;                                  /* n_filters (64)                                  */
@@ -612,6 +620,14 @@ int yolat_linear_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uin
 /* the same with A given pre-split: Ap = yolat_split_bf16x3_packed(A, lda, M, K, NULL) — for long K                */
 int yolat_linear_x6_pre(const uint16_t* Ap, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
                         int64_t N, float* out, int64_t ldo, yolat_stream_t stream);
+/* Node side of a factorised conv layer (eval, Cin = C = 64) on the bf16x6 rows kernel: UV [N,128] = f_in . Wuv'^T + uvb,
+ * f_out [N,64] = f_in . Wr^T + br (stacked weights Wfr [192,64] pre-split, shifts tfr [192]) and s_out [N,64] =
+ * relu(s_in . (sn (.) Wn)^T + tn_fold) in one launch; same contract as yolat_node_uv_eval with the folded weights.   */
+int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
+                          const uint16_t* Wfr_h, const uint16_t* Wfr_m, const uint16_t* Wfr_l, const float* tfr,
+                          const uint16_t* Wn_h, const uint16_t* Wn_m, const uint16_t* Wn_l, const float* tn_fold,
+                          float* UV, int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
+                          yolat_stream_t stream);
 int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
                               const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,
                               int64_t ldpool, const float* S, int64_t lds, int64_t P, const uint16_t* Wsh,

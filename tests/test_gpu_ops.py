@@ -1107,3 +1107,55 @@ def test_gemm_x6_matches_fp64(M, K, N, relu):
     assert torch.equal(outs[0], outs[1])
     assert lib.yolat_gemm_x6(A.data_ptr(), K, M, K - 1, packed.data_ptr(), None, 0, N, outs[0].data_ptr(), N + 3,
                              work.data_ptr(), st) != 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N", [1, 255, 1000, 43520])
+def test_node_uv_eval_x6_matches_fp32_node_side(N):
+    """yolat_node_uv_eval_x6 (node side of a factorised conv layer on the bf16x6 rows kernel: stacked [Wuvf ; Wr] and
+    the node branch with its BatchNorm scale folded into the weights) against yolat_node_uv_eval (fp32-MFMA tiles) on
+    the same operands, strided outputs (concat slots), ragged N; deterministic."""
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    C = 64
+    gen = torch.Generator().manual_seed(N)
+    f_in = torch.randn(N, 2 * C, generator=gen).cuda()[:, :C]            # ld 128: a concat slot
+    s_in = torch.randn(N, C, generator=gen).cuda()
+    Wuv = (torch.randn(2 * C, C, generator=gen) / 8).cuda()
+    uvb = torch.randn(2 * C, generator=gen).cuda()
+    Wr, br = (torch.randn(C, C, generator=gen) / 8).cuda(), torch.randn(C, generator=gen).cuda()
+    Wn, bn = (torch.randn(C, C, generator=gen) / 8).cuda(), torch.randn(C, generator=gen).cuda()
+    sn, tn = (torch.rand(C, generator=gen) + 0.5).cuda(), torch.randn(C, generator=gen).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def outs():
+        return torch.full((N, 2 * C), -7.0).cuda(), torch.full((N, 3 * C), -7.0).cuda(), torch.full((N, 3 * C), -7.0).cuda()
+    UVa, fa, sa = outs()
+    check(lib.yolat_node_uv_eval(f_in.data_ptr(), 2 * C, s_in.data_ptr(), C, N, C, Wuv.data_ptr(), uvb.data_ptr(),
+                                 Wr.data_ptr(), br.data_ptr(), Wn.data_ptr(), bn.data_ptr(), sn.data_ptr(), tn.data_ptr(), C,
+                                 UVa.data_ptr(), 2 * C, fa[:, C:].data_ptr(), 3 * C, sa[:, C:].data_ptr(), 3 * C, st))
+
+    def split(w, scale):
+        parts = [torch.empty(w.numel(), dtype=torch.bfloat16, device="cuda") for _ in range(3)]
+        check(lib.yolat_split_bf16x3(w.data_ptr(), w.shape[1], w.shape[0], w.shape[1],
+                                     scale.data_ptr() if scale is not None else None, parts[0].data_ptr(),
+                                     parts[1].data_ptr(), parts[2].data_ptr(), st))
+        return parts
+    wfr = torch.cat([Wuv, Wr], 0).contiguous()
+    tfr = torch.cat([uvb, br], 0).contiguous()
+    pfr, pn = split(wfr, None), split(Wn, sn)
+    tnf = (sn * bn + tn).contiguous()
+
+    def run():
+        UV, f, s = outs()
+        check(lib.yolat_node_uv_eval_x6(f_in.data_ptr(), 2 * C, s_in.data_ptr(), C, N, pfr[0].data_ptr(), pfr[1].data_ptr(),
+                                        pfr[2].data_ptr(), tfr.data_ptr(), pn[0].data_ptr(), pn[1].data_ptr(),
+                                        pn[2].data_ptr(), tnf.data_ptr(), UV.data_ptr(), 2 * C, f[:, C:].data_ptr(), 3 * C,
+                                        s[:, C:].data_ptr(), 3 * C, st))
+        return UV, f, s
+    UVb, fb, sb = run()
+    for name, a, b in (("UV", UVa, UVb), ("f_out", fa, fb), ("s_out", sa, sb)):
+        assert float((a - b).abs().max()) <= 3e-6 * float(a.abs().max()), name
+    assert torch.all(fb[:, :C] == -7.0) and torch.all(fb[:, 2 * C:] == -7.0)      # nothing outside the slots
+    assert torch.all(sb[:, :C] == -7.0) and torch.all(sb[:, 2 * C:] == -7.0)
+    for a, b in zip((UVb, fb, sb), run()):
+        assert torch.equal(a, b)

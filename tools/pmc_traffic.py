@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = "yolat_vectorgraphicsrecognition_amd/csrc/"
 # eval-plan stage (forward_eval.hip YL_STAGE names) -> (kernel name prefix, source files)
 STAGES = {
-    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_fusion_rows_x6", [CS + "common.hpp", CS + "x6.hpp", CS + "fusion_x6.hip"]),
+    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_fusion_rows_x6<128>", [CS + "common.hpp", CS + "x6.hpp", CS + "fusion_x6.hip"]),
     "edge_uv_mlp2_mean[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"]),
     "node_uv[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_gemm_nt_node3", [CS + "common.hpp", CS + "dense.hip"]),
     "graph_prep[csr+attr+segments] + node_uv[layer 0]": ("k_prep_rows_node3", [CS + "common.hpp", CS + "graph.hip"]),

@@ -21,9 +21,10 @@ YOLAT_MAX_LAYERS = 8
 
 class ConvEval(ctypes.Structure):
     """yolat_conv_eval (include/yolat_hip.h)"""
-    _fields_ = [("Cin", c_i64)] + [(n, c_p) for n in
-                                   ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn",
-                                    "Wuv", "Wc4", "Wuvf", "uvb", "Wc4f", "t2f")]
+    _fields_ = ([("Cin", c_i64)] + [(n, c_p) for n in
+                                    ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn",
+                                     "Wuv", "Wc4", "Wuvf", "uvb", "Wc4f", "t2f")] +
+                [("Wfr_x6", c_p * 3), ("tfr", c_p), ("Wn_x6", c_p * 3), ("tn_fold", c_p)])
 
 
 class ModelEval(ctypes.Structure):
@@ -152,6 +153,8 @@ SIGNATURES = {
     "yolat_linear_fwd_wt_h": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_edge_uv_sums_h": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_split_bf16x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_node_uv_eval_x6": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64,
+                                      c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_fusion_pair_eval_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p,
                                           c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
     "yolat_bn_csr_work_elems": (c_sz, [c_i64, c_i64]),

@@ -202,10 +202,19 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
         const bool fold = cv.Wuvf && cv.uvb && cv.Wc4f && cv.t2f;
         if (!(l == 0 && node0_in_prep)) {
           snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
+          // large graphs: the three GEMMs as bf16x6-emulated products on the rows kernel (A read once per 256 rows);
+          // small ones stay on the fp32 64x64 tiles (more workgroups: latency).  Measured per launch: N = 200 k 94 -> 89 us,
+          // N = 43.5 k 26 = 26 us, N = 10 k 12.4 -> 18 us
+          const bool node_x6 = fold && cv.Cin == 64 && N >= YOLAT_NODE_X6_MIN_ROWS && cv.Wfr_x6[0] && cv.Wfr_x6[1] &&
+                               cv.Wfr_x6[2] && cv.tfr && cv.Wn_x6[0] && cv.Wn_x6[1] && cv.Wn_x6[2] && cv.tn_fold &&
+                               ld_f % 4 == 0 && ld_s % 4 == 0;
           YL_STAGE(nm, 8.0 * N * cv.Cin * C, 4.0 * (2.0 * N * cv.Cin + 4.0 * N * C),
-                   yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, fold ? cv.Wuvf : cv.Wuv,
-                                      fold ? cv.uvb : nullptr, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn, C, p.UV, 2 * C,
-                                      f_out, ld_out, s_out, ld_out, stream));
+                   node_x6 ? yolat_node_uv_eval_x6(f_in, ld_f, s_in, ld_s, N, cv.Wfr_x6[0], cv.Wfr_x6[1], cv.Wfr_x6[2],
+                                                   cv.tfr, cv.Wn_x6[0], cv.Wn_x6[1], cv.Wn_x6[2], cv.tn_fold, p.UV, 2 * C,
+                                                   f_out, ld_out, s_out, ld_out, stream)
+                           : yolat_node_uv_eval(f_in, ld_f, s_in, ld_s, N, cv.Cin, fold ? cv.Wuvf : cv.Wuv,
+                                                fold ? cv.uvb : nullptr, cv.Wr, cv.br, cv.Wn, cv.bn, cv.sn, cv.tn, C, p.UV,
+                                                2 * C, f_out, ld_out, s_out, ld_out, stream));
         }
         if (E > 0) {
           snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);

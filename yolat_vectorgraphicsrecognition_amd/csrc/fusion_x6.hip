@@ -59,19 +59,22 @@ __device__ __forceinline__ void fx_segmax2(const f32x16& acc0, const f32x16& acc
 }
 }  // namespace
 
-// One GEMM problem of the launch: rows of A against the pre-split weights; seg != NULL -> pooling epilogue into `out`
-// (pool), else plain store of relu(.) into out [rows, F] (fusion_block_super).
+// One GEMM problem of the launch: rows of A against the pre-split weights [F, KD]; seg != NULL -> pooling epilogue into
+// `out` (pool); else plain store of act(.) — column tiles [0, ct2) into out [rows, ldo], column tiles [ct2, ...) into
+// out2 [rows, ldo2] (its column 0 = column 64 * ct2 of the product), act = ReLU when relu != 0.
 struct FxProb {
   const float* A; long lda; int N;
   const yl_bf16_t *Wh, *Wm, *Wl;
   const float* tfold;
   const int* seg;
   float* out; long ldo;
+  float* out2; long ldo2; int ct2;
+  int F, relu;
   int tm, groups, ng;
 };
 
 template <int KD>
-__global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1, int F) {
+__global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1) {
   constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
   constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / 512;   // 16-byte chunks of one W tile, per thread
   static_assert(CHUNKS % 512 == 0, "W tile / thread mismatch");
@@ -96,7 +99,8 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   // the problem's fields as wave-uniform scalars (a reference to "p0 or p1" would make the compiler index the
   // kernel arguments through memory)
   const bool small = id < n1p;
-  struct { const float* A; long lda; int N; const float* tfold; const int* seg; float* out; long ldo; int groups, ng; } P;
+  struct { const float* A; long lda; int N; const float* tfold; const int* seg; float* out; long ldo; float* out2;
+           long ldo2; int ct2, relu, groups, ng; } P;
   P.A = small ? p1.A : p0.A;
   P.lda = small ? p1.lda : p0.lda;
   P.N = small ? p1.N : p0.N;
@@ -104,6 +108,11 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   P.seg = small ? p1.seg : p0.seg;
   P.out = small ? p1.out : p0.out;
   P.ldo = small ? p1.ldo : p0.ldo;
+  P.out2 = small ? p1.out2 : p0.out2;
+  P.ldo2 = small ? p1.ldo2 : p0.ldo2;
+  P.ct2 = small ? p1.ct2 : p0.ct2;
+  P.relu = small ? p1.relu : p0.relu;
+  const int F = small ? p1.F : p0.F;
   P.groups = small ? p1.groups : p0.groups;
   P.ng = small ? p1.ng : p0.ng;
   const float* __restrict__ A = P.A;
@@ -218,13 +227,18 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
       // kept in 32 registers across the MFMA loop
       unsigned rb = (unsigned)(row0 + 4 * lhi);
       asm volatile("" : "+v"(rb));
+      const bool second = ct >= P.ct2;
+      float* const ob = second ? P.out2 : P.out;
+      const unsigned long old = (unsigned long)(second ? P.ldo2 : P.ldo);
+      const int cb = second ? 64 * P.ct2 : 0;
+      const float lo = P.relu ? 0.f : -INFINITY;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned row = rb + (r & 3) + 8 * (r >> 2);
         if ((int)row < N) {
-          float* o = P.out + (unsigned long)row * (unsigned long)P.ldo;
-          if (c0 < F) o[c0] = fmaxf(acc0[r], 0.f);
-          if (c1 < F) o[c1] = fmaxf(acc1[r], 0.f);
+          float* o = ob + (unsigned long)row * old - cb;
+          if (c0 < F) o[c0] = fmaxf(acc0[r], lo);
+          if (c1 < F) o[c1] = fmaxf(acc1[r], lo);
         }
       }
     }
@@ -286,9 +300,9 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   if (forced < 0) { const char* e = getenv("YOLAT_FUSION_X6_GROUPS"); forced = e ? atoi(e) : 0; }
   FxProb p0, p1;
   p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = Wh; p0.Wm = Wm; p0.Wl = Wl; p0.tfold = tfold; p0.seg = node_seg;
-  p0.out = pool; p0.ldo = ldpool;
+  p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1;
   p1.A = S; p1.lda = lds; p1.N = (int)P; p1.Wh = Wsh; p1.Wm = Wsm; p1.Wl = Wsl; p1.tfold = tsfold; p1.seg = nullptr;
-  p1.out = Ys; p1.ldo = ldys;
+  p1.out = Ys; p1.ldo = ldys; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = (int)F; p1.relu = 1;
   p0.tm = yl_cdiv(N, 256);
   p1.tm = yl_cdiv(P, 256);
   p1.groups = tn; p1.ng = 1;
@@ -307,8 +321,39 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L);
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, (int)F);
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, (int)F);
+  if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Node side of a factorised conv layer (eval, C = Cin = 64) on the same rows kernel: UV = f_in . Wuv'^T + uv_bias
+// (two column tiles -> UV [N, 128]) and root = f_in . Wr^T + br (third column tile -> f_out) as one problem with the
+// stacked, pre-split weights Wfr [192, 64] and shifts tfr [192]; the node branch relu(s_in . (sn (.) Wn)^T + tn') as the
+// second problem.  Replaces yolat_node_uv_eval (three fp32-MFMA GEMMs in one launch) — the same launch count, the
+// products on the bf16 matrix cores, A read once per 256 rows.
+extern "C" int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
+                                     const uint16_t* Wfr_h, const uint16_t* Wfr_m, const uint16_t* Wfr_l, const float* tfr,
+                                     const uint16_t* Wn_h, const uint16_t* Wn_m, const uint16_t* Wn_l, const float* tn_fold,
+                                     float* UV, int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
+                                     yolat_stream_t stream) {
+  if (N <= 0 || N >= (1LL << 31) - 256 || !f_in || !s_in || !Wfr_h || !Wfr_m || !Wfr_l || !tfr || !Wn_h || !Wn_m || !Wn_l ||
+      !tn_fold || !UV || !f_out || !s_out)
+    return YOLAT_E_INVALID;
+  if (ld_f < 64 || ld_s < 64 || ld_uv < 128 || ld_fo < 64 || ld_so < 64) return YOLAT_E_INVALID;
+  if (ld_f % 4 != 0 || ld_s % 4 != 0 || !yl_aligned16(f_in) || !yl_aligned16(s_in) || !yl_aligned16(Wfr_h) ||
+      !yl_aligned16(Wfr_m) || !yl_aligned16(Wfr_l) || !yl_aligned16(Wn_h) || !yl_aligned16(Wn_m) || !yl_aligned16(Wn_l))
+    return YOLAT_E_UNSUPPORTED;
+  FxProb p0, p1;
+  p0.A = f_in; p0.lda = ld_f; p0.N = (int)N; p0.Wh = Wfr_h; p0.Wm = Wfr_m; p0.Wl = Wfr_l; p0.tfold = tfr; p0.seg = nullptr;
+  p0.out = UV; p0.ldo = ld_uv; p0.out2 = f_out; p0.ldo2 = ld_fo; p0.ct2 = 2; p0.F = 192; p0.relu = 0;
+  p0.tm = yl_cdiv(N, 256); p0.groups = 1; p0.ng = 3;
+  p1.A = s_in; p1.lda = ld_s; p1.N = (int)N; p1.Wh = Wn_h; p1.Wm = Wn_m; p1.Wl = Wn_l; p1.tfold = tn_fold; p1.seg = nullptr;
+  p1.out = s_out; p1.ldo = ld_so; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = 64; p1.relu = 1;
+  p1.tm = yl_cdiv(N, 256); p1.groups = 1; p1.ng = 1;
+  const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L);
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, p0, p1);
   YL_LAUNCH_CHECK();
   return 0;
 }

@@ -78,6 +78,7 @@ class EvalPlan(object):
             c.Wr, c.br = ptr(cv.lin_r.weight), ptr(cv.lin_r.bias)
             c.Wn, c.bn = ptr(cv.mlp_node[0].weight), ptr(cv.mlp_node[0].bias)
             c.sn, c.tn = folded(cv.mlp_node[1])
+            keep_sn = keep[-1]
             C = cv.nn[0].out_features
             # factorised first edge Linear: per-node weights [W1a - W1b | W1b] and the 4 attr columns
             wuv = torch.empty(2 * C, cv.in_channels, dtype=torch.float32, device=dev)
@@ -98,6 +99,29 @@ class EvalPlan(object):
                                                                      fold2[0], fold2[1])
                     keep += [wuvf, uvb, wc4f, t2f]
                     c.Wuvf, c.uvb, c.Wc4f, c.t2f = wuvf.data_ptr(), uvb.data_ptr(), wc4f.data_ptr(), t2f.data_ptr()
+                    if (cv.in_channels == 64 and C == 64 and os.environ.get("YOLAT_NODE_X6", "1") != "0"
+                            and cv.lin_r.bias is not None):
+                        # node side on the bf16x6 rows kernel (yolat_node_uv_eval_x6): [Wuvf ; Wr] stacked and split,
+                        # shifts [uvb ; br]; node branch with its BatchNorm scale folded into the weight rows
+                        def split_rows(w, row_scale):
+                            rows, cols = w.shape
+                            parts = [torch.empty(rows * cols, dtype=torch.bfloat16, device=dev) for _ in range(3)]
+                            check(lib.yolat_split_bf16x3(w.data_ptr(), cols, rows, cols,
+                                                         row_scale.data_ptr() if row_scale is not None else None,
+                                                         parts[0].data_ptr(), parts[1].data_ptr(), parts[2].data_ptr(),
+                                                         ops._stream()), "yolat_split_bf16x3")
+                            return parts
+                        wfr = torch.cat([wuvf, cv.lin_r.weight.detach()], 0).contiguous()
+                        tfr = torch.cat([uvb, cv.lin_r.bias.detach()], 0).contiguous()
+                        sn_t, tn_t = keep_sn[0], keep_sn[1]
+                        bn_b = cv.mlp_node[0].bias
+                        bn_b = bn_b.detach() if bn_b is not None else torch.zeros_like(sn_t)
+                        tnf = (sn_t * bn_b + tn_t).contiguous()
+                        pfr, pn = split_rows(wfr, None), split_rows(cv.mlp_node[0].weight.detach().contiguous(), sn_t)
+                        keep += [wfr, tfr, tnf] + pfr + pn
+                        for i in range(3):
+                            c.Wfr_x6[i], c.Wn_x6[i] = pfr[i].data_ptr(), pn[i].data_ptr()
+                        c.tfr, c.tn_fold = tfr.data_ptr(), tnf.data_ptr()
         fb, fs = net.fusion_block, net.fusion_block_super
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
