@@ -620,6 +620,17 @@ def test_fusion_pool_train_matches_autograd_of_materialised_path(N_P):
     A64 = A.double().requires_grad_(True)
     y = torch.relu(bn64(lin64(A64)))
     pooled = orc.scatter(y, torch.from_numpy(bb), dim=0, dim_size=P, reduce="max")
+    # arg-max routing is discontinuous: where the two largest activations of a (proposal, column) are closer than fp32
+    # GEMM rounding can resolve (1e-5 relative; the fp32-MFMA and the bf16x6-emulated GEMM both sit at ~1e-7..3e-7),
+    # either row is a valid answer — take those entries out of the upstream gradient instead of hoping no near-tie
+    # occurs among 300 x 1024 maxima
+    with torch.no_grad():
+        off = np.concatenate([[0], np.cumsum(n_p)])
+        for pi in range(P):
+            rows = y[off[pi]:off[pi + 1]]
+            if rows.shape[0] >= 2:
+                top = torch.topk(rows, 2, dim=0).values
+                gZ[pi][((top[0] - top[1]) < 1e-5 * (top[0].abs() + 1e-3)) & (top[0] > 0)] = 0.0
     pooled.backward(gZ.double())
     # HIP
     g = yv.ops.build_graph(torch.zeros(0, 2, dtype=torch.int64).cuda(), torch.zeros(0, 4).cuda(), dev(bb), Nn, P)

@@ -663,6 +663,10 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
                      int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr, const float* br,
                      const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
                      int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so);
+// training-mode fusion GEMM with the key64 pooling epilogue on the bf16x6 rows kernel (fusion_x6.hip)
+int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const float* W, const float* bias, long F,
+                            const float* sgn, const int* node_seg, unsigned long long* keys, uint16_t* wsplit,
+                            yolat_stream_t stream);
 // stage profiler hooks (forward_eval.hip): HIP-event pair around one stage of a whole-forward entry point
 bool yl_profile_on();
 void yl_stage_begin(const char* name, double flops, double bytes, yolat_stream_t stream);

@@ -23,6 +23,7 @@
 //        db = 0 (BatchNorm removes the Linear bias from the loss)
 //    i.e. two sparse P*F-term kernels plus K x K / F x K sized dense algebra.
 #include "common.hpp"
+#include <stdlib.h>
 
 #define YL_TRY(call)            \
   do {                          \
@@ -139,7 +140,8 @@ extern "C" size_t yolat_fusion_pool_train_work_elems(int64_t N, int64_t K, int64
   const size_t colsum = (size_t)yl_cdiv(N, CS_ROWS) * K;
   const size_t gram = yolat_linear_bwd_w_work_elems(N, K, K);
   const size_t keys = 2 * (size_t)P * F + 4;                                  // 64-bit keys
-  const size_t fwd = colsum + gram + keys;
+  const size_t wsplit = (3 * (size_t)F * K + 1) / 2 + 8;                      // bf16 split of W (bf16x6 forward GEMM)
+  const size_t fwd = colsum + gram + keys + wsplit;
   // backward: GM[P*F] | column partials | sparse-dW partials | small vectors / matrices
   const size_t bwd = (size_t)P * F + 2 * (size_t)yl_cdiv(P, 128) * F + 64 * (size_t)F * K + 4 * F + 2 * K * K +
                      (size_t)F * K + yolat_linear_bwd_w_work_elems(F, K, K) + 64;
@@ -197,7 +199,17 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
   YL_LAUNCH_CHECK();
   // 4. GEMM with the per-(proposal, column) extreme-of-z epilogue; nothing of shape [N, F] is written
   if (hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)P * F, st) != hipSuccess) return YOLAT_E_INVALID;
-  {
+  // K in {64, 128}: as an fp32 GEMM emulated with six bf16 MFMA products on the rows kernel (fusion_x6.hip; the weight
+  // split lives behind the keys in `work`)
+  static int use_x6 = -1;
+  if (use_x6 < 0) { const char* e = getenv("YOLAT_FUSION_TRAIN_X6"); use_x6 = (e && e[0] == '0') ? 0 : 1; }
+  int x6rc = YOLAT_E_UNSUPPORTED;
+  if (use_x6 && bias != nullptr) {
+    uint16_t* wsplit = reinterpret_cast<uint16_t*>(((uintptr_t)(keys + (size_t)P * F) + 15) & ~(uintptr_t)15);
+    x6rc = yl_fusion_rows_x6_key64(A, lda, N, K, W, bias, F, coef, node_seg, keys, wsplit, stream);
+    if (x6rc != 0 && x6rc != YOLAT_E_UNSUPPORTED) return x6rc;
+  }
+  if (x6rc != 0) {
     DenseOp a = yl_dense(A, lda, N, K), b = yl_dense(W, K, F, K);
     Epilogue ep;
     ep.bias = bias; ep.scale = coef; ep.shift = coef + F; ep.relu = 0;

@@ -57,6 +57,33 @@ __device__ __forceinline__ void fx_segmax2(const f32x16& acc0, const f32x16& acc
     }
   }
 }
+// training-mode epilogue: the extreme of s*z per run with its (lowest) row, as the key of wave_epilogue's key64 branch
+// (common.hpp) — same key, same tie rule
+__device__ __forceinline__ unsigned long long fx_key(float z, bool neg, unsigned row) {
+  unsigned u = __float_as_uint(neg ? -z : z);
+  u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                // order-preserving float -> uint
+  return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - row);
+}
+__device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1, unsigned long long* keys, unsigned ldk,
+                                         const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, bool neg0, bool neg1,
+                                         unsigned rbase, const FxRuns& sr) {
+  unsigned long long cur0 = 0ull, cur1 = 0ull;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned row = rbase + (r & 3) + 8 * (r >> 2);
+    const unsigned long long k0 = fx_key(acc0[r], neg0, row), k1 = fx_key(acc1[r], neg1, row);
+    const bool cont = sr.keep[r] != 0.f;
+    cur0 = (cont && cur0 > k0) ? cur0 : k0;
+    cur1 = (cont && cur1 > k1) ? cur1 : k1;
+    if ((sr.uflush >> r) & 1u) {
+      if ((sr.flush_bits >> r) & 1u) {
+        unsigned long long* o = keys + ((unsigned long)(unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldk + c0);
+        if (ok0) atomicMax(o, cur0);
+        if (ok1) atomicMax(o + 32, cur1);
+      }
+    }
+  }
+}
 }  // namespace
 
 // One GEMM problem of the launch: rows of A against the pre-split weights [F, KD]; seg != NULL -> pooling epilogue into
@@ -71,6 +98,10 @@ struct FxProb {
   float* out2; long ldo2; int ct2;
   int F, relu;
   int tm, groups, ng;
+  // training-mode pooling (fusion_train.hip): key64 != NULL (with seg) -> for every (proposal, column) the row with the
+  // largest s*z (s = sign of sgn[column], z = the accumulator) is recorded by a 64-bit atomicMax on
+  // orderable(s*z) << 32 | ~row (ties -> lowest row); nothing else is written
+  unsigned long long* key64; const float* sgn;
 };
 
 template <int KD>
@@ -100,7 +131,7 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
   // kernel arguments through memory)
   const bool small = id < n1p;
   struct { const float* A; long lda; int N; const float* tfold; const int* seg; float* out; long ldo; float* out2;
-           long ldo2; int ct2, relu, groups, ng; } P;
+           long ldo2; int ct2, relu, groups, ng; unsigned long long* key64; const float* sgn; } P;
   P.A = small ? p1.A : p0.A;
   P.lda = small ? p1.lda : p0.lda;
   P.N = small ? p1.N : p0.N;
@@ -112,6 +143,8 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
   P.ldo2 = small ? p1.ldo2 : p0.ldo2;
   P.ct2 = small ? p1.ct2 : p0.ct2;
   P.relu = small ? p1.relu : p0.relu;
+  P.key64 = small ? p1.key64 : p0.key64;
+  P.sgn = small ? p1.sgn : p0.sgn;
   const int F = small ? p1.F : p0.F;
   P.groups = small ? p1.groups : p0.groups;
   P.ng = small ? p1.ng : p0.ng;
@@ -220,7 +253,10 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
     // whole MFMA phase ago: waiting now costs nothing and keeps the compiler from waiting on the shifts at the top
     // of the next tile, where the wait would also cover this tile's atomics (vmcnt retires in order)
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
-    if (pooling) {
+    if (pooling && P.key64 != nullptr) {
+      fx_key64(acc0, acc1, P.key64, (unsigned)F, segs, lhi, (unsigned)c0, c0 < F, c1 < F,
+               P.sgn[yl_min(c0, F - 1)] < 0.f, P.sgn[yl_min(c1, F - 1)] < 0.f, (unsigned)(row0 + 4 * lhi), runs);
+    } else if (pooling) {
       fx_segmax2(acc0, acc1, P.out, (unsigned)P.ldo, segs, lhi, (unsigned)c0, c0 < F, c1 < F, runs);
     } else {
       // the row base goes through an opaque asm so that the 16 row addresses are recomputed here instead of being
@@ -300,9 +336,9 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   if (forced < 0) { const char* e = getenv("YOLAT_FUSION_X6_GROUPS"); forced = e ? atoi(e) : 0; }
   FxProb p0, p1;
   p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = Wh; p0.Wm = Wm; p0.Wl = Wl; p0.tfold = tfold; p0.seg = node_seg;
-  p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1;
+  p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1; p0.key64 = nullptr; p0.sgn = nullptr;
   p1.A = S; p1.lda = lds; p1.N = (int)P; p1.Wh = Wsh; p1.Wm = Wsm; p1.Wl = Wsl; p1.tfold = tsfold; p1.seg = nullptr;
-  p1.out = Ys; p1.ldo = ldys; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = (int)F; p1.relu = 1;
+  p1.out = Ys; p1.ldo = ldys; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = (int)F; p1.relu = 1; p1.key64 = nullptr; p1.sgn = nullptr;
   p0.tm = yl_cdiv(N, 256);
   p1.tm = yl_cdiv(P, 256);
   p1.groups = tn; p1.ng = 1;
@@ -322,6 +358,45 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Training-mode fusion GEMM (fusion_train.hip step 4) on the rows kernel: z = A . W^T + bias never stored, per
+// (proposal, column) extreme-of-z keys.  W [F, K] fp32 is split here (it changes every step) into `wsplit`
+// (3 * F * K bfloat16, 16-byte aligned).  K in {64, 128}, F % 64 == 0; returns YOLAT_E_UNSUPPORTED otherwise.
+int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const float* W, const float* bias, long F,
+                            const float* sgn, const int* node_seg, unsigned long long* keys, uint16_t* wsplit,
+                            yolat_stream_t stream) {
+  if ((K != 64 && K != 128) || F % 64 != 0 || lda % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(wsplit) || !bias)
+    return YOLAT_E_UNSUPPORTED;
+  if (N >= (1LL << 31) - 256) return YOLAT_E_UNSUPPORTED;
+  uint16_t *wh = wsplit, *wm = wsplit + F * K, *wl = wsplit + 2 * F * K;
+  const int rc = yolat_split_bf16x3(W, K, F, K, nullptr, wh, wm, wl, stream);
+  if (rc != 0) return rc;
+  const int tn = (int)(F / 64);
+  FxProb p0, p1;
+  p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = wh; p0.Wm = wm; p0.Wl = wl; p0.tfold = bias; p0.seg = node_seg;
+  p0.out = nullptr; p0.ldo = F; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 0;
+  p0.key64 = keys; p0.sgn = sgn;
+  p0.tm = yl_cdiv(N, 256);
+  int best_g = 1;
+  double best = 1e300;
+  for (int g = 1; g <= tn; g *= 2) {
+    const int ng = yl_cdiv(tn, g);
+    const long wgs = (long)p0.tm * yl_cdiv(tn, ng);
+    const double cost = (double)((wgs + 255) / 256) * (1.0 + ng);
+    if (cost < best) { best = cost; best_g = g; }
+  }
+  p0.ng = yl_cdiv(tn, best_g);
+  p0.groups = yl_cdiv(tn, p0.ng);
+  p1 = p0;
+  p1.tm = 0; p1.groups = 1; p1.ng = 1;
+  const long total = (long)p0.tm * p0.groups;
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
   else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
   YL_LAUNCH_CHECK();
   return 0;
@@ -347,6 +422,7 @@ extern "C" int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const floa
   FxProb p0, p1;
   p0.A = f_in; p0.lda = ld_f; p0.N = (int)N; p0.Wh = Wfr_h; p0.Wm = Wfr_m; p0.Wl = Wfr_l; p0.tfold = tfr; p0.seg = nullptr;
   p0.out = UV; p0.ldo = ld_uv; p0.out2 = f_out; p0.ldo2 = ld_fo; p0.ct2 = 2; p0.F = 192; p0.relu = 0;
+  p0.key64 = nullptr; p0.sgn = nullptr; p1.key64 = nullptr; p1.sgn = nullptr;
   p0.tm = yl_cdiv(N, 256); p0.groups = 1; p0.ng = 3;
   p1.A = s_in; p1.lda = ld_s; p1.N = (int)N; p1.Wh = Wn_h; p1.Wm = Wn_m; p1.Wl = Wn_l; p1.tfold = tn_fold; p1.seg = nullptr;
   p1.out = s_out; p1.ldo = ld_so; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = 64; p1.relu = 1;
