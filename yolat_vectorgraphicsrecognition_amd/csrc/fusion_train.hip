@@ -120,6 +120,78 @@ static __global__ void __launch_bounds__(256) k_pool_finish(const unsigned long 
 }
 
 
+// partial[s] [128][128] = sum over the rows of slab s of (a_r + negmean)(a_r + negmean)^T,  A [N, 128] fp32.
+// 256 threads = 2 x 2 waves, each wave a 64 x 64 quadrant (4 accumulators); per 32-row stage the centered tile goes to
+// LDS once ([32][132] floats) and every wave issues 64 v_mfma_f32_32x32x2_f32 on it; next stage's loads in flight
+// meanwhile.  Fixed slab partition and summation order: deterministic.
+static __global__ void __launch_bounds__(256) k_gram128(const float* __restrict__ A, long lda, long N,
+                                                        const float* __restrict__ negmean, int rows_per,
+                                                        float* __restrict__ partial) {
+  constexpr int LD = 132;
+  __shared__ __attribute__((aligned(16))) float As[2][32 * LD];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const long r_begin = (long)blockIdx.x * rows_per;
+  long r_end = r_begin + rows_per;
+  if (r_end > N) r_end = N;
+  // staging role: 4 float4 per thread and stage: rows (tid >> 5) + 8 t, columns 4 (tid & 31)
+  const int sc = 4 * (tid & 31), sr = tid >> 5;
+  const float4 nm = *reinterpret_cast<const float4*>(negmean + sc);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+  float4 rg[4];
+  auto fetch = [&](long r0) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long r = r0 + sr + 8 * t;
+      rg[t] = *reinterpret_cast<const float4*>(A + (r < r_end ? r : r_end - 1) * lda + sc);
+    }
+  };
+  auto stage = [&](long r0, int buf) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bool ok = r0 + sr + 8 * t < r_end;           // rows are the reduction dimension: mask them
+      const float4 v = ok ? make_float4(rg[t].x + nm.x, rg[t].y + nm.y, rg[t].z + nm.z, rg[t].w + nm.w)
+                          : make_float4(0.f, 0.f, 0.f, 0.f);
+      *reinterpret_cast<float4*>(&As[buf][(sr + 8 * t) * LD + sc]) = v;
+    }
+  };
+  if (r_begin < r_end) { fetch(r_begin); stage(r_begin, 0); }
+  __syncthreads();
+  int buf = 0;
+  for (long r0 = r_begin; r0 < r_end; r0 += 32) {
+    if (r0 + 32 < r_end) fetch(r0 + 32);
+    const float* t = As[buf];
+#pragma unroll 4
+    for (int rr = 0; rr < 32; rr += 2) {
+      const float* row = t + (rr + lhi) * LD + l31;
+      const float a0 = row[wm * 64], a1 = row[wm * 64 + 32], b0 = row[wn * 64], b1 = row[wn * 64 + 32];
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+    }
+    if (r0 + 32 < r_end) stage(r0 + 32, buf ^ 1);       // the other buffer: its readers passed the last barrier
+    __syncthreads();
+    buf ^= 1;
+  }
+  float* P = partial + (long)blockIdx.x * 128 * 128;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int n = wm * 64 + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        P[(long)n * 128 + wn * 64 + 32 * j + l31] = acc[i][j][r];
+      }
+}
+
 // ---- saved-state layout (fp32 elements): sumA[K] | ones[K] | negmean[K] | G[K*K] | T[F*K] | zstar[P*F] | arg[P*F]
 struct FusSaved { float *sumA, *ones, *negmean, *G, *T, *zstar; int* arg; size_t elems; };
 static FusSaved fus_saved(float* base, long K, long F, long P) {
@@ -178,8 +250,23 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
   hipLaunchKernelGGL(k_center_vecs, dim3(yl_cdiv(K, 256)), dim3(256), 0, st, sv.sumA, (int)K, 1.f / (float)N, sv.ones,
                      sv.negmean);
   YL_LAUNCH_CHECK();
-  // 2. centered Gram matrix G = (A - mean)^T (A - mean): the weight-gradient TN GEMM with both operands centered
-  {
+  // 2. centered Gram matrix G = (A - mean)^T (A - mean)
+  if (K == 128 && yl_aligned16(A)) {
+    // dedicated kernel: one workgroup owns a slab of rows and the WHOLE 128 x 128 product (the tile is loaded once per
+    // 32 rows and feeds 64 MFMAs per wave between barriers; the generic TN GEMM — 64 x 64 output tiles, 16 MFMAs per
+    // wave and stage — was latency bound: 234 us at N = 174 k)
+    int S = (int)yl_cdiv(N, 32 * 8);                    // >= 256 rows per workgroup
+    if (S > 256) S = 256;                               // one workgroup per CU; fits the TN GEMM's partial area
+    const int rows_per = (int)yl_cdiv(yl_cdiv(N, S), 32) * 32;
+    S = (int)yl_cdiv(N, rows_per);
+    if ((size_t)S * K * K > yolat_linear_bwd_w_work_elems(N, K, K)) return YOLAT_E_INVALID;
+    hipLaunchKernelGGL(k_gram128, dim3(S), dim3(256), 0, st, A, (long)lda, (long)N, sv.negmean, rows_per, grampart);
+    YL_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(K * K, 32)), dim3(256), 0, st, grampart, (long)(K * K), S, sv.G,
+                       (long)K, (int)K, 0);
+    YL_LAUNCH_CHECK();
+  } else {
+    // the weight-gradient TN GEMM with both operands centered
     TnPlan p = yl_tn_plan(N, K, K);
     DenseProOp y = yl_dense_pro(A, lda, N, K, sv.ones, sv.negmean, 0);
     dim3 grid(yl_cdiv(K, 64), yl_cdiv(K, 64), p.S);
