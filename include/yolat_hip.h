@@ -599,6 +599,12 @@ int yolat_linear_bwd_w_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, con
                            int accumulate, float* partial, yolat_stream_t stream);
 int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, const float* W, int64_t ldw, int64_t Nout,
                             float* dA, int64_t ldda, yolat_stream_t stream);
+/* both of the above in ONE kernel for C = K = Nout = 64 (the edge MLP's second Linear): dY tiles formed once.  work:
+ * yolat_bn_csr_l2_bwd_work_elems() floats.                                                                     */
+size_t yolat_bn_csr_l2_bwd_work_elems(void);
+int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const float* A, int64_t lda, const float* a_scale,
+                        const float* a_shift, int a_relu, const float* W, int64_t ldw, float* dW, int64_t lddw, float* db,
+                        int accumulate, float* dA, int64_t ldda, float* work, yolat_stream_t stream);
 
 /* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
  * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).
@@ -609,6 +615,8 @@ int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, co
 size_t yolat_gemm_x6_packed_elems(int64_t N, int64_t K);
 int yolat_gemm_x6_pack(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale, uint16_t* packed,
                        yolat_stream_t stream);
+/* the weight given transposed, Wt [K, N] row-major: packs it for dX [M, N] = dY [M, K] . Wt (backward of a Linear)   */
+int yolat_gemm_x6_pack_t(const float* Wt, int64_t ldw, int64_t N, int64_t K, uint16_t* packed, yolat_stream_t stream);
 size_t yolat_gemm_x6_work_elems(int64_t M, int64_t N, int64_t K);
 int yolat_gemm_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
                   int64_t N, float* out, int64_t ldo, float* work, yolat_stream_t stream);

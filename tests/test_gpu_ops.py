@@ -965,6 +965,20 @@ def test_fused_bn_csr_backward_matches_materialised_path(N, E):
     got = fused()
     for name, a, b in zip(("dgamma", "dbeta", "dW", "db", "dA"), (dg_a, db_a, dW_a, dbias_a, dA_a), got):
         assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-6), name
+
+    def fused_one_kernel():
+        dg, db = torch.empty(C).cuda(), torch.empty(C).cuda()
+        dW, dbias, dA = torch.empty(C, C).cuda(), torch.empty(C).cuda(), torch.full((E, C), -7.0).cuda()
+        h = yv.ops.BnCsrGrad(d_f, g, H2, coefs[2], coefs[3], coefs[0], coefs[1], relu=True)
+        h.stats(dg, db)
+        h.bwd_w_and_x(H1, W, dW, dbias, dA, a_pro=(c1[0], c1[1]), a_relu=True)
+        return dg, db, dW, dbias, dA
+    one = fused_one_kernel()
+    for name, a, b in zip(("dgamma", "dbeta", "dW", "db", "dA"), (dg_a, db_a, dW_a, dbias_a, dA_a), one):
+        ref_scale = float(dA_a.abs().sum(0).max()) if name == "db" else max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * ref_scale, name
+    for a, b in zip(one, fused_one_kernel()):
+        assert torch.equal(a, b)
     again = fused()
     for a, b in zip(got, again):
         assert torch.equal(a, b)                                             # deterministic
@@ -1170,3 +1184,22 @@ def test_node_uv_eval_x6_matches_fp32_node_side(N):
     assert torch.all(sb[:, :C] == -7.0) and torch.all(sb[:, 2 * C:] == -7.0)
     for a, b in zip((UVb, fb, sb), run()):
         assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(8000, 512, 2304), (2000, 512, 2304), (1024, 256, 512)])
+def test_linear_fwd_wt_x6_path_matches_fp64(M, K, N):
+    """ops.linear_fwd_wt (dX = dY . W of a Linear's backward) on the bf16x6 GEMM with the transposed pack
+    (yolat_gemm_x6_pack_t) — the shapes that take that path — against the float64 product; deterministic."""
+    yv = _yv()
+    gen = torch.Generator().manual_seed(M + N)
+    dY = torch.randn(M, K, generator=gen).cuda()
+    W = (torch.randn(K, N, generator=gen) / K ** 0.5).cuda()
+    outs = []
+    for _ in range(2):
+        dX = torch.full((M, N), -7.0).cuda()
+        yv.ops.linear_fwd_wt(dY, W, dX)
+        outs.append(dX)
+    ref = dY.double() @ W.double()
+    assert float((outs[0].double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    assert torch.equal(outs[0], outs[1])

@@ -146,6 +146,29 @@ __global__ void __launch_bounds__(1024) k_bn_csr_finalize(const float2* part, lo
   }
 }
 
+// out (+)= sum over the workgroup slabs in order: element i < 4096 -> dW[i / 64][i % 64], the rest -> db
+__global__ void k_reduce_slabs(const float* __restrict__ partial, int S, int slab, float* dW, long lddw, float* db,
+                               int accumulate) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= slab) return;
+  float s = 0.f;
+  for (int w = 0; w < S; w += 8) {                       // 8 loads in flight, summed in order
+    float v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] = partial[(long)yl_min(w + k, S - 1) * slab + i];
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      if (w + k < S) s += v[k];
+  }
+  if (i < 64 * 64) {
+    float* o = dW + (long)(i >> 6) * lddw + (i & 63);
+    *o = accumulate ? *o + s : s;
+  } else if (db != nullptr) {
+    float* o = db + (i - 64 * 64);
+    *o = accumulate ? *o + s : s;
+  }
+}
+
 int check_grad(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
   if (!g || E <= 0 || C <= 0 || E >= (1LL << 31)) return YOLAT_E_INVALID;
   if (!g->d_out || !g->dst || !g->inv_deg || !g->Y || !g->mean || !g->invstd || !g->scale || !g->shift || !g->coef)
@@ -164,6 +187,156 @@ BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
   return o;
 }
 }  // namespace
+
+// ------------------------------------------------------------------------------------------------------------------
+// Both consumers of dY in ONE kernel (C = K = 64): per 64-row tile the gradient tile dY (formed from Y, the gathered
+// d_out rows and the coefficients) and the prologue'd input tile A1 = relu(A * a_scale + a_shift) go to LDS once and
+// feed  dA[tile] = dY . W  (32 MFMAs per wave)  and  dW += dY^T . A1  (32 MFMAs per wave, accumulated in registers over
+// all the tiles of the persistent workgroup) and the column sums db.  Reads Y and A once, writes dA: 3 passes over
+// [E,64] instead of the 4 of the two separate GEMMs, and the element-wise dY arithmetic runs once instead of twice (it
+// made the TN GEMM 2x slower: 134 -> 273 us per layer at E = 1.2 M).  Partials [workgroup][64*64 + 64] are summed in a
+// fixed order by k_reduce_splits: deterministic.
+// ------------------------------------------------------------------------------------------------------------------
+#define BCL_WGS 512
+__global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOp y, const float* __restrict__ A, long lda,
+                                                       const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                       float a_floor, const float* __restrict__ W, long ldw,
+                                                       float* __restrict__ dA, long ldda, int E, int tiles_per_wg,
+                                                       float* __restrict__ partial) {
+  constexpr int LD = 65;
+  __shared__ float Ds[64 * LD], As[64 * LD], Ws[64 * LD];
+  __shared__ float dbs[4][64];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = tid & 15, rb = tid >> 4;                 // staging role: columns 4q.., rows rb + 16 t
+  const int ntiles = (E + 63) >> 6;
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = yl_min(ntiles, t0 + tiles_per_wg);
+  // W [64 c][64 k] -> LDS as is
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = rb + 16 * t;
+    const float4 w = *reinterpret_cast<const float4*>(W + (long)r * ldw + 4 * q);
+    float* d = Ws + r * LD + 4 * q;
+    d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+  }
+  const float4 mu = *reinterpret_cast<const float4*>(y.mean + 4 * q), is = *reinterpret_cast<const float4*>(y.invstd + 4 * q);
+  const float4 sc = *reinterpret_cast<const float4*>(y.scale + 4 * q), sh = *reinterpret_cast<const float4*>(y.shift + 4 * q);
+  const float4 k1 = *reinterpret_cast<const float4*>(y.coef + 4 * q), k2 = *reinterpret_cast<const float4*>(y.coef + 64 + 4 * q);
+  float4 as = make_float4(1.f, 1.f, 1.f, 1.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a_scale) { as = *reinterpret_cast<const float4*>(a_scale + 4 * q); ah = *reinterpret_cast<const float4*>(a_shift + 4 * q); }
+  f32x16 accw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+  float dbacc = 0.f;                                     // threads 0..63: column tid of db
+
+  float4 ry[4], rg[4], ra[4];
+  float rw[4];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = yl_min(tile * 64 + rb + 16 * t, E - 1);
+      const int n = y.dst[e];
+      rw[t] = y.inv_deg[n];
+      ry[t] = *reinterpret_cast<const float4*>(y.Y + (long)e * y.ldy + 4 * q);
+      rg[t] = *reinterpret_cast<const float4*>(y.dout + (long)n * y.ldo + 4 * q);
+      ra[t] = *reinterpret_cast<const float4*>(A + (long)e * lda + 4 * q);
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+    // ---- the two tiles into LDS (rows beyond E: zero — they are in the reduction of dW / db)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 16 * t;
+      const bool ok = tile * 64 + r < E;
+      float* d = Ds + r * LD + 4 * q;
+      float* a = As + r * LD + 4 * q;
+      d[0] = ok ? y.one(rg[t].x, rw[t], ry[t].x, mu.x, is.x, sc.x, sh.x, k1.x, k2.x) : 0.f;
+      d[1] = ok ? y.one(rg[t].y, rw[t], ry[t].y, mu.y, is.y, sc.y, sh.y, k1.y, k2.y) : 0.f;
+      d[2] = ok ? y.one(rg[t].z, rw[t], ry[t].z, mu.z, is.z, sc.z, sh.z, k1.z, k2.z) : 0.f;
+      d[3] = ok ? y.one(rg[t].w, rw[t], ry[t].w, mu.w, is.w, sc.w, sh.w, k1.w, k2.w) : 0.f;
+      a[0] = ok ? fmaxf(fmaf(ra[t].x, as.x, ah.x), a_floor) : 0.f;
+      a[1] = ok ? fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor) : 0.f;
+      a[2] = ok ? fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor) : 0.f;
+      a[3] = ok ? fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor) : 0.f;
+    }
+    __syncthreads();
+    if (tile + 1 < t1) fetch(tile + 1);                  // in flight under the MFMAs
+    // ---- dA tile = dY . W   (rows wm*32.., columns wn*32..)
+    f32x16 acca;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acca[r] = 0.f;
+#pragma unroll 8
+    for (int c = 0; c < 64; c += 2) {
+      const float av = Ds[(wm * 32 + l31) * LD + c + lhi];
+      const float bv = Ws[(c + lhi) * LD + wn * 32 + l31];
+      acca = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acca, 0, 0, 0);
+    }
+    // ---- dW += dY^T . A1   (rows = dY columns wm*32.., columns = A1 columns wn*32..)
+#pragma unroll 8
+    for (int e = 0; e < 64; e += 2) {
+      const float av = Ds[(e + lhi) * LD + wm * 32 + l31];
+      const float bv = As[(e + lhi) * LD + wn * 32 + l31];
+      accw = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accw, 0, 0, 0);
+    }
+    // ---- db: wave w sums rows 16w..16w+15 of column `lane`, combined in wave order below
+    {
+      float s = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) s += Ds[(wave * 16 + r) * LD + lane];
+      dbs[wave][lane] = s;
+    }
+    // ---- store the dA tile
+    {
+      const int col = wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = tile * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        if (row < E) dA[(long)row * ldda + col] = acca[r];
+      }
+    }
+    __syncthreads();                                     // all reads of Ds / As done; dbs complete
+    if (tid < 64) dbacc += ((dbs[0][tid] + dbs[1][tid]) + dbs[2][tid]) + dbs[3][tid];
+  }
+  float* P = partial + (long)blockIdx.x * (64 * 64 + 64);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    P[c * 64 + wn * 32 + l31] = accw[r];
+  }
+  if (tid < 64) P[64 * 64 + tid] = dbacc;
+}
+
+extern "C" size_t yolat_bn_csr_l2_bwd_work_elems(void) { return (size_t)BCL_WGS * (64 * 64 + 64); }
+
+// C = K = Nout = 64 only.  dW [64, 64] (+= when accumulate) = dY^T . pro(A), db [64] (+=) = column sums of dY (nullable),
+// dA [E, 64] = dY . W (W = the Linear's weight [64, 64], row-major).  work: yolat_bn_csr_l2_bwd_work_elems() floats.
+extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const float* A, int64_t lda, const float* a_scale,
+                                   const float* a_shift, int a_relu, const float* W, int64_t ldw, float* dW, int64_t lddw,
+                                   float* db, int accumulate, float* dA, int64_t ldda, float* work,
+                                   yolat_stream_t stream) {
+  const int rc = check_grad(g, E, 64);
+  if (rc) return rc;
+  if (!A || !W || !dW || !dA || !work || lda < 64 || ldw < 64 || lddw < 64 || ldda < 64) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
+  BnCsrOp y = make_op(g, E, 64);
+  if (!y.vec || lda % 4 != 0 || ldw % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(W) ||
+      (a_scale && (!yl_aligned16(a_scale) || !yl_aligned16(a_shift))))
+    return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const int ntiles = (int)yl_cdiv(E, 64);
+  int wgs = ntiles < BCL_WGS ? ntiles : BCL_WGS;
+  const int per = yl_cdiv(ntiles, wgs);
+  wgs = yl_cdiv(ntiles, per);
+  hipLaunchKernelGGL(k_bn_csr_l2_bwd, dim3(wgs), dim3(256), 0, st, y, A, (long)lda, a_scale, a_shift,
+                     a_relu ? 0.f : -INFINITY, W, (long)ldw, dA, (long)ldda, (int)E, per, work);
+  YL_LAUNCH_CHECK();
+  // partial layout [wg][64*64 | 64]: reduce the two pieces with the element stride of the slab
+  hipLaunchKernelGGL(k_reduce_slabs, dim3(yl_cdiv(64 * 64 + 64, 256)), dim3(256), 0, st, work, wgs, 64 * 64 + 64, dW,
+                     (long)lddw, db, accumulate);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
 
 extern "C" size_t yolat_bn_csr_work_elems(int64_t E, int64_t C) { return (size_t)(2 * yl_cdiv(E, BCS_ROWS) * C + 4); }
 

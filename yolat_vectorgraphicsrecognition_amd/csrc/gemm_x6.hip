@@ -210,8 +210,9 @@ __global__ void k_gemm_x6_reduce(const float* __restrict__ partial, int S, long 
 }
 
 // W [N, K] fp32 (optionally scaled per row) -> packed[ct][ks][part][gx_slot(col, k half)]; columns beyond N are zero
+// transposed != 0: W is given as [K, N] row-major (the GEMM's weight is its transpose: dX = dY . W of a Linear)
 __global__ void k_gemm_x6_pack(const float* __restrict__ W, long ldw, int N, int K, const float* __restrict__ row_scale,
-                               yl_bf16_t* __restrict__ packed) {
+                               int transposed, yl_bf16_t* __restrict__ packed) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (ct, ks, col j, k half)
   const int nks = K >> 4, tn = (N + GX_BN - 1) / GX_BN;
   if (i >= (long)tn * nks * GX_BN * 2) return;
@@ -222,7 +223,9 @@ __global__ void k_gemm_x6_pack(const float* __restrict__ W, long ldw, int N, int
   float x[8];
 #pragma unroll
   for (int e = 0; e < 8; ++e)
-    x[e] = n < N ? W[(long)n * ldw + 16 * ks + 8 * half + e] * (row_scale ? row_scale[n] : 1.f) : 0.f;
+    x[e] = n < N ? (transposed ? W[(long)(16 * ks + 8 * half + e) * ldw + n] : W[(long)n * ldw + 16 * ks + 8 * half + e]) *
+                       (row_scale ? row_scale[n] : 1.f)
+                 : 0.f;
   fx_bf16x8 h, m, l;
   fx_split8(x, h, m, l);
   yl_bf16_t* o = packed + ((long)ct * nks + ks) * (3 * GX_PART) + gx_slot(j, half);
@@ -245,15 +248,25 @@ extern "C" size_t yolat_gemm_x6_packed_elems(int64_t N, int64_t K) {
   return (N <= 0 || K <= 0) ? 0 : (size_t)yl_cdiv(N, GX_BN) * (size_t)(K / 16) * 3 * GX_PART;
 }
 // packed: yolat_gemm_x6_packed_elems(N, K) bfloat16 values, 16-byte aligned; K % 16 == 0.  Once per weight version.
-extern "C" int yolat_gemm_x6_pack(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale,
-                                  uint16_t* packed, yolat_stream_t stream) {
-  if (N <= 0 || K <= 0 || !W || !packed || ldw < K || N >= (1LL << 31) - GX_BN || K >= (1LL << 31)) return YOLAT_E_INVALID;
+static int gx_pack(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale, int transposed,
+                   uint16_t* packed, yolat_stream_t stream) {
+  if (N <= 0 || K <= 0 || !W || !packed || ldw < (transposed ? N : K) || N >= (1LL << 31) - GX_BN || K >= (1LL << 31))
+    return YOLAT_E_INVALID;
   if (K % 16 != 0 || !yl_aligned16(packed)) return YOLAT_E_UNSUPPORTED;
   const long items = (long)yl_cdiv(N, GX_BN) * (K / 16) * GX_BN * 2;
   hipLaunchKernelGGL(k_gemm_x6_pack, dim3((unsigned)yl_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
-                     (int)N, (int)K, row_scale, reinterpret_cast<yl_bf16_t*>(packed));
+                     (int)N, (int)K, row_scale, transposed, reinterpret_cast<yl_bf16_t*>(packed));
   YL_LAUNCH_CHECK();
   return 0;
+}
+extern "C" int yolat_gemm_x6_pack(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale,
+                                  uint16_t* packed, yolat_stream_t stream) {
+  return gx_pack(W, ldw, N, K, row_scale, 0, packed, stream);
+}
+// the weight given transposed: Wt [K, N] row-major (ldw >= N) — for  dX [M, N] = dY [M, K] . Wt  of a Linear's backward
+extern "C" int yolat_gemm_x6_pack_t(const float* Wt, int64_t ldw, int64_t N, int64_t K, uint16_t* packed,
+                                    yolat_stream_t stream) {
+  return gx_pack(Wt, ldw, N, K, nullptr, 1, packed, stream);
 }
 // fp32 elements of the split-K workspace yolat_gemm_x6 needs for this shape (0: none)
 extern "C" size_t yolat_gemm_x6_work_elems(int64_t M, int64_t N, int64_t K) {

@@ -260,8 +260,12 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
             # instead of being written and re-read: 5 instead of 11 passes over [E,C] (bn_csr.hip)
             dh2 = ops.BnCsrGrad(d_f, g, H2, c2[2], c2[3], c2[0], c2[1], relu=True)
             dh2.stats(sink.get(bn4.weight), sink.get(bn4.bias))
-            dh2.bwd_w(H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
-            dh2.fwd_wt(nn3.weight, dA1)
+            if C == 64 and nn3.in_features == 64 and nn3.weight.is_contiguous():
+                dh2.bwd_w_and_x(H1, nn3.weight, sink.get(nn3.weight), sink.get(nn3.bias), dA1, a_pro=(c1[0], c1[1]),
+                                a_relu=True)
+            else:
+                dh2.bwd_w(H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
+                dh2.fwd_wt(nn3.weight, dA1)
         else:
             dM = torch.empty(E, C, dtype=H1.dtype, device=dev)
             ops.csr_mean_bwd(d_f, g, dM)

@@ -5,6 +5,7 @@ kernel(s) on torch's current stream.  torch is used for device memory and stream
 arithmetic is in libyolat_hip.so.  There is no CPU path: a non-CUDA tensor raises.
 """
 import ctypes
+import os
 
 import torch
 
@@ -197,6 +198,9 @@ def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False
     return Y
 
 
+X6_TRAIN_GEMM = os.environ.get("YOLAT_TRAIN_X6_GEMM", "1") != "0"
+
+
 def linear_fwd_wt(A, Wt, Y, accumulate=False):
     """Y = A @ Wt   (Wt: [K, Nout] row-major, e.g. dX = dY @ W)."""
     M, K = A.shape
@@ -207,6 +211,17 @@ def linear_fwd_wt(A, Wt, Y, accumulate=False):
         wwork = torch.empty(Nout * K, dtype=torch.bfloat16, device=A.device)
         check(lib.yolat_linear_fwd_wt_h(_h(A, "A"), _ld(A), M, K, _f(Wt, "Wt"), _ld(Wt), Nout, _h(Y, "Y"), _ld(Y),
                                         wwork.data_ptr(), _stream()), "yolat_linear_fwd_wt_h")
+        return Y
+    if (X6_TRAIN_GEMM and not accumulate and M >= 1024 and K >= 256 and K % 16 == 0 and Nout >= 512
+            and _ld(A) % 4 == 0 and A.data_ptr() % 16 == 0):
+        # long-K, many-row backward GEMM (the classifier's first layer: dZ [P, 2304] = dC1 [P, 512] . Wc1): bf16x6-
+        # emulated on the LDS-tiled kernel (gemm_x6.hip); the weight changes every step, so it is packed here (a few us)
+        packed = torch.empty(int(lib.yolat_gemm_x6_packed_elems(Nout, K)), dtype=torch.bfloat16, device=A.device)
+        check(lib.yolat_gemm_x6_pack_t(_f(Wt, "Wt"), _ld(Wt), Nout, K, packed.data_ptr(), _stream()),
+              "yolat_gemm_x6_pack_t")
+        work = torch.empty(max(1, int(lib.yolat_gemm_x6_work_elems(M, Nout, K))), dtype=torch.float32, device=A.device)
+        check(lib.yolat_gemm_x6(_f(A, "A"), _ld(A), M, K, packed.data_ptr(), None, 0, Nout, _f(Y, "Y"), _ld(Y),
+                                work.data_ptr(), _stream()), "yolat_gemm_x6")
         return Y
     check(lib.yolat_linear_fwd_wt(_f(A, "A"), _ld(A), M, K, _f(Wt, "Wt"), _ld(Wt), Nout, _f(Y, "Y"),
                                   _ld(Y), int(accumulate), _stream()), "yolat_linear_fwd_wt")
@@ -266,6 +281,16 @@ class BnCsrGrad(object):
                                          _ld(dW), _f(db, "db", True), int(accumulate), work.data_ptr(), _stream()),
               "yolat_linear_bwd_w_csr")
         return dW
+
+    def bwd_w_and_x(self, A, W, dW, db, dA, a_pro=None, a_relu=False, accumulate=False):
+        """dW (+)= dY^T . pro(A), db (+)= column sums, dA = dY . W in one kernel (C = K = 64)."""
+        asc, ash = (a_pro if a_pro is not None else (None, None))
+        work = torch.empty(int(lib.yolat_bn_csr_l2_bwd_work_elems()), dtype=torch.float32, device=self.dev)
+        check(lib.yolat_bn_csr_l2_bwd(ctypes.byref(self._d), self.E, _f(A, "A"), _ld(A), _f(asc, "a_scale", True),
+                                      _f(ash, "a_shift", True), int(a_relu), _f(W, "W"), _ld(W), _f(dW, "dW"), _ld(dW),
+                                      _f(db, "db", True), int(accumulate), _f(dA, "dA"), _ld(dA), work.data_ptr(),
+                                      _stream()), "yolat_bn_csr_l2_bwd")
+        return dA
 
     def fwd_wt(self, W, dA):
         check(lib.yolat_linear_fwd_wt_csr(ctypes.byref(self._d), self.E, self.C, _f(W, "W"), _ld(W), W.shape[1],
