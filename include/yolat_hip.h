@@ -636,6 +636,13 @@ int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const float* s_in, in
                           const uint16_t* Wn_h, const uint16_t* Wn_m, const uint16_t* Wn_l, const float* tn_fold,
                           float* UV, int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so,
                           yolat_stream_t stream);
+/* Training-mode Linear for many rows on the bf16x6 rows kernel: Y [M, Nout] = pro(A) . W^T + bias (pre-activation; bias
+ * required), optional BatchNorm+ReLU prologue on A, optional BatchNorm partial statistics of Y (same layout as
+ * yolat_linear_fwd's `stats`).  K in {64, 128}, Nout % 64 == 0, lda % 4 == 0; wsplit: 3 * Nout * K bfloat16 values
+ * (the weight is split on every call).  Replaces yolat_linear_fwd for the second edge Linear of a training conv layer. */
+int yolat_linear_fwd_rows_x6(const float* A, int64_t lda, int64_t M, int64_t K, const float* a_scale, const float* a_shift,
+                             int a_relu, const float* W, int64_t ldw, const float* bias, int64_t Nout, float* Y,
+                             int64_t ldy, float* stats, uint16_t* wsplit, yolat_stream_t stream);
 int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
                               const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,
                               int64_t ldpool, const float* S, int64_t lds, int64_t P, const uint16_t* Wsh,

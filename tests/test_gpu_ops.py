@@ -1203,3 +1203,42 @@ def test_linear_fwd_wt_x6_path_matches_fp64(M, K, N):
     ref = dY.double() @ W.double()
     assert float((outs[0].double() - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(70000, 64, 64), (65536 + 17, 128, 128)])
+def test_linear_fwd_rows_x6_path_matches_fp32_kernel_and_statistics(M, K, N):
+    """ops.linear_fwd on the bf16x6 rows kernel (yolat_linear_fwd_rows_x6: many rows, K in {64, 128}, BatchNorm + ReLU
+    prologue on A, pre-activation output + BatchNorm partial statistics) against the fp32-MFMA kernel on the same
+    operands (ops.X6_TRAIN_ROWS flipped in-process; the path is opt-in: it measured equal to the fp32 tiles), and the
+    finalized statistics against float64."""
+    yv = _yv()
+    gen = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=gen).cuda()
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=gen).cuda()
+    pro = ((torch.rand(K, generator=gen) + 0.5).cuda(), torch.randn(K, generator=gen).cuda())
+
+    def run(x6):
+        old = yv.ops.X6_TRAIN_ROWS
+        yv.ops.X6_TRAIN_ROWS = x6
+        try:
+            Y = torch.full((M, N + 4), -7.0).cuda()
+            st = yv.ops.stats_buffer(M, N, A.device)
+            yv.ops.linear_fwd(A, W, b, Y[:, :N], a_pro=pro, a_relu=True, stats=st)
+            bn = torch.nn.BatchNorm1d(N).cuda()
+            coef = torch.empty(4, N).cuda()
+            yv.ops.bn_finalize(st, M, bn, coef[0], coef[1], coef[2], coef[3])
+            return Y, coef
+        finally:
+            yv.ops.X6_TRAIN_ROWS = old
+    Ya, ca = run(False)
+    Yb, cb = run(True)
+    scale = float(Ya[:, :N].abs().max())
+    assert float((Ya[:, :N] - Yb[:, :N]).abs().max()) <= 3e-6 * scale
+    assert torch.all(Yb[:, N:] == -7.0)
+    ref = torch.relu(A.double() * pro[0].double() + pro[1].double()) @ W.double().t() + b.double()
+    close(cb[2], ref.mean(0).float(), rtol=1e-4, atol=1e-5, msg="batch mean")
+    close(cb[3], (1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).float(), rtol=1e-4, atol=1e-6, msg="invstd")
+    Yc, cc = run(True)
+    assert torch.equal(Yb, Yc) and torch.equal(cb, cc)

@@ -153,6 +153,8 @@ SIGNATURES = {
     "yolat_linear_fwd_wt_h": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_edge_uv_sums_h": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_split_bf16x3": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_linear_fwd_rows_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64, c_p, c_i64, c_p,
+                                         c_p, c_p]),
     "yolat_node_uv_eval_x6": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64,
                                       c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_fusion_pair_eval_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p,

@@ -102,6 +102,11 @@ struct FxProb {
   // largest s*z (s = sign of sgn[column], z = the accumulator) is recorded by a 64-bit atomicMax on
   // orderable(s*z) << 32 | ~row (ties -> lowest row); nothing else is written
   unsigned long long* key64; const float* sgn;
+  // training-mode Linear (yolat_linear_fwd_rows_x6): optional prologue on A, v = max(a * a_scale[k] + a_shift[k],
+  // a_floor) (BatchNorm + ReLU of the producer), and optional BatchNorm partial statistics of the stored values:
+  // stats[(row / 32) * F + col] = (sum, M2) of the 32-row group (the layout yolat_bn_finalize reads)
+  const float *a_scale, *a_shift; float a_floor;
+  float* stats;
 };
 
 template <int KD>
@@ -131,7 +136,8 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
   // kernel arguments through memory)
   const bool small = id < n1p;
   struct { const float* A; long lda; int N; const float* tfold; const int* seg; float* out; long ldo; float* out2;
-           long ldo2; int ct2, relu, groups, ng; unsigned long long* key64; const float* sgn; } P;
+           long ldo2; int ct2, relu, groups, ng; unsigned long long* key64; const float* sgn; const float *a_scale,
+           *a_shift; float a_floor; float* stats; } P;
   P.A = small ? p1.A : p0.A;
   P.lda = small ? p1.lda : p0.lda;
   P.N = small ? p1.N : p0.N;
@@ -145,6 +151,10 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
   P.relu = small ? p1.relu : p0.relu;
   P.key64 = small ? p1.key64 : p0.key64;
   P.sgn = small ? p1.sgn : p0.sgn;
+  P.a_scale = small ? p1.a_scale : p0.a_scale;
+  P.a_shift = small ? p1.a_shift : p0.a_shift;
+  P.a_floor = small ? p1.a_floor : p0.a_floor;
+  P.stats = small ? p1.stats : p0.stats;
   const int F = small ? p1.F : p0.F;
   P.groups = small ? p1.groups : p0.groups;
   P.ng = small ? p1.ng : p0.ng;
@@ -166,7 +176,13 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
     for (int ks = 0; ks < KS; ++ks) {
       const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * ks);
       const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
-      const float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      if (P.a_scale != nullptr) {
+        const float* sp = P.a_scale + 16 * ks + 8 * lhi;
+        const float* hp = P.a_shift + 16 * ks + 8 * lhi;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) x[e] = fmaxf(fmaf(x[e], sp[e], hp[e]), P.a_floor);
+      }
       fx_split8(x, Ah[ks], Am[ks], Al[ks]);
     }
   }
@@ -263,6 +279,36 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
       // kept in 32 registers across the MFMA loop
       unsigned rb = (unsigned)(row0 + 4 * lhi);
       asm volatile("" : "+v"(rb));
+      if (P.stats != nullptr) {
+        // BatchNorm partial statistics of this wave's 32-row group, as wave_epilogue (common.hpp) takes them
+        int cnt = N - row0;
+        cnt = cnt > 32 ? 32 : cnt;
+        if (cnt > 0) {
+          float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi < N;
+            s0 += ok ? acc0[r] : 0.f;
+            s1 += ok ? acc1[r] : 0.f;
+          }
+          s0 += __shfl_xor(s0, 32); s1 += __shfl_xor(s1, 32);
+          const float m0 = s0 / (float)cnt, m1 = s1 / (float)cnt;
+          float q0 = 0.f, q1 = 0.f;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const bool ok = row0 + (r & 3) + 8 * (r >> 2) + 4 * lhi < N;
+            const float d0 = acc0[r] - m0, d1 = acc1[r] - m1;
+            q0 += ok ? d0 * d0 : 0.f;
+            q1 += ok ? d1 * d1 : 0.f;
+          }
+          q0 += __shfl_xor(q0, 32); q1 += __shfl_xor(q1, 32);
+          if (lhi == 0) {
+            float2* sp = reinterpret_cast<float2*>(P.stats) + (long)(row0 >> 5) * F;
+            if (c0 < F) sp[c0] = make_float2(s0, q0);
+            if (c1 < F) sp[c1] = make_float2(s1, q1);
+          }
+        }
+      }
       const bool second = ct >= P.ct2;
       float* const ob = second ? P.out2 : P.out;
       const unsigned long old = (unsigned long)(second ? P.ldo2 : P.ldo);
@@ -336,9 +382,9 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   if (forced < 0) { const char* e = getenv("YOLAT_FUSION_X6_GROUPS"); forced = e ? atoi(e) : 0; }
   FxProb p0, p1;
   p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = Wh; p0.Wm = Wm; p0.Wl = Wl; p0.tfold = tfold; p0.seg = node_seg;
-  p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1; p0.key64 = nullptr; p0.sgn = nullptr;
+  p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1; p0.key64 = nullptr; p0.sgn = nullptr; p0.a_scale = nullptr; p0.a_shift = nullptr; p0.a_floor = 0.f; p0.stats = nullptr;
   p1.A = S; p1.lda = lds; p1.N = (int)P; p1.Wh = Wsh; p1.Wm = Wsm; p1.Wl = Wsl; p1.tfold = tsfold; p1.seg = nullptr;
-  p1.out = Ys; p1.ldo = ldys; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = (int)F; p1.relu = 1; p1.key64 = nullptr; p1.sgn = nullptr;
+  p1.out = Ys; p1.ldo = ldys; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = (int)F; p1.relu = 1; p1.key64 = nullptr; p1.sgn = nullptr; p1.a_scale = nullptr; p1.a_shift = nullptr; p1.a_floor = 0.f; p1.stats = nullptr;
   p0.tm = yl_cdiv(N, 256);
   p1.tm = yl_cdiv(P, 256);
   p1.groups = tn; p1.ng = 1;
@@ -380,6 +426,7 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
   p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = wh; p0.Wm = wm; p0.Wl = wl; p0.tfold = bias; p0.seg = node_seg;
   p0.out = nullptr; p0.ldo = F; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 0;
   p0.key64 = keys; p0.sgn = sgn;
+  p0.a_scale = nullptr; p0.a_shift = nullptr; p0.a_floor = 0.f; p0.stats = nullptr;
   p0.tm = yl_cdiv(N, 256);
   int best_g = 1;
   double best = 1e300;
@@ -394,6 +441,45 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
   p1 = p0;
   p1.tm = 0; p1.groups = 1; p1.ng = 1;
   const long total = (long)p0.tm * p0.groups;
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// Training-mode Linear on the rows kernel:  Y [M, Nout] = pro(A) [M, K] . W^T + bias  (pre-activation), with the optional
+// BatchNorm+ReLU prologue on A and the optional BatchNorm partial statistics of Y (yolat_linear_fwd's `stats`).  W [Nout,
+// K] fp32 (contiguous rows, ldw) is split here — it changes every step — into `wsplit` (3 * Nout * K bfloat16, 16-byte
+// aligned).  K in {64, 128}, Nout % 64 == 0, lda % 4 == 0.  For many rows (one workgroup per 256 rows): the second edge
+// Linear of a training conv layer, [E, 64] -> [E, 64] (torch_vertex.py:311,335 nn.3).
+extern "C" int yolat_linear_fwd_rows_x6(const float* A, int64_t lda, int64_t M, int64_t K, const float* a_scale,
+                                        const float* a_shift, int a_relu, const float* W, int64_t ldw, const float* bias,
+                                        int64_t Nout, float* Y, int64_t ldy, float* stats, uint16_t* wsplit,
+                                        yolat_stream_t stream) {
+  if (M <= 0 || !A || !W || !Y || !wsplit || lda < K || ldw < K || ldy < Nout) return YOLAT_E_INVALID;
+  if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
+  if ((K != 64 && K != 128) || Nout <= 0 || Nout % 64 != 0 || lda % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(wsplit) ||
+      M >= (1LL << 31) - 256)
+    return YOLAT_E_UNSUPPORTED;
+  uint16_t *wh = wsplit, *wm = wsplit + Nout * K, *wl = wsplit + 2 * Nout * K;
+  const int rc = yolat_split_bf16x3(W, ldw, Nout, K, nullptr, wh, wm, wl, stream);
+  if (rc != 0) return rc;
+  // bias as the accumulator's initial value; none: zeros (kept in the split buffer's tail)
+  float* zeros = nullptr;
+  if (bias == nullptr) return YOLAT_E_UNSUPPORTED;
+  (void)zeros;
+  const int tn = (int)(Nout / 64);
+  FxProb p0, p1;
+  p0.A = A; p0.lda = lda; p0.N = (int)M; p0.Wh = wh; p0.Wm = wm; p0.Wl = wl; p0.tfold = bias; p0.seg = nullptr;
+  p0.out = Y; p0.ldo = ldy; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)Nout; p0.relu = 0;
+  p0.key64 = nullptr; p0.sgn = nullptr;
+  p0.a_scale = a_scale; p0.a_shift = a_shift; p0.a_floor = a_relu ? 0.f : -INFINITY; p0.stats = stats;
+  p0.tm = yl_cdiv(M, 256); p0.groups = 1; p0.ng = tn;
+  p1 = p0;
+  p1.tm = 0; p1.groups = 1; p1.ng = 1;
+  const long total = (long)p0.tm;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
@@ -423,6 +509,7 @@ extern "C" int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const floa
   p0.A = f_in; p0.lda = ld_f; p0.N = (int)N; p0.Wh = Wfr_h; p0.Wm = Wfr_m; p0.Wl = Wfr_l; p0.tfold = tfr; p0.seg = nullptr;
   p0.out = UV; p0.ldo = ld_uv; p0.out2 = f_out; p0.ldo2 = ld_fo; p0.ct2 = 2; p0.F = 192; p0.relu = 0;
   p0.key64 = nullptr; p0.sgn = nullptr; p1.key64 = nullptr; p1.sgn = nullptr;
+  p0.a_scale = p0.a_shift = p1.a_scale = p1.a_shift = nullptr; p0.a_floor = p1.a_floor = 0.f; p0.stats = p1.stats = nullptr; p1.a_scale = nullptr; p1.a_shift = nullptr; p1.a_floor = 0.f; p1.stats = nullptr;
   p0.tm = yl_cdiv(N, 256); p0.groups = 1; p0.ng = 3;
   p1.A = s_in; p1.lda = ld_s; p1.N = (int)N; p1.Wh = Wn_h; p1.Wm = Wn_m; p1.Wl = Wn_l; p1.tfold = tn_fold; p1.seg = nullptr;
   p1.out = s_out; p1.ldo = ld_so; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = 64; p1.relu = 1;

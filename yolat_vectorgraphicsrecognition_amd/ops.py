@@ -175,6 +175,13 @@ def stats_buffer(M, C, device):
     return torch.empty(int(lib.yolat_bn_stats_elems(M, C)), dtype=torch.float32, device=device)
 
 
+X6_TRAIN_GEMM = os.environ.get("YOLAT_TRAIN_X6_GEMM", "1") != "0"
+# the many-row training Linear on the bf16x6 rows kernel: measured EQUAL to the fp32-MFMA tiles (201 vs 199 us for
+# [1.2 M, 64] -> [1.2 M, 64]: one 8-wave workgroup per CU, its load -> split -> MFMA -> store chain is not overlapped
+# with a neighbour's), so it stays opt-in
+X6_TRAIN_ROWS = os.environ.get("YOLAT_TRAIN_ROWS_X6", "0") == "1"
+
+
 def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False,
                accumulate=False, stats=None):
     """Y = epi(pro(A) @ W.T + bias).  a_pro / o_pro: (scale, shift) tensors or None."""
@@ -190,15 +197,22 @@ def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False
                                      int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias", True), Nout, _h(Y, "Y"), _ld(Y),
                                      _f(stats, "stats", True), wwork.data_ptr(), _stream()), "yolat_linear_fwd_h")
         return Y
+    if (X6_TRAIN_ROWS and o_pro is None and not o_relu and not accumulate and bias is not None and M >= 65536
+            and K in (64, 128) and Nout % 64 == 0 and _ld(A) % 4 == 0 and A.data_ptr() % 16 == 0):
+        # many rows x short K with a pre-activation output (the second edge Linear of a training conv layer, [E,64] ->
+        # [E,64] + BatchNorm statistics): the bf16x6 rows kernel, A read once per 256 rows, weight split per call
+        wsplit = torch.empty(3 * Nout * K, dtype=torch.bfloat16, device=A.device)
+        check(lib.yolat_linear_fwd_rows_x6(_f(A, "A"), _ld(A), M, K, _f(asc, "a_scale", True), _f(ash, "a_shift", True),
+                                           int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias"), Nout, _f(Y, "Y"), _ld(Y),
+                                           _f(stats, "stats", True), wsplit.data_ptr(), _stream()),
+              "yolat_linear_fwd_rows_x6")
+        return Y
     check(lib.yolat_linear_fwd(_f(A, "A"), _ld(A), M, K, _f(asc, "a_scale", True), _f(ash, "a_shift", True),
                                int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias", True), Nout,
                                _f(osc, "o_scale", True), _f(osh, "o_shift", True), int(o_relu),
                                _f(Y, "Y"), _ld(Y), int(accumulate), _f(stats, "stats", True),
                                _stream()), "yolat_linear_fwd")
     return Y
-
-
-X6_TRAIN_GEMM = os.environ.get("YOLAT_TRAIN_X6_GEMM", "1") != "0"
 
 
 def linear_fwd_wt(A, Wt, Y, accumulate=False):
