@@ -298,6 +298,21 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   if (tid <= 16 * NG) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
   const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t
   const int col = wn * 32 + l31;                      // MFMA role: output column of this lane
+  // the tile's edge range straight from global (same two addresses in every lane: one broadcast load each), so that
+  // the first pass's index loads go out before the barrier below instead of after it, and the f_out rows this thread
+  // finishes with at the very end: both shorten the workgroup's chain of dependent global round trips, which is what
+  // a small graph's launch time consists of (715 workgroups, all resident at once, at E = 40 k)
+  const int e0g = row_ptr[n0], e1g = row_ptr[n0 + nn];
+  int di0[4], si0[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = yl_min(e0g + rb + 16 * t, E - 1);
+    di0[t] = dst[e]; si0[t] = src[e];
+  }
+  float4 fo[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j)
+    fo[j] = *reinterpret_cast<const float4*>(f_out + (long)yl_min(n0 + rb + 16 * j, N - 1) * ld_fo + 4 * q);
   float rw2[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
@@ -318,7 +333,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
     d[0] = rw2[t][0]; d[1] = rw2[t][1]; d[2] = rw2[t][2]; d[3] = rw2[t][3];
   }
   __syncthreads();
-  const int e0 = rp[0], e1 = rp[nn];
+  const int e0 = e0g, e1 = e1g;
   int my_b[NG], my_e[NG];                             // aggregation role: nodes rb + 16 j, columns 4q..
   float4 sum[NG];
 #pragma unroll
@@ -330,8 +345,11 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
     int di[4], si[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const int e = yl_min(c0 + rb + 16 * t, E - 1);
-      di[t] = dst[e]; si[t] = src[e];
+      if (c0 == e0) { di[t] = di0[t]; si[t] = si0[t]; }          // loaded before the barrier
+      else {
+        const int e = yl_min(c0 + rb + 16 * t, E - 1);
+        di[t] = dst[e]; si[t] = src[e];
+      }
     }
     float4 u[4], v[4], a[4];
 #pragma unroll
@@ -390,7 +408,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
     if (rb + 16 * j < nn && deg > 0) {
       const float inv = 1.f / (float)deg;
       float4* o = reinterpret_cast<float4*>(f_out + (long)(n0 + rb + 16 * j) * ld_fo + 4 * q);
-      float4 d = *o;
+      float4 d = fo[j];                                // this workgroup is the only writer of its nodes' rows
       // explicit mul then add (no fma contraction): the same two roundings as k_csr_mean_fwd*
       d.x = yl_mul_rn(sum[j].x, inv) + d.x; d.y = yl_mul_rn(sum[j].y, inv) + d.y;
       d.z = yl_mul_rn(sum[j].z, inv) + d.z; d.w = yl_mul_rn(sum[j].w, inv) + d.w;
