@@ -585,11 +585,14 @@ typedef struct {
   const float* d_out; int64_t ld_out;   /* [N, C] gradient w.r.t. the aggregated output                        */
   const int32_t* dst;                   /* [E] destination node of every CSR slot                              */
   const float* inv_deg;                 /* [N] 1 / max(in-degree, 1)                                           */
-  const float* Y; int64_t ldy;          /* [E, C] BatchNorm input (the second edge Linear's pre-activation)    */
+  const void* Y; int64_t ldy;           /* [E, C] BatchNorm input (the second edge Linear's pre-activation): fp32,
+                                         * or bfloat16-stored when `half` != 0                                  */
   const float *mean, *invstd;           /* [C] saved batch statistics                                          */
   const float *scale, *shift;           /* [C] gamma * invstd, beta - mean * scale                             */
   const float* coef;                    /* [2C] (c1 | c2) written by yolat_bn_csr_bwd_stats                    */
-  int32_t relu, reserved;
+  int32_t relu;
+  int32_t half;                         /* bfloat16 storage of Y (and of A / dA in yolat_bn_csr_l2_bwd); the loader-
+                                         * fused GEMM entry points are fp32 only                                 */
 } yolat_bn_csr_grad;
 size_t yolat_bn_csr_work_elems(int64_t E, int64_t C);
 int yolat_bn_csr_bwd_stats(const yolat_bn_csr_grad* g, int64_t E, int64_t C, float* dgamma, float* dbeta, int accumulate,
@@ -602,9 +605,9 @@ int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, co
 /* both of the above in ONE kernel for C = K = Nout = 64 (the edge MLP's second Linear): dY tiles formed once.  work:
  * yolat_bn_csr_l2_bwd_work_elems() floats.                                                                     */
 size_t yolat_bn_csr_l2_bwd_work_elems(void);
-int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const float* A, int64_t lda, const float* a_scale,
+int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const void* A, int64_t lda, const float* a_scale,
                         const float* a_shift, int a_relu, const float* W, int64_t ldw, float* dW, int64_t lddw, float* db,
-                        int accumulate, float* dA, int64_t ldda, float* work, yolat_stream_t stream);
+                        int accumulate, void* dA, int64_t ldda, float* work, yolat_stream_t stream);
 
 /* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
  * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).

@@ -394,3 +394,45 @@ def test_bf16_storage_ops_round_to_nearest_even_and_reject_fp32_mixups():
     assert torch.equal(out32, out16)                                   # exact widening, same summation order
     with pytest.raises(ValueError):
         yv.ops.linear_fwd(dm16, torch.randn(64, 64, device="cuda"), None, torch.empty(E, 64, device="cuda"))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("N,E", [(300, 1000), (4000, 30000)])
+def test_fused_bn_csr_backward_bf16_storage_matches_fp32_on_the_same_values(N, E):
+    """ops.BnCsrGrad with bfloat16-STORED Y / A / dA (bn_csr.hip, one-kernel form): the fp32 instantiation run on the
+    same (bf16-representable) values is the reference — dgamma / dbeta / dW / db agree to fp32 summation noise, dA to one
+    bf16 rounding of the output."""
+    import numpy as np
+    yv = _yv()
+    C = 64
+    rng = np.random.default_rng(N + E)
+    src = rng.integers(0, N, E); dst = np.sort(rng.integers(0, N, E))
+    g = yv.ops.build_graph(torch.from_numpy(np.stack([src, dst], 1)).cuda(), torch.rand(E, 4).cuda(), None, N, 1)
+    tg = torch.Generator().manual_seed(E)
+    d_f = torch.randn(N, C, generator=tg).cuda()
+    H2 = torch.randn(E, C, generator=tg).cuda().bfloat16()
+    H1 = torch.randn(E, C, generator=tg).cuda().bfloat16()
+    W = (torch.randn(C, C, generator=tg) / 8).cuda()
+    c1 = torch.stack([torch.rand(C, generator=tg) + 0.5, torch.randn(C, generator=tg)]).cuda()
+    gamma, beta = (torch.rand(C, generator=tg) + 0.5).cuda(), torch.randn(C, generator=tg).cuda()
+    h2f = H2.float()
+    mean, invstd = h2f.mean(0), 1 / torch.sqrt(h2f.var(0, unbiased=False) + 1e-5)
+    scale = gamma * invstd
+    coefs = torch.stack([scale, beta - mean * scale, mean, invstd]).contiguous()
+
+    def run(Y, A, dt):
+        dg, db = torch.empty(C).cuda(), torch.empty(C).cuda()
+        dW, dbias, dA = torch.empty(C, C).cuda(), torch.empty(C).cuda(), torch.empty(E, C, dtype=dt).cuda()
+        h = yv.ops.BnCsrGrad(d_f, g, Y, coefs[2], coefs[3], coefs[0], coefs[1], relu=True)
+        h.stats(dg, db)
+        h.bwd_w_and_x(A, W, dW, dbias, dA, a_pro=(c1[0], c1[1]), a_relu=True)
+        return dg, db, dW, dbias, dA.float()
+    ref = run(h2f, H1.float(), torch.float32)
+    got = run(H2, H1, torch.bfloat16)
+    for name, a, b in zip(("dgamma", "dbeta", "dW", "db"), ref[:4], got[:4]):
+        tol = 2e-5 * (float(ref[4].abs().sum(0).max()) if name == "db" else max(float(a.abs().max()), 1e-6))
+        assert float((a - b).abs().max()) <= tol, name
+    assert float((ref[4] - got[4]).abs().max()) <= 2.0 ** -8 * float(ref[4].abs().max())
+    again = run(H2, H1, torch.bfloat16)
+    for a, b in zip(got, again):
+        assert torch.equal(a, b)

@@ -42,7 +42,7 @@ class BnCsrGrad(ctypes.Structure):
     """yolat_bn_csr_grad (include/yolat_hip.h)"""
     _fields_ = [("d_out", c_p), ("ld_out", c_i64), ("dst", c_p), ("inv_deg", c_p), ("Y", c_p), ("ldy", c_i64),
                 ("mean", c_p), ("invstd", c_p), ("scale", c_p), ("shift", c_p), ("coef", c_p),
-                ("relu", ctypes.c_int32), ("reserved", ctypes.c_int32)]
+                ("relu", ctypes.c_int32), ("half", ctypes.c_int32)]
 
 
 class ModelEvalBf16(ctypes.Structure):

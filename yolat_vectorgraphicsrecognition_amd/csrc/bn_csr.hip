@@ -14,10 +14,11 @@
 #include "common.hpp"
 
 // dY rows formed on the fly (loader contract of the GEMM tile kernels, common.hpp)
-struct BnCsrOp {
+template <class T>
+struct BnCsrOpT {
   const float* dout; long ldo;           // [N, C]
   const int* dst; const float* inv_deg;  // [E], [N]
-  const float* Y; long ldy;              // [E, C]
+  const T* Y; long ldy;                  // [E, C], fp32 or bfloat16-stored
   const float *mean, *invstd, *scale, *shift, *coef;   // [C] each, coef [2C]
   int C, relu;
   int rows, cols, vec;
@@ -35,7 +36,7 @@ struct BnCsrOp {
     const float w = inv_deg[n];
     if (FAST) {
       const float4 g = *reinterpret_cast<const float4*>(dout + (long)n * ldo + k);
-      const float4 y = *reinterpret_cast<const float4*>(Y + (long)rr * ldy + k);
+      const float4 y = yl_ld4(Y + (long)rr * ldy + k);
       const float4 mu = *reinterpret_cast<const float4*>(mean + k), is = *reinterpret_cast<const float4*>(invstd + k);
       const float4 sc = *reinterpret_cast<const float4*>(scale + k), sh = *reinterpret_cast<const float4*>(shift + k);
       const float4 k1 = *reinterpret_cast<const float4*>(coef + k), k2 = *reinterpret_cast<const float4*>(coef + C + k);
@@ -47,21 +48,23 @@ struct BnCsrOp {
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         const int kc = yl_min(k + j, cols - 1);
-        const float t = one(dout[(long)n * ldo + kc], w, Y[(long)rr * ldy + kc], mean[kc], invstd[kc], scale[kc], shift[kc],
-                            coef[kc], coef[C + kc]);
+        const float t = one(dout[(long)n * ldo + kc], w, yl_ld1(Y + (long)rr * ldy + kc), mean[kc], invstd[kc], scale[kc],
+                            shift[kc], coef[kc], coef[C + kc]);
         v[j] = (k + j < cols) ? t : 0.f;
       }
     }
   }
 };
+typedef BnCsrOpT<float> BnCsrOp;
 
 namespace {
 #define BCS_ROWS 512
 // per 512-row block and column: (sum g, sum g*xhat), g = relu'(.) * d_out[dst] / deg — k_bn_bwd_partial_v4 with the
 // gradient gathered instead of read
+template <class T>
 __global__ void __launch_bounds__(256) k_bn_csr_partial(const float* __restrict__ dout, long ldo,
                                                         const int* __restrict__ dst, const float* __restrict__ inv_deg,
-                                                        const float* __restrict__ Y, long ldy, long M, int C,
+                                                        const T* __restrict__ Y, long ldy, long M, int C,
                                                         const float* __restrict__ mean, const float* __restrict__ invstd,
                                                         const float* __restrict__ scale, const float* __restrict__ shift,
                                                         int relu, float2* part) {
@@ -88,7 +91,7 @@ __global__ void __launch_bounds__(256) k_bn_csr_partial(const float* __restrict_
         const long rr = (r + 16 * k < r1) ? r + 16 * k : r1 - 1;
         const int n = dst[rr];
         w[k] = inv_deg[n];
-        y[k] = *reinterpret_cast<const float4*>(Y + rr * ldy + c);
+        y[k] = yl_ld4(Y + rr * ldy + c);
         g[k] = *reinterpret_cast<const float4*>(dout + (long)n * ldo + c);
       }
 #pragma unroll
@@ -176,16 +179,19 @@ int check_grad(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
   if (g->ld_out < C || g->ldy < C) return YOLAT_E_INVALID;
   return 0;
 }
-BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
-  BnCsrOp o;
-  o.dout = g->d_out; o.ldo = g->ld_out; o.dst = g->dst; o.inv_deg = g->inv_deg; o.Y = g->Y; o.ldy = g->ldy;
+template <class T>
+BnCsrOpT<T> make_op_t(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
+  BnCsrOpT<T> o;
+  o.dout = g->d_out; o.ldo = g->ld_out; o.dst = g->dst; o.inv_deg = g->inv_deg;
+  o.Y = reinterpret_cast<const T*>(g->Y); o.ldy = g->ldy;
   o.mean = g->mean; o.invstd = g->invstd; o.scale = g->scale; o.shift = g->shift; o.coef = g->coef;
   o.C = (int)C; o.relu = g->relu; o.rows = (int)E; o.cols = (int)C;
-  o.vec = (C % 4 == 0) && (g->ld_out % 4 == 0) && (g->ldy % 4 == 0) && yl_aligned16(g->d_out) && yl_aligned16(g->Y) &&
-          yl_aligned16(g->mean) && yl_aligned16(g->invstd) && yl_aligned16(g->scale) && yl_aligned16(g->shift) &&
-          yl_aligned16(g->coef);
+  o.vec = (C % 4 == 0) && (g->ld_out % 4 == 0) && (g->ldy % 4 == 0) && yl_aligned16(g->d_out) &&
+          ((uintptr_t)g->Y % (4 * sizeof(T)) == 0) && yl_aligned16(g->mean) && yl_aligned16(g->invstd) &&
+          yl_aligned16(g->scale) && yl_aligned16(g->shift) && yl_aligned16(g->coef);
   return o;
 }
+BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) { return make_op_t<float>(g, E, C); }
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -198,10 +204,13 @@ BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) {
 // fixed order by k_reduce_splits: deterministic.
 // ------------------------------------------------------------------------------------------------------------------
 #define BCL_WGS 512
-__global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOp y, const float* __restrict__ A, long lda,
+__device__ __forceinline__ void bcl_store(float* p, float v) { *p = v; }
+__device__ __forceinline__ void bcl_store(yl_bf16_t* p, float v) { *p = (yl_bf16_t)(yl_pack_bf16(v, 0.f) & 0xffffu); }
+template <class T>
+__global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* __restrict__ A, long lda,
                                                        const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                        float a_floor, const float* __restrict__ W, long ldw,
-                                                       float* __restrict__ dA, long ldda, int E, int tiles_per_wg,
+                                                       T* __restrict__ dA, long ldda, int E, int tiles_per_wg,
                                                        float* __restrict__ partial) {
   constexpr int LD = 65;
   __shared__ float Ds[64 * LD], As[64 * LD], Ws[64 * LD];
@@ -237,9 +246,9 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOp y, const float* _
       const int e = yl_min(tile * 64 + rb + 16 * t, E - 1);
       const int n = y.dst[e];
       rw[t] = y.inv_deg[n];
-      ry[t] = *reinterpret_cast<const float4*>(y.Y + (long)e * y.ldy + 4 * q);
+      ry[t] = yl_ld4(y.Y + (long)e * y.ldy + 4 * q);
       rg[t] = *reinterpret_cast<const float4*>(y.dout + (long)n * y.ldo + 4 * q);
-      ra[t] = *reinterpret_cast<const float4*>(A + (long)e * lda + 4 * q);
+      ra[t] = yl_ld4(A + (long)e * lda + 4 * q);
     }
   };
   if (t0 < t1) fetch(t0);
@@ -286,13 +295,13 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOp y, const float* _
       for (int r = 0; r < 16; ++r) s += Ds[(wave * 16 + r) * LD + lane];
       dbs[wave][lane] = s;
     }
-    // ---- store the dA tile
+    // ---- store the dA tile (bfloat16 storage: round to nearest even, as yl_st4 does)
     {
       const int col = wn * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int row = tile * 64 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
-        if (row < E) dA[(long)row * ldda + col] = acca[r];
+        if (row < E) bcl_store(dA + (long)row * ldda + col, acca[r]);
       }
     }
     __syncthreads();                                     // all reads of Ds / As done; dbs complete
@@ -311,16 +320,16 @@ extern "C" size_t yolat_bn_csr_l2_bwd_work_elems(void) { return (size_t)BCL_WGS 
 
 // C = K = Nout = 64 only.  dW [64, 64] (+= when accumulate) = dY^T . pro(A), db [64] (+=) = column sums of dY (nullable),
 // dA [E, 64] = dY . W (W = the Linear's weight [64, 64], row-major).  work: yolat_bn_csr_l2_bwd_work_elems() floats.
-extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const float* A, int64_t lda, const float* a_scale,
+extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const void* A, int64_t lda, const float* a_scale,
                                    const float* a_shift, int a_relu, const float* W, int64_t ldw, float* dW, int64_t lddw,
-                                   float* db, int accumulate, float* dA, int64_t ldda, float* work,
+                                   float* db, int accumulate, void* dA, int64_t ldda, float* work,
                                    yolat_stream_t stream) {
   const int rc = check_grad(g, E, 64);
   if (rc) return rc;
   if (!A || !W || !dW || !dA || !work || lda < 64 || ldw < 64 || lddw < 64 || ldda < 64) return YOLAT_E_INVALID;
   if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
-  BnCsrOp y = make_op(g, E, 64);
-  if (!y.vec || lda % 4 != 0 || ldw % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(W) ||
+  const size_t al = g->half ? 8 : 16;
+  if (lda % 4 != 0 || ldw % 4 != 0 || ((uintptr_t)A % al) != 0 || !yl_aligned16(W) ||
       (a_scale && (!yl_aligned16(a_scale) || !yl_aligned16(a_shift))))
     return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
@@ -328,8 +337,19 @@ extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const 
   int wgs = ntiles < BCL_WGS ? ntiles : BCL_WGS;
   const int per = yl_cdiv(ntiles, wgs);
   wgs = yl_cdiv(ntiles, per);
-  hipLaunchKernelGGL(k_bn_csr_l2_bwd, dim3(wgs), dim3(256), 0, st, y, A, (long)lda, a_scale, a_shift,
-                     a_relu ? 0.f : -INFINITY, W, (long)ldw, dA, (long)ldda, (int)E, per, work);
+  const float floor = a_relu ? 0.f : -INFINITY;
+  if (g->half) {
+    BnCsrOpT<yl_bf16_t> y = make_op_t<yl_bf16_t>(g, E, 64);
+    if (!y.vec) return YOLAT_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_bn_csr_l2_bwd<yl_bf16_t>, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const yl_bf16_t*>(A),
+                       (long)lda, a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<yl_bf16_t*>(dA), (long)ldda, (int)E,
+                       per, work);
+  } else {
+    BnCsrOp y = make_op(g, E, 64);
+    if (!y.vec) return YOLAT_E_UNSUPPORTED;
+    hipLaunchKernelGGL(k_bn_csr_l2_bwd<float>, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const float*>(A), (long)lda,
+                       a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<float*>(dA), (long)ldda, (int)E, per, work);
+  }
   YL_LAUNCH_CHECK();
   // partial layout [wg][64*64 | 64]: reduce the two pieces with the element stride of the slab
   hipLaunchKernelGGL(k_reduce_slabs, dim3(yl_cdiv(64 * 64 + 64, 256)), dim3(256), 0, st, work, wgs, 64 * 64 + 64, dW,
@@ -348,15 +368,21 @@ extern "C" int yolat_bn_csr_bwd_stats(const yolat_bn_csr_grad* g, int64_t E, int
   if (!g->d_out || !g->dst || !g->inv_deg || !g->Y || !g->mean || !g->invstd || !g->scale || !g->shift)
     return YOLAT_E_INVALID;
   if (g->ld_out < C || g->ldy < C) return YOLAT_E_INVALID;
-  if (C % 4 != 0 || g->ld_out % 4 != 0 || g->ldy % 4 != 0 || !yl_aligned16(g->d_out) || !yl_aligned16(g->Y) ||
-      !yl_aligned16(g->mean) || !yl_aligned16(g->invstd) || !yl_aligned16(g->scale) || !yl_aligned16(g->shift))
+  if (C % 4 != 0 || g->ld_out % 4 != 0 || g->ldy % 4 != 0 || !yl_aligned16(g->d_out) ||
+      ((uintptr_t)g->Y % (g->half ? 8 : 16)) != 0 || !yl_aligned16(g->mean) || !yl_aligned16(g->invstd) ||
+      !yl_aligned16(g->scale) || !yl_aligned16(g->shift))
     return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   const long nb = yl_cdiv(E, BCS_ROWS);
   float2* part = reinterpret_cast<float2*>(work);
-  hipLaunchKernelGGL(k_bn_csr_partial, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, g->d_out, (long)g->ld_out,
-                     g->dst, g->inv_deg, g->Y, (long)g->ldy, (long)E, (int)C, g->mean, g->invstd, g->scale, g->shift,
-                     g->relu, part);
+  if (g->half)
+    hipLaunchKernelGGL(k_bn_csr_partial<yl_bf16_t>, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, g->d_out,
+                       (long)g->ld_out, g->dst, g->inv_deg, reinterpret_cast<const yl_bf16_t*>(g->Y), (long)g->ldy, (long)E,
+                       (int)C, g->mean, g->invstd, g->scale, g->shift, g->relu, part);
+  else
+  hipLaunchKernelGGL(k_bn_csr_partial<float>, dim3(yl_cdiv(C, 64), (unsigned)nb), dim3(256), 0, st, g->d_out, (long)g->ld_out,
+                     g->dst, g->inv_deg, reinterpret_cast<const float*>(g->Y), (long)g->ldy, (long)E, (int)C, g->mean, g->invstd,
+                     g->scale, g->shift, g->relu, part);
   YL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_csr_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, part, nb, (long)E, (int)C, dgamma, dbeta,
                      accumulate, coef_out);
@@ -371,6 +397,7 @@ extern "C" int yolat_linear_bwd_w_csr(const yolat_bn_csr_grad* g, int64_t E, int
                                       int64_t lddw, float* db, int accumulate, float* partial, yolat_stream_t stream) {
   const int rc = check_grad(g, E, C);
   if (rc) return rc;
+  if (g->half) return YOLAT_E_UNSUPPORTED;             // bfloat16 storage: yolat_bn_csr_l2_bwd only
   if (K <= 0 || !A || !dW || !partial || lda < K || lddw < K) return YOLAT_E_INVALID;
   if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
@@ -405,6 +432,7 @@ extern "C" int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, in
                                        int64_t Nout, float* dA, int64_t ldda, yolat_stream_t stream) {
   const int rc = check_grad(g, E, C);
   if (rc) return rc;
+  if (g->half) return YOLAT_E_UNSUPPORTED;
   if (Nout <= 0 || !W || !dA || ldw < Nout || ldda < Nout) return YOLAT_E_INVALID;
   BnCsrOp a = make_op(g, E, C);
   TransOp b;

@@ -458,7 +458,7 @@ extern "C" int yolat_linear_fwd_rows_x6(const float* A, int64_t lda, int64_t M, 
                                         const float* a_shift, int a_relu, const float* W, int64_t ldw, const float* bias,
                                         int64_t Nout, float* Y, int64_t ldy, float* stats, uint16_t* wsplit,
                                         yolat_stream_t stream) {
-  if (M <= 0 || !A || !W || !Y || !wsplit || lda < K || ldw < K || ldy < Nout) return YOLAT_E_INVALID;
+  if (M <= 0 || !A || !W || !bias || !Y || !wsplit || lda < K || ldw < K || ldy < Nout) return YOLAT_E_INVALID;
   if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
   if ((K != 64 && K != 128) || Nout <= 0 || Nout % 64 != 0 || lda % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(wsplit) ||
       M >= (1LL << 31) - 256)
@@ -466,11 +466,7 @@ extern "C" int yolat_linear_fwd_rows_x6(const float* A, int64_t lda, int64_t M, 
   uint16_t *wh = wsplit, *wm = wsplit + Nout * K, *wl = wsplit + 2 * Nout * K;
   const int rc = yolat_split_bf16x3(W, ldw, Nout, K, nullptr, wh, wm, wl, stream);
   if (rc != 0) return rc;
-  // bias as the accumulator's initial value; none: zeros (kept in the split buffer's tail)
-  float* zeros = nullptr;
-  if (bias == nullptr) return YOLAT_E_UNSUPPORTED;
-  (void)zeros;
-  const int tn = (int)(Nout / 64);
+  const int tn = (int)(Nout / 64);                     // the bias is the accumulators' initial value
   FxProb p0, p1;
   p0.A = A; p0.lda = lda; p0.N = (int)M; p0.Wh = wh; p0.Wm = wm; p0.Wl = wl; p0.tfold = bias; p0.seg = nullptr;
   p0.out = Y; p0.ldo = ldy; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)Nout; p0.relu = 0;

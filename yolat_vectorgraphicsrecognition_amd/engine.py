@@ -255,12 +255,14 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
     if E > 0:
         H1, H2, c1, c2 = sv["H1"], sv["H2"], sv["c1"], sv["c2"]
         dA1 = torch.empty(E, C, dtype=H1.dtype, device=dev)
-        if FUSED_BN_CSR_BWD and H1.dtype == torch.float32 and C % 4 == 0 and d_f.stride(0) % 4 == 0:
+        one_kernel = C == 64 and nn3.in_features == 64 and nn3.weight.is_contiguous()
+        if (FUSED_BN_CSR_BWD and C % 4 == 0 and d_f.stride(0) % 4 == 0
+                and (H1.dtype == torch.float32 or one_kernel)):
             # the gradient w.r.t. H2 (mean aggregation -> ReLU -> BatchNorm backward) is formed inside its two consumers
             # instead of being written and re-read: 5 instead of 11 passes over [E,C] (bn_csr.hip)
             dh2 = ops.BnCsrGrad(d_f, g, H2, c2[2], c2[3], c2[0], c2[1], relu=True)
             dh2.stats(sink.get(bn4.weight), sink.get(bn4.bias))
-            if C == 64 and nn3.in_features == 64 and nn3.weight.is_contiguous():
+            if one_kernel:
                 dh2.bwd_w_and_x(H1, nn3.weight, sink.get(nn3.weight), sink.get(nn3.bias), dA1, a_pro=(c1[0], c1[1]),
                                 a_relu=True)
             else:

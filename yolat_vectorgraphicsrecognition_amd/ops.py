@@ -275,7 +275,8 @@ class BnCsrGrad(object):
         d = _S()
         d.d_out, d.ld_out = _f(d_out, "d_out"), _ld(d_out)
         d.dst, d.inv_deg = g.dst.data_ptr(), g.inv_deg().data_ptr()
-        d.Y, d.ldy = _f(Y, "Y"), _ld(Y)
+        d.half = int(_is_h(Y))
+        d.Y, d.ldy = (_h(Y, "Y") if d.half else _f(Y, "Y")), _ld(Y)
         d.mean, d.invstd, d.scale, d.shift = _f(save_mean), _f(save_invstd), _f(scale), _f(shift)
         d.coef, d.relu = self.coef.data_ptr(), int(relu)
         self._d = d
@@ -300,10 +301,14 @@ class BnCsrGrad(object):
         """dW (+)= dY^T . pro(A), db (+)= column sums, dA = dY . W in one kernel (C = K = 64)."""
         asc, ash = (a_pro if a_pro is not None else (None, None))
         work = torch.empty(int(lib.yolat_bn_csr_l2_bwd_work_elems()), dtype=torch.float32, device=self.dev)
-        check(lib.yolat_bn_csr_l2_bwd(ctypes.byref(self._d), self.E, _f(A, "A"), _ld(A), _f(asc, "a_scale", True),
-                                      _f(ash, "a_shift", True), int(a_relu), _f(W, "W"), _ld(W), _f(dW, "dW"), _ld(dW),
-                                      _f(db, "db", True), int(accumulate), _f(dA, "dA"), _ld(dA), work.data_ptr(),
-                                      _stream()), "yolat_bn_csr_l2_bwd")
+        hp = bool(self._d.half)
+        if _is_h(A) != hp or _is_h(dA) != hp:
+            raise ValueError("BnCsrGrad.bwd_w_and_x: A and dA must use the storage type of Y")
+        check(lib.yolat_bn_csr_l2_bwd(ctypes.byref(self._d), self.E, _h(A, "A") if hp else _f(A, "A"), _ld(A),
+                                      _f(asc, "a_scale", True), _f(ash, "a_shift", True), int(a_relu), _f(W, "W"), _ld(W),
+                                      _f(dW, "dW"), _ld(dW), _f(db, "db", True), int(accumulate),
+                                      _h(dA, "dA") if hp else _f(dA, "dA"), _ld(dA), work.data_ptr(), _stream()),
+              "yolat_bn_csr_l2_bwd")
         return dA
 
     def fwd_wt(self, W, dA):
