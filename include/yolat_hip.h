@@ -605,9 +605,17 @@ int yolat_linear_fwd_wt_csr(const yolat_bn_csr_grad* g, int64_t E, int64_t C, co
 /* both of the above in ONE kernel for C = K = Nout = 64 (the edge MLP's second Linear): dY tiles formed once.  work:
  * yolat_bn_csr_l2_bwd_work_elems() floats.                                                                     */
 size_t yolat_bn_csr_l2_bwd_work_elems(void);
+/* next_mean != NULL: also the statistics of the BatchNorm in front of A (a_scale / a_shift / a_relu describe it) for ITS
+ * backward on dA: next_dgamma / next_dbeta [64], next_coef [128] = (c1 | c2) for yolat_bn_relu_bwd_apply.             */
 int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const void* A, int64_t lda, const float* a_scale,
                         const float* a_shift, int a_relu, const float* W, int64_t ldw, float* dW, int64_t lddw, float* db,
-                        int accumulate, void* dA, int64_t ldda, float* work, yolat_stream_t stream);
+                        int accumulate, void* dA, int64_t ldda, float* work, const float* next_mean,
+                        const float* next_invstd, float* next_dgamma, float* next_dbeta, float* next_coef,
+                        yolat_stream_t stream);
+/* the apply pass of yolat_bn_relu_bwd alone (coefficients given); half != 0: bfloat16-stored dZ / Y / dY           */
+int yolat_bn_relu_bwd_apply(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t M, int64_t C,
+                            const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
+                            int relu, const float* coef, void* dY, int64_t lddy, int half, yolat_stream_t stream);
 
 /* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
  * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).

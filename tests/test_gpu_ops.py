@@ -979,6 +979,27 @@ def test_fused_bn_csr_backward_matches_materialised_path(N, E):
         assert float((a - b).abs().max()) <= 2e-5 * ref_scale, name
     for a, b in zip(one, fused_one_kernel()):
         assert torch.equal(a, b)
+    # ... and with the statistics of the NEXT BatchNorm's backward (the one behind the prologue of A) taken in the same
+    # kernel: against bn_relu_bwd on the materialised dA
+    m1, is1 = H1.mean(0), 1 / torch.sqrt(H1.var(0, unbiased=False) + 1e-5)
+    g1 = (torch.rand(C, generator=tg) + 0.5).cuda()
+    b1 = torch.randn(C, generator=tg).cuda()
+    cc1 = torch.stack([g1 * is1, b1 - m1 * g1 * is1, m1, is1]).contiguous()
+    dW_r, dbias_r = torch.empty(C, C).cuda(), torch.empty(C).cuda()
+    yv.ops.linear_bwd_w(dM, H1, dW_r, dbias_r, a_pro=(cc1[0], cc1[1]), a_relu=True)
+    dg1_r, db1_r, dH1_r = torch.empty(C).cuda(), torch.empty(C).cuda(), torch.empty(E, C).cuda()
+    yv.ops.bn_relu_bwd(dA_a, H1, g1, cc1[2], cc1[3], cc1[0], cc1[1], True, dg1_r, db1_r, dH1_r)
+    h = yv.ops.BnCsrGrad(d_f, g, H2, coefs[2], coefs[3], coefs[0], coefs[1], relu=True)
+    h.stats(torch.empty(C).cuda(), torch.empty(C).cuda())
+    dW_n, dbias_n, dA_n = torch.empty(C, C).cuda(), torch.empty(C).cuda(), torch.empty(E, C).cuda()
+    dg1_n, db1_n = torch.empty(C).cuda(), torch.empty(C).cuda()
+    coef1 = h.bwd_w_and_x(H1, W, dW_n, dbias_n, dA_n, a_pro=(cc1[0], cc1[1]), a_relu=True,
+                          next_bn=(cc1[2], cc1[3], dg1_n, db1_n))
+    assert float((dA_n - dA_a).abs().max()) <= 2e-5 * float(dA_a.abs().max())
+    assert float((dW_n - dW_r).abs().max()) <= 2e-5 * float(dW_r.abs().max())
+    yv.ops.bn_relu_bwd_apply(dA_n, H1, cc1[2], cc1[3], cc1[0], cc1[1], True, coef1, dA_n)
+    for name, a, b in (("dgamma1", dg1_r, dg1_n), ("dbeta1", db1_r, db1_n), ("dH1", dH1_r, dA_n)):
+        assert float((a - b).abs().max()) <= 5e-5 * max(float(a.abs().max()), 1e-6), name
     again = fused()
     for a, b in zip(got, again):
         assert torch.equal(a, b)                                             # deterministic

@@ -166,7 +166,9 @@ SIGNATURES = {
     "yolat_linear_fwd_wt_csr": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_bn_csr_l2_bwd_work_elems": (c_sz, []),
     "yolat_bn_csr_l2_bwd": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_p, c_i64, c_p, c_p, c_int, c_p, c_i64, c_p, c_i64,
-                                    c_p, c_int, c_p, c_i64, c_p, c_p]),
+                                    c_p, c_int, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_bn_relu_bwd_apply": (c_int, [c_p, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_int, c_p, c_p, c_i64,
+                                        c_int, c_p]),
     "yolat_gemm_x6_packed_elems": (c_sz, [c_i64, c_i64]),
     "yolat_gemm_x6_pack": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "yolat_gemm_x6_pack_t": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),

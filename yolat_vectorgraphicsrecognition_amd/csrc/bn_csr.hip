@@ -206,14 +206,21 @@ BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) { return make_
 #define BCL_WGS 512
 __device__ __forceinline__ void bcl_store(float* p, float v) { *p = v; }
 __device__ __forceinline__ void bcl_store(yl_bf16_t* p, float v) { *p = (yl_bf16_t)(yl_pack_bf16(v, 0.f) & 0xffffu); }
+__device__ __forceinline__ float bcl_round(float v) { return __uint_as_float((yl_pack_bf16(v, 0.f) & 0xffffu) << 16); }
 template <class T>
 __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* __restrict__ A, long lda,
                                                        const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                        float a_floor, const float* __restrict__ W, long ldw,
                                                        T* __restrict__ dA, long ldda, int E, int tiles_per_wg,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, const float* __restrict__ bn_mean,
+                                                       const float* __restrict__ bn_invstd, float2* __restrict__ part1) {
+  // part1 != NULL: also the partial sums of the NEXT BatchNorm backward (the one in front of A: dA goes through
+  // relu'(pro(A)) and that BatchNorm), per workgroup and column (sum g, sum g*xhat) with g = relu'(.) dA and xhat =
+  // (A - bn_mean) bn_invstd — the dA tile is passed through LDS into the staging layout, where the raw A values still
+  // sit in registers, and leaves for global memory from there with 16-byte stores
   constexpr int LD = 65;
-  __shared__ float Ds[64 * LD], As[64 * LD], Ws[64 * LD];
+  __shared__ float Ds[64 * LD], As[64 * LD];
+  __shared__ __attribute__((aligned(16))) float Ws[64 * LD];
   __shared__ float dbs[4][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -238,8 +245,11 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
   for (int r = 0; r < 16; ++r) accw[r] = 0.f;
   float dbacc = 0.f;                                     // threads 0..63: column tid of db
 
-  float4 ry[4], rg[4], ra[4];
+  float4 ry[4], rg[4], ra[4], rh[4];
   float rw[4];
+  float4 p1 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p1;   // next BatchNorm's partial sums, columns 4q..4q+3
+  float4 bm = p1, bi = p1;
+  if (part1 != nullptr) { bm = *reinterpret_cast<const float4*>(bn_mean + 4 * q); bi = *reinterpret_cast<const float4*>(bn_invstd + 4 * q); }
   auto fetch = [&](int tile) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
@@ -268,6 +278,7 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
       a[1] = ok ? fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor) : 0.f;
       a[2] = ok ? fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor) : 0.f;
       a[3] = ok ? fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor) : 0.f;
+      rh[t] = ra[t];                                     // raw A of this tile (ra is refilled by the prefetch)
     }
     __syncthreads();
     if (tile + 1 < t1) fetch(tile + 1);                  // in flight under the MFMAs
@@ -295,8 +306,8 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
       for (int r = 0; r < 16; ++r) s += Ds[(wave * 16 + r) * LD + lane];
       dbs[wave][lane] = s;
     }
-    // ---- store the dA tile (bfloat16 storage: round to nearest even, as yl_st4 does)
-    {
+    if (part1 == nullptr) {
+      // ---- store the dA tile (bfloat16 storage: round to nearest even, as yl_st4 does)
       const int col = wn * 32 + l31;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
@@ -306,6 +317,53 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
     }
     __syncthreads();                                     // all reads of Ds / As done; dbs complete
     if (tid < 64) dbacc += ((dbs[0][tid] + dbs[1][tid]) + dbs[2][tid]) + dbs[3][tid];
+    if (part1 != nullptr) {
+      // ---- dA tile -> LDS (Ds is free now) -> staging layout: next BatchNorm's partial sums + 16-byte stores
+      const int col = wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Ds[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LD + col] = acca[r];
+      __syncthreads();
+      auto acc1 = [&](float h, float g, float m, float i, float a, float b, float& t1s, float& t2s) {
+        if (a_floor == 0.f && !(fmaf(h, a, b) > 0.f)) g = 0.f;
+        t1s += g;
+        t2s += g * ((h - m) * i);
+      };
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int r = rb + 16 * t;
+        const long row = (long)tile * 64 + r;
+        if (row < E) {
+          const float* d = Ds + r * LD + 4 * q;
+          float4 v = make_float4(d[0], d[1], d[2], d[3]);
+          T* o = dA + row * ldda + 4 * q;
+          yl_st4(o, v);
+          // the statistics take the STORED values (bfloat16 storage: rounded), as the apply pass will read them
+          if (sizeof(T) != 4) v = make_float4(bcl_round(d[0]), bcl_round(d[1]), bcl_round(d[2]), bcl_round(d[3]));
+          acc1(rh[t].x, v.x, bm.x, bi.x, as.x, ah.x, p1.x, p2.x);
+          acc1(rh[t].y, v.y, bm.y, bi.y, as.y, ah.y, p1.y, p2.y);
+          acc1(rh[t].z, v.z, bm.z, bi.z, as.z, ah.z, p1.z, p2.z);
+          acc1(rh[t].w, v.w, bm.w, bi.w, as.w, ah.w, p1.w, p2.w);
+        }
+      }
+      __syncthreads();                                   // before the next tile's fill overwrites Ds
+    }
+  }
+  if (part1 != nullptr) {
+    // the 16 row groups of a column quad, summed in order by row group 0
+    float4* red1 = reinterpret_cast<float4*>(Ws);        // Ws (64 * 65 floats) holds 2 x 16 x 16 float4
+    float4* red2 = red1 + 256;
+    __syncthreads();
+    red1[rb * 16 + q] = p1; red2[rb * 16 + q] = p2;
+    __syncthreads();
+    if (rb == 0) {
+      float4 a = red1[q], b = red2[q];
+      for (int t = 1; t < 16; ++t) {
+        a.x += red1[t * 16 + q].x; a.y += red1[t * 16 + q].y; a.z += red1[t * 16 + q].z; a.w += red1[t * 16 + q].w;
+        b.x += red2[t * 16 + q].x; b.y += red2[t * 16 + q].y; b.z += red2[t * 16 + q].z; b.w += red2[t * 16 + q].w;
+      }
+      float2* o = part1 + (long)blockIdx.x * 64 + 4 * q;
+      o[0] = make_float2(a.x, b.x); o[1] = make_float2(a.y, b.y); o[2] = make_float2(a.z, b.z); o[3] = make_float2(a.w, b.w);
+    }
   }
   float* P = partial + (long)blockIdx.x * (64 * 64 + 64);
 #pragma unroll
@@ -316,17 +374,25 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
   if (tid < 64) P[64 * 64 + tid] = dbacc;
 }
 
-extern "C" size_t yolat_bn_csr_l2_bwd_work_elems(void) { return (size_t)BCL_WGS * (64 * 64 + 64); }
+extern "C" size_t yolat_bn_csr_l2_bwd_work_elems(void) { return (size_t)BCL_WGS * (64 * 64 + 64 + 128) + 8; }
 
 // C = K = Nout = 64 only.  dW [64, 64] (+= when accumulate) = dY^T . pro(A), db [64] (+=) = column sums of dY (nullable),
 // dA [E, 64] = dY . W (W = the Linear's weight [64, 64], row-major).  work: yolat_bn_csr_l2_bwd_work_elems() floats.
+// next_mean != NULL (then a_scale / a_shift / a_relu describe the BatchNorm + ReLU in front of A): also the statistics
+// of THAT BatchNorm's backward on dA — next_dgamma / next_dbeta [64] and next_coef [128] = (c1 | c2), ready for
+// yolat_bn_relu_bwd_apply — so that no separate pass over dA and A is needed for them.
 extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const void* A, int64_t lda, const float* a_scale,
                                    const float* a_shift, int a_relu, const float* W, int64_t ldw, float* dW, int64_t lddw,
                                    float* db, int accumulate, void* dA, int64_t ldda, float* work,
-                                   yolat_stream_t stream) {
+                                   const float* next_mean, const float* next_invstd, float* next_dgamma,
+                                   float* next_dbeta, float* next_coef, yolat_stream_t stream) {
   const int rc = check_grad(g, E, 64);
   if (rc) return rc;
   if (!A || !W || !dW || !dA || !work || lda < 64 || ldw < 64 || lddw < 64 || ldda < 64) return YOLAT_E_INVALID;
+  const bool next = next_mean != nullptr;
+  if (next && (!next_invstd || !next_dgamma || !next_dbeta || !next_coef || !a_scale || ldda % 4 != 0 ||
+               !yl_aligned16(next_mean) || !yl_aligned16(next_invstd) || ((uintptr_t)dA % (g->half ? 8 : 16)) != 0))
+    return YOLAT_E_INVALID;
   if ((a_scale == nullptr) != (a_shift == nullptr) || (a_relu && !a_scale)) return YOLAT_E_INVALID;
   const size_t al = g->half ? 8 : 16;
   if (lda % 4 != 0 || ldw % 4 != 0 || ((uintptr_t)A % al) != 0 || !yl_aligned16(W) ||
@@ -338,23 +404,30 @@ extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const 
   const int per = yl_cdiv(ntiles, wgs);
   wgs = yl_cdiv(ntiles, per);
   const float floor = a_relu ? 0.f : -INFINITY;
+  float2* part1 = next ? reinterpret_cast<float2*>(work + (size_t)BCL_WGS * (64 * 64 + 64)) : nullptr;
   if (g->half) {
     BnCsrOpT<yl_bf16_t> y = make_op_t<yl_bf16_t>(g, E, 64);
     if (!y.vec) return YOLAT_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_bn_csr_l2_bwd<yl_bf16_t>, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const yl_bf16_t*>(A),
                        (long)lda, a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<yl_bf16_t*>(dA), (long)ldda, (int)E,
-                       per, work);
+                       per, work, next_mean, next_invstd, part1);
   } else {
     BnCsrOp y = make_op(g, E, 64);
     if (!y.vec) return YOLAT_E_UNSUPPORTED;
     hipLaunchKernelGGL(k_bn_csr_l2_bwd<float>, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const float*>(A), (long)lda,
-                       a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<float*>(dA), (long)ldda, (int)E, per, work);
+                       a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<float*>(dA), (long)ldda, (int)E, per, work,
+                       next_mean, next_invstd, part1);
   }
   YL_LAUNCH_CHECK();
   // partial layout [wg][64*64 | 64]: reduce the two pieces with the element stride of the slab
   hipLaunchKernelGGL(k_reduce_slabs, dim3(yl_cdiv(64 * 64 + 64, 256)), dim3(256), 0, st, work, wgs, 64 * 64 + 64, dW,
                      (long)lddw, db, accumulate);
   YL_LAUNCH_CHECK();
+  if (next) {
+    hipLaunchKernelGGL(k_bn_csr_finalize, dim3(1), dim3(1024), 0, st, part1, (long)wgs, (long)E, 64, next_dgamma, next_dbeta,
+                       0, next_coef);
+    YL_LAUNCH_CHECK();
+  }
   return 0;
 }
 

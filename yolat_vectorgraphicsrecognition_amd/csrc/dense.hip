@@ -704,6 +704,34 @@ extern "C" int yolat_bn_relu_bwd(const float* dZ, int64_t lddz, const float* Y, 
   return 0;
 }
 
+// The apply pass alone: dY = scale * (g - c1 - xhat * c2) with coef = (c1 | c2) [2C] computed elsewhere
+// (yolat_bn_csr_l2_bwd's next_coef).  half != 0: dZ / Y / dY bfloat16-stored.  C % 4 == 0, 16-byte (8-byte) aligned rows.
+extern "C" int yolat_bn_relu_bwd_apply(const void* dZ, int64_t lddz, const void* Y, int64_t ldy, int64_t M, int64_t C,
+                                       const float* save_mean, const float* save_invstd, const float* scale,
+                                       const float* shift, int relu, const float* coef, void* dY, int64_t lddy, int half,
+                                       yolat_stream_t stream) {
+  if (M <= 0 || C <= 0 || !dZ || !Y || !save_mean || !save_invstd || !scale || !shift || !coef || !dY) return YOLAT_E_INVALID;
+  const uintptr_t al = half ? 7 : 15;
+  if (C % 4 != 0 || lddz % 4 != 0 || ldy % 4 != 0 || lddy % 4 != 0 || (((uintptr_t)dZ | (uintptr_t)Y | (uintptr_t)dY) & al) ||
+      !yl_aligned16(save_mean) || !yl_aligned16(save_invstd) || !yl_aligned16(scale) || !yl_aligned16(shift) ||
+      !yl_aligned16(coef))
+    return YOLAT_E_UNSUPPORTED;
+  int gy = yl_cdiv(M, 64);
+  if (gy > 4096) gy = 4096;
+  hipStream_t st = (hipStream_t)stream;
+  if (half)
+    hipLaunchKernelGGL(k_bn_bwd_apply_v4<yl_bf16_t>, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st,
+                       reinterpret_cast<const yl_bf16_t*>(dZ), (long)lddz, reinterpret_cast<const yl_bf16_t*>(Y), (long)ldy,
+                       (long)M, (int)C, save_mean, save_invstd, scale, shift, relu, coef, reinterpret_cast<yl_bf16_t*>(dY),
+                       (long)lddy);
+  else
+    hipLaunchKernelGGL(k_bn_bwd_apply_v4<float>, dim3(yl_cdiv(C, 64), gy), dim3(256), 0, st,
+                       reinterpret_cast<const float*>(dZ), (long)lddz, reinterpret_cast<const float*>(Y), (long)ldy, (long)M,
+                       (int)C, save_mean, save_invstd, scale, shift, relu, coef, reinterpret_cast<float*>(dY), (long)lddy);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 // The same backward on bfloat16-stored dZ / Y / dY ([M,C], C % 4 == 0, 8-byte aligned rows); sums in fp32 / fp64.
 extern "C" int yolat_bn_relu_bwd_h(const uint16_t* dZ, int64_t lddz, const uint16_t* Y, int64_t ldy, int64_t M,
                                    int64_t C, const float* save_mean, const float* save_invstd, const float* scale,

@@ -255,6 +255,7 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
     if E > 0:
         H1, H2, c1, c2 = sv["H1"], sv["H2"], sv["c1"], sv["c2"]
         dA1 = torch.empty(E, C, dtype=H1.dtype, device=dev)
+        bn1_done = False
         one_kernel = C == 64 and nn3.in_features == 64 and nn3.weight.is_contiguous()
         if (FUSED_BN_CSR_BWD and C % 4 == 0 and d_f.stride(0) % 4 == 0
                 and (H1.dtype == torch.float32 or one_kernel)):
@@ -263,8 +264,12 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
             dh2 = ops.BnCsrGrad(d_f, g, H2, c2[2], c2[3], c2[0], c2[1], relu=True)
             dh2.stats(sink.get(bn4.weight), sink.get(bn4.bias))
             if one_kernel:
-                dh2.bwd_w_and_x(H1, nn3.weight, sink.get(nn3.weight), sink.get(nn3.bias), dA1, a_pro=(c1[0], c1[1]),
-                                a_relu=True)
+                # ... which also takes the statistics of BatchNorm 1's backward on dA1: only its apply pass is left
+                coef1 = dh2.bwd_w_and_x(H1, nn3.weight, sink.get(nn3.weight), sink.get(nn3.bias), dA1,
+                                        a_pro=(c1[0], c1[1]), a_relu=True,
+                                        next_bn=(c1[2], c1[3], sink.get(bn1.weight), sink.get(bn1.bias)))
+                ops.bn_relu_bwd_apply(dA1, H1, c1[2], c1[3], c1[0], c1[1], True, coef1, dA1)
+                bn1_done = True
             else:
                 dh2.bwd_w(H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
                 dh2.fwd_wt(nn3.weight, dA1)
@@ -275,8 +280,9 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
                             sink.get(bn4.weight), sink.get(bn4.bias), dM)            # dM -> dH2 in place
             ops.linear_bwd_w(dM, H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
             ops.linear_fwd_wt(dM, nn3.weight, dA1)
-        ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
-                        sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
+        if not bn1_done:
+            ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
+                            sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
         hdt = H1.dtype
         if hdt == torch.bfloat16 or (FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous()
                                      and nn0.bias is not None):

@@ -297,24 +297,42 @@ class BnCsrGrad(object):
               "yolat_linear_bwd_w_csr")
         return dW
 
-    def bwd_w_and_x(self, A, W, dW, db, dA, a_pro=None, a_relu=False, accumulate=False):
-        """dW (+)= dY^T . pro(A), db (+)= column sums, dA = dY . W in one kernel (C = K = 64)."""
+    def bwd_w_and_x(self, A, W, dW, db, dA, a_pro=None, a_relu=False, accumulate=False, next_bn=None):
+        """dW (+)= dY^T . pro(A), db (+)= column sums, dA = dY . W in one kernel (C = K = 64).  next_bn = (save_mean,
+        save_invstd, dgamma, dbeta) of the BatchNorm behind a_pro: its backward statistics on dA come out of the same
+        kernel; returns their coefficient vector [2C] for bn_relu_bwd_apply (else None)."""
         asc, ash = (a_pro if a_pro is not None else (None, None))
         work = torch.empty(int(lib.yolat_bn_csr_l2_bwd_work_elems()), dtype=torch.float32, device=self.dev)
         hp = bool(self._d.half)
         if _is_h(A) != hp or _is_h(dA) != hp:
             raise ValueError("BnCsrGrad.bwd_w_and_x: A and dA must use the storage type of Y")
+        coef1 = None
+        nm = ni = ng = nb = nc = None
+        if next_bn is not None:
+            coef1 = torch.empty(2 * self.C, dtype=torch.float32, device=self.dev)
+            nm, ni, ng, nb, nc = _f(next_bn[0]), _f(next_bn[1]), _f(next_bn[2]), _f(next_bn[3]), coef1.data_ptr()
         check(lib.yolat_bn_csr_l2_bwd(ctypes.byref(self._d), self.E, _h(A, "A") if hp else _f(A, "A"), _ld(A),
                                       _f(asc, "a_scale", True), _f(ash, "a_shift", True), int(a_relu), _f(W, "W"), _ld(W),
                                       _f(dW, "dW"), _ld(dW), _f(db, "db", True), int(accumulate),
-                                      _h(dA, "dA") if hp else _f(dA, "dA"), _ld(dA), work.data_ptr(), _stream()),
-              "yolat_bn_csr_l2_bwd")
-        return dA
+                                      _h(dA, "dA") if hp else _f(dA, "dA"), _ld(dA), work.data_ptr(), nm, ni, ng, nb, nc,
+                                      _stream()), "yolat_bn_csr_l2_bwd")
+        return coef1
 
     def fwd_wt(self, W, dA):
         check(lib.yolat_linear_fwd_wt_csr(ctypes.byref(self._d), self.E, self.C, _f(W, "W"), _ld(W), W.shape[1],
                                           _f(dA, "dA"), _ld(dA), _stream()), "yolat_linear_fwd_wt_csr")
         return dA
+
+
+def bn_relu_bwd_apply(dZ, Y, save_mean, save_invstd, scale, shift, relu, coef, dY):
+    """The apply pass of bn_relu_bwd alone, with the coefficient vector [2C] = (c1 | c2) given."""
+    M, C = Y.shape
+    hp = _is_h(Y)
+    check(lib.yolat_bn_relu_bwd_apply(_h(dZ, "dZ") if hp else _f(dZ, "dZ"), _ld(dZ), _h(Y, "Y") if hp else _f(Y, "Y"), _ld(Y),
+                                      M, C, _f(save_mean), _f(save_invstd), _f(scale), _f(shift), int(relu), _f(coef),
+                                      _h(dY, "dY") if hp else _f(dY, "dY"), _ld(dY), int(hp), _stream()),
+          "yolat_bn_relu_bwd_apply")
+    return dY
 
 
 def bn_finalize(stats, M, bn, scale, shift, save_mean, save_invstd, update_running=True):
