@@ -814,12 +814,13 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
 
 // ------------------------------------------------------------------------------------------------
 // TN GEMM (weight gradients):  P[s][n][k] = sum_{r in split s} Y[r][n] * A[r][k]
-// Output tile 64(n) x 64(k); 32 rows per LDS stage; grid = (n tiles, k tiles, splits).
+// Output tile 64(n) x 64(k); 64 rows per LDS stage (32 MFMAs per wave between barriers; 32-row stages left the
+// N-row weight gradients latency bound: 97 us for [64,64] over 200 k rows); grid = (n tiles, k tiles, splits).
 // ------------------------------------------------------------------------------------------------
 template <class YL, class AL>
 __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial, float* dbpart,
                                                   int M, int Nout, int K, int rows_per_split) {
-  constexpr int BR = 32, BT = 64;
+  constexpr int BR = 64, BT = 64, NT = BR * 16 / 256;   // rows per LDS stage, tile edge, float4 slots per thread
   __shared__ __attribute__((aligned(16))) float Ys[BR][BT];
   __shared__ __attribute__((aligned(16))) float As[BR][BT];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -838,30 +839,30 @@ __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial,
   float dbacc = 0.f;
   const bool do_db = (dbpart != nullptr) && (blockIdx.y == 0);
 
-  float ry[2][4], rx[2][4];
+  float ry[NT][4], rx[NT][4];
   auto fetch = [&](int r0) {
     if (fastY) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int i = tid + t * 256;
         Yop.template load4<true>(r0 + i / 16, n0 + 4 * (i % 16), ry[t]);
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int i = tid + t * 256;
         Yop.template load4<false>(r0 + i / 16, n0 + 4 * (i % 16), ry[t]);
       }
     }
     if (fastA) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int i = tid + t * 256;
         Aop.template load4<true>(r0 + i / 16, k0 + 4 * (i % 16), rx[t]);
       }
     } else {
 #pragma unroll
-      for (int t = 0; t < 2; ++t) {
+      for (int t = 0; t < NT; ++t) {
         const int i = tid + t * 256;
         Aop.template load4<false>(r0 + i / 16, k0 + 4 * (i % 16), rx[t]);
       }
@@ -871,7 +872,7 @@ __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial,
   if (r_begin < r_end) fetch(r_begin);
   for (int r0 = r_begin; r0 < r_end; r0 += BR) {
 #pragma unroll
-    for (int t = 0; t < 2; ++t) {
+    for (int t = 0; t < NT; ++t) {
       const int i = tid + t * 256;
       const int r = i / 16, q = i % 16;
       const bool ok = (r0 + r) < r_end;          // rows are the reduction dimension: mask them
