@@ -467,13 +467,16 @@ static __global__ void __launch_bounds__(256) k_fus_dw_finish(const float* __res
 // deterministic), so the number of loop trips per wave is the largest match count among its 32 rows (~5),
 // not the number of columns.  Measured at N = 175k / P = 8000: v1 (test every column in every lane) 1078 us,
 // v2 (wave-uniform scalar walk, one match per trip) 551 us, this version: see profiles/.
-template <int TPR>   // threads per row: 2 (128 rows per workgroup, 64 accumulators) or 4 (64 rows, 32 accumulators)
-static __global__ void __launch_bounds__(256) k_fus_da_sparse(const float* __restrict__ W, int K, int F,
+// TPR threads per row (128 / TPR accumulators each), THREADS / TPR rows per workgroup.  Every workgroup streams ALL of W
+// (F x 128 floats = 512 KB) through its LDS, so rows per workgroup set the L2 -> LDS traffic: 32 rows (256 threads, TPR 8)
+// = 2.8 GB at N = 175 k; 128 rows (1024 threads) = 0.7 GB.
+template <int TPR, int THREADS>
+static __global__ void __launch_bounds__(THREADS) k_fus_da_sparse(const float* __restrict__ W, int K, int F,
                                                               const int* __restrict__ node_seg,
                                                               const float* __restrict__ GM,
                                                               const int* __restrict__ arg, int N, float* dA,
                                                               long ldda) {
-  constexpr int CH = 32, LDI = CH + 1, LDW = 132, ROWS = 256 / TPR, NK = 128 / TPR;
+  constexpr int CH = 32, LDI = CH + 1, LDW = 132, ROWS = THREADS / TPR, NK = 128 / TPR;
   __shared__ __attribute__((aligned(16))) float Ws[CH * LDW];
   __shared__ int argP[ROWS * LDI];
   __shared__ float gmP[ROWS * LDI];
@@ -491,12 +494,12 @@ static __global__ void __launch_bounds__(256) k_fus_da_sparse(const float* __res
   for (int c0 = 0; c0 < F; c0 += CH) {
     __syncthreads();
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {        // W chunk: 32 columns x 32 float4
-      const int i = tid + t * 256;
+    for (int t = 0; t < 1024 / THREADS; ++t) {        // W chunk: 32 columns x 32 float4
+      const int i = tid + t * THREADS;
       *reinterpret_cast<float4*>(Ws + (i >> 5) * LDW + 4 * (i & 31)) =
           *reinterpret_cast<const float4*>(W + (long)(c0 + (i >> 5)) * K + 4 * (i & 31));
     }
-    for (int i = tid; i < np * 8; i += 256) {   // arg / GM: np proposals x 8 x (4 columns)
+    for (int i = tid; i < np * 8; i += THREADS) {   // arg / GM: np proposals x 8 x (4 columns)
       const int pp = i >> 3, q = i & 7;
       const long off = (long)(p_first + pp) * F + c0 + 4 * q;
       const int4 av = *reinterpret_cast<const int4*>(arg + off);
@@ -617,7 +620,16 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
                      nq2, sv.sumA, sv.T, dW);
   YL_LAUNCH_CHECK();
   // 3. input gradient: sparse scatter term, then  dA += (A - mean_A) . (-Q) - u   with Q = W^T diag(q2) W
-  hipLaunchKernelGGL(k_fus_da_sparse<8>, dim3(yl_cdiv(N, 32)), dim3(256), 0, st, W, (int)K, (int)F, node_seg, GM,
+  static int da_threads = -1;
+  if (da_threads < 0) { const char* e = getenv("YOLAT_FUS_DA_THREADS"); da_threads = e ? atoi(e) : 256; }   // measured at N = 175 k: 256 -> 3.78, 512 -> 3.75, 1024 -> 3.86 ms per cfg-3 step (not the W re-staging: the walk)
+  if (da_threads == 1024)
+    hipLaunchKernelGGL((k_fus_da_sparse<8, 1024>), dim3(yl_cdiv(N, 128)), dim3(1024), 0, st, W, (int)K, (int)F, node_seg, GM,
+                       sv.arg, (int)N, dA, (long)ldda);
+  else if (da_threads == 512)
+    hipLaunchKernelGGL((k_fus_da_sparse<8, 512>), dim3(yl_cdiv(N, 64)), dim3(512), 0, st, W, (int)K, (int)F, node_seg, GM,
+                       sv.arg, (int)N, dA, (long)ldda);
+  else
+  hipLaunchKernelGGL((k_fus_da_sparse<8, 256>), dim3(yl_cdiv(N, 32)), dim3(256), 0, st, W, (int)K, (int)F, node_seg, GM,
                      sv.arg, (int)N, dA, (long)ldda);
   YL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_row_scale, dim3(yl_cdiv(F * K, 256)), dim3(256), 0, st, W, nq2, (long)(F * K), (int)K, Wq);
