@@ -631,6 +631,10 @@ int yolat_gemm_x6_pack_t(const float* Wt, int64_t ldw, int64_t N, int64_t K, uin
 size_t yolat_gemm_x6_work_elems(int64_t M, int64_t N, int64_t K);
 int yolat_gemm_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
                   int64_t N, float* out, int64_t ldo, float* work, yolat_stream_t stream);
+/* yolat_gemm_x6 with bias only (pre-activation output) + the BatchNorm partial statistics of the output in
+ * yolat_linear_fwd's `stats` layout: the training-mode Linear in front of a BatchNorm; shapes without K split only    */
+int yolat_gemm_x6_stats(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* bias, int64_t N,
+                        float* out, int64_t ldo, float* stats, yolat_stream_t stream);
 size_t yolat_split_bf16x3_packed_elems(int64_t N, int64_t K);
 int yolat_split_bf16x3_packed(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale,
                               uint16_t* packed, yolat_stream_t stream);

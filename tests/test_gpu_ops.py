@@ -1263,3 +1263,38 @@ def test_linear_fwd_rows_x6_path_matches_fp32_kernel_and_statistics(M, K, N):
     close(cb[3], (1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).float(), rtol=1e-4, atol=1e-6, msg="invstd")
     Yc, cc = run(True)
     assert torch.equal(Yb, Yc) and torch.equal(cb, cc)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,K,N", [(8000, 2304, 512), (4100, 256, 130)])
+def test_linear_fwd_gemm_x6_stats_path_matches_fp32_kernel(M, K, N):
+    """ops.linear_fwd with BatchNorm statistics on the bf16x6 LDS-tiled GEMM (yolat_gemm_x6_stats: the training-mode
+    classifier layer at P = 8000) against the fp32-MFMA kernel (ops.X6_TRAIN_GEMM flipped in-process): outputs, and the
+    finalized statistics against float64."""
+    yv = _yv()
+    gen = torch.Generator().manual_seed(M + N)
+    A = torch.randn(M, K, generator=gen).cuda()
+    W = (torch.randn(N, K, generator=gen) / K ** 0.5).cuda()
+    b = torch.randn(N, generator=gen).cuda()
+
+    def run(x6):
+        old = yv.ops.X6_TRAIN_GEMM
+        yv.ops.X6_TRAIN_GEMM = x6
+        try:
+            Y = torch.full((M, N + 4), -7.0).cuda()
+            st = yv.ops.stats_buffer(M, N, A.device)
+            yv.ops.linear_fwd(A, W, b, Y[:, :N], stats=st)
+            coef = torch.empty(4, N).cuda()
+            yv.ops.bn_finalize(st, M, torch.nn.BatchNorm1d(N).cuda(), coef[0], coef[1], coef[2], coef[3])
+            return Y, coef
+        finally:
+            yv.ops.X6_TRAIN_GEMM = old
+    Ya, ca = run(False)
+    Yb, cb = run(True)
+    assert float((Ya[:, :N] - Yb[:, :N]).abs().max()) <= 5e-6 * float(Ya[:, :N].abs().max())
+    assert torch.all(Yb[:, N:] == -7.0)
+    ref = A.double() @ W.double().t() + b.double()
+    close(cb[2], ref.mean(0).float(), rtol=1e-4, atol=1e-5, msg="batch mean")
+    close(cb[3], (1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).float(), rtol=1e-4, atol=1e-6, msg="invstd")
+    Yc, cc = run(True)
+    assert torch.equal(Yb, Yc) and torch.equal(cb, cc)

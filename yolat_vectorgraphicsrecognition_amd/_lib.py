@@ -174,6 +174,7 @@ SIGNATURES = {
     "yolat_gemm_x6_pack_t": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "yolat_gemm_x6_work_elems": (c_sz, [c_i64, c_i64, c_i64]),
     "yolat_gemm_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p, c_p]),
+    "yolat_gemm_x6_stats": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_split_bf16x3_packed_elems": (c_sz, [c_i64, c_i64]),
     "yolat_split_bf16x3_packed": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p]),
     "yolat_linear_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p]),

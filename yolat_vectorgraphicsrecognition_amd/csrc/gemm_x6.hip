@@ -33,7 +33,9 @@ template <bool SPLITK>
 __global__ void __launch_bounds__(512) k_gemm_x6(const float* __restrict__ A, long lda, int M, int K,
                                                  const yl_bf16_t* __restrict__ Wp, const float* __restrict__ shift,
                                                  int relu, int N, float* __restrict__ out, long ldo, int tn,
-                                                 int st_per_split) {
+                                                 int st_per_split, float* __restrict__ stats) {
+  // stats != NULL (!SPLITK only): BatchNorm partial statistics of the stored pre-activation values, per 32-row group and
+  // column (sum, M2) in the layout yolat_bn_finalize reads (training-mode Linear)
   // one stage = GX_KS k steps of 16; images [k step][part][row slot]
   __shared__ __attribute__((aligned(16))) yl_bf16_t As[3][GX_KS * 3 * GX_BM * 16];
   __shared__ __attribute__((aligned(16))) yl_bf16_t Bs[3][GX_KS * 3 * GX_PART];
@@ -179,6 +181,26 @@ __global__ void __launch_bounds__(512) k_gemm_x6(const float* __restrict__ A, lo
   for (int i = 0; i < 2; ++i) {
     const int col = col0 + 32 * wc + l31;
     const float sh = (!SPLITK && shift && col < N) ? shift[col] : 0.f;
+    if (!SPLITK && stats != nullptr) {
+      const int rbase = row0 + 64 * wr + 32 * i;
+      int cnt = M - rbase;
+      cnt = cnt > 32 ? 32 : cnt;
+      if (cnt > 0) {
+        float sum = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sum += (rbase + (r & 3) + 8 * (r >> 2) + 4 * lhi < M) ? acc[i][r] + sh : 0.f;
+        sum += __shfl_xor(sum, 32);
+        const float mu = sum / (float)cnt;
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float d = acc[i][r] + sh - mu;
+          m2 += (rbase + (r & 3) + 8 * (r >> 2) + 4 * lhi < M) ? d * d : 0.f;
+        }
+        m2 += __shfl_xor(m2, 32);
+        if (lhi == 0 && col < N) reinterpret_cast<float2*>(stats)[(long)(rbase >> 5) * N + col] = make_float2(sum, m2);
+      }
+    }
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int row = row0 + 64 * wr + 32 * i + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -277,8 +299,22 @@ extern "C" size_t yolat_gemm_x6_work_elems(int64_t M, int64_t N, int64_t K) {
 // out [M, N] = act(A [M, K] . W'^T + shift): W' packed by yolat_gemm_x6_pack, shift NULL = none, relu != 0 = ReLU.
 // K % 16 == 0, lda % 4 == 0, A / Wp 16-byte aligned; work: yolat_gemm_x6_work_elems(M, N, K) floats (may be NULL
 // when that is 0).
+static int gx_run(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
+                  int64_t N, float* out, int64_t ldo, float* work, float* stats, yolat_stream_t stream);
 extern "C" int yolat_gemm_x6(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift,
                              int relu, int64_t N, float* out, int64_t ldo, float* work, yolat_stream_t stream) {
+  return gx_run(A, lda, M, K, Wp, shift, relu, N, out, ldo, work, nullptr, stream);
+}
+// the same with the BatchNorm partial statistics of the (pre-activation) output, yolat_linear_fwd's `stats` layout; only
+// for shapes that need no K split (yolat_gemm_x6_work_elems(M, N, K) == 0), YOLAT_E_UNSUPPORTED otherwise
+extern "C" int yolat_gemm_x6_stats(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* bias,
+                                   int64_t N, float* out, int64_t ldo, float* stats, yolat_stream_t stream) {
+  if (!stats) return YOLAT_E_INVALID;
+  if (M > 0 && N > 0 && K >= 16 && gx_splits(M, N, K) != 1) return YOLAT_E_UNSUPPORTED;
+  return gx_run(A, lda, M, K, Wp, bias, 0, N, out, ldo, nullptr, stats, stream);
+}
+static int gx_run(const float* A, int64_t lda, int64_t M, int64_t K, const uint16_t* Wp, const float* shift, int relu,
+                  int64_t N, float* out, int64_t ldo, float* work, float* stats, yolat_stream_t stream) {
   if (M <= 0 || N <= 0 || K <= 0 || !A || !Wp || !out) return YOLAT_E_INVALID;
   if (lda < K || ldo < N || M >= (1LL << 31) - GX_BM || N >= (1LL << 31) - GX_BN) return YOLAT_E_INVALID;
   if (K % 16 != 0 || lda % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(Wp)) return YOLAT_E_UNSUPPORTED;
@@ -290,14 +326,14 @@ extern "C" int yolat_gemm_x6(const float* A, int64_t lda, int64_t M, int64_t K, 
   const yl_bf16_t* wp = reinterpret_cast<const yl_bf16_t*>(Wp);
   if (S == 1) {
     hipLaunchKernelGGL(k_gemm_x6<false>, dim3((unsigned)(tm * tn), 1), dim3(512), 0, st, A, (long)lda, (int)M, (int)K, wp,
-                       shift, relu, (int)N, out, (long)ldo, (int)tn, nst);
+                       shift, relu, (int)N, out, (long)ldo, (int)tn, nst, stats);
     YL_LAUNCH_CHECK();
     return 0;
   }
   if (!work) return YOLAT_E_INVALID;
   const int per = yl_cdiv(nst, S), S2 = yl_cdiv(nst, per);
   hipLaunchKernelGGL(k_gemm_x6<true>, dim3((unsigned)(tm * tn), (unsigned)S2), dim3(512), 0, st, A, (long)lda, (int)M,
-                     (int)K, wp, shift, relu, (int)N, work, (long)N, (int)tn, per);
+                     (int)K, wp, shift, relu, (int)N, work, (long)N, (int)tn, per, (float*)nullptr);
   YL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_gemm_x6_reduce, dim3((unsigned)yl_cdiv(M * N, 256)), dim3(256), 0, st, work, S2, (long)M, (int)N,
                      shift, relu, out, (long)ldo);

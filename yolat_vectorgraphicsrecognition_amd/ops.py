@@ -197,6 +197,16 @@ def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False
                                      int(a_relu), _f(W, "W"), _ld(W), _f(bias, "bias", True), Nout, _h(Y, "Y"), _ld(Y),
                                      _f(stats, "stats", True), wwork.data_ptr(), _stream()), "yolat_linear_fwd_h")
         return Y
+    if (X6_TRAIN_GEMM and stats is not None and a_pro is None and o_pro is None and not o_relu and not accumulate
+            and bias is not None and M >= 1024 and K >= 256 and K % 16 == 0 and Nout >= 128 and _ld(A) % 4 == 0
+            and A.data_ptr() % 16 == 0 and int(lib.yolat_gemm_x6_work_elems(M, Nout, K)) == 0):
+        # many rows x long K in front of a training BatchNorm (the classifier's first layer at P = 8000): bf16x6-emulated
+        # LDS-tiled GEMM with the statistics epilogue; the weight is packed per call
+        packed = torch.empty(int(lib.yolat_gemm_x6_packed_elems(Nout, K)), dtype=torch.bfloat16, device=A.device)
+        check(lib.yolat_gemm_x6_pack(_f(W, "W"), _ld(W), Nout, K, None, packed.data_ptr(), _stream()), "yolat_gemm_x6_pack")
+        check(lib.yolat_gemm_x6_stats(_f(A, "A"), _ld(A), M, K, packed.data_ptr(), _f(bias, "bias"), Nout, _f(Y, "Y"), _ld(Y),
+                                      _f(stats, "stats"), _stream()), "yolat_gemm_x6_stats")
+        return Y
     if (X6_TRAIN_ROWS and o_pro is None and not o_relu and not accumulate and bias is not None and M >= 65536
             and K in (64, 128) and Nout % 64 == 0 and _ld(A) % 4 == 0 and A.data_ptr() % 16 == 0):
         # many rows x short K with a pre-activation output (the second edge Linear of a training conv layer, [E,64] ->
