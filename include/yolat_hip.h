@@ -594,6 +594,7 @@ typedef struct {
   int32_t half;                         /* bfloat16 storage of Y (and of A / dA in yolat_bn_csr_l2_bwd); the loader-
                                          * fused GEMM entry points are fp32 only                                 */
 } yolat_bn_csr_grad;
+int yolat_inv_degree(const int32_t* row_ptr, int64_t N, float* inv_deg, yolat_stream_t stream);
 size_t yolat_bn_csr_work_elems(int64_t E, int64_t C);
 int yolat_bn_csr_bwd_stats(const yolat_bn_csr_grad* g, int64_t E, int64_t C, float* dgamma, float* dbeta, int accumulate,
                            float* coef_out, float* work, yolat_stream_t stream);

@@ -159,6 +159,7 @@ SIGNATURES = {
                                       c_p, c_i64, c_p, c_i64, c_p]),
     "yolat_fusion_pair_eval_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p,
                                           c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p]),
+    "yolat_inv_degree": (c_int, [c_p, c_i64, c_p, c_p]),
     "yolat_bn_csr_work_elems": (c_sz, [c_i64, c_i64]),
     "yolat_bn_csr_bwd_stats": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_i64, c_p, c_p, c_int, c_p, c_p, c_p]),
     "yolat_linear_bwd_w_csr": (c_int, [ctypes.POINTER(BnCsrGrad), c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_int, c_p,

@@ -431,6 +431,23 @@ extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const 
   return 0;
 }
 
+namespace {
+__global__ void k_inv_degree(const int* __restrict__ row_ptr, int N, float* __restrict__ inv_deg) {
+  const int n = blockIdx.x * blockDim.x + threadIdx.x;
+  if (n >= N) return;
+  const int deg = row_ptr[n + 1] - row_ptr[n];
+  inv_deg[n] = 1.f / (float)(deg > 1 ? deg : 1);       // the factor k_csr_mean_bwd applies
+}
+}  // namespace
+
+// inv_deg [N] = 1 / max(in-degree, 1) from the CSR row pointers (yolat_bn_csr_grad.inv_deg)
+extern "C" int yolat_inv_degree(const int32_t* row_ptr, int64_t N, float* inv_deg, yolat_stream_t stream) {
+  if (N <= 0 || N >= (1LL << 31) || !row_ptr || !inv_deg) return YOLAT_E_INVALID;
+  hipLaunchKernelGGL(k_inv_degree, dim3(yl_cdiv(N, 256)), dim3(256), 0, (hipStream_t)stream, row_ptr, (int)N, inv_deg);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" size_t yolat_bn_csr_work_elems(int64_t E, int64_t C) { return (size_t)(2 * yl_cdiv(E, BCS_ROWS) * C + 4); }
 
 // dgamma / dbeta (+= when accumulate) of the BatchNorm and g->coef = (c1 | c2) [2C] for the two consumers below.

@@ -91,8 +91,9 @@ class Graph(object):
     def inv_deg(self):
         """[N] fp32 1 / max(in-degree, 1) (the factor of the mean aggregation's backward), built once per graph."""
         if getattr(self, "_inv_deg", None) is None:
-            deg = (self.row_ptr[1:] - self.row_ptr[:-1]).clamp_min(1).to(torch.float32)
-            self._inv_deg = torch.ones_like(deg) / deg
+            inv = torch.empty(self.N, dtype=torch.float32, device=self.row_ptr.device)
+            check(lib.yolat_inv_degree(self.row_ptr.data_ptr(), self.N, inv.data_ptr(), _stream()), "yolat_inv_degree")
+            self._inv_deg = inv
         return self._inv_deg
 
     def ensure_csc(self):
