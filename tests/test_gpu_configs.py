@@ -47,13 +47,52 @@ def _oracle_train(ref, optkw, data, dtype=torch.float32):
     return out[0].detach(), loss.detach()
 
 
-def _grad_check(model_grads, ref, rtol, name):
+class _KinkReLU(torch.autograd.Function):
+    """ReLU whose sub-gradient switches at `thr` instead of 0 (the value is the ordinary ReLU)."""
+
+    @staticmethod
+    def forward(ctx, z, thr):
+        ctx.save_for_backward(z > thr)
+        return z.clamp_min(0)
+
+    @staticmethod
+    def backward(ctx, g):
+        (m,) = ctx.saved_tensors
+        return g * m, None
+
+
+def _kink_band(make_ref, optkw, data, tau=4e-6):
+    """|grad(ReLU' switching at +tau) - grad(ReLU' switching at -tau)| per parameter, from the fp64 oracle.
+
+    A pre-activation closer to 0 than the fp32 forward rounding (BatchNorm outputs are O(1); 4e-6 is ~32 ulp) gets its
+    ReLU derivative from rounding, not from the math: either value is a correct sub-gradient.  Where few rows feed a sum
+    (a [P,1024] block with P of a few hundred, a node with one in-edge that holds a proposal's arg-max) ONE such element
+    moves a bias gradient by percents — measured on seed 6 of the random-shape test: the fp64 oracle has |z| = 2.6e-8 in
+    head.gconv.nn.5, and flipping that single element reproduces the device's deviation to 3 digits (nn.4.bias 2.31e-2,
+    nn.3.weight 1.49e-2 relative).  The band is the oracle's own statement of that ambiguity."""
+    grads = []
+    for thr in (tau, -tau):
+        ref = make_ref().double()
+        ref.train()
+        for m in ref.modules():
+            if isinstance(m, torch.nn.ReLU):
+                m.forward = (lambda z, thr=thr: _KinkReLU.apply(z, thr))
+        _oracle_train(ref, optkw, data, torch.float64)
+        grads.append({n: p.grad for n, p in ref.named_parameters()})
+    return {n: (grads[0][n] - grads[1][n]).abs() for n in grads[0]}
+
+
+def _grad_check(model_grads, ref, rtol, name, band=None):
     rp = dict(ref.named_parameters())
     gmax = max(float(p.grad.abs().max()) for p in ref.parameters())
     for n, g in model_grads.items():
         a, b = g.cpu().double(), rp[n].grad.double()
         scale = float(b.abs().max())
-        err = float((a - b).abs().max())
+        if band is not None:
+            # outside the sub-gradient band (twice its width: flips need not be additive) the usual tolerance holds
+            err = float(((a - b).abs() - 2.0 * band[n]).clamp_min(0).max())
+        else:
+            err = float((a - b).abs().max())
         # floor = a fraction of the LARGEST gradient: the network is discontinuous (per-proposal arg-max, ReLU kinks); a
         # near-tie that fp32 rounding resolves the other way — which one changes with every summation order — moves a
         # small-gradient tensor by a discrete amount of that order (same rule as tests/test_gpu_model.py)
@@ -372,3 +411,39 @@ def test_training_mode_dropout2d_matches_oracle_with_the_same_mask():
     plain = _model(yv, dict(optkw, dropout=0.0), 8).eval()
     with torch.no_grad():
         assert torch.equal(fresh(data, None)[0], plain(data, None)[0])
+
+
+@pytest.mark.parametrize("seed", list(range(10)))
+def test_random_shapes_eval_and_train_match_oracle(seed):
+    """Seeded random batch shapes (1..5 graphs, 1..120 proposals, 2..40 nodes per proposal, sparse to dense edge sets,
+    2..4 blocks, n_blocks_out 1..n_blocks) through the eval plan (bf16x6 fusion / classifier / node-side kernels, both
+    edge-kernel families) and one training forward/backward, against the torch oracle: ragged tiles, small proposals,
+    graphs whose edge count crosses the factorised-layer thresholds.  Gradients are compared outside the oracle's own
+    ReLU sub-gradient band (_kink_band)."""
+    yv = _yv()
+    rng = np.random.default_rng(1000 + seed)
+    n_graphs = int(rng.integers(1, 6))
+    nb = int(rng.integers(2, 5))
+    optkw = dict(n_classes=int(rng.integers(2, 23)), n_blocks=nb, n_blocks_out=int(rng.integers(1, nb + 1)))
+    kw = dict(num_proposals=int(rng.integers(1, 121)), nodes_lo=int(rng.integers(2, 5)), nodes_hi=int(rng.integers(5, 41)),
+              n_classes=optkw["n_classes"])
+    if rng.random() < 0.5:
+        kw["edge_factor"] = float(rng.uniform(0.3, 3.0))
+    else:
+        kw["edges_per_proposal"] = int(rng.integers(1, 200))
+    data, slices = yv.synth_batch(n_graphs, 500 + seed, **kw)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), seed).cuda()
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), seed)
+    model.eval(); ref.eval()
+    with torch.no_grad():
+        got = model(data, slices)[0].cpu()
+        want = ref(data, None)[0]
+    _elementwise(got, want, 1e-4, "logits seed %d %s %s" % (seed, optkw, kw))
+    model.train(); ref.train().double()
+    out = model(data, slices)
+    loss = yv.DetectionLoss(yv.Opt(**optkw))(out, data)["loss"]
+    loss.backward()
+    _, rloss = _oracle_train(ref, optkw, data, torch.float64)
+    assert abs(float(loss.detach()) - float(rloss)) <= 1e-4 * abs(float(rloss))
+    band = _kink_band(lambda: gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), seed), optkw, data)
+    _grad_check({n: p.grad for n, p in model.named_parameters()}, ref, 5e-3, "seed %d" % seed, band=band)
