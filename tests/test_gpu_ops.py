@@ -64,16 +64,24 @@ def test_coo_to_csr_and_csc_match_fixture(golden_dir, transposed):
         np.testing.assert_array_equal(g.attr[:E].cpu().numpy(), attr.cpu().numpy()[z["csr_%s/perm" % tag]])
 
 
-def test_csr_large_random_matches_numpy_and_properties():
+@pytest.mark.parametrize("N,E", [(20000, 90001), (20000, 140001), (70000, 100000), (300, 20000), (4097, 4096)])
+def test_csr_large_random_matches_numpy_and_properties(N, E):
+    """Both forms of yolat_graph_prepare (graph.hip): the 3-launch one for small graphs (N + 1 <= 16 * 4096 and
+    E <= 131072: ticket scan, row emitted by the thread that completes it, wave-cooperative rows above 16 items) and
+    the 5-launch one above that, against numpy's stable argsort.  (300, 20000): every row is a heavy row, one of them
+    holds 3000 edges (above the LDS-staged row length)."""
     yv = _yv()
     rng = np.random.default_rng(5)
-    N, E = 20000, 90001
     src = rng.integers(0, N, size=E).astype(np.int64)
     dst = (rng.integers(0, N, size=E) ** 2 // N).astype(np.int64)        # skewed in-degrees
-    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), torch.zeros(E, 4).cuda(), None, N, 1)
+    if N == 300:
+        dst[rng.permutation(E)[:3000]] = 17
+    attr = torch.from_numpy(rng.standard_normal((E, 4)).astype(np.float32)).cuda()
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1)), attr, None, N, 1)
     g.ensure_csc()
     g.check_status()
     order = np.argsort(dst, kind="stable")
+    np.testing.assert_array_equal(g.attr[:E].cpu().numpy(), attr.cpu().numpy()[order])
     np.testing.assert_array_equal(g.perm.cpu().numpy(), order.astype(np.int32))
     np.testing.assert_array_equal(g.dst.cpu().numpy(), dst[order].astype(np.int32))
     np.testing.assert_array_equal(g.src.cpu().numpy(), src[order].astype(np.int32))
