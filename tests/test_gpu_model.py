@@ -511,3 +511,38 @@ def test_other_model_shapes_match_oracle(cin, blocks, blocks_out, classes):
     for (n, p), (_, q) in zip(model.named_parameters(), ref64.named_parameters()):
         err = float((p.grad.cpu().double() - q.grad).abs().max())
         assert err <= 1e-3 * max(float(q.grad.abs().max()), 1e-12) + 2e-5 * gmax, (n, err)
+
+
+def test_pooling_riders_are_bit_identical_to_the_pool_prepare_launch(tmp_path):
+    """Small graphs: the pooling prologue (zero / per-proposal max of feats / mean of the node branch) rides as extra
+    workgroups in the last edge launch and the fusion launch (common.hpp PoolRider, forward_eval.hip) instead of being
+    a launch of its own.  Same arithmetic in the same order: the logits of cfg 2 and of a one-block model must be
+    bit-identical with YOLAT_POOL_RIDERS=0 (the switch is read once per process, hence two child processes)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import golden_util as gu\n"
+        "import yolat_vectorgraphicsrecognition_amd as yv\n"
+        "outs = []\n"
+        "for cfg, kw in (('2', None), (None, dict(n_classes=5, n_blocks=1, n_blocks_out=1))):\n"
+        "    if cfg:\n"
+        "        data, slices, optkw, _ = yv.config(cfg)\n"
+        "    else:\n"
+        "        optkw = kw; data, slices = yv.synth_batch(2, 7, num_proposals=37, nodes_lo=2, nodes_hi=30, n_classes=5)\n"
+        "    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 3).cuda().eval()\n"
+        "    with torch.no_grad():\n"
+        "        outs.append(model(data, slices)[0].cpu())\n"
+        "    model.check_last_status()\n"
+        "torch.save(outs, sys.argv[1])\n" % (root, os.path.join(root, "tests")))
+    got = {}
+    for flag in ("0", "1"):
+        out = str(tmp_path / ("logits_%s.pt" % flag))
+        env = dict(os.environ, YOLAT_POOL_RIDERS=flag)
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=600)
+        got[flag] = torch.load(out)
+    for a, b in zip(got["0"], got["1"]):
+        assert a.shape == b.shape and torch.isfinite(a).all()
+        assert torch.equal(a, b)

@@ -667,6 +667,76 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
 int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const float* W, const float* bias, long F,
                             const float* sgn, const int* node_seg, unsigned long long* keys, uint16_t* wsplit,
                             yolat_stream_t stream);
+// ------------------------------------------------------------------------------------------------
+// Pooling prologue as a RIDER of other launches (small graphs, where a launch of its own is ~5 us of latency):
+// the parts of k_pool_prepare (segment.hip) done by `blocks` extra workgroups appended to a kernel whose own
+// workgroups do not depend on them:
+//   YL_POOL_ZERO  Z[p, 0:F] = 0                      } ride in the LAST conv layer's edge kernel (need the node branch
+//   YL_POOL_MEAN  Z[p, 2F+D:2F+2D] = mean(fsup rows)  } of that layer, ready one launch earlier; read by the fusion launch)
+//   YL_POOL_MAX   Z[p, F:F+D] = max(feats rows)        ride in the fusion launch itself (reads feats, like its GEMM)
+// Same arithmetic, in the same (row) order, as k_pool_prepare.
+// ------------------------------------------------------------------------------------------------
+#define YL_POOL_ZERO 1
+#define YL_POOL_MAX 2
+#define YL_POOL_MEAN 4
+struct PoolRider {
+  const float* feats; const float* fsup; long ld; int D, F, P; const int* seg_ptr; float* Z; long ldz;
+  int parts, blocks;
+};
+// virtual block vb of nvb, thread tid of nthreads (grid-stride over the items of the selected parts)
+__device__ __forceinline__ void yl_pool_rider(const PoolRider& r, int vb, int nvb, int tid, int nthreads) {
+  const int wz = (r.parts & YL_POOL_ZERO) ? r.F : 0, wx = (r.parts & YL_POOL_MAX) ? r.D : 0,
+            wm = (r.parts & YL_POOL_MEAN) ? r.D : 0;
+  const int W = wz + wx + wm;
+  const long total = (long)r.P * W;
+  for (long i = (long)vb * nthreads + tid; i < total; i += (long)nvb * nthreads) {
+    const int p = (int)(i / W), c = (int)(i - (long)p * W);
+    float* z = r.Z + (long)p * r.ldz;
+    if (c < wz) { z[c] = 0.f; continue; }
+    const bool is_max = c < wz + wx;
+    const int k = is_max ? c - wz : c - wz - wx;
+    const float* src = (is_max ? r.feats : r.fsup) + k;
+    const int r0 = r.seg_ptr[p], r1 = r.seg_ptr[p + 1];
+    float best = 0.f, sm = 0.f;
+    bool any = false;
+    int q = r0;
+    for (; q + 8 <= r1; q += 8) {
+      float v[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] = src[(long)(q + j) * r.ld];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if (!any || v[j] > best) { best = v[j]; any = true; }
+        sm += v[j];
+      }
+    }
+    for (; q < r1; ++q) {
+      const float v = src[(long)q * r.ld];
+      if (!any || v > best) { best = v; any = true; }
+      sm += v;
+    }
+    if (is_max) z[r.F + k] = best;
+    else {
+      const int cnt = r1 - r0;
+      z[2 * r.F + r.D + k] = sm / (float)(cnt > 1 ? cnt : 1);
+    }
+  }
+}
+// yolat_edge_uv_mlp2_mean_eval_variant with an optional rider (edge.hip): *rode = 1 when the launched kernel carried it
+int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                                   const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                                   const float* b1, const float* s1, const float* t1, const float* W2, const float* b2,
+                                   const float* s2, const float* t2, int64_t C, float* f_out, int64_t ld_fo, int variant,
+                                   const PoolRider* rider, int* rode, yolat_stream_t stream);
+// yolat_fusion_pair_eval_x6 with an optional rider (fusion_x6.hip)
+int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
+                                const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,
+                                int64_t ldpool, const float* S, int64_t lds, int64_t P, const uint16_t* Wsh,
+                                const uint16_t* Wsm, const uint16_t* Wsl, const float* tsfold, float* Ys, int64_t ldys,
+                                const PoolRider* rider, yolat_stream_t stream);
+// k_pool_prepare restricted to `parts` (segment.hip)
+int yl_pool_prepare_parts(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F, const int32_t* seg_ptr,
+                          int64_t P, float* Z, int64_t ldz, int parts, yolat_stream_t stream);
 // stage profiler hooks (forward_eval.hip): HIP-event pair around one stage of a whole-forward entry point
 bool yl_profile_on();
 void yl_stage_begin(const char* name, double flops, double bytes, yolat_stream_t stream);

@@ -286,7 +286,12 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
                                                            const float* __restrict__ b2,
                                                            const float* __restrict__ s2,
                                                            const float* __restrict__ t2, float* f_out, long ld_fo,
-                                                           int E) {
+                                                           int E, int tiles, PoolRider rider) {
+  // workgroups past the node tiles: pooling-prologue rider (common.hpp), independent of this layer's messages
+  if ((int)blockIdx.x >= tiles) {
+    yl_pool_rider(rider, blockIdx.x - tiles, rider.blocks, threadIdx.x, 256);
+    return;
+  }
   constexpr int LDH = 65;
   __shared__ float Hs[64 * LDH];      // layer-1 activations of the pass, then the layer-2 messages
   __shared__ float W2s[64 * LDH];
@@ -760,12 +765,12 @@ __global__ void __launch_bounds__(512, 4) k_edge_uv_mlp2_mean_ws(const float* __
   aggregate(np - 1);
 }
 
-extern "C" int yolat_edge_uv_mlp2_mean_eval_variant(const float* UV, int64_t ld_uv, const int32_t* src_csr,
-                                                    const int32_t* dst_csr, const float* attr_csr,
-                                                    const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
-                                                    const float* b1, const float* s1, const float* t1, const float* W2,
-                                                    const float* b2, const float* s2, const float* t2, int64_t C,
-                                                    float* f_out, int64_t ld_fo, int variant, yolat_stream_t stream) {
+int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                                   const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                                   const float* b1, const float* s1, const float* t1, const float* W2, const float* b2,
+                                   const float* s2, const float* t2, int64_t C, float* f_out, int64_t ld_fo, int variant,
+                                   const PoolRider* rider, int* rode, yolat_stream_t stream) {
+  if (rode) *rode = 0;
   if (E < 0 || N <= 0 || !UV || !Wc4 || !W2 || !row_ptr || !f_out) return YOLAT_E_INVALID;
   if (variant < YOLAT_EDGE_AUTO || variant > YOLAT_EDGE_WS_X6) return YOLAT_E_INVALID;
   if (C != 64) return YOLAT_E_UNSUPPORTED;
@@ -819,16 +824,30 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval_variant(const float* UV, int64_t ld_
   if (npt < 1) npt = 1;
   if (npt > 64) npt = 64;
   DenseOp w2 = yl_dense(W2, C, C, C);
+  const int tiles = yl_cdiv(N, npt);
+  PoolRider pr{};
+  if (rider && rider->blocks > 0) { pr = *rider; if (rode) *rode = 1; }
+  const unsigned grid = (unsigned)tiles + (unsigned)pr.blocks;
   if (npt <= 16)
-    hipLaunchKernelGGL(k_edge_uv_mlp2_mean<1>, dim3(yl_cdiv(N, npt)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
+    hipLaunchKernelGGL(k_edge_uv_mlp2_mean<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
                        src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
-                       (long)ld_fo, (int)E);
+                       (long)ld_fo, (int)E, tiles, pr);
   else
-    hipLaunchKernelGGL(k_edge_uv_mlp2_mean<4>, dim3(yl_cdiv(N, npt)), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
+    hipLaunchKernelGGL(k_edge_uv_mlp2_mean<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
                        src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
-                       (long)ld_fo, (int)E);
+                       (long)ld_fo, (int)E, tiles, pr);
   YL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int yolat_edge_uv_mlp2_mean_eval_variant(const float* UV, int64_t ld_uv, const int32_t* src_csr,
+                                                    const int32_t* dst_csr, const float* attr_csr,
+                                                    const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                                                    const float* b1, const float* s1, const float* t1, const float* W2,
+                                                    const float* b2, const float* s2, const float* t2, int64_t C,
+                                                    float* f_out, int64_t ld_fo, int variant, yolat_stream_t stream) {
+  return yl_edge_uv_mlp2_mean_eval_impl(UV, ld_uv, src_csr, dst_csr, attr_csr, row_ptr, N, E, Wc4, b1, s1, t1, W2, b2, s2,
+                                        t2, C, f_out, ld_fo, variant, nullptr, nullptr, stream);
 }
 
 extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,

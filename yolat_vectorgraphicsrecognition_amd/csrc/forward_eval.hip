@@ -180,6 +180,21 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
                                p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, stream));
   }
 
+  // ---- pooling prologue (segment.hip k_pool_prepare): a launch of its own for large graphs; for small ones
+  // (YOLAT_POOL_RIDERS != 0, P * (F + 2 D) below ~1 M items) its parts ride in the last edge launch and the fusion
+  // launch (common.hpp PoolRider) — at cfg 2 that launch is 5 us of pure latency
+  static const bool riders_on = []() { const char* v = getenv("YOLAT_POOL_RIDERS"); return !(v && v[0] == '0'); }();
+  const bool fusion_x6 = m->Wf_hi && m->Wf_mid && m->Wf_lo && m->tf_fold && m->Wfs_hi && m->Wfs_mid && m->Wfs_lo &&
+                         m->tfs_fold && (D == 64 || D == 128) && F % 64 == 0 && (long)P * ZW < (1LL << 32);
+  const bool small_pool = riders_on && (long)P * (F + 2 * D) <= (1L << 20);
+  PoolRider ride_a{}, ride_b{};
+  ride_a.feats = ride_b.feats = p.feats; ride_a.fsup = ride_b.fsup = p.fsup; ride_a.ld = ride_b.ld = D;
+  ride_a.D = ride_b.D = (int)D; ride_a.F = ride_b.F = (int)F; ride_a.P = ride_b.P = (int)P;
+  ride_a.seg_ptr = ride_b.seg_ptr = p.seg_ptr; ride_a.Z = ride_b.Z = p.Z; ride_a.ldz = ride_b.ldz = ZW;
+  ride_a.parts = YL_POOL_ZERO | YL_POOL_MEAN; ride_a.blocks = small_pool && fusion_x6 ? 256 : 0;
+  ride_b.parts = YL_POOL_MAX; ride_b.blocks = small_pool && fusion_x6 ? 64 : 0;
+  int pool_done = 0;
+
   // ---- conv layers (torch_vertex.py:319-337), outputs written into their concat slots
   const float* f_in = x; long ld_f = ldx;
   const float* s_in = x; long ld_s = ldx;
@@ -217,14 +232,19 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
                                                 2 * C, f_out, ld_out, s_out, ld_out, stream));
         }
         if (E > 0) {
+          // last layer of a small graph: the parts of the pooling prologue that do not need this layer's messages
+          // (zero the pooled maxima, per-proposal mean of the node branch) ride in this launch
+          const PoolRider* rd = (l == m->n_blocks - 1 && ride_a.blocks > 0) ? &ride_a : nullptr;
+          int rode = 0;
           snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
           YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C,
-                   fold ? yolat_edge_uv_mlp2_mean_eval(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4f,
-                                                       nullptr, nullptr, nullptr, cv.W2, nullptr, cv.s2, cv.t2f, C,
-                                                       f_out, ld_out, stream)
-                        : yolat_edge_uv_mlp2_mean_eval(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.b1,
-                                                       cv.s1, cv.t1, cv.W2, cv.b2, cv.s2, cv.t2, C, f_out, ld_out,
-                                                       stream));
+                   fold ? yl_edge_uv_mlp2_mean_eval_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4f,
+                                                         nullptr, nullptr, nullptr, cv.W2, nullptr, cv.s2, cv.t2f, C,
+                                                         f_out, ld_out, YOLAT_EDGE_AUTO, rd, &rode, stream)
+                        : yl_edge_uv_mlp2_mean_eval_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4,
+                                                         cv.b1, cv.s1, cv.t1, cv.W2, cv.b2, cv.s2, cv.t2, C, f_out,
+                                                         ld_out, YOLAT_EDGE_AUTO, rd, &rode, stream));
+          if (rode) pool_done |= ride_a.parts;
         }
       } else {
       // three launches per layer: edge MLP (hidden activation in LDS); root Linear | node-branch Linear as one
@@ -273,17 +293,19 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
 
   // ---- fusion over nodes + per-proposal max (arch:61-63,122)
   float* sup = p.Z + 2 * F + D;
-  YL_STAGE("pool_prepare[max(feats), mean(fsup), zero]", 2.0 * N * D, 8.0 * N * D + 4.0 * P * (F + 2 * D),
-           yolat_pool_prepare(p.feats, p.fsup, D, D, F, p.seg_ptr, P, p.Z, ZW, stream));
+  const bool ride_max = ride_b.blocks > 0 && (pool_done & YL_POOL_ZERO);       // riders all the way, or not at all
+  const int pool_left = (YL_POOL_ZERO | YL_POOL_MAX | YL_POOL_MEAN) & ~pool_done & ~(ride_max ? YL_POOL_MAX : 0);
+  if (pool_left) {
+    YL_STAGE("pool_prepare[max(feats), mean(fsup), zero]", 2.0 * N * D, 8.0 * N * D + 4.0 * P * (F + 2 * D),
+             yl_pool_prepare_parts(p.feats, p.fsup, D, D, F, p.seg_ptr, P, p.Z, ZW, pool_left, stream));
+  }
   // fusion block over the nodes + per-proposal max, and fusion_block_super over the per-proposal means
   // (arch:61-63,65-69,122): two independent GEMMs in one flattened launch
   snprintf(nm, sizeof nm, "fusion_gemm+segmax[N x %ld -> %ld -> P] | super[P x %ld -> %ld]", D, F, D, F);
-  const bool fusion_x6 = m->Wf_hi && m->Wf_mid && m->Wf_lo && m->tf_fold && m->Wfs_hi && m->Wfs_mid && m->Wfs_lo &&
-                         m->tfs_fold && (D == 64 || D == 128) && F % 64 == 0 && (long)P * ZW < (1LL << 32);
   YL_STAGE(nm, 2.0 * (N + P) * D * F, 4.0 * (N * D + 2.0 * D * F + 2.0 * P * F + N + P * D),
-           fusion_x6 ? yolat_fusion_pair_eval_x6(p.feats, D, N, D, m->Wf_hi, m->Wf_mid, m->Wf_lo, m->tf_fold, F, p.node_seg,
-                                                 p.Z, ZW, sup, ZW, P, m->Wfs_hi, m->Wfs_mid, m->Wfs_lo, m->tfs_fold,
-                                                 p.Z + F + D, ZW, stream)
+           fusion_x6 ? yl_fusion_pair_eval_x6_impl(p.feats, D, N, D, m->Wf_hi, m->Wf_mid, m->Wf_lo, m->tf_fold, F,
+                                                   p.node_seg, p.Z, ZW, sup, ZW, P, m->Wfs_hi, m->Wfs_mid, m->Wfs_lo,
+                                                   m->tfs_fold, p.Z + F + D, ZW, ride_max ? &ride_b : nullptr, stream)
                      : yolat_fusion_pair_eval(p.feats, D, N, D, m->Wf, m->bf, m->sf, m->tf, F, p.node_seg, p.Z, ZW, sup,
                                               ZW, P, m->Wfs, m->bfs, m->sfs, m->tfs, p.Z + F + D, ZW, stream));
   // ---- classifier (arch:91-93,127-128)

@@ -110,7 +110,7 @@ struct FxProb {
 };
 
 template <int KD>
-__global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1) {
+__global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1, PoolRider rider) {
   constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
   constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / 512;   // 16-byte chunks of one W tile, per thread
   static_assert(CHUNKS % 512 == 0, "W tile / thread mismatch");
@@ -121,6 +121,12 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1)
   // id % 8 = XCD alignment): they start with the first round of workgroups instead of forming a tail
   const int n1 = p1.tm * p1.groups, n1p = (n1 + 7) & ~7;
   const int id = blockIdx.x;
+  // workgroups past both problems: pooling-prologue rider (common.hpp; reads A like the GEMM, writes columns of the
+  // pooled rows that nothing in this launch reads)
+  if (rider.blocks > 0 && id >= n1p + p0.tm * p0.groups) {
+    yl_pool_rider(rider, id - (n1p + p0.tm * p0.groups), rider.blocks, tid, 512);
+    return;
+  }
   int logical;
   if (id < n1p) {
     if (id >= n1) return;
@@ -358,12 +364,11 @@ extern "C" int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int
 // pool[p, 0:F] = max over the rows of proposal p of relu(A . (sf (.) Wf)^T + tfold),  Ys = relu(S . (sfs (.) Wfs)^T
 // + tsfold): both fusion blocks with pre-split weights (yolat_split_bf16x3 of the scaled rows) and folded shifts
 // (s*b + t).  `pool` must be zero-filled first (yolat_pool_prepare).  D in {64, 128}, F % 64 == 0.
-extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh,
-                                         const uint16_t* Wm, const uint16_t* Wl, const float* tfold, int64_t F,
-                                         const int32_t* node_seg, float* pool, int64_t ldpool, const float* S,
-                                         int64_t lds, int64_t P, const uint16_t* Wsh, const uint16_t* Wsm,
-                                         const uint16_t* Wsl, const float* tsfold, float* Ys, int64_t ldys,
-                                         yolat_stream_t stream) {
+int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
+                                const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,
+                                int64_t ldpool, const float* S, int64_t lds, int64_t P, const uint16_t* Wsh,
+                                const uint16_t* Wsm, const uint16_t* Wsl, const float* tsfold, float* Ys, int64_t ldys,
+                                const PoolRider* rider, yolat_stream_t stream) {
   if (N <= 0 || P <= 0 || F <= 0 || !A || !Wh || !Wm || !Wl || !tfold || !node_seg || !pool || !S || !Wsh || !Wsm || !Wsl ||
       !tsfold || !Ys)
     return YOLAT_E_INVALID;
@@ -400,13 +405,25 @@ extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N,
   if (forced > 0) best_g = forced < tn ? forced : tn;
   p0.ng = yl_cdiv(tn, best_g);
   p0.groups = yl_cdiv(tn, p0.ng);
-  const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L);
+  PoolRider pr{};
+  if (rider && rider->blocks > 0) pr = *rider;
+  const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L) + pr.blocks;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
   YL_LAUNCH_CHECK();
   return 0;
+}
+
+extern "C" int yolat_fusion_pair_eval_x6(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh,
+                                         const uint16_t* Wm, const uint16_t* Wl, const float* tfold, int64_t F,
+                                         const int32_t* node_seg, float* pool, int64_t ldpool, const float* S,
+                                         int64_t lds, int64_t P, const uint16_t* Wsh, const uint16_t* Wsm,
+                                         const uint16_t* Wsl, const float* tsfold, float* Ys, int64_t ldys,
+                                         yolat_stream_t stream) {
+  return yl_fusion_pair_eval_x6_impl(A, lda, N, D, Wh, Wm, Wl, tfold, F, node_seg, pool, ldpool, S, lds, P, Wsh, Wsm, Wsl,
+                                     tsfold, Ys, ldys, nullptr, stream);
 }
 
 // Training-mode fusion GEMM (fusion_train.hip step 4) on the rows kernel: z = A . W^T + bias never stored, per
@@ -443,8 +460,8 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
   const long total = (long)p0.tm * p0.groups;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -478,8 +495,8 @@ extern "C" int yolat_linear_fwd_rows_x6(const float* A, int64_t lda, int64_t M, 
   const long total = (long)p0.tm;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -512,7 +529,7 @@ extern "C" int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const floa
   p1.tm = yl_cdiv(N, 256); p1.groups = 1; p1.ng = 1;
   const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L);
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, p0, p1);
+  hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, p0, p1, PoolRider{});
   YL_LAUNCH_CHECK();
   return 0;
 }

@@ -78,14 +78,15 @@ __global__ void __launch_bounds__(256) k_segment_max_fwd(const float* X, long ld
 //   Z[p, F:F+D]            = max over rows of feats  (pass-through half of out_feat, arch:63,122)
 //   Z[p, 2F+D:2F+2D]       = mean over rows of fsup  (arch:67)
 __global__ void __launch_bounds__(256) k_pool_prepare(const float* feats, const float* fsup, long ld, int D,
-                                                      int F, const int* seg_ptr, float* Z, long ldz) {
+                                                      int F, const int* seg_ptr, float* Z, long ldz, int parts) {
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int p = blockIdx.y;
   float* z = Z + (long)p * ldz;
-  if (c < F) { z[c] = 0.f; return; }
+  if (c < F) { if (parts & YL_POOL_ZERO) z[c] = 0.f; return; }
   if (c >= F + 2 * D || (fsup == nullptr && c >= F + D)) return;
   const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
   const bool is_max = c < F + D;
+  if (!(parts & (is_max ? YL_POOL_MAX : YL_POOL_MEAN))) return;
   const int k = is_max ? c - F : c - F - D;
   const float* src = (is_max ? feats : fsup) + k;
   // rows are read 8 at a time (independent loads in flight) — a one-row-per-iteration loop is a chain of
@@ -116,19 +117,25 @@ __global__ void __launch_bounds__(256) k_pool_prepare(const float* feats, const 
   }
 }
 
-extern "C" int yolat_pool_prepare(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F,
-                                  const int32_t* seg_ptr, int64_t P, float* Z, int64_t ldz,
-                                  yolat_stream_t stream) {
+int yl_pool_prepare_parts(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F, const int32_t* seg_ptr,
+                          int64_t P, float* Z, int64_t ldz, int parts, yolat_stream_t stream) {
   if (P <= 0 || D <= 0 || F <= 0 || !feats || !seg_ptr || !Z || ld < D || ldz < 2 * (F + D))
     return YOLAT_E_INVALID;
   for (int64_t p0 = 0; p0 < P; p0 += 65535) {
     const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
     hipLaunchKernelGGL(k_pool_prepare, dim3(yl_cdiv(F + (fsup ? 2 : 1) * D, 256), (unsigned)np), dim3(256), 0,
                        (hipStream_t)stream, feats, fsup, (long)ld, (int)D, (int)F, seg_ptr + p0, Z + p0 * ldz,
-                       (long)ldz);
+                       (long)ldz, parts);
     YL_LAUNCH_CHECK();
   }
   return 0;
+}
+
+extern "C" int yolat_pool_prepare(const float* feats, const float* fsup, int64_t ld, int64_t D, int64_t F,
+                                  const int32_t* seg_ptr, int64_t P, float* Z, int64_t ldz,
+                                  yolat_stream_t stream) {
+  return yl_pool_prepare_parts(feats, fsup, ld, D, F, seg_ptr, P, Z, ldz, YL_POOL_ZERO | YL_POOL_MAX | YL_POOL_MEAN,
+                               stream);
 }
 
 static int seg_args_ok(const float* X, int64_t ldx, int64_t D, const float* s, const float* b,
