@@ -186,7 +186,8 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
   static const bool riders_on = []() { const char* v = getenv("YOLAT_POOL_RIDERS"); return !(v && v[0] == '0'); }();
   const bool fusion_x6 = m->Wf_hi && m->Wf_mid && m->Wf_lo && m->tf_fold && m->Wfs_hi && m->Wfs_mid && m->Wfs_lo &&
                          m->tfs_fold && (D == 64 || D == 128) && F % 64 == 0 && (long)P * ZW < (1LL << 32);
-  const bool small_pool = riders_on && (long)P * (F + 2 * D) <= (1L << 20);
+  static const long rider_items = []() { const char* v = getenv("YOLAT_POOL_RIDER_ITEMS"); return v ? atol(v) : (1L << 20); }();
+  const bool small_pool = riders_on && (long)P * (F + 2 * D) <= rider_items;
   PoolRider ride_a{}, ride_b{};
   ride_a.feats = ride_b.feats = p.feats; ride_a.fsup = ride_b.fsup = p.fsup; ride_a.ld = ride_b.ld = D;
   ride_a.D = ride_b.D = (int)D; ride_a.F = ride_b.F = (int)F; ride_a.P = ride_b.P = (int)P;
