@@ -504,6 +504,16 @@ int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx, c
                        const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, float* logits,
                        int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
                        yolat_stream_t stream);
+/* The same forward for a caller that keeps `workspace` to itself (a serving loop, plan.EvalPlan): the PREVIOUS use of
+ * this workspace was yolat_forward_eval / yolat_forward_eval_primed with the same m layout, N, E and P, enqueued on
+ * the same stream or already complete, and nothing else has written into it since.  Every forward leaves the
+ * CSR-build counters zero, so this call skips their memset launch (3.8 us of the ~120 us cfg-2 forward).  A broken
+ * promise gives a wrong CSR (undefined results, memory-safe).                                                       */
+int yolat_forward_eval_primed(const yolat_model_eval* m, const float* x, int64_t ldx, const int64_t* edge,
+                              int64_t stride_e, int64_t stride_c, const float* e_attr,
+                              const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, float* logits,
+                              int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
+                              yolat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * bf16-storage eval forward (bf16_eval.hip): the precision mode of BASELINE.json's large-graph

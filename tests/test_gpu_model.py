@@ -546,3 +546,36 @@ def test_pooling_riders_are_bit_identical_to_the_pool_prepare_launch(tmp_path):
     for a, b in zip(got["0"], got["1"]):
         assert a.shape == b.shape and torch.isfinite(a).all()
         assert torch.equal(a, b)
+
+
+def test_primed_workspace_forwards_equal_self_contained_forwards():
+    """plan.EvalPlan skips the memset of the CSR-build counters when its workspace was last used by a forward of the same
+    shape (yolat_forward_eval_primed: every forward leaves the counters zero).  A sequence that repeats and alternates
+    batch shapes on ONE plan must give, bit for bit, what the self-contained calls give; the status word stays clean."""
+    import yolat_vectorgraphicsrecognition_amd as yv
+    from yolat_vectorgraphicsrecognition_amd import plan as plan_mod
+    optkw = dict(n_classes=9, n_blocks=2, n_blocks_out=2)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 5).cuda().eval()
+    batches = [yv.synth_batch(2, 40 + i, num_proposals=25 + 10 * (i % 2), nodes_lo=2, nodes_hi=24, n_classes=9)
+               for i in range(3)]
+    order = [0, 0, 0, 1, 1, 0, 2, 2, 1, 1, 1]
+
+    def run(primed):
+        old = plan_mod.PRIMED_WS
+        plan_mod.PRIMED_WS = primed
+        try:
+            outs = []
+            with torch.no_grad():
+                for i in order:
+                    data, slices = batches[i]
+                    outs.append(model(data, slices)[0].clone())
+                    model.check_last_status()
+            return outs
+        finally:
+            plan_mod.PRIMED_WS = old
+    a, b = run(False), run(True)
+    for x, y in zip(a, b):
+        assert torch.isfinite(x).all() and torch.equal(x, y)
+    first = {}
+    for i, x in zip(order, b):                      # and the same batch always gives the same logits
+        assert torch.equal(first.setdefault(i, x), x)

@@ -137,6 +137,8 @@ SIGNATURES = {
     "yolat_forward_eval_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEval), c_i64, c_i64, c_i64]),
     "yolat_forward_eval": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64,
                                    c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_forward_eval_primed": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
+                                          c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
     "yolat_edge_uv_lin1_fwd": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_nms_work_bytes": (c_sz, [c_i64]),
     "yolat_nms": (c_int, [c_p, c_p, c_i64, c_f, c_p, c_p, c_p, c_sz, c_p]),

@@ -677,7 +677,7 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     a.euv.scale = mh->uv_scale[0]; a.euv.shift = mh->uv_shift[0];
     a.en.Y = nullptr; a.en.Yh = s_slot(0); a.en.ldy = ld_slot(0);
     YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
-                                 p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, stream));
+                                 p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, false, stream));
   });
   long npt = E > 0 ? (56 * N) / E : 64;
   {

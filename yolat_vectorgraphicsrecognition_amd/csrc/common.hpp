@@ -746,7 +746,7 @@ void yl_stage_end(yolat_stream_t stream);
 int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
                           const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr, int32_t* perm,
                           int32_t* src_csr, int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
-                          int32_t* work, int32_t* status, const NodeUv* extra, yolat_stream_t stream);
+                          int32_t* work, int32_t* status, const NodeUv* extra, bool primed, yolat_stream_t stream);
 // tile y of row tile x: y = 0,1 -> UV halves, 2 -> root Linear, 3 -> node-branch Linear
 template <int BK>
 __device__ __forceinline__ void node_uv_tile(const NodeUv& a, int x, int y) {

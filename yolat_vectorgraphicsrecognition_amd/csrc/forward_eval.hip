@@ -48,6 +48,20 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
 }
 }  // namespace
 
+// yolat_graph_prepare_node_uv with the `primed` promise (graph.hip yl_graph_prepare_impl)
+static int prep_node_uv(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                        const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, const Plan& p, int32_t* status,
+                        const float* x, int64_t ldx, int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr,
+                        const float* br, const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C,
+                        float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so, bool primed, yolat_stream_t stream) {
+  NodeUv a;
+  const int rc = yl_build_node_uv(&a, x, ldx, x, ldx, N, Cin, Wuv, uv_bias, Wr, br, Wn, bn, sn, tn, C, p.UV, 2 * C, f_out,
+                                  ld_fo, s_out, ld_so);
+  if (rc != 0) return rc;
+  return yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
+                               p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, primed, stream);
+}
+
 #define YL_TRY(call)            \
   do {                          \
     int rc__ = (call);          \
@@ -140,11 +154,37 @@ extern "C" size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, 
   return carve(m, N, E, P, nullptr).bytes;
 }
 
+static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t ldx, const int64_t* edge,
+                             int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                             int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                             size_t workspace_bytes, int32_t* status, bool primed, yolat_stream_t stream);
+
 extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx,
                                   const int64_t* edge, int64_t stride_e, int64_t stride_c,
                                   const float* e_attr, const int64_t* bbox_idx, int64_t N, int64_t E,
                                   int64_t P, float* logits, int64_t ld_logits, void* workspace,
                                   size_t workspace_bytes, int32_t* status, yolat_stream_t stream) {
+  return forward_eval_impl(m, x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, logits, ld_logits, workspace,
+                           workspace_bytes, status, false, stream);
+}
+
+// The same forward for a caller that keeps `workspace` to itself: the previous call on this workspace was
+// yolat_forward_eval / yolat_forward_eval_primed with the SAME m (layout), N, E, P and has been enqueued on the same
+// stream (or completed).  Every forward leaves the CSR-build counters zero, so this one skips their memset launch
+// (3.8 us of the 120 us cfg-2 forward).  Anything else written into the workspace in between voids the promise.
+extern "C" int yolat_forward_eval_primed(const yolat_model_eval* m, const float* x, int64_t ldx,
+                                         const int64_t* edge, int64_t stride_e, int64_t stride_c,
+                                         const float* e_attr, const int64_t* bbox_idx, int64_t N, int64_t E,
+                                         int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                         size_t workspace_bytes, int32_t* status, yolat_stream_t stream) {
+  return forward_eval_impl(m, x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, logits, ld_logits, workspace,
+                           workspace_bytes, status, true, stream);
+}
+
+static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t ldx, const int64_t* edge,
+                             int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                             int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                             size_t workspace_bytes, int32_t* status, bool primed, yolat_stream_t stream) {
   if (!m || !x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0)
     return YOLAT_E_INVALID;
   if (m->n_blocks < 1 || m->n_blocks > YOLAT_MAX_LAYERS || m->n_blocks_out < 1 ||
@@ -169,15 +209,13 @@ extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int
     const long ld0 = slot0 >= 0 ? D : C;
     YL_STAGE("graph_prep[csr+attr+segments] + node_uv[layer 0]", 8.0 * N * cv0.Cin * C,
              16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N + 4.0 * (2.0 * N * cv0.Cin + 4.0 * N * C),
-             yolat_graph_prepare_node_uv(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
-                                         p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, x, ldx, cv0.Cin,
-                                         fold0 ? cv0.Wuvf : cv0.Wuv, fold0 ? cv0.uvb : nullptr, cv0.Wr, cv0.br, cv0.Wn,
-                                         cv0.bn, cv0.sn, cv0.tn, C, p.UV, 2 * C, f0,
-                                         ld0, s0, ld0, stream));
+             prep_node_uv(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p, status, x, ldx, cv0.Cin,
+                          fold0 ? cv0.Wuvf : cv0.Wuv, fold0 ? cv0.uvb : nullptr, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn,
+                          cv0.tn, C, f0, ld0, s0, ld0, primed, stream));
   } else {
   YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N,
-           yolat_graph_prepare(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
-                               p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, stream));
+           yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
+                                 p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, nullptr, primed, stream));
   }
 
   // ---- pooling prologue (segment.hip k_pool_prepare): a launch of its own for large graphs; for small ones

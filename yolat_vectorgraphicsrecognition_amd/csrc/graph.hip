@@ -143,7 +143,7 @@ extern "C" int yolat_coo_to_csr(const int64_t* edge, int64_t stride_e, int64_t s
 // col_ptr[i] = block-local exclusive scan + prefix of the block totals; the counters are zeroed so they
 // can serve as the fill cursors.  n = N + 1 (the last element is the grand total).
 __global__ void k_csc_ptr(int* local, const int* btot, int n, int* ptr);
-__global__ void __launch_bounds__(1024) k_prep_scan(const int* cnt, int n, int* local, int* btot);
+__global__ void __launch_bounds__(1024) k_prep_scan(int* cnt, int n, int* local, int* btot);
 
 extern "C" size_t yolat_csc_work_elems(int64_t N) { return (size_t)(N + 1 + (N + 1 + 4095) / 4096 + 16); }
 
@@ -244,13 +244,18 @@ __global__ void k_prep_count(const int64_t* edge, long se, long sc, int E, int N
 }
 
 // local[i] = exclusive scan of cnt inside its PREP_BLK block; btot[b] = block total.  n = N + 1.
-__global__ void __launch_bounds__(1024) k_prep_scan(const int* cnt, int n, int* local, int* btot) {
+// cnt is left ZERO (its only reader is this kernel): a caller that keeps the work buffer to itself can skip the memset of
+// the next call with the same shape (yl_graph_prepare_impl's `primed`).
+__global__ void __launch_bounds__(1024) k_prep_scan(int* cnt, int n, int* local, int* btot) {
   __shared__ int wsum[16];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int idx = blockIdx.x * PREP_BLK + tid * 4;
   int v[4];
 #pragma unroll
-  for (int j = 0; j < 4; ++j) v[j] = (idx + j < n) ? cnt[idx + j] : 0;
+  for (int j = 0; j < 4; ++j) {
+    v[j] = (idx + j < n) ? cnt[idx + j] : 0;
+    if (idx + j < n) cnt[idx + j] = 0;
+  }
   const int t = v[0] + v[1] + v[2] + v[3];
   int incl = t;
 #pragma unroll
@@ -395,7 +400,7 @@ extern "C" size_t yolat_graph_work_elems(int64_t N, int64_t E) {
 int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
                               const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr,
                               int32_t* perm, int32_t* src_csr, int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr,
-                              int32_t* node_seg, int32_t* work, int32_t* status, const NodeUv* extra,
+                              int32_t* node_seg, int32_t* work, int32_t* status, const NodeUv* extra, bool primed,
                               yolat_stream_t stream) {
   if (N <= 0 || E < 0 || N >= (1LL << 31) - 8192 || E >= (1LL << 31) - 256) return YOLAT_E_INVALID;
   if (!row_ptr || !work || !status) return YOLAT_E_INVALID;
@@ -413,8 +418,11 @@ int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_
   int* dst32 = src32 + E;
   int* rank = dst32 + E;
   int* items = rank + E;
-  hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n1p, st);
-  if (err != hipSuccess) return (int)err;
+  // primed: the caller vouches that the counters are zero (left so by the previous call with this shape on this buffer)
+  if (!primed) {
+    hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n1p, st);
+    if (err != hipSuccess) return (int)err;
+  }
   const long nthreads = (E > N + 1) ? E : N + 1;
   hipLaunchKernelGGL(k_prep_count, dim3(yl_cdiv(nthreads, 256)), dim3(256), 0, st, edge, (long)stride_e,
                      (long)stride_c, (int)E, (int)N, src32, dst32, rank, cnt, bbox_idx, (long)P, seg_ptr,
@@ -453,7 +461,7 @@ extern "C" int yolat_graph_prepare(const int64_t* edge, int64_t stride_e, int64_
                                    int32_t* dst_csr, float* attr_csr, int32_t* seg_ptr, int32_t* node_seg,
                                    int32_t* work, int32_t* status, yolat_stream_t stream) {
   return yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
-                            attr_csr, seg_ptr, node_seg, work, status, nullptr, stream);
+                            attr_csr, seg_ptr, node_seg, work, status, nullptr, false, stream);
 }
 
 // yolat_graph_prepare with the node side of the first conv layer (yolat_node_uv_eval on the raw node
@@ -473,7 +481,7 @@ extern "C" int yolat_graph_prepare_node_uv(const int64_t* edge, int64_t stride_e
                                   ld_fo, s_out, ld_so);
   if (rc != 0) return rc;
   return yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, row_ptr, perm, src_csr, dst_csr,
-                            attr_csr, seg_ptr, node_seg, work, status, &a, stream);
+                            attr_csr, seg_ptr, node_seg, work, status, &a, false, stream);
 }
 
 __global__ void k_gather_rows(const float* src, long ld_src, const int* idx, long rows, int width,

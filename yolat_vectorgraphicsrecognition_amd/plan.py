@@ -12,6 +12,10 @@ import torch
 from . import ops
 from ._lib import lib, check, ModelEval, ModelEvalBf16, YOLAT_MAX_LAYERS
 
+# skip the memset of the CSR-build counters when the plan's workspace was last used by a forward of the same shape
+# (yolat_forward_eval_primed, include/yolat_hip.h); YOLAT_PRIMED_WS=0: always the self-contained call
+PRIMED_WS = os.environ.get("YOLAT_PRIMED_WS", "1") != "0"
+
 
 def _fold(bn, dev):
     coef = torch.empty(2, bn.num_features, dtype=torch.float32, device=dev)
@@ -36,12 +40,16 @@ class EvalPlan(object):
         self._ws = None
         self._status = None
         self._graphs = {}
+        self._primed = None        # (workspace, descriptor build, N, E, P, stream) of the last completed direct launch
+        self._desc_key = 0
         self.use_graph = os.environ.get("YOLAT_HIP_GRAPH", "0") == "1"
 
     def _version_key(self):
         return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(), ops.weight_epoch())
 
     def _build(self):
+        self._desc_key += 1
+        self._primed = None
         from .engine import model_convs
         m = self.model
         dev = self._tensors[0].device
@@ -247,11 +255,22 @@ class EvalPlan(object):
                                               logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
                                               self._status.data_ptr(), ops._stream()), "yolat_forward_eval_bf16")
             return logits
-        check(lib.yolat_forward_eval(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x),
-                                     ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
-                                     ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
-                                     logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
-                                     self._status.data_ptr(), ops._stream()), "yolat_forward_eval")
+        # the workspace is this plan's own: when its previous use was a forward of the same shape on the same stream,
+        # the CSR-build counters are already zero (yolat_forward_eval_primed: no memset launch).  A hipGraph capture
+        # always records the self-contained form (a replay may follow a forward of any other shape).
+        stream = ops._stream()
+        capturing = torch.cuda.is_current_stream_capturing()
+        key = (self._ws.data_ptr(), self._desc_key, N, E, P, stream)
+        primed = PRIMED_WS and not capturing and self._primed == key
+        self._primed = None
+        fn = lib.yolat_forward_eval_primed if primed else lib.yolat_forward_eval
+        check(fn(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x),
+                 ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
+                 ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
+                 logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
+                 self._status.data_ptr(), stream), "yolat_forward_eval")
+        if not capturing:
+            self._primed = key
         return logits
 
     def _run_graph(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
@@ -280,6 +299,7 @@ class EvalPlan(object):
                 static_out = self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
             ent = self._graphs[gkey] = (g, static_out, (x, edge, e_attr, bbox_idx))   # keep the inputs alive
         g, static_out, _ = ent
+        self._primed = None        # the next direct launch must not assume which shape used the workspace last
         g.replay()
         return static_out.clone()
 
