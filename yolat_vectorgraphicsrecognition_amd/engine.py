@@ -23,6 +23,9 @@ from . import ops
 # training-mode fusion block + max pooling without the [N, 1024] activation (csrc/fusion_train.hip);
 # YOLAT_FUSED_FUSION_TRAIN=0 selects the materialising schedule (kept as the cross-check in the tests)
 FACTORISED_TRAIN = os.environ.get("YOLAT_FACTORISED_TRAIN", "1") != "0"
+# edges per node from which the factorised first edge Linear is used (forward / backward chosen separately)
+FACT_FWD_RATIO = float(os.environ.get("YOLAT_FACT_FWD_RATIO", "2.0"))
+FACT_BWD_RATIO = float(os.environ.get("YOLAT_FACT_BWD_RATIO", "1.0"))     # measured: cfg 3 (E = 1.2 N) 3.77 -> 3.66 ms, cfg 4 3.63 -> 3.53 ms
 FUSED_FUSION_TRAIN = os.environ.get("YOLAT_FUSED_FUSION_TRAIN", "1") != "0"
 
 
@@ -206,7 +209,7 @@ def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False):
     # root term first, the aggregation accumulates onto it:  out = lin_r(x) + mean_e(m_e)   (:325)
     ops.linear_fwd(x, conv.lin_r.weight, conv.lin_r.bias, out_f)
     if E > 0:
-        factorised = (training and FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous()
+        factorised = (training and FACTORISED_TRAIN and C == 64 and E >= FACT_FWD_RATIO * N and nn0.weight.is_contiguous()
                       and nn0.bias is not None)
         # bf16 STORAGE of the two [E,C] activations (and, in conv_bwd, of their gradients): halves the traffic of the
         # bandwidth-bound part of the step; accumulation, statistics, parameters and node tensors stay fp32
@@ -284,7 +287,7 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
             ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
                             sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
         hdt = H1.dtype
-        if hdt == torch.bfloat16 or (FACTORISED_TRAIN and C == 64 and E >= 2 * N and nn0.weight.is_contiguous()
+        if hdt == torch.bfloat16 or (FACTORISED_TRAIN and C == 64 and E >= FACT_BWD_RATIO * N and nn0.weight.is_contiguous()
                                      and nn0.bias is not None):
             # per-node sums of dH1 + N-row dense algebra instead of the gathered E-row GEMMs (pays when E >> N)
             ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), sink.get(nn0.bias),
