@@ -460,6 +460,12 @@ typedef struct {
   const float *tfr;
   const uint16_t *Wn_x6[3];
   const float *tn_fold;
+  /* nullable (both or none; Cin == C == 64, folded form present): the node side of THIS layer prepared for the edge
+   * kernel of the PREVIOUS layer (small graphs: one launch per conv layer, csrc/common.hpp EdgeNext) — the stacked
+   * W' = [Wuvf ; Wr] [192, 64] in v_mfma_f32_16x16x4_f32 B-fragment order,
+   *   Wnx[(ct * 16 + ks) * 64 + l] = W'[ct * 16 + (l & 15)][4 * ks + (l >> 4)],   ct < 12, ks < 16, l < 64,
+   * and tnx = [uvb ; br] [192].                                                                                    */
+  const float *Wnx, *tnx;
 } yolat_conv_eval;
 
 #define YOLAT_CLS_X6_MAX_ROWS 2048

@@ -513,11 +513,15 @@ def test_other_model_shapes_match_oracle(cin, blocks, blocks_out, classes):
         assert err <= 1e-3 * max(float(q.grad.abs().max()), 1e-12) + 2e-5 * gmax, (n, err)
 
 
-def test_pooling_riders_are_bit_identical_to_the_pool_prepare_launch(tmp_path):
-    """Small graphs: the pooling prologue (zero / per-proposal max of feats / mean of the node branch) rides as extra
-    workgroups in the last edge launch and the fusion launch (common.hpp PoolRider, forward_eval.hip) instead of being
-    a launch of its own.  Same arithmetic in the same order: the logits of cfg 2 and of a one-block model must be
-    bit-identical with YOLAT_POOL_RIDERS=0 (the switch is read once per process, hence two child processes)."""
+def test_launch_merging_of_the_small_graph_forward(tmp_path):
+    """Small graphs run fewer launches than the op list has stages (forward_eval.hip): the pooling prologue (zero / max of
+    feats / mean of the node branch) rides as extra workgroups in the last edge launch and the fusion launch
+    (common.hpp PoolRider), and layer l's edge launch computes layer l + 1's node side (EdgeNext: UV / root rows in the
+    tile epilogue on 16x16x4 MFMAs, the node branch in extra workgroups).  The switches are read once per process,
+    hence child processes:
+      YOLAT_POOL_RIDERS=0   same arithmetic in the same order -> logits bit-identical to the default;
+      YOLAT_NODE_CHAIN=0    the node side as its own launch on 32x32x2 MFMAs -> equal up to fp32 summation grouping.
+    cfg 2, a one-block model, and a 4-block model that concatenates only its last two layers."""
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -527,25 +531,27 @@ def test_pooling_riders_are_bit_identical_to_the_pool_prepare_launch(tmp_path):
         "import golden_util as gu\n"
         "import yolat_vectorgraphicsrecognition_amd as yv\n"
         "outs = []\n"
-        "for cfg, kw in (('2', None), (None, dict(n_classes=5, n_blocks=1, n_blocks_out=1))):\n"
+        "for cfg, kw in (('2', None), (None, dict(n_classes=5, n_blocks=1, n_blocks_out=1)),\n"
+        "                (None, dict(n_classes=7, n_blocks=4, n_blocks_out=2))):\n"
         "    if cfg:\n"
         "        data, slices, optkw, _ = yv.config(cfg)\n"
         "    else:\n"
-        "        optkw = kw; data, slices = yv.synth_batch(2, 7, num_proposals=37, nodes_lo=2, nodes_hi=30, n_classes=5)\n"
+        "        optkw = kw\n"
+        "        data, slices = yv.synth_batch(2, 7, num_proposals=37, nodes_lo=2, nodes_hi=30, n_classes=kw['n_classes'])\n"
         "    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 3).cuda().eval()\n"
         "    with torch.no_grad():\n"
         "        outs.append(model(data, slices)[0].cpu())\n"
         "    model.check_last_status()\n"
         "torch.save(outs, sys.argv[1])\n" % (root, os.path.join(root, "tests")))
     got = {}
-    for flag in ("0", "1"):
-        out = str(tmp_path / ("logits_%s.pt" % flag))
-        env = dict(os.environ, YOLAT_POOL_RIDERS=flag)
-        subprocess.run([sys.executable, "-c", script, out], check=True, env=env, timeout=600)
-        got[flag] = torch.load(out)
-    for a, b in zip(got["0"], got["1"]):
-        assert a.shape == b.shape and torch.isfinite(a).all()
+    for tag, env in (("default", {}), ("no_riders", {"YOLAT_POOL_RIDERS": "0"}), ("no_chain", {"YOLAT_NODE_CHAIN": "0"})):
+        out = str(tmp_path / ("logits_%s.pt" % tag))
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, **env), timeout=600)
+        got[tag] = torch.load(out)
+    for a, b, c in zip(got["default"], got["no_riders"], got["no_chain"]):
+        assert a.shape == b.shape == c.shape and torch.isfinite(a).all()
         assert torch.equal(a, b)
+        assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max())
 
 
 def test_primed_workspace_forwards_equal_self_contained_forwards():

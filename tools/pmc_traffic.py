@@ -12,11 +12,16 @@ import sys
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CS = "yolat_vectorgraphicsrecognition_amd/csrc/"
 # eval-plan stage (forward_eval.hip YL_STAGE names) -> (kernel name prefix, source files)
+# pick: which launch grid of the kernel belongs to the stage when one forward launches the kernel with several grids
+#   "all"  average over every grid;  "last_layer" / "with_next": the node-tile edge kernel of a small graph is launched once
+#   per conv layer — the last layer's launch carries the pooling rider (the largest grid), the others the next layer's node
+#   side (EdgeNext: smaller grids)
 STAGES = {
-    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_fusion_rows_x6<128>", [CS + "common.hpp", CS + "x6.hpp", CS + "fusion_x6.hip"]),
-    "edge_uv_mlp2_mean[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"]),
-    "node_uv[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_gemm_nt_node3", [CS + "common.hpp", CS + "dense.hip"]),
-    "graph_prep[csr+attr+segments] + node_uv[layer 0]": ("k_prep_rows_node3", [CS + "common.hpp", CS + "graph.hip"]),
+    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_fusion_rows_x6<128>", [CS + "common.hpp", CS + "x6.hpp", CS + "fusion_x6.hip"], "all"),
+    "edge_uv_mlp2_mean[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "last_layer"),
+    "edge_uv_mlp2_mean+node_uv_next[E x (U+V+attr) -> 64 -> 64 -> mean; N x 64 -> 128+64+64]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "with_next"),
+    "node_uv[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_gemm_nt_node3", [CS + "common.hpp", CS + "dense.hip"], "all"),
+    "graph_prep[csr+attr+segments] + node_uv[layer 0]": ("k_prep_rows_node3", [CS + "common.hpp", CS + "graph.hip"], "all"),
 }
 
 
@@ -28,17 +33,34 @@ def digest(files):
 
 
 def parse(path):
-    """rocpd_pmc.py table -> {kernel name: (calls, value)} for the launch grid with the most samples (the benched
-    workload; other grids of the same kernel come from warm-up / side measurements of other graph sizes)."""
-    out = {}
+    """rocpd_pmc.py table -> {kernel name: [(grid_x, calls, value), ...]}, restricted per kernel to the grids with the
+    most samples (the benched workload; other grids of the same kernel come from warm-up / side measurements of other
+    graph sizes and have fewer calls)."""
+    rows = {}
     for line in open(path):
         m = re.match(r"^(\S.*?)\s+(\d+)\s+(\d+)\s+(\d+)\s+([0-9.]+)\s*$", line.rstrip())
         if not m or line.startswith("kernel"):
             continue
-        name, calls, val = m.group(1).strip(), int(m.group(4)), float(m.group(5))
-        if name not in out or calls > out[name][0]:
-            out[name] = (calls, val)
+        name, grid, calls, val = m.group(1).strip(), int(m.group(2)), int(m.group(4)), float(m.group(5))
+        rows.setdefault(name, []).append((grid, calls, val))
+    out = {}
+    for name, lst in rows.items():
+        top = max(c for _, c, _ in lst)
+        out[name] = [r for r in lst if r[1] == top]
     return out
+
+
+def select(table, kern, pick):
+    rows = [r for k in table if k.startswith(kern) for r in table[k]]
+    if not rows:
+        return None
+    if pick != "all" and len(rows) > 1:
+        gmax = max(r[0] for r in rows)
+        rows = [r for r in rows if (r[0] == gmax) == (pick == "last_layer")]
+    elif pick == "with_next" and len(rows) == 1:
+        return None                      # a single grid: no launch carried the next layer's node side
+    calls = sum(r[1] for r in rows)
+    return calls, sum(r[1] * r[2] for r in rows) / calls
 
 
 def main():
@@ -47,15 +69,16 @@ def main():
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
     ent = table.setdefault("cfg%s" % cfg, {})
-    for stage, (kern, srcs) in STAGES.items():
-        fk = [k for k in f if k.startswith(kern)]
-        wk = [k for k in w if k.startswith(kern)]
-        if not fk or not wk:
+    for stage in list(ent):
+        if stage not in STAGES:
+            del ent[stage]
+    for stage, (kern, srcs, pick) in STAGES.items():
+        fs, ws = select(f, kern, pick), select(w, kern, pick)
+        if fs is None or ws is None:
+            ent.pop(stage, None)
             continue
-        # several launches of one kernel per forward (edge: one per layer): average per launch
-        fc = sum(f[k][0] for k in fk); fv = sum(f[k][0] * f[k][1] for k in fk) / fc
-        wc = sum(w[k][0] for k in wk); wv = sum(w[k][0] * w[k][1] for k in wk) / wc
-        ent[stage] = {"kernel": kern, "fetch_kib": round(fv, 1), "write_kib": round(wv, 1), "launches_sampled": fc,
+        ent[stage] = {"kernel": kern, "fetch_kib": round(fs[1], 1), "write_kib": round(ws[1], 1), "launches_sampled": fs[0],
+                      "launch_pick": pick,
                       "file": "profiles/%s_pmc_fetch.txt + profiles/%s_pmc_write.txt" % (prefix, prefix),
                       "sources": srcs, "source_digest": digest(srcs)}
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)

@@ -24,7 +24,7 @@ class ConvEval(ctypes.Structure):
     _fields_ = ([("Cin", c_i64)] + [(n, c_p) for n in
                                     ("W1", "b1", "s1", "t1", "W2", "b2", "s2", "t2", "Wr", "br", "Wn", "bn", "sn", "tn",
                                      "Wuv", "Wc4", "Wuvf", "uvb", "Wc4f", "t2f")] +
-                [("Wfr_x6", c_p * 3), ("tfr", c_p), ("Wn_x6", c_p * 3), ("tn_fold", c_p)])
+                [("Wfr_x6", c_p * 3), ("tfr", c_p), ("Wn_x6", c_p * 3), ("tn_fold", c_p), ("Wnx", c_p), ("tnx", c_p)])
 
 
 class ModelEval(ctypes.Structure):

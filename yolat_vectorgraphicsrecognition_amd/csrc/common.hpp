@@ -18,6 +18,7 @@
 #include "../../include/yolat_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 #define YL_LAUNCH_CHECK()                          \
   do {                                             \
@@ -722,12 +723,30 @@ __device__ __forceinline__ void yl_pool_rider(const PoolRider& r, int vb, int nv
     }
   }
 }
-// yolat_edge_uv_mlp2_mean_eval_variant with an optional rider (edge.hip): *rode = 1 when the launched kernel carried it
+// The node side of the NEXT conv layer computed inside the edge launch (small graphs, node tiles of <= 16 nodes), so
+// that a conv layer is ONE launch instead of two (k_gemm_nt_node3 was ~10 us of latency at N = 10 k):
+//  * UV' / root': a tile owns its destination nodes, so once their rows of f_out are final it multiplies them by the next
+//    layer's stacked [Wuv' ; Wr'] (192 x 64) — 12 column tiles x 16 v_mfma_f32_16x16x4_f32, B fragments prefetched from the
+//    packed weight — and writes the next UV rows and the next root term;
+//      Wp   Wp[(ct * 16 + ks) * 64 + l] = W'[ct * 16 + (l & 15)][4 * ks + (l >> 4)]   (coalesced B fragments)
+//      bias [192] = [uvb' ; br'];  UV [N, 2C] of the next layer (NOT the buffer this launch gathers from), root = next f_out
+//  * the node branch s' = relu(bn(s . Wn'^T)) of the next layer does not depend on this layer's messages at all: s_tiles
+//    extra workgroups run it as 64 x 64 x 64 tiles on the edge kernel's own LDS tiles and MFMA loop.
+struct EdgeNext {
+  const float* Wp; const float* bias; float* UV; long ld_uv; float* root; long ld_root;
+  const float* s_in; long ld_si; const float* Wn; const float* bn; const float* sn; const float* tn;
+  float* s_out; long ld_so; int s_tiles;
+};
+// 0: the automatic choice is not the node-tile kernel; 1 / 4: node tiles with <= 16 / <= 64 nodes (edge.hip)
+int yl_edge_tile_groups(int64_t N, int64_t E);
+// yolat_edge_uv_mlp2_mean_eval_variant with an optional rider / next-layer node side (edge.hip): *rode = 1 when the
+// launched kernel carried the rider, *did_next = 1 when it computed `next`
 int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                                    const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
                                    const float* b1, const float* s1, const float* t1, const float* W2, const float* b2,
                                    const float* s2, const float* t2, int64_t C, float* f_out, int64_t ld_fo, int variant,
-                                   const PoolRider* rider, int* rode, yolat_stream_t stream);
+                                   const PoolRider* rider, int* rode, const EdgeNext* next, int* did_next,
+                                   yolat_stream_t stream);
 // yolat_fusion_pair_eval_x6 with an optional rider (fusion_x6.hip)
 int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wh, const uint16_t* Wm,
                                 const uint16_t* Wl, const float* tfold, int64_t F, const int32_t* node_seg, float* pool,

@@ -286,10 +286,11 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
                                                            const float* __restrict__ b2,
                                                            const float* __restrict__ s2,
                                                            const float* __restrict__ t2, float* f_out, long ld_fo,
-                                                           int E, int tiles, PoolRider rider) {
-  // workgroups past the node tiles: pooling-prologue rider (common.hpp), independent of this layer's messages
-  if ((int)blockIdx.x >= tiles) {
-    yl_pool_rider(rider, blockIdx.x - tiles, rider.blocks, threadIdx.x, 256);
+                                                           int E, int tiles, PoolRider rider, EdgeNext nx) {
+  // workgroups past the node tiles: the next layer's node-branch tiles (EdgeNext), then the pooling-prologue rider
+  // (common.hpp) — both independent of this layer's messages
+  if ((int)blockIdx.x >= tiles + nx.s_tiles) {
+    yl_pool_rider(rider, blockIdx.x - tiles - nx.s_tiles, rider.blocks, threadIdx.x, 256);
     return;
   }
   constexpr int LDH = 65;
@@ -298,6 +299,39 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   __shared__ int rp[16 * NG + 1];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1, l31 = lane & 31, lhi = lane >> 5;
+  if ((int)blockIdx.x >= tiles) {
+    // s'[r0 .. r0+63] = relu(((s . Wn'^T) + bn') * sn' + tn'): one 64 x 64 x 64 tile on the same LDS tiles and the same
+    // MFMA loop (k ascending in pairs) as layer 2 below — bit-identical to k_gemm_nt_node3's tile
+    const int r0 = (blockIdx.x - tiles) * 64;
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int i = tid + t * 256, row = i >> 4, c4 = 4 * (i & 15);
+      const float4 av = *reinterpret_cast<const float4*>(nx.s_in + (long)yl_min(r0 + row, N - 1) * nx.ld_si + c4);
+      const float4 wv = *reinterpret_cast<const float4*>(nx.Wn + row * 64 + c4);
+      float* da = Hs + row * LDH + c4;
+      float* dw = W2s + row * LDH + c4;
+      da[0] = av.x; da[1] = av.y; da[2] = av.z; da[3] = av.w;
+      dw[0] = wv.x; dw[1] = wv.y; dw[2] = wv.z; dw[3] = wv.w;
+    }
+    const int colS = wn * 32 + l31;
+    const float bS = nx.bn ? nx.bn[colS] : 0.f, scS = nx.sn[colS], shS = nx.tn[colS];
+    __syncthreads();
+    f32x16 accS;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) accS[r] = 0.f;
+#pragma unroll 8
+    for (int kk = 0; kk < 64; kk += 2) {
+      const float av = Hs[(wm * 32 + l31) * LDH + kk + lhi];
+      const float bv = W2s[(wn * 32 + l31) * LDH + kk + lhi];
+      accS = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, accS, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int row = r0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+      if (row < N) nx.s_out[(long)row * nx.ld_so + colS] = fmaxf(fmaf(accS[r] + bS, scS, shS), 0.f);
+    }
+    return;
+  }
   const int n0 = blockIdx.x * npt;
   const int nn = yl_min(npt, N - n0);                 // nodes of this tile
   if (tid <= 16 * NG) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
@@ -336,6 +370,15 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
     const int i = tid + t * 256;
     float* d = W2s + (i >> 4) * LDH + 4 * (i & 15);
     d[0] = rw2[t][0]; d[1] = rw2[t][1]; d[2] = rw2[t][2]; d[3] = rw2[t][3];
+  }
+  // next layer's node side (NG == 1): the first column tile's B fragments travel with the loads above, the other two
+  // are fetched under the previous tile's MFMAs (see the end of the kernel)
+  float bf0[16];
+  if constexpr (NG == 1) {
+    if (nx.Wp != nullptr) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bf0[ks] = nx.Wp[(wave * 16 + ks) * 64 + lane];
+    }
   }
   __syncthreads();
   const int e0 = e0g, e1 = e1g;
@@ -418,6 +461,47 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       d.x = yl_mul_rn(sum[j].x, inv) + d.x; d.y = yl_mul_rn(sum[j].y, inv) + d.y;
       d.z = yl_mul_rn(sum[j].z, inv) + d.z; d.w = yl_mul_rn(sum[j].w, inv) + d.w;
       *o = d;
+      fo[j] = d;
+    }
+  }
+  // ---- node side of the NEXT layer for this tile's nodes (EdgeNext, common.hpp): [nn <= 16, 64] x [192, 64]^T
+  if constexpr (NG == 1) {
+    if (nx.Wp != nullptr) {
+      // the loop above ended with a barrier (or never ran): Hs is free; rows >= nn hold the clamped load of row N-1 or
+      // stale sums — finite or not, their products only reach output rows that are never stored
+      float* frow = Hs + rb * LDH + 4 * q;
+      const float4 fz = (rb < nn) ? fo[0] : make_float4(0.f, 0.f, 0.f, 0.f);
+      frow[0] = fz.x; frow[1] = fz.y; frow[2] = fz.z; frow[3] = fz.w;
+      __syncthreads();
+      const int fr = lane & 15, fk = lane >> 4;
+      float bfa[16], bfb[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bfa[ks] = bf0[ks];
+#pragma unroll
+      for (int t = 0; t < 3; ++t) {
+        const int ct = wave + 4 * t;                   // 12 column tiles of 16: UV' 0..7, root' 8..11
+        if (t < 2) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) bfb[ks] = nx.Wp[((ct + 4) * 16 + ks) * 64 + lane];
+        }
+        const int col = ct * 16 + fr;
+        const float bias = nx.bias[col];
+        f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks)
+          acc = __builtin_amdgcn_mfma_f32_16x16x4f32(Hs[fr * LDH + 4 * ks + fk], bfa[ks], acc, 0, 0, 0);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int row = 4 * fk + r;
+          if (row < nn) {
+            const float v = acc[r] + bias;
+            if (col < 128) nx.UV[(long)(n0 + row) * nx.ld_uv + col] = v;
+            else nx.root[(long)(n0 + row) * nx.ld_root + (col - 128)] = v;
+          }
+        }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bfa[ks] = bfb[ks];
+      }
     }
   }
 }
@@ -765,12 +849,42 @@ __global__ void __launch_bounds__(512, 4) k_edge_uv_mlp2_mean_ws(const float* __
   aggregate(np - 1);
 }
 
+// nodes per node-tile workgroup: ~56 edges on average so that a single 64-edge pass is the common case
+// (measured at cfg 5: 9 nodes / one pass 208 us, 12 nodes / a second mostly-empty pass 242 us, 16 nodes /
+// two full passes 194 us — on big graphs two passes halve the per-workgroup W2 staging)
+static long edge_tile_npt(long N, long E) {
+  long npt = (56 * N) / E;
+  const long npt2 = (112 * N) / E < 16 ? (112 * N) / E : 16;
+  if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
+  if (const char* e = getenv("YOLAT_EDGE_NPT")) npt = atol(e);     // tuning hook
+  if (npt < 1) npt = 1;
+  if (npt > 64) npt = 64;
+  return npt;
+}
+static int edge_env_variant() {
+  static int env_variant = -1;
+  if (env_variant < 0) {
+    const char* e = getenv("YOLAT_EDGE_VARIANT");
+    env_variant = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
+  }
+  return env_variant;
+}
+int yl_edge_tile_groups(int64_t N, int64_t E) {
+  if (N <= 0 || E <= 0) return 0;
+  const int ev = edge_env_variant();
+  const int variant = ev != 0 ? ev : (E >= 131072 ? YOLAT_EDGE_WS_X6 : YOLAT_EDGE_TILES);
+  if (variant != YOLAT_EDGE_TILES) return 0;
+  return edge_tile_npt(N, E) <= 16 ? 1 : 4;
+}
+
 int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                                    const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
                                    const float* b1, const float* s1, const float* t1, const float* W2, const float* b2,
                                    const float* s2, const float* t2, int64_t C, float* f_out, int64_t ld_fo, int variant,
-                                   const PoolRider* rider, int* rode, yolat_stream_t stream) {
+                                   const PoolRider* rider, int* rode, const EdgeNext* next, int* did_next,
+                                   yolat_stream_t stream) {
   if (rode) *rode = 0;
+  if (did_next) *did_next = 0;
   if (E < 0 || N <= 0 || !UV || !Wc4 || !W2 || !row_ptr || !f_out) return YOLAT_E_INVALID;
   if (variant < YOLAT_EDGE_AUTO || variant > YOLAT_EDGE_WS_X6) return YOLAT_E_INVALID;
   if (C != 64) return YOLAT_E_UNSUPPORTED;
@@ -784,12 +898,11 @@ int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t
   const bool fold = b1 == nullptr && s1 == nullptr && b2 == nullptr;
   // YOLAT_EDGE_VARIANT (1..3) overrides the automatic choice, YOLAT_EDGE_WGS the number of persistent workgroups
   // (bench A/B hooks; an explicit `variant` argument always wins)
-  static int env_variant = -1;
-  static long ws_wgs = 512;
-  if (env_variant < 0) {
-    const char* e = getenv("YOLAT_EDGE_VARIANT");
-    env_variant = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
-    if (const char* w = getenv("YOLAT_EDGE_WGS")) ws_wgs = atol(w) > 0 ? atol(w) : 512;
+  const int env_variant = edge_env_variant();
+  static long ws_wgs = -1;
+  if (ws_wgs < 0) {
+    const char* w = getenv("YOLAT_EDGE_WGS");
+    ws_wgs = (w && atol(w) > 0) ? atol(w) : 512;
   }
   // the persistent kernel addresses UV / attr / the index arrays with 32-bit byte offsets
   const bool ws_ok = yl_aligned16(W2) && E >= 64 && N * ld_uv * 4 < (1LL << 32) && E * 16 < (1LL << 32);
@@ -814,28 +927,29 @@ int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t
     YL_LAUNCH_CHECK();
     return 0;
   }
-  // nodes per workgroup: ~56 edges on average so that a single 64-edge pass is the common case
-  // (measured at cfg 5: 9 nodes / one pass 208 us, 12 nodes / a second mostly-empty pass 242 us, 16 nodes /
-  // two full passes 194 us — on big graphs two passes halve the per-workgroup W2 staging)
-  long npt = (56 * N) / E;
-  const long npt2 = (112 * N) / E < 16 ? (112 * N) / E : 16;
-  if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
-  if (const char* e = getenv("YOLAT_EDGE_NPT")) npt = atol(e);     // tuning hook
-  if (npt < 1) npt = 1;
-  if (npt > 64) npt = 64;
+  const long npt = edge_tile_npt(N, E);
   DenseOp w2 = yl_dense(W2, C, C, C);
   const int tiles = yl_cdiv(N, npt);
   PoolRider pr{};
   if (rider && rider->blocks > 0) { pr = *rider; if (rode) *rode = 1; }
-  const unsigned grid = (unsigned)tiles + (unsigned)pr.blocks;
+  EdgeNext nx{};
+  if (next && next->Wp && npt <= 16) {
+    if (!next->bias || !next->UV || !next->root || next->UV == UV) return YOLAT_E_INVALID;
+    if (next->s_tiles > 0 && (!next->s_in || !next->Wn || !next->sn || !next->tn || !next->s_out || next->ld_si % 4 != 0 ||
+                              !yl_aligned16(next->s_in) || !yl_aligned16(next->Wn)))
+      return YOLAT_E_INVALID;
+    nx = *next;
+    if (did_next) *did_next = 1;
+  }
+  const unsigned grid = (unsigned)tiles + (unsigned)nx.s_tiles + (unsigned)pr.blocks;
   if (npt <= 16)
     hipLaunchKernelGGL(k_edge_uv_mlp2_mean<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
                        src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
-                       (long)ld_fo, (int)E, tiles, pr);
+                       (long)ld_fo, (int)E, tiles, pr, nx);
   else
     hipLaunchKernelGGL(k_edge_uv_mlp2_mean<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, UV, (long)ld_uv,
                        src_csr, dst_csr, attr_csr, row_ptr, (int)N, (int)npt, Wc4, b1, s1, t1, w2, b2, s2, t2, f_out,
-                       (long)ld_fo, (int)E, tiles, pr);
+                       (long)ld_fo, (int)E, tiles, pr, nx);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -847,7 +961,7 @@ extern "C" int yolat_edge_uv_mlp2_mean_eval_variant(const float* UV, int64_t ld_
                                                     const float* b2, const float* s2, const float* t2, int64_t C,
                                                     float* f_out, int64_t ld_fo, int variant, yolat_stream_t stream) {
   return yl_edge_uv_mlp2_mean_eval_impl(UV, ld_uv, src_csr, dst_csr, attr_csr, row_ptr, N, E, Wc4, b1, s1, t1, W2, b2, s2,
-                                        t2, C, f_out, ld_fo, variant, nullptr, nullptr, stream);
+                                        t2, C, f_out, ld_fo, variant, nullptr, nullptr, nullptr, nullptr, stream);
 }
 
 extern "C" int yolat_edge_uv_mlp2_mean_eval(const float* UV, int64_t ld_uv, const int32_t* src_csr,

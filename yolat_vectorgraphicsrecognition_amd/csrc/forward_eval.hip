@@ -17,7 +17,7 @@ struct Carver {
 
 struct Plan {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
-  float* H1; float* H2; float* UV; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
+  float* H1; float* H2; float* UV; float* UV2; float* f_tmp[YOLAT_MAX_LAYERS]; float* s_tmp[YOLAT_MAX_LAYERS];
   float* feats; float* fsup; float* Z; float* c1; float* c2;
   float* gx_work;                                      // split-K partials of cls1 on yolat_gemm_x6 (few proposals)
   uint16_t* Zs;                                        // Z pre-split for the skinny bf16x6 classifier (few proposals)
@@ -32,6 +32,8 @@ Plan carve(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   p.attr = c.take<float>(Ee * 4); p.work = c.take<int>(yolat_graph_work_elems(N, E));
   p.seg_ptr = c.take<int>(P + 1); p.node_seg = c.take<int>(N);
   p.H1 = c.take<float>(Ee * C); p.H2 = c.take<float>(Ee * C); p.UV = c.take<float>(N * 2 * C);
+  // second UV buffer: layer l + 1's node side is written by layer l's edge launch while that launch still gathers from UV
+  p.UV2 = (m->n_blocks >= 2 && yl_edge_tile_groups(N, E) == 1) ? c.take<float>(N * 2 * C) : nullptr;
   const int lo = m->n_blocks - m->n_blocks_out;
   for (int l = 0; l < m->n_blocks; ++l) {
     p.f_tmp[l] = (l < lo) ? c.take<float>(N * C) : nullptr;
@@ -196,12 +198,26 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
   const int lo = m->n_blocks - m->n_blocks_out;
 
   // ---- graph structure (CSR by destination, e_attr in CSR order, proposal segments)
-  char nm[96];
+  char nm[128];
   // The node side of layer 0 (UV products, root Linear, node-branch Linear) reads only x: its GEMM tiles are
   // co-scheduled with the last, latency-bound pre-processing launch instead of being a launch of their own.
   const yolat_conv_eval& cv0 = m->conv[0];
   const bool node0_in_prep = C == 64 && cv0.Wuv != nullptr && cv0.Wc4 != nullptr;
   const bool fold0 = cv0.Wuvf && cv0.uvb && cv0.Wc4f && cv0.t2f;
+  // One launch per conv layer (small graphs on the <= 16-node tiles, every layer factorised + folded, packed next-layer
+  // weights present): layer l's edge launch computes layer l + 1's UV / root rows for its own nodes and, in extra
+  // workgroups, layer l + 1's node branch (EdgeNext, common.hpp) — k_gemm_nt_node3 is not launched at all.
+  // YOLAT_NODE_CHAIN=0: node side as a launch per layer.
+  static const bool chain_on = []() { const char* v = getenv("YOLAT_NODE_CHAIN"); return !(v && v[0] == '0'); }();
+  bool chain_mode = chain_on && node0_in_prep && fold0 && E > 0 && m->n_blocks >= 2 && p.UV2 != nullptr &&
+                    yl_edge_tile_groups(N, E) == 1;
+  for (int l = 1; l < m->n_blocks && chain_mode; ++l) {
+    const yolat_conv_eval& c = m->conv[l];
+    chain_mode = c.Cin == 64 && c.Wuv && c.Wc4 && c.Wuvf && c.uvb && c.Wc4f && c.t2f && c.Wnx && c.tnx && c.Wn &&
+                 c.sn && c.tn && yl_aligned16(c.Wn);
+  }
+  bool next_done = false;             // the previous edge launch computed this layer's UV / root ...
+  float* uv_next = nullptr;           // ... into this buffer
   if (node0_in_prep) {
     const int slot0 = 0 - lo;
     float* f0 = slot0 >= 0 ? p.feats + slot0 * C : p.f_tmp[0];
@@ -254,7 +270,9 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
         // folded form (yolat_conv_eval.{Wuvf, uvb, Wc4f, t2f}): layer 1's bias / BatchNorm ride in the node-side
         // epilogue and the scaled weights, layer 2's bias in t2f
         const bool fold = cv.Wuvf && cv.uvb && cv.Wc4f && cv.t2f;
-        if (!(l == 0 && node0_in_prep)) {
+        float* uv_l = next_done ? uv_next : p.UV;
+        if (!(l == 0 && node0_in_prep) && !next_done) {
+          uv_l = p.UV;
           snprintf(nm, sizeof nm, "node_uv[UV | lin_r | mlp_node, N x %ld -> %ld+%ld+%ld]", (long)cv.Cin, 2 * C, C, C);
           // large graphs: the three GEMMs as bf16x6-emulated products on the rows kernel (A read once per 256 rows);
           // small ones stay on the fp32 64x64 tiles (more workgroups: latency).  Measured per launch: N = 200 k 94 -> 89 us,
@@ -274,16 +292,41 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
           // last layer of a small graph: the parts of the pooling prologue that do not need this layer's messages
           // (zero the pooled maxima, per-proposal mean of the node branch) ride in this launch
           const PoolRider* rd = (l == m->n_blocks - 1 && ride_a.blocks > 0) ? &ride_a : nullptr;
-          int rode = 0;
-          snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
-          YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C,
-                   fold ? yl_edge_uv_mlp2_mean_eval_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4f,
+          int rode = 0, did_next = 0;
+          EdgeNext nx{};
+          if (chain_mode && l + 1 < m->n_blocks) {
+            const int sn = l + 1 - lo;
+            nx.Wp = m->conv[l + 1].Wnx; nx.bias = m->conv[l + 1].tnx;
+            nx.UV = (uv_l == p.UV) ? p.UV2 : p.UV; nx.ld_uv = 2 * C;
+            nx.root = sn >= 0 ? p.feats + sn * C : p.f_tmp[l + 1]; nx.ld_root = sn >= 0 ? D : C;
+            const yolat_conv_eval& cn = m->conv[l + 1];
+            nx.s_in = s_out; nx.ld_si = ld_out;                 // this layer's node branch: written one launch earlier
+            nx.Wn = cn.Wn; nx.bn = cn.bn; nx.sn = cn.sn; nx.tn = cn.tn;
+            nx.s_out = sn >= 0 ? p.fsup + sn * C : p.s_tmp[l + 1]; nx.ld_so = sn >= 0 ? D : C;
+            nx.s_tiles = yl_cdiv(N, 64);
+          }
+          // a launch that also carries the next layer's node side is a stage of its own (its algorithmic work includes
+          // that GEMM set: reads s, writes UV' / root' / s')
+          const bool with_next = nx.Wp != nullptr;
+          if (with_next)
+            snprintf(nm, sizeof nm, "edge_uv_mlp2_mean+node_uv_next[E x (U+V+attr) -> %ld -> %ld -> mean; N x %ld -> %ld+%ld+%ld]",
+                     C, C, C, 2 * C, C, C);
+          else
+            snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
+          YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C) + (with_next ? 8.0 * N * C * C : 0.0),
+                   E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C + (with_next ? 4.0 * (N * C + 4.0 * N * C) : 0.0),
+                   fold ? yl_edge_uv_mlp2_mean_eval_impl(uv_l, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4f,
                                                          nullptr, nullptr, nullptr, cv.W2, nullptr, cv.s2, cv.t2f, C,
-                                                         f_out, ld_out, YOLAT_EDGE_AUTO, rd, &rode, stream)
-                        : yl_edge_uv_mlp2_mean_eval_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4,
+                                                         f_out, ld_out, YOLAT_EDGE_AUTO, rd, &rode,
+                                                         nx.Wp ? &nx : nullptr, &did_next, stream)
+                        : yl_edge_uv_mlp2_mean_eval_impl(uv_l, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4,
                                                          cv.b1, cv.s1, cv.t1, cv.W2, cv.b2, cv.s2, cv.t2, C, f_out,
-                                                         ld_out, YOLAT_EDGE_AUTO, rd, &rode, stream));
+                                                         ld_out, YOLAT_EDGE_AUTO, rd, &rode, nullptr, nullptr, stream));
           if (rode) pool_done |= ride_a.parts;
+          // (had the launch not taken `next`, the following layer's node side runs as its own launch into p.UV,
+          // recomputing the node branch the chain already wrote — same values)
+          next_done = did_next != 0;
+          uv_next = nx.UV;
         }
       } else {
       // three launches per layer: edge MLP (hidden activation in LDS); root Linear | node-branch Linear as one

@@ -107,6 +107,15 @@ class EvalPlan(object):
                                                                      fold2[0], fold2[1])
                     keep += [wuvf, uvb, wc4f, t2f]
                     c.Wuvf, c.uvb, c.Wc4f, c.t2f = wuvf.data_ptr(), uvb.data_ptr(), wc4f.data_ptr(), t2f.data_ptr()
+                    if (l > 0 and cv.in_channels == 64 and C == 64 and cv.lin_r.bias is not None
+                            and os.environ.get("YOLAT_NODE_CHAIN", "1") != "0"):
+                        # the node side of this layer in the form the PREVIOUS layer's edge kernel consumes (small
+                        # graphs: EdgeNext, csrc/common.hpp): [Wuvf ; Wr] in 16x16x4 MFMA B-fragment order, [uvb ; br]
+                        wst = torch.cat([wuvf, cv.lin_r.weight.detach()], 0)                 # [192, 64]
+                        wnx = wst.view(12, 16, 16, 4).permute(0, 2, 3, 1).contiguous()         # [ct, ks, k & 3, row]
+                        tnx = torch.cat([uvb, cv.lin_r.bias.detach()], 0).contiguous()
+                        keep += [wnx, tnx]
+                        c.Wnx, c.tnx = wnx.data_ptr(), tnx.data_ptr()
                     if (cv.in_channels == 64 and C == 64 and os.environ.get("YOLAT_NODE_X6", "1") != "0"
                             and cv.lin_r.bias is not None):
                         # node side on the bf16x6 rows kernel (yolat_node_uv_eval_x6): [Wuvf ; Wr] stacked and split,
