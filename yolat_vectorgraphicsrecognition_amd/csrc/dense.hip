@@ -318,8 +318,33 @@ __device__ __forceinline__ void chan_merge(Chan& a, double nb, double mb, double
   a.n = tot;
 }
 
+__device__ __forceinline__ void bn_emit(const Chan& a, int c, const float* gamma, const float* beta, float* running_mean,
+                                        float* running_var, float momentum, float eps, float* save_mean,
+                                        float* save_invstd, float* scale, float* shift) {
+  const double var_b = a.n > 0.0 ? a.m2 / a.n : 0.0;                 // biased: used to normalise
+  const double var_u = a.n > 1.0 ? a.m2 / (a.n - 1.0) : var_b;       // unbiased: running update
+  const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+  const float meanf = (float)a.mean;
+  save_mean[c] = meanf;
+  save_invstd[c] = invstd;
+  const float sc = gamma[c] * invstd;
+  scale[c] = sc;
+  shift[c] = beta[c] - meanf * sc;
+  if (running_mean != nullptr) {
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
+  }
+}
+
+// FINAL (a single level-1 workgroup per column block, i.e. M <= 8192 rows: the per-proposal BatchNorms): the level-2
+// step would merge ONE triple into an empty accumulator — exactly the triple itself — so the coefficients are emitted
+// here and the second launch is dropped; same values bit for bit.
+template <bool FINAL>
 __global__ void __launch_bounds__(1024) k_bn_merge_l1(const float2* stats, long M, int C, long nb,
-                                                      long per_wg, double* l1) {
+                                                      long per_wg, double* l1, const float* gamma, const float* beta,
+                                                      float* running_mean, float* running_var, float momentum,
+                                                      float eps, float* save_mean, float* save_invstd, float* scale,
+                                                      float* shift) {
   __shared__ double s_n[16][64], s_mean[16][64], s_m2[16][64];
   const int cl = threadIdx.x & 63, part = threadIdx.x >> 6;
   const int c = blockIdx.x * 64 + cl;
@@ -342,8 +367,12 @@ __global__ void __launch_bounds__(1024) k_bn_merge_l1(const float2* stats, long 
   __syncthreads();
   if (part == 0 && c < C) {
     for (int p = 1; p < 16; ++p) chan_merge(a, s_n[p][cl], s_mean[p][cl], s_m2[p][cl]);
-    double* o = l1 + ((long)blockIdx.y * C + c) * 3;
-    o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
+    if (FINAL) {
+      bn_emit(a, c, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+    } else {
+      double* o = l1 + ((long)blockIdx.y * C + c) * 3;
+      o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
+    }
   }
 }
 
@@ -370,19 +399,7 @@ __global__ void __launch_bounds__(1024) k_bn_finalize_l2(const double* l1, int G
   __syncthreads();
   if (part != 0 || c >= C) return;
   for (int p = 1; p < 16; ++p) chan_merge(a, s_n[p][cl], s_mean[p][cl], s_m2[p][cl]);
-  const double var_b = a.n > 0.0 ? a.m2 / a.n : 0.0;                 // biased: used to normalise
-  const double var_u = a.n > 1.0 ? a.m2 / (a.n - 1.0) : var_b;       // unbiased: running update
-  const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
-  const float meanf = (float)a.mean;
-  save_mean[c] = meanf;
-  save_invstd[c] = invstd;
-  const float sc = gamma[c] * invstd;
-  scale[c] = sc;
-  shift[c] = beta[c] - meanf * sc;
-  if (running_mean != nullptr) {
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * meanf;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)var_u;
-  }
+  bn_emit(a, c, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
 }
 
 static inline void bn_l1_plan(long M, long* nb, long* G, long* per_wg) {
@@ -414,8 +431,16 @@ extern "C" int yolat_bn_finalize(const float* stats, int64_t M, int64_t C, const
   off = (off + 1) & ~(size_t)1;                       // 8-byte alignment for the fp64 triples
   double* l1 = reinterpret_cast<double*>(const_cast<float*>(stats) + off);
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL(k_bn_merge_l1, dim3(yl_cdiv(C, 64), (unsigned)G), dim3(1024), 0, st,
-                     reinterpret_cast<const float2*>(stats), (long)M, (int)C, nb, per, l1);
+  if (G == 1) {
+    hipLaunchKernelGGL(k_bn_merge_l1<true>, dim3(yl_cdiv(C, 64), 1), dim3(1024), 0, st,
+                       reinterpret_cast<const float2*>(stats), (long)M, (int)C, nb, per, l1, gamma, beta, running_mean,
+                       running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
+  hipLaunchKernelGGL(k_bn_merge_l1<false>, dim3(yl_cdiv(C, 64), (unsigned)G), dim3(1024), 0, st,
+                     reinterpret_cast<const float2*>(stats), (long)M, (int)C, nb, per, l1, gamma, beta, running_mean,
+                     running_var, momentum, eps, save_mean, save_invstd, scale, shift);
   YL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_bn_finalize_l2, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, l1, (int)G, (int)C,
                      gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd,
