@@ -506,14 +506,8 @@ extern "C" int yolat_linear_bwd_w_csr(const yolat_bn_csr_grad* g, int64_t E, int
   }
   YL_LAUNCH_CHECK();
   const long elems = C * K;
-  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 32)), dim3(256), 0, st, partial, elems, p.S, dW, (long)lddw,
-                     (int)K, accumulate);
+  yl_reduce_dw_db(st, partial, elems, p.S, dW, (long)lddw, (int)K, dbpart, db, (long)C, accumulate);
   YL_LAUNCH_CHECK();
-  if (db) {
-    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(C, 32)), dim3(256), 0, st, dbpart, (long)C, p.S, db, (long)C, (int)C,
-                       accumulate);
-    YL_LAUNCH_CHECK();
-  }
   return 0;
 }
 

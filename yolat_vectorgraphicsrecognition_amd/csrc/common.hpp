@@ -998,12 +998,11 @@ __global__ void __launch_bounds__(256) k_gemm_tn(YL Yop, AL Aop, float* partial,
 // group sums in order).  32 consecutive elements x 8 split groups per workgroup; 8 independent loads in
 // flight per thread — a one-thread-per-element loop over S=512 splits is a chain of 512 dependent
 // L2 round trips (130 us for a 64x64 weight).
-static __global__ void __launch_bounds__(256) k_reduce_splits(const float* partial, long elems, int S,
-                                                              float* dst, long ld_dst, int cols,
-                                                              int accumulate) {
+__device__ __forceinline__ void reduce_splits_body(long blk, const float* partial, long elems, int S, float* dst,
+                                                   long ld_dst, int cols, int accumulate) {
   __shared__ float gs[8][33];
   const int e = threadIdx.x & 31, g = threadIdx.x >> 5;
-  const long i = (long)blockIdx.x * 32 + e;
+  const long i = blk * 32 + e;
   const int per = (S + 7) / 8;
   const int t0 = g * per, t1 = (t0 + per < S) ? t0 + per : S;
   float s = 0.f;
@@ -1028,6 +1027,30 @@ static __global__ void __launch_bounds__(256) k_reduce_splits(const float* parti
     float* d = dst + (i / cols) * ld_dst + (i % cols);
     if (accumulate) tot += *d;
     *d = tot;
+  }
+}
+static __global__ void __launch_bounds__(256) k_reduce_splits(const float* partial, long elems, int S,
+                                                              float* dst, long ld_dst, int cols,
+                                                              int accumulate) {
+  reduce_splits_body(blockIdx.x, partial, elems, S, dst, ld_dst, cols, accumulate);
+}
+// two reductions with the same split count in one launch (a weight gradient and its bias gradient: the second one is a
+// handful of workgroups that used to be a ~5 us launch of their own)
+static __global__ void __launch_bounds__(256) k_reduce_splits2(const float* pa, long ea, float* da, long lda, int ca,
+                                                               const float* pb, long eb, float* db, long ldb, int cb,
+                                                               int S, int accumulate, int blocks_a) {
+  if ((int)blockIdx.x < blocks_a) reduce_splits_body(blockIdx.x, pa, ea, S, da, lda, ca, accumulate);
+  else reduce_splits_body(blockIdx.x - blocks_a, pb, eb, S, db, ldb, cb, accumulate);
+}
+// dW (+)= sum of `partial` [S][Nout*K];  db (+)= sum of `dbpart` [S][Nout] when db != NULL
+static inline void yl_reduce_dw_db(hipStream_t st, const float* partial, long elems, int S, float* dW, long lddw, int K,
+                                   const float* dbpart, float* db, long Nout, int accumulate) {
+  const int ba = yl_cdiv(elems, 32);
+  if (db != nullptr) {
+    hipLaunchKernelGGL(k_reduce_splits2, dim3(ba + yl_cdiv(Nout, 32)), dim3(256), 0, st, partial, elems, dW, lddw, K,
+                       dbpart, Nout, db, Nout, (int)Nout, S, accumulate, ba);
+  } else {
+    hipLaunchKernelGGL(k_reduce_splits, dim3(ba), dim3(256), 0, st, partial, elems, S, dW, lddw, K, accumulate);
   }
 }
 

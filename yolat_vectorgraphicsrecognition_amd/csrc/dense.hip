@@ -244,14 +244,8 @@ extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int6
   }
   YL_LAUNCH_CHECK();
   const long elems = Nout * K;
-  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 32)), dim3(256), 0, st, partial, elems,
-                     p.S, dW, (long)lddw, (int)K, accumulate);
+  yl_reduce_dw_db(st, partial, elems, p.S, dW, (long)lddw, (int)K, dbpart, db, (long)Nout, accumulate);
   YL_LAUNCH_CHECK();
-  if (db) {
-    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(Nout, 32)), dim3(256), 0, st, dbpart,
-                       (long)Nout, p.S, db, (long)Nout, (int)Nout, accumulate);
-    YL_LAUNCH_CHECK();
-  }
   return 0;
 }
 
@@ -289,14 +283,8 @@ extern "C" int yolat_linear_bwd_w_h(const uint16_t* dY, int64_t lddy, int64_t M,
   }
   YL_LAUNCH_CHECK();
   const long elems = Nout * K;
-  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 32)), dim3(256), 0, st, partial, elems, p.S, dW, (long)lddw,
-                     (int)K, accumulate);
+  yl_reduce_dw_db(st, partial, elems, p.S, dW, (long)lddw, (int)K, dbpart, db, (long)Nout, accumulate);
   YL_LAUNCH_CHECK();
-  if (db) {
-    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(Nout, 32)), dim3(256), 0, st, dbpart, (long)Nout, p.S, db,
-                       (long)Nout, (int)Nout, accumulate);
-    YL_LAUNCH_CHECK();
-  }
   return 0;
 }
 

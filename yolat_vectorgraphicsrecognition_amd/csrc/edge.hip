@@ -1119,14 +1119,8 @@ extern "C" int yolat_edge_lin1_bwd_w(const float* dH1, int64_t lddh, int64_t E, 
                      (int)E, (int)C, (int)K, p.rows_per_split);
   YL_LAUNCH_CHECK();
   const long elems = C * K;
-  hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(elems, 32)), dim3(256), 0, st, partial, elems,
-                     p.S, dW1, (long)lddw, (int)K, accumulate);
+  yl_reduce_dw_db(st, partial, elems, p.S, dW1, (long)lddw, (int)K, dbpart, db1, (long)C, accumulate);
   YL_LAUNCH_CHECK();
-  if (db1) {
-    hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(C, 32)), dim3(256), 0, st, dbpart, (long)C,
-                       p.S, db1, (long)C, (int)C, accumulate);
-    YL_LAUNCH_CHECK();
-  }
   return 0;
 }
 
