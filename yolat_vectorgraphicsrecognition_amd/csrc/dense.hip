@@ -392,7 +392,9 @@ __global__ void __launch_bounds__(1024) k_bn_finalize_l2(const double* l1, int G
 
 static inline void bn_l1_plan(long M, long* nb, long* G, long* per_wg) {
   *nb = (M + 31) / 32;
-  long g = (*nb + 255) / 256;          // >= 256 row groups (8192 rows) per level-1 workgroup
+  // <= 8192 rows: one level-1 workgroup (the fused finalize); above that >= 64 row groups (2048 rows) per level-1
+  // workgroup, up to BN_L1_MAX of them (E = 210 k: 26 workgroups of 256 groups took 13 us, 103 of 64 take ~7)
+  long g = (*nb <= 256) ? 1 : (*nb + 63) / 64;
   if (g > BN_L1_MAX) g = BN_L1_MAX;
   if (g < 1) g = 1;
   *per_wg = (*nb + g - 1) / g;
