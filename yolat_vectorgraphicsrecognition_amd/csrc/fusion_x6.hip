@@ -109,7 +109,9 @@ struct FxProb {
   float* stats;
 };
 
-template <int KD>
+// RIDER = false: the rider argument is never read (an instantiation that reads it keeps more kernel arguments live:
+// 75 -> 121 spilled SGPRs, and the cfg-5 fusion launch went 332 -> 365 us until the two were separated)
+template <int KD, bool RIDER = false>
 __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1, PoolRider rider) {
   constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
   constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / 512;   // 16-byte chunks of one W tile, per thread
@@ -123,9 +125,11 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   const int id = blockIdx.x;
   // workgroups past both problems: pooling-prologue rider (common.hpp; reads A like the GEMM, writes columns of the
   // pooled rows that nothing in this launch reads)
-  if (rider.blocks > 0 && id >= n1p + p0.tm * p0.groups) {
-    yl_pool_rider(rider, id - (n1p + p0.tm * p0.groups), rider.blocks, tid, 512);
-    return;
+  if constexpr (RIDER) {
+    if (id >= n1p + p0.tm * p0.groups) {
+      yl_pool_rider(rider, id - (n1p + p0.tm * p0.groups), rider.blocks, tid, 512);
+      return;
+    }
   }
   int logical;
   if (id < n1p) {
@@ -410,8 +414,13 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
   const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L) + pr.blocks;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (D == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+  if (pr.blocks > 0) {
+    if (D == 128) hipLaunchKernelGGL((k_fusion_rows_x6<128, true>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+    else hipLaunchKernelGGL((k_fusion_rows_x6<64, true>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+  } else {
+    if (D == 128) hipLaunchKernelGGL((k_fusion_rows_x6<128>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+    else hipLaunchKernelGGL((k_fusion_rows_x6<64>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+  }
   YL_LAUNCH_CHECK();
   return 0;
 }
