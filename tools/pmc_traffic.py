@@ -17,7 +17,7 @@ CS = "yolat_vectorgraphicsrecognition_amd/csrc/"
 #   per conv layer — the last layer's launch carries the pooling rider (the largest grid), the others the next layer's node
 #   side (EdgeNext: smaller grids)
 STAGES = {
-    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_fusion_rows_x6<128>", [CS + "common.hpp", CS + "x6.hpp", CS + "fusion_x6.hip"], "all"),
+    "fusion_gemm+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_fusion_rows_x6<128", [CS + "common.hpp", CS + "x6.hpp", CS + "fusion_x6.hip"], "all"),
     "edge_uv_mlp2_mean[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "last_layer"),
     "edge_uv_mlp2_mean+node_uv_next[E x (U+V+attr) -> 64 -> 64 -> mean; N x 64 -> 128+64+64]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "with_next"),
     "node_uv[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_gemm_nt_node3", [CS + "common.hpp", CS + "dense.hip"], "all"),
