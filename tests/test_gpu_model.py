@@ -585,3 +585,37 @@ def test_primed_workspace_forwards_equal_self_contained_forwards():
     first = {}
     for i, x in zip(order, b):                      # and the same batch always gives the same logits
         assert torch.equal(first.setdefault(i, x), x)
+
+
+def test_hip_graph_replay_survives_many_replays():
+    """600 replays of the captured cfg-2 forward.  With hipMemsetAsync inside the captured sequence, ROCm 7.2 raised a
+    GPU memory access fault ("write access to a read-only page") after a few dozen replays; the counters are now zeroed
+    by a kernel (graph.hip k_zero_i32), so the graph holds kernel nodes only.  Runs in a child process: a fault kills
+    the process that owns the context."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import golden_util as gu\n"
+        "import yolat_vectorgraphicsrecognition_amd as yv\n"
+        "data, slices, optkw, _ = yv.config('2')\n"
+        "model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 0).cuda().eval()\n"
+        "for k in ('x', 'edge', 'e_attr', 'bbox_idx', 'bbox'):\n"
+        "    setattr(data, k, getattr(data, k).cuda())\n"
+        "with torch.no_grad():\n"
+        "    want = model(data, slices)[0].clone()\n"
+        "model.use_hip_graphs(True)\n"
+        "for i in range(600):\n"
+        "    data._yolat_stage = None\n"
+        "    with torch.no_grad():\n"
+        "        out = model(data, slices)[0]\n"
+        "    if i %% 100 == 99:\n"
+        "        assert torch.equal(out, want), i\n"
+        "torch.cuda.synchronize()\n"
+        "plan = next(iter(model._yolat_plans.values()))\n"
+        "assert any(v not in (False, None) for v in plan._graphs.values())\n"
+        "print('replays ok')\n" % (root, os.path.join(root, "tests")))
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "replays ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])

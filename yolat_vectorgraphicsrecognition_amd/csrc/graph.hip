@@ -214,6 +214,12 @@ extern "C" int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, 
 //                     emit perm / src / dst / attr at row start + rank; row n: the final row_ptr
 // ------------------------------------------------------------------------------------------------
 #define PREP_BLK 4096
+__global__ void __launch_bounds__(256) k_zero_i32(int* p, int n) {      // n a multiple of 4, p 16-byte aligned or not
+  const int i = (blockIdx.x * 256 + threadIdx.x) * 4;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    if (i + j < n) p[i + j] = 0;
+}
 __global__ void k_prep_count(const int64_t* edge, long se, long sc, int E, int N, int* src32, int* dst32,
                              int* rank, int* cnt, const int64_t* bbox, long P, int* seg_ptr, int* node_seg,
                              int* status) {
@@ -419,9 +425,12 @@ int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_
   int* rank = dst32 + E;
   int* items = rank + E;
   // primed: the caller vouches that the counters are zero (left so by the previous call with this shape on this buffer)
+  // (a kernel, not hipMemsetAsync: the eval plan may be captured into a hipGraph, and ROCm 7.2's memset graph node
+  // faulted — "write access to a read-only page", gigabytes away from every buffer of the graph — after a few dozen
+  // replays of a graph that was otherwise all kernel nodes; tools/exp/graphs_probe2.py)
   if (!primed) {
-    hipError_t err = hipMemsetAsync(cnt, 0, sizeof(int) * (size_t)n1p, st);
-    if (err != hipSuccess) return (int)err;
+    hipLaunchKernelGGL(k_zero_i32, dim3(yl_cdiv(n1p, 1024)), dim3(256), 0, st, cnt, n1p);
+    YL_LAUNCH_CHECK();
   }
   const long nthreads = (E > N + 1) ? E : N + 1;
   hipLaunchKernelGGL(k_prep_count, dim3(yl_cdiv(nthreads, 256)), dim3(256), 0, st, edge, (long)stride_e,
