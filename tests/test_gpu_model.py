@@ -619,3 +619,31 @@ def test_hip_graph_replay_survives_many_replays():
         "print('replays ok')\n" % (root, os.path.join(root, "tests")))
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0 and "replays ok" in r.stdout, (r.returncode, r.stdout[-300:], r.stderr[-600:])
+
+
+def test_training_step_releases_its_activations_without_the_cyclic_collector():
+    """The saved state of a step (hundreds of MB to GB of [E,64] activations) must die with the loss tensor, by reference
+    counting: with Python's cyclic collector switched off, device memory after every step returns to the same level.
+    (The autograd node used to return the very logits tensor its saved state holds — a cycle — and up to seven steps
+    of activations piled up in the caching allocator between collector runs.)"""
+    import gc
+    yv = _yv()
+    optkw = dict(n_classes=6, n_blocks=2, n_blocks_out=2)
+    data, slices = yv.synth_batch(3, 21, num_proposals=60, nodes_lo=3, nodes_hi=30, n_classes=6)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 8).cuda()
+    tr = yv.Trainer(model, yv.Opt(**optkw), lr=1e-3, weight_decay=0.0)
+    for _ in range(2):
+        tr.step(data, slices)
+    gc.collect()
+    torch.cuda.synchronize()
+    gc.disable()
+    try:
+        levels = []
+        for _ in range(6):
+            loss = tr.step(data, slices)
+            del loss
+            torch.cuda.synchronize()
+            levels.append(torch.cuda.memory_allocated())
+    finally:
+        gc.enable()
+    assert max(levels) - min(levels) <= 64 * 1024, levels

@@ -71,22 +71,32 @@ class _ModelFn(torch.autograd.Function):
         training = model.training
         logits, sv = engine.model_fwd(model, g, x, training)
         ctx.model, ctx.g, ctx.sv, ctx.params = model, g, sv, params
-        return logits
+        # the saved state holds the logits buffer itself (the last Linear's output): returning that very tensor object
+        # would close a cycle output -> grad_fn -> ctx -> sv -> output, and a step's saved activations (0.6 GB at cfg 4,
+        # several GB at cfg 5) would wait for Python's cyclic collector instead of being freed with the loss — up to
+        # seven steps of garbage in the caching allocator, and hipMalloc calls in the middle of timed steps
+        return logits.detach() if sv is not None else logits
 
     @staticmethod
     def backward(ctx, dlogits):
         if ctx.sv is None:
+            if getattr(ctx, "released", False):
+                raise RuntimeError("second backward through the same SparseCADGCN forward: the saved activations are "
+                                   "released after the first one (retain_graph is not supported by the HIP path)")
             raise RuntimeError("backward through an eval-mode SparseCADGCN is not supported by the HIP path")
         model = ctx.model
         flat = getattr(model, "_yolat_flat", None)
         dl = dlogits.contiguous().clone()
+        sv, g, params = ctx.sv, ctx.g, ctx.params
+        ctx.released = True
+        ctx.sv = ctx.g = None           # one backward per forward (as retain_graph=False means): release the activations now
         if flat is not None and flat.direct_grads:
             # trainer path: gradients land in the flat buffer, autograd sees no per-tensor grads
-            engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink(flat.grad_views, getattr(flat, "on_head_done", None)))
+            engine.model_bwd(model, g, sv, dl, GradSink(flat.grad_views, getattr(flat, "on_head_done", None)))
             flat.grads_ready = True
-            return (None, None, None) + tuple(None for _ in ctx.params)
-        sink = engine.model_bwd(model, ctx.g, ctx.sv, dl, GradSink())
-        return (None, None, None) + tuple(sink.out.get(id(p)) for p in ctx.params)
+            return (None, None, None) + tuple(None for _ in params)
+        sink = engine.model_bwd(model, g, sv, dl, GradSink())
+        return (None, None, None) + tuple(sink.out.get(id(p)) for p in params)
 
 
 class SparseCADGCN(nn.Module):
