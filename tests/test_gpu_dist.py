@@ -86,3 +86,58 @@ def test_dp_train_step_two_ranks_matches_single_process_average(tmp_path):
     ref = flat.param.cpu().numpy()
     scale = np.abs(ref).max()
     assert np.abs(r0["param"] - ref).max() <= 2e-6 * scale
+
+
+def _nccl_worker(rank, world, port, outdir):
+    sys.path.insert(0, os.path.dirname(HERE))
+    sys.path.insert(0, HERE)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    import yolat_vectorgraphicsrecognition_amd as yv
+    import golden_util as gu
+    opt = yv.Opt()
+    res = {}
+    for mode in ("exchange", "local"):
+        model = gu.fill_state_(yv.SparseCADGCN(opt), 61).cuda()
+        tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5, force_exchange=(mode == "exchange"))
+        assert tr.flat.conv_end > 0                       # the two-bucket branch is the one that runs
+        fired = []
+        if mode == "exchange":
+            real = dist.all_reduce
+
+            def spy(t, *a, **k):
+                fired.append((int(t.numel()), bool(k.get("async_op", False))))
+                return real(t, *a, **k)
+            dist.all_reduce = spy
+        data, slices = _batch(yv, 0)
+        losses = []
+        for _ in range(3):
+            data._yolat_stage = None
+            losses.append(float(tr.step(data, slices)))
+        torch.cuda.synchronize()
+        if mode == "exchange":
+            dist.all_reduce = real
+            # per step: bucket 1 (fusion + classifier) from inside the backward, bucket 2 (conv layers) after it
+            assert len(fired) == 6 and all(a for _, a in fired), fired
+            assert fired[0][0] == tr.flat.numel - tr.flat.conv_end and fired[1][0] == tr.flat.conv_end, fired
+        res[mode] = (tr.flat.param.cpu().numpy().copy(), np.array(losses))
+    np.savez(os.path.join(outdir, "nccl.npz"), p_ex=res["exchange"][0], p_lo=res["local"][0],
+             l_ex=res["exchange"][1], l_lo=res["local"][1], backend=np.array(dist.get_backend()))
+    dist.destroy_process_group()
+
+
+def test_dp_exchange_over_rccl_in_a_one_rank_group_equals_the_local_step(tmp_path):
+    """The exchange branch of Trainer.step (async all-reduce fired from inside the backward, second bucket, wait, Adam
+    with the 1/world scale) over the `nccl` backend = librccl, in a process group of ONE rank on the one GPU: the
+    collective runs on RCCL's own stream, ordered against the HIP kernels' stream by events — the ordering gloo's
+    host-staged path never exercises.  SUM over one rank is the identity, so parameters and losses must be
+    bit-identical to the step without the exchange."""
+    port = _free_port()
+    mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
+    r = np.load(tmp_path / "nccl.npz")
+    assert str(r["backend"]) == "nccl"
+    np.testing.assert_array_equal(r["l_ex"], r["l_lo"])
+    np.testing.assert_array_equal(r["p_ex"], r["p_lo"])

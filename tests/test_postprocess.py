@@ -5,6 +5,8 @@ import os
 
 import numpy as np
 import pytest
+
+pytestmark = pytest.mark.host      # host code: CPU suite, and also the GPU box's -m gpu pass (conftest.py)
 import torch
 
 from oracle import oracle_np as onp

@@ -13,6 +13,8 @@ Data parallelism shards whole graphs (dataset items) across ranks; there are no 
 (Datasets/graph_dict3.py:594-600), BatchNorm statistics stay per replica (the reference has no
 SyncBN), parameters and optimizer state are replicated.
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -158,7 +160,9 @@ def load_reference_checkpoint(model, checkpoint, optimizer=None, strict=True):
     parameter / buffer names are the reference's.  `checkpoint`: a path or the loaded dict.
     Returns (epoch, best_value)."""
     if not isinstance(checkpoint, dict):
-        checkpoint = torch.load(checkpoint, map_location="cpu")
+        # reference checkpoints are full pickles (train.py:313-321): `best_value` is a numpy.float64 (train.py:311,508),
+        # next to optimizer / scheduler dicts — torch >= 2.6's default weights_only=True refuses them
+        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
     sd = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
     own_multi = next(iter(model.state_dict())).startswith("module.")
     ckpt_multi = next(iter(sd)).startswith("module.")
@@ -210,7 +214,8 @@ def allreduce_mean_(flat_grad):
 
 
 class Trainer(object):
-    def __init__(self, model, opt, lr=2.5e-4, weight_decay=1e-5, precision=None):
+    def __init__(self, model, opt, lr=2.5e-4, weight_decay=1e-5, precision=None, check_inputs_every=0,
+                 force_exchange=None):
         self.model = model
         if precision is not None:
             model.set_train_precision(precision)
@@ -218,8 +223,17 @@ class Trainer(object):
         broadcast_parameters(self.flat, model)
         self.optimizer = FlatAdam(self.flat, lr=lr, weight_decay=weight_decay)
         self.criterion = DetectionLoss(opt)
-        self._checked_inputs = False
+        self._steps = 0
+        # the input-validity word of the forward (edge ids inside [0, N), bbox_idx sorted) is read back — one
+        # synchronisation — on the first step and then every `check_inputs_every` steps (0: first step only),
+        # always BEFORE Adam applies the update, so a malformed batch never reaches the weights
+        self.check_inputs_every = int(check_inputs_every)
         self.exchange_gradients = True      # False: skip the all-reduce (bench.py: cost of the exchange after overlap)
+        # run the exchange branch (async bucket from inside backward, second bucket, wait) in a process group of ONE
+        # rank as well: exercises the RCCL stream ordering on a single GPU (tests/test_gpu_dist.py, bench.py)
+        if force_exchange is None:
+            force_exchange = os.environ.get("YOLAT_FORCE_DP", "0") == "1"
+        self.force_exchange = bool(force_exchange)
 
     def step(self, data, slices=None):
         """One training step on this rank's batch.  Returns the (device) loss tensor."""
@@ -227,10 +241,12 @@ class Trainer(object):
         self.optimizer.zero_grad()
         out = self.model(data, slices)
         loss = self.criterion(out, data)["loss"]
-        world = dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
-        if not self.exchange_gradients:
+        grouped = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if grouped else 1
+        exchange = self.exchange_gradients and grouped and (world > 1 or self.force_exchange)
+        if not exchange:
             world = 1
-        if world > 1 and self.flat.conv_end > 0:
+        if exchange and self.flat.conv_end > 0:
             # bucket 1 (fusion blocks + classifier, 93 % of the bytes) is all-reduced while the conv layers'
             # backward still runs; bucket 2 (conv layers) after the backward
             handles = []
@@ -246,10 +262,12 @@ class Trainer(object):
             scale = 1.0 / world
         else:
             loss.backward()
-            scale = allreduce_mean_(self.flat.grad) if world > 1 else 1.0
+            scale = 1.0
+            if exchange:
+                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+                scale = 1.0 / world
+        if self._steps == 0 or (self.check_inputs_every > 0 and self._steps % self.check_inputs_every == 0):
+            self.model.check_last_status()      # raises before the update is applied
+        self._steps += 1
         self.optimizer.step(grad_scale=scale)
-        if not self._checked_inputs:
-            # first batch only (synchronises): edge ids inside [0, N), bbox_idx sorted — see SparseCADGCN.forward
-            self._checked_inputs = True
-            self.model.check_last_status()
         return loss.detach()
