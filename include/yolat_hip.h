@@ -539,13 +539,30 @@ typedef struct {
   const uint16_t* Wuv[YOLAT_MAX_LAYERS];      /* bf16 of conv[l].Wuv [2C,Cin]                   */
   const uint16_t* Wr[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].Wr  [C,Cin]                    */
   const uint16_t* Wn[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].Wn  [C,Cin]                    */
-  const uint16_t* W2[YOLAT_MAX_LAYERS];       /* bf16 of conv[l].W2  [C,C]                      */
+  const uint16_t* W2[YOLAT_MAX_LAYERS];       /* bf16 of diag(s2) . conv[l].W2  [C,C]: the scale of the edge MLP's second
+                                               * BatchNorm folded into the weight rows BEFORE rounding (ABI 4)   */
   /* layer 1's folded BatchNorm, applied by the node-side GEMM epilogue instead of per edge:
    * uv_scale[l] = [s1 | s1], uv_shift[l] = [s1*b1 + t1 | 0]   (fp32 [2C] each; s1 = 1, t1 = 0 without a norm) */
   const float* uv_scale[YOLAT_MAX_LAYERS];
   const float* uv_shift[YOLAT_MAX_LAYERS];
   const uint16_t *Wf, *Wfs, *Wc1, *Wc2, *Wc3; /* bf16 of the fusion / classifier weights        */
+  const float* t2f[YOLAT_MAX_LAYERS];         /* fp32 [C]: s2*b2 + t2, the shift that goes with the folded W2 (ABI 4) */
 } yolat_model_eval_bf16;
+
+/* The edge stage of the bf16-storage forward on its own (op tests, benchmarks): factorised edge MLP + mean
+ * aggregation of one conv layer, gcn_lib/sparse/torch_vertex.py:319-337 in eval mode.
+ *   UV [N, ld_uv] bf16: per-node products U' | V' with layer 1's folded BatchNorm applied (node-side epilogue);
+ *   src/dst/attr/row_ptr: the CSR (destination-sorted) edge arrays of yolat_graph_prepare;
+ *   Wc4 [C,4] fp32 attr columns of the first Linear, s1 [C] their scale (NULL = 1);
+ *   W2f [C,C] bf16 = bf16(diag(s2) W2), t2f [C] fp32 = s2*b2 + t2;  root [N, ld_r] fp32 = lin_r(x);
+ *   f_out [N, ld_fo] bf16 = bf16(root + mean over in-edges of relu(W2f . relu(U'[dst] + V'[src] + s1*Wc4 . attr) + t2f)).
+ * variant: 0 = automatic, 1 = node tiles (k_edge_uv_mlp2_mean_h), 2 = register-chained MFMA waves (edge_chain.hip).
+ * C = 64 only. */
+int yolat_edge_uv_mlp2_mean_eval_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                                      const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E,
+                                      const float* Wc4, const float* s1, const uint16_t* W2f, const float* t2f,
+                                      const float* root, int64_t ld_r, uint16_t* f_out, int64_t ld_fo, int variant,
+                                      yolat_stream_t stream);
 
 /* dst[i] = bfloat16(src[i]), round-to-nearest-even (what torch's .to(torch.bfloat16) does); dst 4-byte aligned */
 int yolat_f32_to_bf16(const float* src, int64_t n, uint16_t* dst, yolat_stream_t stream);

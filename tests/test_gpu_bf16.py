@@ -436,3 +436,87 @@ def test_fused_bn_csr_backward_bf16_storage_matches_fp32_on_the_same_values(N, E
     again = run(H2, H1, torch.bfloat16)
     for a, b in zip(got, again):
         assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+# the edge stage on its own (yolat_edge_uv_mlp2_mean_eval_bf16): node tiles vs register-chained MFMA waves
+# ---------------------------------------------------------------------------------------------
+def _edge_stage_case(yv, n_props, nodes_lo, nodes_hi, seed, **kw):
+    data, _ = yv.synth_batch(1, seed, num_proposals=n_props, nodes_lo=nodes_lo, nodes_hi=nodes_hi, **kw)
+    N, P = int(data.x.shape[0]), int(data.bbox.shape[0])
+    g = yv.ops.build_graph(data.edge.cuda(), data.e_attr.cuda(), data.bbox_idx.cuda(), N, P)
+    gen = torch.Generator().manual_seed(seed)
+    C = 64
+    UV = torch.randn(N, 2 * C, generator=gen).to(torch.bfloat16).cuda()
+    wc4 = (torch.randn(C, 4, generator=gen) * 2).cuda()
+    s1 = (torch.rand(C, generator=gen) + 0.5).cuda()
+    W2f = (torch.randn(C, C, generator=gen) / 8).to(torch.bfloat16).cuda()
+    t2f = (torch.randn(C, generator=gen) * 0.3).cuda()
+    root = torch.randn(N, C, generator=gen).cuda()
+    return g, UV, wc4, s1, W2f, t2f, root
+
+
+def _edge_stage_reference(g, UV, wc4, s1, W2f, t2f, root):
+    """fp64 restatement of torch_vertex.py:330-337 on the factorised inputs, hidden activation rounded to bf16 (the
+    one rounding both kernels share); returns (unrounded output, message scale)."""
+    U, V = UV[:, :64].double(), UV[:, 64:].double()
+    dst, src = g.dst.long(), g.src.long()
+    z = U[dst] + V[src] + g.attr.double() @ (wc4.double() * s1.double()[:, None]).t()
+    h1 = torch.relu(z).float().to(torch.bfloat16).double()
+    m = torch.relu(h1 @ W2f.double().t() + t2f.double())
+    N = U.shape[0]
+    sums = torch.zeros(N, 64, dtype=torch.float64, device=U.device).index_add_(0, dst, m)
+    deg = torch.bincount(dst, minlength=N).clamp(min=1).double()
+    # (exact output, message scale, the most one bf16 rounding flip of a hidden activation can move a message)
+    return root.double() + sums / deg[:, None], float(m.abs().max()), float(h1.abs().max() * W2f.double().abs().max()) * 2.0 ** -7
+
+
+def _run_edge_stage(yv, g, UV, wc4, s1, W2f, t2f, root, variant):
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    N = UV.shape[0]
+    out = torch.full((N, 64), float("nan"), dtype=torch.bfloat16, device="cuda")
+    check(lib.yolat_edge_uv_mlp2_mean_eval_bf16(UV.data_ptr(), 128, g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(),
+                                                g.row_ptr.data_ptr(), N, g.E, wc4.data_ptr(), s1.data_ptr(),
+                                                W2f.data_ptr(), t2f.data_ptr(), root.data_ptr(), 64, out.data_ptr(), 64,
+                                                variant, torch.cuda.current_stream().cuda_stream),
+          "yolat_edge_uv_mlp2_mean_eval_bf16")
+    return out
+
+
+@pytest.mark.parametrize("shape", [
+    dict(n_props=3000, nodes_lo=25, nodes_hi=25, edges_per_proposal=150),      # cfg-5-like: 6 in-edges per node
+    dict(n_props=900, nodes_lo=3, nodes_hi=40, edge_factor=3.0),               # ragged, many nodes without in-edges
+    dict(n_props=40, nodes_lo=30, nodes_hi=60, edges_per_proposal=3000),       # in-degree ~65: nodes span many steps
+    dict(n_props=2500, nodes_lo=4, nodes_hi=30, edge_factor=1.2),              # ~1.2 edges per node: up to 16 ends per step
+    dict(n_props=7, nodes_lo=5, nodes_hi=9, edge_factor=2.0),                  # a handful of edges: most waves idle
+])
+def test_edge_stage_bf16_chained_mfma_kernel_matches_reference_and_node_tiles(shape):
+    """k_edge_chain_h (edge_chain.hip: layer 1 as identity-MFMAs on the gathered chunks, register-chained into layer 2,
+    per-node running sums in registers) against the fp64 restatement and against the node-tile kernel: every output
+    within one bf16 rounding of the exact value (2^-8 of its magnitude + the fp32 noise of the sum), every node
+    written (incl. nodes without in-edges), bit-identical run to run."""
+    yv = _yv()
+    kw = dict(shape)
+    args = _edge_stage_case(yv, kw.pop("n_props"), kw.pop("nodes_lo"), kw.pop("nodes_hi"), 7, **kw)
+    g = args[0]
+    want, mscale, flip = _edge_stage_reference(*args)
+    tiles = _run_edge_stage(yv, *args, variant=1)
+    if g.E < 16:
+        pytest.skip("the chained kernel needs >= 16 edges")
+    chain = _run_edge_stage(yv, *args, variant=2)
+    again = _run_edge_stage(yv, *args, variant=2)
+    assert torch.isfinite(chain.float()).all()
+    assert torch.equal(chain.view(torch.int16), again.view(torch.int16))
+    for name, got in (("node tiles", tiles), ("chained", chain)):
+        d = (got.double() - want).abs()
+        tol = want.abs() * 2.0 ** -8 + 2e-5 * mscale
+        # a hidden activation whose fp32 pre-activation sits on a bf16 rounding boundary may round the other way than
+        # in the fp64 restatement and move one message by up to `flip`: a few outputs per 100 000 (measured 8 of 4.8 M)
+        # land beyond the one-rounding band, none beyond band + flip
+        assert float((d > tol).float().mean()) < 2e-5, "%s: %d of %d outputs off by more than a bf16 rounding" % (
+            name, int((d > tol).sum()), d.numel())
+        assert not bool((d > tol + flip).any()), "%s: worst excess %.3e (flip bound %.3e)" % (
+            name, float((d - tol).max()), flip)
+    # the two kernels agree except where the exact value sits next to a bf16 rounding boundary
+    differ = float((tiles.view(torch.int16) != chain.view(torch.int16)).float().mean())
+    assert differ < 0.02, differ

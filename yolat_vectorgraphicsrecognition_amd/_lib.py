@@ -49,7 +49,8 @@ class ModelEvalBf16(ctypes.Structure):
     """yolat_model_eval_bf16 (include/yolat_hip.h)"""
     _fields_ = ([("base", ctypes.POINTER(ModelEval))] +
                 [(n, c_p * YOLAT_MAX_LAYERS) for n in ("Wuv", "Wr", "Wn", "W2", "uv_scale", "uv_shift")] +
-                [(n, c_p) for n in ("Wf", "Wfs", "Wc1", "Wc2", "Wc3")])
+                [(n, c_p) for n in ("Wf", "Wfs", "Wc1", "Wc2", "Wc3")] +
+                [("t2f", c_p * YOLAT_MAX_LAYERS)])
 
 
 # name -> (restype, argtypes); order mirrors include/yolat_hip.h
@@ -190,6 +191,8 @@ SIGNATURES = {
     "yolat_proposals_get": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_proposals_window_counts": (c_int, [c_p, c_p, c_p]),
     "yolat_proposals_free": (None, [c_p]),
+    "yolat_edge_uv_mlp2_mean_eval_bf16": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
+                                                   c_i64, c_p, c_i64, c_int, c_p]),
     "yolat_forward_eval_bf16_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEvalBf16), c_i64, c_i64, c_i64]),
     "yolat_forward_eval_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),

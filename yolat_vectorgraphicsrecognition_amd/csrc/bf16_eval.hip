@@ -419,8 +419,9 @@ static __global__ void __launch_bounds__(256, (NG == 1 ? 4 : 3)) k_edge_uv_mlp2_
       wp[j >> 1][2][j & 1] = w.z * scv[j]; wp[j >> 1][3][j & 1] = w.w * scv[j];
     }
   }
+  // folded form (the product path since ABI 4): W2h already carries s2, t2 is the complete shift -> b2 = s2 = NULL
   const float sc2 = s2 ? s2[col] : 1.f;
-  const float sh2 = fmaf(b2 ? b2[col] : 0.f, sc2, s2 ? t2[col] : 0.f);    // (acc + b2)*s2 + t2 = acc*s2 + sh2
+  const float sh2 = fmaf(b2 ? b2[col] : 0.f, sc2, t2 ? t2[col] : 0.f);    // (acc + b2)*s2 + t2 = acc*s2 + sh2
   __syncthreads();
   const int e0 = rp[0], e1 = rp[nn];
   int my_b[NG], my_e[NG];                             // aggregation role: nodes rb + 16 j, columns 4q..
@@ -553,6 +554,62 @@ static __global__ void __launch_bounds__(256) k_pool_prepare_h(const u16* feats,
 }
 
 // ------------------------------------------------------------------------------------------------
+// edge stage dispatch: register-chained MFMA waves (edge_chain.hip) for large, dense-enough graphs, node tiles
+// otherwise.  Both take the folded second Linear (W2f = bf16(diag(s2) W2), t2f = s2 b2 + t2).
+// ------------------------------------------------------------------------------------------------
+int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                       const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                       const float* s1, const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
+                       uint16_t* f_out, int64_t ld_fo, hipStream_t st);
+
+static int yl_edge_uv_mlp2_mean_bf16_impl(const u16* UV, long ld_uv, const int* src, const int* dst, const float* attr,
+                                          const int* row_ptr, long N, long E, const float* Wc4, const float* s1,
+                                          const u16* W2f, const float* t2f, const float* root, long ld_r, u16* f_out,
+                                          long ld_fo, int variant, hipStream_t st) {
+  static int env_variant = -1;
+  if (env_variant < 0) {
+    const char* e = getenv("YOLAT_HEDGE_VARIANT");
+    env_variant = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
+  }
+  if (variant == 0) variant = env_variant;
+  // the chained kernel walks the EDGE list: it needs enough edges to fill 2048 waves and pays per finished node
+  if (variant == 0) variant = (E >= 131072 && E >= 2 * N) ? 2 : 1;
+  if (variant == 2) {
+    if (E < 16) return YOLAT_E_UNSUPPORTED;
+    return yl_edge_chain_bf16(UV, ld_uv, src, dst, attr, row_ptr, N, E, Wc4, s1, W2f, t2f, root, ld_r, f_out, ld_fo, st);
+  }
+  long npt = E > 0 ? (56 * N) / E : 64;
+  {
+    const long npt2 = E > 0 ? ((112 * N) / E < 16 ? (112 * N) / E : 16) : 16;
+    if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
+    if (npt < 1) npt = 1;
+    if (npt > 64) npt = 64;
+  }
+  hipLaunchKernelGGL((npt <= 16 ? k_edge_uv_mlp2_mean_h<1> : k_edge_uv_mlp2_mean_h<4>), dim3(yl_cdiv(N, npt)), dim3(256), 0,
+                     st, UV, (unsigned)ld_uv, src, dst, attr, row_ptr, (int)N, (int)npt, Wc4, s1, W2f, (const float*)nullptr,
+                     (const float*)nullptr, t2f, root, (unsigned)ld_r, f_out, (unsigned)ld_fo, (int)(E > 0 ? E : 1));
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_edge_uv_mlp2_mean_eval_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr,
+                                                 const int32_t* dst_csr, const float* attr_csr, const int32_t* row_ptr,
+                                                 int64_t N, int64_t E, const float* Wc4, const float* s1,
+                                                 const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
+                                                 uint16_t* f_out, int64_t ld_fo, int variant, yolat_stream_t stream) {
+  if (!UV || !row_ptr || !Wc4 || !W2f || !t2f || !root || !f_out || N <= 0 || E < 0 || variant < 0 || variant > 2)
+    return YOLAT_E_INVALID;
+  if (E > 0 && (!src_csr || !dst_csr || !attr_csr)) return YOLAT_E_INVALID;
+  if (N > (1LL << 23) || E > (1LL << 29)) return YOLAT_E_UNSUPPORTED;          // 32-bit element offsets in the gathers
+  if (ld_uv < 128 || ld_uv % 8 != 0 || ld_r < 64 || ld_r % 4 != 0 || ld_fo < 64 || ld_fo % 4 != 0 || !yl_aligned16(UV) ||
+      !yl_aligned16(root) || !yl_aligned16(attr_csr) || !yl_aligned16(Wc4) || (((uintptr_t)f_out) & 7) != 0 ||
+      (((uintptr_t)W2f) & 7) != 0)
+    return YOLAT_E_UNSUPPORTED;
+  return yl_edge_uv_mlp2_mean_bf16_impl(UV, ld_uv, src_csr, dst_csr, attr_csr, row_ptr, N, E, Wc4, s1, W2f, t2f, root, ld_r,
+                                        f_out, ld_fo, variant, (hipStream_t)stream);
+}
+
+// ------------------------------------------------------------------------------------------------
 // host side
 // ------------------------------------------------------------------------------------------------
 namespace {
@@ -601,7 +658,7 @@ int model_ok(const yolat_model_eval_bf16* mh) {
     return YOLAT_E_UNSUPPORTED;
   for (int l = 0; l < m->n_blocks; ++l) {
     const yolat_conv_eval& cv = m->conv[l];
-    if (!cv.Wuv || !cv.Wc4 || !mh->W2[l] || !mh->uv_scale[l] || !mh->uv_shift[l]) return YOLAT_E_INVALID;
+    if (!cv.Wuv || !cv.Wc4 || !mh->W2[l] || !mh->t2f[l] || !mh->uv_scale[l] || !mh->uv_shift[l]) return YOLAT_E_INVALID;
     if (l == 0 ? (cv.Cin > 16) : (cv.Cin != 64)) return YOLAT_E_UNSUPPORTED;
     if (l > 0 && (!mh->Wuv[l] || !mh->Wr[l] || !mh->Wn[l])) return YOLAT_E_INVALID;
   }
@@ -678,13 +735,6 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
                                  p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, false, stream));
   });
-  long npt = E > 0 ? (56 * N) / E : 64;
-  {
-    const long npt2 = E > 0 ? ((112 * N) / E < 16 ? (112 * N) / E : 16) : 16;
-    if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
-    if (npt < 1) npt = 1;
-    if (npt > 64) npt = 64;
-  }
   for (int l = 0; l < m->n_blocks; ++l) {
     const yolat_conv_eval& cv = m->conv[l];
     if (l > 0) {
@@ -706,10 +756,8 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     }
     snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
     YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 2.0 + 16.0 + 8.0) + 4.0 * N * C + 2.0 * N * C + 4.0 * N, {
-    hipLaunchKernelGGL((npt <= 16 ? k_edge_uv_mlp2_mean_h<1> : k_edge_uv_mlp2_mean_h<4>), dim3(yl_cdiv(N, npt)), dim3(256), 0, st, p.UV, (unsigned)(2 * C), p.src,
-                         p.dst, p.attr, p.row_ptr, (int)N, (int)npt, cv.Wc4, cv.s1, mh->W2[l], cv.b2, cv.s2, cv.t2, p.root,
-                         (unsigned)C, f_slot(l), (unsigned)ld_slot(l), (int)(E > 0 ? E : 1));
-    YL_LAUNCH_CHECK();
+      YL_TRY(yl_edge_uv_mlp2_mean_bf16_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.s1, mh->W2[l],
+                                            mh->t2f[l], p.root, C, f_slot(l), ld_slot(l), 0, st));
     });
   }
 

@@ -1,0 +1,434 @@
+// edge_chain.hip — the factorised edge MLP + mean aggregation as a REGISTER-CHAINED MFMA pipeline (round 3).
+//
+// Reference op: AttrRelativeEdgeConvGlobalPool2.forward, gcn_lib/sparse/torch_vertex.py:319-337 (eval):
+//     message_e = relu(bn2(W2 . relu(bn1(W1 . [x_i | x_j - x_i | attr_e]))))      aggr = mean over the in-edges
+// with the first Linear factorised into per-node products (U' = s1 (W1a - W1b) x + s1 b1 + t1, V' = s1 W1b x; computed
+// by the node-side GEMM) and the 4 attr columns:   h1_e = relu(U'[dst_e] + V'[src_e] + Wc4' . attr_e).
+//
+// Why a new structure (profiles/r01_fwd_cfg5_bf16_kernel_stats_v1.txt: 99 us per layer at E = 1.2 M, 0.17 of its bound):
+// the node-tile kernel (bf16_eval.hip, k_edge_uv_mlp2_mean_h) unpacks every gathered bf16 pair, adds, runs four packed
+// FMAs, packs, writes the 64 x 64 tile to LDS, reads it back as MFMA fragments, writes the fp32 messages to LDS and
+// reads them a third time for the per-node sums: ~13 vector-ALU operations and three LDS passes per hidden element.
+// The matrix cores, which run BESIDE the vector ALUs, sit at 4 % utilisation.
+//
+// Here ONE WAVE owns a contiguous CSR edge range and never touches LDS for activations:
+//   (1) the gathered 16-byte row chunks U'[dst_e][16 ks + 8 lhi ..+8] ARE the B operand of v_mfma_f32_32x32x16_bf16 (lane =
+//       edge, 8 consecutive k per lane half).  Layer 1 is computed TRANSPOSED, Z^T[channel][edge] = I . U^T + I . V^T +
+//       Wc4'_split . attr_split^T: the identity fragments pick each chunk's channels (exact: one non-zero product per
+//       output, fp32 accumulate), the attr term rides as one more MFMA with attr and Wc4' split into bf16 pairs (error
+//       2^-16 of the term, far below the bf16 rounding of h1).  No unpack, no add, no FMA on the vector ALUs.
+//   (2) the transposed result leaves every lane holding, for ITS edge, 16 channels of each 32-channel block in fp32:
+//       after ReLU + v_cvt_pk_bf16_f32 these registers are exactly the A operand (lane = edge, 8 k per lane half) of the
+//       second Linear, with the k order permuted — W2's fragments are loaded once in the same permutation.
+//   (3) layer 2 runs in the normal orientation: lane = output channel, registers = the wave's 32 edges.  Lane m gathers
+//       edge (stream (m >> 2) & 1, row (m & 3) + 4 (m >> 3)) so that lane half h holds 16 CONSECUTIVE edges of stream h:
+//       the wave walks two independent edge streams, and each half's per-node running sum lives in a register across
+//       steps — plain CSR order, no cross-lane traffic, the same summation order wherever a node falls.
+//   (4) a finished node's sum goes to a per-wave LDS row; 16 lanes per node then add the root Linear's row (prefetched at
+//       the start of the step), scale by 1/deg and store the bf16 output row with 8-byte stores.
+// Vector-ALU work per hidden element drops from ~13 to ~1 (ReLU/convert) + 2 per message (ReLU, add); 20 MFMAs per 32
+// edges.  Deterministic: fixed summation order, no float atomics.
+#include "common.hpp"
+#include <stdlib.h>
+
+typedef unsigned short u16;
+typedef unsigned ec_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned ec_u32x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 ec_bf16x8 __attribute__((ext_vector_type(8)));
+typedef short ec_s16x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+__device__ __forceinline__ ec_bf16x8 ec_frag(ec_u32x4 v) { return __builtin_bit_cast(ec_bf16x8, v); }
+__device__ __forceinline__ ec_bf16x8 ec_frag(unsigned a, unsigned b, unsigned c, unsigned d) {
+  ec_u32x4 v = {a, b, c, d};
+  return __builtin_bit_cast(ec_bf16x8, v);
+}
+// relu on a packed bfloat16 pair: as int16 a negative bf16 is negative, so max with 0 clears it (v_pk_max_i16)
+__device__ __forceinline__ unsigned ec_relu_pk(unsigned p) {
+  ec_s16x2 v = __builtin_bit_cast(ec_s16x2, p);
+  const ec_s16x2 z = {0, 0};
+  v = __builtin_elementwise_max(v, z);
+  return __builtin_bit_cast(unsigned, v);
+}
+__device__ __forceinline__ int ec_clamp(int v, int lo, int hi) { return v < lo ? lo : (v > hi ? hi : v); }
+// max(x, 0) as ONE instruction: a signed-integer max on the float's bits (negative floats are negative integers; -0 -> 0).
+// fmaxf / v_med3 cost a canonicalising v_max x, x, x in front (IEEE mode), and an inline-asm v_max is invisible to the
+// compiler's MFMA hazard recogniser — it read the accumulators before the matrix core had written them (seen as
+// run-to-run different sums).
+__device__ __forceinline__ float ec_relu(float x) {
+  const int b = __float_as_int(x);
+  return __int_as_float(b > 0 ? b : 0);
+}
+
+// A value in a register of its own.  Used for 1/deg, which arrives as the HIGH half of an 8-byte LDS read (node, 1/deg):
+// left alone, the compiler multiplies with v_pk_fma_f32 ... op_sel:[0,1,0] (low result <- high half of the pair), and on
+// the MI355X that form sporadically used the LOW half (the node id, a denormal: output = root + 0) for the low results —
+// run-to-run different outputs in columns 4q and 4q + 2 of a few nodes per launch (tools/exp/hchain_dbg.py).  With the
+// factor in its own register the packed FMA reads low halves only.
+__device__ __forceinline__ float ec_own_reg(float x) {
+  asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(x));
+  return x;
+}
+
+struct EcRows { ec_u32x4 u[4], v[4]; float4 a; };
+// indices of one step: gather role (my edge: dst, src, edge id) and flag role (edge f of the (stream, row) this lane
+// describes: its dst, the next edge's dst, and the CSR row bounds of its dst for 1/deg)
+struct EcIdx { int gd, gs, ge; int fd, fnext, f; int rp0, rp1; };
+
+// raw buffer resources: base pointer in SGPRs, 32-bit byte offsets per lane (one VALU operation per address instead of
+// 64-bit pointer arithmetic), out-of-range reads return 0
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ec_rsrc(const void* p, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), 0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ float4 ec_f4(ec_u32x4 v) { return __builtin_bit_cast(float4, v); }
+
+// first edge / first node of the stream that starts at chunk boundary c (moved forward to a node boundary), from the
+// destination d = dst[c] of the boundary edge and its CSR row bounds (all three boundaries' loads are issued together:
+// two dependent memory rounds per wave instead of six)
+__device__ __forceinline__ void ec_bound(long c, int N, int E, int d, int rs, int re, int& e, int& n) {
+  if (c <= 0) { e = 0; n = 0; return; }
+  if (c >= E) { e = E; n = N; return; }
+  if (rs == (int)c) { e = (int)c; n = d; }
+  else { e = re; n = d + 1; }
+}
+
+// ABL: ablation switches for tools/exp/hedge_bench.py (YOLAT_HCHAIN_ABL; results are then WRONG on purpose):
+//   1 = no row gathers inside the loop (the first step's rows are reused), 2 = no per-node sums / output stage,
+//   4 = no MFMAs (accumulators taken from the gathered registers).  The product path instantiates ABL = 0.
+template <int ABL>
+__global__ void __launch_bounds__(256, 3) k_edge_chain_h(
+    const u16* __restrict__ UV, unsigned ld_uv, const int* __restrict__ src, const int* __restrict__ dst,
+    const float* __restrict__ attr, const int* __restrict__ row_ptr, int N, int E, int chunk,
+    const float* __restrict__ Wc4, const float* __restrict__ s1, const u16* __restrict__ W2f,
+    const float* __restrict__ t2f, const float* __restrict__ root, unsigned ld_r, u16* __restrict__ f_out,
+    unsigned ld_fo) {
+  __shared__ __attribute__((aligned(16))) float stage_s[4][32 * 64];
+  __shared__ __attribute__((aligned(8))) int2 slot_s[4][32];          // (node, bits of 1/deg) of the step's finished nodes
+  __shared__ __attribute__((aligned(16))) ec_u32x4 w2_s[8][64];       // W2's 8 B fragments (nb, k-step) x lane
+  const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63, l31 = lane & 31, lhi = lane >> 5;
+  float* stage = stage_s[wv];
+  int2* slot_tab = slot_s[wv];
+  const long w = (long)blockIdx.x * 4 + wv;
+
+  // ---- W2 (row scale of BatchNorm 2 folded, bf16) as B operand fragments of layer 2, k order = the order layer 1
+  // leaves h1 in; kept in LDS (one copy per workgroup), read just in time: 32 registers less per wave
+  {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int fi = 2 * wv + i, nb = fi >> 2, sk = fi & 3;
+      const u16* p = W2f + (32 * nb + l31) * 64 + 16 * sk + 4 * lhi;
+      const ec_u32x2 lo = *reinterpret_cast<const ec_u32x2*>(p), hi = *reinterpret_cast<const ec_u32x2*>(p + 8);
+      const ec_u32x4 f = {lo.x, lo.y, hi.x, hi.y};
+      w2_s[fi][lane] = f;
+    }
+  }
+  __syncthreads();
+
+  // ---- the wave's two edge streams [e0, e1), [e1, e2) and its node range [n0, n2) (wave-uniform)
+  int e0, e1, e2, n0, n1, n2;
+  {
+    const long cb[3] = {(2 * w) * chunk, (2 * w + 1) * chunk, (2 * w + 2) * chunk};
+    int d[3], rs[3], re[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) d[i] = dst[cb[i] < E ? cb[i] : E - 1];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { rs[i] = row_ptr[d[i]]; re[i] = row_ptr[d[i] + 1]; }
+    ec_bound(cb[0], N, E, d[0], rs[0], re[0], e0, n0);
+    ec_bound(cb[1], N, E, d[1], rs[1], re[1], e1, n1);
+    ec_bound(cb[2], N, E, d[2], rs[2], re[2], e2, n2);
+  }
+  if (e1 < e0) e1 = e0;
+  if (e2 < e1) e2 = e1;
+  if (n2 <= n0) return;
+  const int len0 = e1 - e0, len1 = e2 - e1;
+  const int nsteps = ((len0 > len1 ? len0 : len1) + 15) >> 4;
+
+  const __amdgpu_buffer_rsrc_t rUV = ec_rsrc(UV, (unsigned)N * ld_uv * 2u), rAttr = ec_rsrc(attr, (unsigned)E * 16u),
+                               rDst = ec_rsrc(dst, (unsigned)E * 4u), rSrc = ec_rsrc(src, (unsigned)E * 4u),
+                               rRoot = ec_rsrc(root, (unsigned)N * ld_r * 4u),
+                               rRp = ec_rsrc(row_ptr, (unsigned)(N + 1) * 4u),
+                               rOut = ec_rsrc(f_out, (unsigned)N * ld_fo * 2u);
+  const unsigned ldb_uv = ld_uv * 2u, ldb_r = ld_r * 4u, ldb_fo = ld_fo * 2u;
+
+  // ---- constant fragments
+  // identity fragments: A[m][k] = 1 iff k == m - 16 j   (m = lane & 31 = channel inside the 32-block, j = k-step)
+  ec_bf16x8 Id[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const bool mine = ((l31 >> 4) == j) && (((l31 >> 3) & 1) == lhi);
+    const int i = l31 & 7;
+    unsigned d[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) d[k] = (mine && (i >> 1) == k) ? (0x3F80u << (16 * (i & 1))) : 0u;
+    Id[j] = ec_frag(d[0], d[1], d[2], d[3]);
+  }
+  // attr weights Wc4' = s1 * Wc4 for channel 32 b + m as bf16 (hi, lo) pairs:
+  //   lane half 0: [wh0..3 | wh0..3]  (x attr_hi, x attr_lo)     lane half 1: [wl0..3 | 0]  (x attr_hi)
+  ec_bf16x8 WcA[2];
+#pragma unroll
+  for (int b = 0; b < 2; ++b) {
+    const int c = 32 * b + l31;
+    const float sc = s1 ? s1[c] : 1.f;
+    const float4 wq = *reinterpret_cast<const float4*>(Wc4 + 4 * c);
+    const float wv4[4] = {wq.x * sc, wq.y * sc, wq.z * sc, wq.w * sc};
+    const unsigned h01 = yl_pack_bf16(wv4[0], wv4[1]), h23 = yl_pack_bf16(wv4[2], wv4[3]);
+    const unsigned l01 = yl_pack_bf16(wv4[0] - yl_bf16_lo(h01), wv4[1] - yl_bf16_hi(h01));
+    const unsigned l23 = yl_pack_bf16(wv4[2] - yl_bf16_lo(h23), wv4[3] - yl_bf16_hi(h23));
+    WcA[b] = lhi ? ec_frag(l01, l23, 0u, 0u) : ec_frag(h01, h23, h01, h23);
+  }
+  // layer 2's shift t2f (= s2 b2 + t2) enters through one more MFMA: ones x [t_hi, t_mid, t_lo]
+  const ec_bf16x8 OnesA = lhi ? ec_frag(0u, 0u, 0u, 0u) : ec_frag(0x3F803F80u, 0x00003F80u, 0u, 0u);
+  ec_bf16x8 TB[2];
+#pragma unroll
+  for (int nb = 0; nb < 2; ++nb) {
+    const float t = t2f ? t2f[32 * nb + l31] : 0.f;
+    const unsigned th = __float_as_uint(t) & 0xFFFF0000u;
+    const float r1 = t - __uint_as_float(th);
+    const unsigned tm = __float_as_uint(r1) & 0xFFFF0000u;
+    const float r2 = r1 - __uint_as_float(tm);
+    const unsigned tl = yl_pack_bf16(r2, 0.f) & 0xFFFFu;
+    TB[nb] = lhi ? ec_frag(0u, 0u, 0u, 0u) : ec_frag((th >> 16) | tm, tl, 0u, 0u);
+  }
+
+  // ---- lane roles
+  const int gs = (l31 >> 2) & 1, gr = (l31 & 3) + 4 * (l31 >> 3);   // gather role: stream, row of my edge
+  const int gE1 = (gs ? e2 : e1) > 0 ? (gs ? e2 : e1) - 1 : 0;      // last edge of my stream (clamp target)
+  int g_run = (gs ? e1 : e0) + gr;                                   // my edge of the step being indexed
+  const int fs = l31 >> 4, fr = l31 & 15;                            // flag role (lanes 0..31; 32..63 mirror)
+  const int fE = fs ? e2 : e1, Em1 = E - 1;
+  int f_run = (fs ? e1 : e0) + fr;
+  const unsigned fr_below = (1u << fr) - 1u;
+  const unsigned c_u = 16u * lhi, c_v = 128u + 16u * lhi, q16 = 16u * (lane & 15), q8 = 8u * (lane & 15);
+  const int t_k0 = lane >> 4, t_k1 = 4 + (lane >> 4);               // finalize: slot of my task in round 0 / 1
+
+  auto load_idx = [&](EcIdx& ix) {                                   // indices of the next step not indexed yet
+    const int e = yl_min(g_run, gE1);
+    g_run += 16;
+    ix.ge = e;
+    ix.gd = __builtin_amdgcn_raw_buffer_load_b32(rDst, 4 * e, 0, 0);
+    ix.gs = __builtin_amdgcn_raw_buffer_load_b32(rSrc, 4 * e, 0, 0);
+    const int f = f_run;
+    f_run += 16;
+    ix.f = f;
+    ix.fd = __builtin_amdgcn_raw_buffer_load_b32(rDst, 4 * yl_min(f, Em1), 0, 0);
+    ix.fnext = __builtin_amdgcn_raw_buffer_load_b32(rDst, 4 * yl_min(f + 1, Em1), 0, 0);
+  };
+  auto gather = [&](EcIdx& ix, EcRows& r) {
+    const unsigned uo = __umul24((unsigned)ix.gd, ldb_uv) + c_u, vo = __umul24((unsigned)ix.gs, ldb_uv) + c_v;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      r.u[ks] = __builtin_amdgcn_raw_buffer_load_b128(rUV, uo + 32 * ks, 0, 0);
+      r.v[ks] = __builtin_amdgcn_raw_buffer_load_b128(rUV, vo + 32 * ks, 0, 0);
+    }
+    r.a = ec_f4(__builtin_amdgcn_raw_buffer_load_b128(rAttr, 16 * ix.ge, 0, 0));
+    ix.rp0 = __builtin_amdgcn_raw_buffer_load_b32(rRp, 4 * ix.fd, 0, 0);
+    ix.rp1 = __builtin_amdgcn_raw_buffer_load_b32(rRp, 4 * ix.fd + 4, 0, 0);
+  };
+
+  float cur0 = 0.f, cur1 = 0.f;      // running sums of the open node of stream lhi, columns l31 and 32 + l31
+  auto mfma = [&](const ec_bf16x8& a, const ec_bf16x8& b, const f32x16& c) -> f32x16 {
+    if (ABL & 4) {
+      f32x16 o = c;
+      o[0] += __builtin_bit_cast(ec_u32x4, a).x * 1e-30f + __builtin_bit_cast(ec_u32x4, b).y * 1e-30f;
+      return o;
+    }
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+  };
+
+  // One step = 16 edges of each stream.  `ix` = this step's indices, `r` = its gathered rows; `nx` = the next step's
+  // indices: its row gathers are issued into `r` as soon as layer 2's MFMAs have been issued (layer 1 has consumed `r`
+  // by then), so they fly during the per-node sums and the output stage of this step.
+  auto step = [&](const EcIdx& ix, EcRows& r, EcIdx& nx) {
+    // ---- finished nodes of the step (flag role): bit j of `em` = row j of stream 0, bit 16 + j = stream 1
+    const bool endf = ix.f < fE && (ix.f == fE - 1 || ix.fd != ix.fnext);
+    const unsigned em = (unsigned)__builtin_amdgcn_ballot_w64(endf);
+    const unsigned en0 = em & 0xFFFFu, en1 = em >> 16;
+    const int c0 = __builtin_popcount(en0), nslots = c0 + __builtin_popcount(en1);
+    {
+      const int deg = ix.rp1 - ix.rp0;
+      const float inv = 1.f / (float)(deg > 1 ? deg : 1);
+      const int k = (fs ? c0 + __builtin_popcount(en1 & fr_below) : __builtin_popcount(en0 & fr_below));
+      if (endf && lane < 32) slot_tab[k] = make_int2(ix.fd, __float_as_int(inv));
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- output-stage prefetch: (node, 1/deg) and the root row quad of my tasks in the first two rounds
+    const int ntask = nslots * 16, last = nslots > 0 ? nslots - 1 : 0;
+    const int2 sl0 = slot_tab[yl_min(t_k0, last)], sl1 = slot_tab[yl_min(t_k1, last)];
+    const float4 rt0 = ec_f4(__builtin_amdgcn_raw_buffer_load_b128(rRoot, __umul24((unsigned)sl0.x, ldb_r) + q16, 0, 0));
+    const float4 rt1 = ec_f4(__builtin_amdgcn_raw_buffer_load_b128(rRoot, __umul24((unsigned)sl1.x, ldb_r) + q16, 0, 0));
+
+    // ---- layer 1, transposed, one 32-channel block at a time:
+    //      z[r] = pre-activation of channel 32 b + (r & 3) + 8 (r >> 2) + 4 lhi for MY edge; ReLU + bf16 -> hp
+    // attr as bf16 (hi, lo): lane half 0 [ah0..3 | al0..3], lane half 1 [ah0..3 | 0]
+    const unsigned ah01 = yl_pack_bf16(r.a.x, r.a.y), ah23 = yl_pack_bf16(r.a.z, r.a.w);
+    const unsigned al01 = yl_pack_bf16(r.a.x - yl_bf16_lo(ah01), r.a.y - yl_bf16_hi(ah01));
+    const unsigned al23 = yl_pack_bf16(r.a.z - yl_bf16_lo(ah23), r.a.w - yl_bf16_hi(ah23));
+    const ec_bf16x8 ab = ec_frag(ah01, ah23, lhi ? 0u : al01, lhi ? 0u : al23);
+    unsigned hp[16];
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      f32x16 z;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) z[i] = 0.f;
+      z = mfma(Id[0], ec_frag(r.u[2 * b]), z);
+      z = mfma(Id[1], ec_frag(r.u[2 * b + 1]), z);
+      z = mfma(Id[0], ec_frag(r.v[2 * b]), z);
+      z = mfma(Id[1], ec_frag(r.v[2 * b + 1]), z);
+      z = mfma(WcA[b], ab, z);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) hp[8 * b + i] = ec_relu_pk(yl_pack_bf16(z[2 * i], z[2 * i + 1]));
+    }
+    // ---- layer 2: m_nb[r] = pre-ReLU message of edge (stream lhi, row r), channel 32 nb + l31
+    f32x16 m0, m1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { m0[i] = 0.f; m1[i] = 0.f; }
+    m0 = mfma(OnesA, TB[0], m0);
+    m1 = mfma(OnesA, TB[1], m1);
+#pragma unroll
+    for (int sk = 0; sk < 4; ++sk) {
+      const ec_bf16x8 hA = ec_frag(hp[4 * sk], hp[4 * sk + 1], hp[4 * sk + 2], hp[4 * sk + 3]);
+      m0 = mfma(hA, ec_frag(w2_s[sk][lane]), m0);
+      m1 = mfma(hA, ec_frag(w2_s[4 + sk][lane]), m1);
+    }
+    // ---- the next step's row gathers (into the registers layer 1 has just consumed)
+    if (!(ABL & 1)) gather(nx, r);
+    // ---- per-node running sums in CSR order; a finished node's sums go to its slot row and the sums restart.
+    // (A node starts where the previous one ended, and rows beyond the end of a stream never end a node, so the end
+    // flags alone drive the walk.)  The test for "some half finishes a node at this row" is scalar: rows where nobody
+    // does cost two ReLUs and one packed add.
+    if (ABL & 2) {
+      float acc = 0.f;
+#pragma unroll
+      for (int rr = 0; rr < 16; ++rr) acc += m0[rr] + m1[rr];
+      cur0 += acc;
+      return;
+    }
+    const unsigned anyen = en0 | en1;
+    const unsigned myen = lhi ? en1 : en0;
+    float* srow = stage + (lhi ? c0 : 0) * 64 + l31;
+#pragma unroll
+    for (int rr = 0; rr < 16; ++rr) {
+      cur0 += ec_relu(m0[rr]);
+      cur1 += ec_relu(m1[rr]);
+      if ((anyen >> rr) & 1u) {
+        asm volatile("; node end in row %0" ::"n"(rr));      // keeps the uniform test a scalar branch
+        if ((myen >> rr) & 1u) {
+          srow[0] = cur0;
+          srow[32] = cur1;
+          srow += 64;
+          cur0 = 0.f;
+          cur1 = 0.f;
+        }
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+    // ---- output stage: out = bf16(root + sum / deg), 16 lanes per node
+    if (lane < ntask) {
+      const float4 sv = *reinterpret_cast<const float4*>(stage + t_k0 * 64 + (q16 >> 2));
+      const float inv = ec_own_reg(__int_as_float(sl0.y));
+      ec_u32x2 o;
+      o.x = yl_pack_bf16(fmaf(sv.x, inv, rt0.x), fmaf(sv.y, inv, rt0.y));
+      o.y = yl_pack_bf16(fmaf(sv.z, inv, rt0.z), fmaf(sv.w, inv, rt0.w));
+      __builtin_amdgcn_raw_buffer_store_b64(o, rOut, __umul24((unsigned)sl0.x, ldb_fo) + q8, 0, 0);
+    }
+    if (ntask > 64) {
+      if (lane + 64 < ntask) {
+        const float4 sv = *reinterpret_cast<const float4*>(stage + t_k1 * 64 + (q16 >> 2));
+        const float inv = ec_own_reg(__int_as_float(sl1.y));
+        ec_u32x2 o;
+        o.x = yl_pack_bf16(fmaf(sv.x, inv, rt1.x), fmaf(sv.y, inv, rt1.y));
+        o.y = yl_pack_bf16(fmaf(sv.z, inv, rt1.z), fmaf(sv.w, inv, rt1.w));
+        __builtin_amdgcn_raw_buffer_store_b64(o, rOut, __umul24((unsigned)sl1.x, ldb_fo) + q8, 0, 0);
+      }
+      for (int task = lane + 128; task < ntask; task += 64) {       // more than 8 finished nodes in one step: rare
+        const int2 sl = slot_tab[task >> 4];
+        const float4 rt = ec_f4(__builtin_amdgcn_raw_buffer_load_b128(rRoot, __umul24((unsigned)sl.x, ldb_r) + q16, 0, 0));
+        const float4 sv = *reinterpret_cast<const float4*>(stage + (task >> 4) * 64 + (q16 >> 2));
+        const float inv = ec_own_reg(__int_as_float(sl.y));
+        ec_u32x2 o;
+        o.x = yl_pack_bf16(fmaf(sv.x, inv, rt.x), fmaf(sv.y, inv, rt.y));
+        o.y = yl_pack_bf16(fmaf(sv.z, inv, rt.z), fmaf(sv.w, inv, rt.w));
+        __builtin_amdgcn_raw_buffer_store_b64(o, rOut, __umul24((unsigned)sl.x, ldb_fo) + q8, 0, 0);
+      }
+    }
+    __builtin_amdgcn_wave_barrier();
+  };
+
+  // ---- software pipeline: indices two steps ahead, row gathers most of a step ahead
+  if (nsteps > 0) {
+    EcIdx i0, i1;
+    EcRows rows;
+    load_idx(i0);
+    load_idx(i1);
+    gather(i0, rows);
+    for (int t = 0; t < nsteps; t += 2) {
+      step(i0, rows, i1);          // step t; gathers step t + 1
+      load_idx(i0);                // indices of step t + 2
+      if (t + 1 < nsteps) {
+        step(i1, rows, i0);        // step t + 1; gathers step t + 2
+        load_idx(i1);              // indices of step t + 3
+      }
+    }
+  }
+
+  if ((ABL & 2) && cur0 == 123.456f) f_out[0] = 1;      // keeps the ablated arithmetic alive
+  // ---- nodes without in-edges: the root Linear alone (torch_vertex.py:324,337: the mean over no message is 0)
+  for (int nb0 = n0; nb0 < n2; nb0 += 64) {
+    const int n = nb0 + lane;
+    const bool z = n < n2 && row_ptr[n + 1] == row_ptr[n];
+    unsigned long long m = __builtin_amdgcn_ballot_w64(z);
+    while (m) {
+      const int j = __builtin_ctzll(m);
+      m &= m - 1;
+      if (lane < 16) {
+        const unsigned node = (unsigned)(nb0 + j);
+        const float4 rt = *reinterpret_cast<const float4*>(root + (node * ld_r + 4u * lane));
+        ec_u32x2 o;
+        o.x = yl_pack_bf16(rt.x, rt.y);
+        o.y = yl_pack_bf16(rt.z, rt.w);
+        *reinterpret_cast<ec_u32x2*>(f_out + (node * ld_fo + 4u * lane)) = o;
+      }
+    }
+  }
+}
+
+}  // namespace
+
+// Launch: `wgs` workgroups of 4 independent waves; every wave walks two streams of `chunk` edges.
+int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
+                       const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
+                       const float* s1, const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
+                       uint16_t* f_out, int64_t ld_fo, hipStream_t st) {
+  static long wgs = -1;
+  if (wgs < 0) {
+    const char* e = getenv("YOLAT_HCHAIN_WGS");
+    wgs = (e && atol(e) > 0) ? atol(e) : 768;
+  }
+  const long streams = 8 * wgs;
+  long chunk = ((E + streams - 1) / streams + 15) / 16 * 16;
+  if (chunk < 16) chunk = 16;
+  // every node must fall into some wave's node range: the last wave's range ends at N by construction
+  const long need = (E + 2 * chunk - 1) / (2 * chunk);           // waves that own at least one chunk boundary < E
+  const long grid = (need + 3) / 4 > 0 ? (need + 3) / 4 : 1;
+  static int abl = -1;
+  if (abl < 0) abl = getenv("YOLAT_HCHAIN_ABL") ? atoi(getenv("YOLAT_HCHAIN_ABL")) : 0;
+#define EC_LAUNCH(A)                                                                                                    \
+  hipLaunchKernelGGL(k_edge_chain_h<A>, dim3((unsigned)grid), dim3(256), 0, st, UV, (unsigned)ld_uv, src_csr, dst_csr,    \
+                     attr_csr, row_ptr, (int)N, (int)E, (int)chunk, Wc4, s1, W2f, t2f, root, (unsigned)ld_r, f_out,       \
+                     (unsigned)ld_fo)
+  switch (abl) {
+    case 1: EC_LAUNCH(1); break;
+    case 2: EC_LAUNCH(2); break;
+    case 3: EC_LAUNCH(3); break;
+    case 4: EC_LAUNCH(4); break;
+    case 5: EC_LAUNCH(5); break;
+    case 6: EC_LAUNCH(6); break;
+    case 7: EC_LAUNCH(7); break;
+    default: EC_LAUNCH(0); break;
+  }
+#undef EC_LAUNCH
+  YL_LAUNCH_CHECK();
+  return 0;
+}

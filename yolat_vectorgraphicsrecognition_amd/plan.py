@@ -73,7 +73,7 @@ class EvalPlan(object):
         d.n_blocks, d.n_blocks_out, d.n_classes = net.n_blocks, net.n_blocks_out, m.n_classes
         d.C = convs[0].nn[0].out_features
         d.F = net.fusion_block[0].out_features
-        wuvs, folds1 = [], []
+        wuvs, folds1, folds2 = [], [], []
         for l, cv in enumerate(convs):
             c = d.conv[l]
             c.Cin = cv.in_channels
@@ -83,6 +83,7 @@ class EvalPlan(object):
             c.W2, c.b2 = ptr(cv.nn[3].weight), ptr(cv.nn[3].bias)
             c.s2, c.t2 = folded(cv.nn[4])
             fold2 = keep[-1]
+            folds2.append(fold2)
             c.Wr, c.br = ptr(cv.lin_r.weight), ptr(cv.lin_r.bias)
             c.Wn, c.bn = ptr(cv.mlp_node[0].weight), ptr(cv.mlp_node[0].bias)
             c.sn, c.tn = folded(cv.mlp_node[1])
@@ -214,7 +215,14 @@ class EvalPlan(object):
                 return o.data_ptr()
 
             for l, cv in enumerate(convs):
-                h.W2[l] = half(cv.nn[3].weight)
+                # the edge MLP's second BatchNorm: scale folded into W2's rows before the bf16 rounding, shift + bias
+                # as one vector (enters the accumulators through an MFMA, csrc/edge_chain.hip)
+                s2, t2 = folds2[l]
+                h.W2[l] = half((cv.nn[3].weight.detach() * s2[:, None]).contiguous())
+                b2 = cv.nn[3].bias.detach() if cv.nn[3].bias is not None else torch.zeros_like(t2)
+                t2f = (s2 * b2 + t2).contiguous()
+                keep.append(t2f)
+                h.t2f[l] = t2f.data_ptr()
                 # layer 1's folded BatchNorm moves into the node-side epilogue: U' = s1*U + (s1*b1 + t1), V' = s1*V
                 s1, t1 = folds1[l]
                 uvs = torch.cat([s1, s1]).contiguous()
