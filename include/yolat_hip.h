@@ -547,6 +547,10 @@ typedef struct {
   const float* uv_shift[YOLAT_MAX_LAYERS];
   const uint16_t *Wf, *Wfs, *Wc1, *Wc2, *Wc3; /* bf16 of the fusion / classifier weights        */
   const float* t2f[YOLAT_MAX_LAYERS];         /* fp32 [C]: s2*b2 + t2, the shift that goes with the folded W2 (ABI 4) */
+  /* fusion_block / fusion_block_super with their BatchNorm folded (ABI 4, optional: NULL keeps the unfolded kernels):
+   * Wf_fold = bf16(diag(sf) Wf) [F, D], tf_fold = sf*bf + tf [F] fp32; same for the super block */
+  const uint16_t *Wf_fold, *Wfs_fold;
+  const float *tf_fold, *tfs_fold;
 } yolat_model_eval_bf16;
 
 /* The edge stage of the bf16-storage forward on its own (op tests, benchmarks): factorised edge MLP + mean

@@ -50,7 +50,8 @@ class ModelEvalBf16(ctypes.Structure):
     _fields_ = ([("base", ctypes.POINTER(ModelEval))] +
                 [(n, c_p * YOLAT_MAX_LAYERS) for n in ("Wuv", "Wr", "Wn", "W2", "uv_scale", "uv_shift")] +
                 [(n, c_p) for n in ("Wf", "Wfs", "Wc1", "Wc2", "Wc3")] +
-                [("t2f", c_p * YOLAT_MAX_LAYERS)])
+                [("t2f", c_p * YOLAT_MAX_LAYERS)] +
+                [(n, c_p) for n in ("Wf_fold", "Wfs_fold", "tf_fold", "tfs_fold")])
 
 
 # name -> (restype, argtypes); order mirrors include/yolat_hip.h

@@ -562,6 +562,10 @@ int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr
                        const float* s1, const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
                        uint16_t* f_out, int64_t ld_fo, hipStream_t st);
 
+int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wf, const float* tf,
+                     const int32_t* seg, float* pool, int64_t ld_pool, int64_t F, const float* As, int64_t lda_s, int64_t P,
+                     const uint16_t* Wfs, const float* tfs, float* sup_out, int64_t ld_sup, hipStream_t st);
+
 static int yl_edge_uv_mlp2_mean_bf16_impl(const u16* UV, long ld_uv, const int* src, const int* dst, const float* attr,
                                           const int* row_ptr, long N, long E, const float* Wc4, const float* s1,
                                           const u16* W2f, const float* t2f, const float* root, long ld_r, u16* f_out,
@@ -779,7 +783,12 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     e1.bias = m->bfs; e1.scale = m->sfs; e1.shift = m->tfs; e1.relu = 1; e1.Y = p.Z + F + D; e1.ldy = ZW;
     const int tm1 = yl_cdiv(P, 64), tn1 = yl_cdiv(F, 64);
     const long n1p = ((long)tm1 * tn1 + 7) & ~7L;
-    if (D <= 256) {
+    static const int h8 = getenv("YOLAT_HFUSION8") ? atoi(getenv("YOLAT_HFUSION8")) : 1;
+    if (h8 && (D == 64 || D == 128) && mh->Wf_fold && mh->Wfs_fold && mh->tf_fold && mh->tfs_fold) {
+      // A-in-registers rows kernel on the BatchNorm-folded weights (fusion_h8.hip)
+      YL_TRY(yl_hfusion_rows8(p.feats, D, N, D, mh->Wf_fold, mh->tf_fold, p.node_seg, p.Z, ZW, F, p.Z + 2 * F + D, ZW, P,
+                              mh->Wfs_fold, mh->tfs_fold, p.Z + F + D, ZW, st));
+    } else if (D <= 256) {
       // A-resident rows kernel: at least 4 column groups, and as many as it takes to put >= ~1024 workgroups on
       // the GPU (each group walks tn / groups consecutive 64-column tiles)
       const int tn = yl_cdiv(F, 64);

@@ -18,45 +18,9 @@
 // bf16_eval.hip's rows kernel (values >= 0: int order == float order, exact, order-independent).
 // fusion_block_super (P rows, its own weights, plain relu store) is a second problem of the same launch.
 #include "x6.hpp"
+#include "segmax.hpp"
 
 namespace {
-// Run structure of a lane's 16 rows (C/D layout of a 32x32 MFMA tile) from their proposal ids — the same for every
-// column tile: keep[r] = 1 when row r continues the run of row r-1, flush bit r = a run ends at row r (uflush: in
-// some lane of the wave).  The proposal id of a flushed row is re-read from LDS (segs: the wave's 32 ids) — rare,
-// and 16 registers cheaper than keeping the offsets.
-struct FxRuns { float keep[16]; unsigned flush_bits, uflush; };
-__device__ __forceinline__ void fx_seg_runs(int segv, int lhi, FxRuns& sr) {
-  int sgs[16];
-#pragma unroll
-  for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);
-  unsigned fb = 0, uf = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    sr.keep[r] = (r > 0 && sgs[r] == sgs[r - 1]) ? 1.f : 0.f;
-    const bool fl = sgs[r] >= 0 && (r == 15 || sgs[r] != sgs[r + 1]);
-    fb |= fl ? (1u << r) : 0u;
-    uf |= (__builtin_amdgcn_ballot_w64(fl) != 0ull) ? (1u << r) : 0u;
-  }
-  sr.flush_bits = fb; sr.uflush = uf;
-}
-// values = relu(acc) (the shift is the accumulator's initial value, the scale is inside the weights).  Both column
-// blocks in one pass: two independent running-max chains (the chain is latency bound) and one test per row.
-__device__ __forceinline__ void fx_segmax2(const f32x16& acc0, const f32x16& acc1, float* pool, unsigned ldpool,
-                                           const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, const FxRuns& sr) {
-  float cur0 = 0.f, cur1 = 0.f;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    cur0 = fmaxf(fmaxf(cur0 * sr.keep[r], acc0[r]), 0.f);
-    cur1 = fmaxf(fmaxf(cur1 * sr.keep[r], acc1[r]), 0.f);
-    if ((sr.uflush >> r) & 1u) {
-      if ((sr.flush_bits >> r) & 1u) {
-        int* o = reinterpret_cast<int*>(pool) + ((unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldpool + c0);
-        if (ok0 && cur0 > 0.f) atomicMax(o, __float_as_int(cur0));
-        if (ok1 && cur1 > 0.f) atomicMax(o + 32, __float_as_int(cur1));
-      }
-    }
-  }
-}
 // training-mode epilogue: the extreme of s*z per run with its (lowest) row, as the key of wave_epilogue's key64 branch
 // (common.hpp) — same key, same tie rule
 __device__ __forceinline__ unsigned long long fx_key(float z, bool neg, unsigned row) {

@@ -232,6 +232,15 @@ class EvalPlan(object):
                 if l > 0:
                     h.Wuv[l], h.Wr[l], h.Wn[l] = half(wuvs[l]), half(cv.lin_r.weight), half(cv.mlp_node[0].weight)
             h.Wf, h.Wfs = half(fb[0].weight), half(fs[0].weight)
+            # the two fusion blocks with their BatchNorm folded (scale into the rows before the bf16 rounding, shift +
+            # bias as one vector): the A-in-registers rows kernel, csrc/fusion_h8.hip
+            for lin, bn, wname, tname in ((fb[0], fb[1], "Wf_fold", "tf_fold"), (fs[0], fs[1], "Wfs_fold", "tfs_fold")):
+                sc, sh = _fold(bn, dev)
+                bias = lin.bias.detach() if lin.bias is not None else torch.zeros_like(sh)
+                tfold = (sc * bias + sh).contiguous()
+                keep.append(tfold)
+                setattr(h, wname, half((lin.weight.detach() * sc[:, None]).contiguous()))
+                setattr(h, tname, tfold.data_ptr())
             h.Wc1, h.Wc2, h.Wc3 = half(m1[0].weight), half(m2[0].weight), half(m3[0].weight)
             self._desc_h = h
         if self._status is None:
