@@ -522,6 +522,61 @@ int yolat_forward_eval_primed(const yolat_model_eval* m, const float* x, int64_t
                               yolat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Batch hand-over as native host code (collate.hip).  Reference: collate (cad_recognition/train.py:
+ * 123-171), the edge / bbox_idx offset fix-up loops (train.py:238-258) and the six synchronous .cuda() copies of
+ * architecture3cc_rpn_gp_iter2.py:107-115.  All three are HOST functions (no stream, no device pointers).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct { const void* ptr; int64_t bytes; } yolat_span;
+/* dst + field_off[f] receives spans[f*n_items + 0 .. n_items) back to back (torch.cat of one key over the items). */
+int yolat_collate_pack(void* dst, const int64_t* field_off, const yolat_span* spans, int64_t n_fields, int64_t n_items);
+/* The destination-sorted (CSR) form of ONE dataset item, the host twin of yolat_graph_prepare: same outputs, same
+ * clamping of out-of-range ids, same YOLAT_STATUS_* flags (written to the HOST word *status).  A dataset item's graph
+ * never changes: computed once per item and cached with it.  bbox_idx == NULL skips the segment outputs.             */
+int yolat_item_csr_host(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                        const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr, int32_t* perm,
+                        int32_t* src, int32_t* dst, float* attr, int32_t* seg_ptr, int32_t* node_seg, int32_t* status);
+typedef struct {
+  int64_t N, E, P;
+  const int32_t *row_ptr, *src, *dst;   /* [N+1], [E], [E]  item-local ids  */
+  const float* attr;                    /* [E,4] in CSR order               */
+  const int32_t *seg_ptr, *node_seg;    /* [P+1], [N]                       */
+} yolat_item_csr;
+/* The batch's CSR = concatenation of the items' CSRs with the node / edge / proposal offsets added (the adjacency of a
+ * collated batch is block diagonal: Datasets/graph_dict3.py:594-600) — bit-identical to yolat_graph_prepare on the
+ * collated, fixed-up COO list.  Outputs sized for the batch totals: row_ptr [N+1], src/dst [E], attr [E,4],
+ * seg_ptr [P+1], node_seg [N]; typically slices of the pinned staging buffer.                                          */
+int yolat_collate_csr_pack(const yolat_item_csr* items, int64_t B, int32_t* row_ptr, int32_t* src, int32_t* dst,
+                           float* attr, int32_t* seg_ptr, int32_t* node_seg);
+
+/* The whole csr-mode hand-over in ONE call.  A caller caches one yolat_item_desc per dataset item (pointers to the item's
+ * dense arrays — x, pos, bbox, labels ... in a fixed key order — their row counts, and its yolat_item_csr).  The call lays
+ * the batch out in `dst` (256-byte aligned fields: key 0 .. n_keys-1, then row_ptr, src, dst, attr, seg_ptr, node_seg;
+ * byte offsets in off[n_keys + 6]), writes the collate slices (slices[k*(B+1) + b] = rows of key k before item b,
+ * train.py:141-147) and totals = {N, E, P}, copies every key of every item and merges the CSRs.  dst == NULL or
+ * cap < *total: only off / total / slices / totals are produced.                                                        */
+#define YOLAT_MAX_KEYS 8
+typedef struct {
+  int64_t n_keys;
+  yolat_span key[YOLAT_MAX_KEYS];
+  int64_t rows[YOLAT_MAX_KEYS];
+  yolat_item_csr csr;
+} yolat_item_desc;
+int yolat_collate_batch(const yolat_item_desc* const* items, int64_t B, void* dst, int64_t cap, int64_t* off,
+                        int64_t* total, int64_t* slices, int64_t* totals);
+
+/* A prepared graph on the DEVICE (the outputs of yolat_graph_prepare, or the device copy of yolat_collate_csr_pack's
+ * staging) for the forwards below: the forward then skips the COO -> CSR conversion (4 launches) and runs the first
+ * layer's node side as a launch of its own.  The caller has validated the ids (host status word).                      */
+typedef struct {
+  const int32_t *row_ptr, *src, *dst;
+  const float* attr;
+  const int32_t *seg_ptr, *node_seg;
+} yolat_graph_csr;
+int yolat_forward_eval_csr(const yolat_model_eval* m, const float* x, int64_t ldx, const yolat_graph_csr* g, int64_t N,
+                           int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                           size_t workspace_bytes, yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * bf16-storage eval forward (bf16_eval.hip): the precision mode of BASELINE.json's large-graph
  * configuration ("N=200k / E=1.2M, n_blocks=4, bf16").  Same contract and kernel sequence as
  * yolat_forward_eval; node activations cross HBM as bfloat16, every Linear with K >= 64 runs on
@@ -575,6 +630,10 @@ int yolat_forward_eval_bf16(const yolat_model_eval_bf16* m, const float* x, int6
                             int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                             int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                             size_t workspace_bytes, int32_t* status, yolat_stream_t stream);
+/* the same forward on a prepared device graph (yolat_graph_csr above) */
+int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* m, const float* x, int64_t ldx, const yolat_graph_csr* g,
+                                int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                size_t workspace_bytes, yolat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Post-processing: torchvision.ops.nms(boxes, scores, iou_threshold) as called by the

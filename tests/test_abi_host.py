@@ -221,3 +221,107 @@ def test_reference_checkpoint_with_numpy_best_value_and_optimizer_state_loads_fr
     assert epoch == 7 and float(got_best) == 0.5
     for k, v in ref.state_dict().items():
         assert torch.equal(model.state_dict()[k], v), k
+
+
+# ---------------------------------------------------------------------------------------------
+# native host side of the batch hand-over (csrc/collate.hip)
+# ---------------------------------------------------------------------------------------------
+def _host_item_csr(src, dst, N, attr=None, bbox_idx=None, P=1):
+    E = len(src)
+    edge = torch.from_numpy(np.stack([src, dst], 1).astype(np.int64)) if E else torch.zeros(0, 2, dtype=torch.long)
+    attr = torch.from_numpy(attr) if attr is not None else torch.zeros(E, 4)
+    i32 = lambda n: np.zeros(max(n, 1), dtype=np.int32)
+    out = dict(row_ptr=i32(N + 1), perm=i32(E), src=i32(E), dst=i32(E), attr=np.zeros((max(E, 1), 4), np.float32),
+               seg_ptr=i32(P + 1), node_seg=i32(N))
+    status = np.zeros(1, np.int32)
+    bb = torch.from_numpy(bbox_idx.astype(np.int64)) if bbox_idx is not None else None
+    _lib.check(_lib.lib.yolat_item_csr_host(edge.data_ptr(), 2, 1, attr.data_ptr(), bb.data_ptr() if bb is not None else None, E, N,
+                                            P, out["row_ptr"].ctypes.data, out["perm"].ctypes.data, out["src"].ctypes.data,
+                                            out["dst"].ctypes.data, out["attr"].ctypes.data, out["seg_ptr"].ctypes.data,
+                                            out["node_seg"].ctypes.data, status.ctypes.data), "yolat_item_csr_host")
+    return out, int(status[0])
+
+
+@pytest.mark.parametrize("case", ["csr_a", "csr_b", "csr_c"])
+def test_item_csr_host_matches_the_integer_fixture_and_the_loop_oracle(golden_dir, case):
+    """yolat_item_csr_host (the host twin of yolat_graph_prepare): stable sort by destination — bit-exact against the
+    committed integer fixture and the naive-loop oracle; e_attr travels with its edge."""
+    z = np.load(os.path.join(golden_dir, "integer_ops.npz"))
+    src, dst, N = z[case + "/src"], z[case + "/dst"], int(z[case + "/N"])
+    attr = np.random.default_rng(3).standard_normal((len(src), 4)).astype(np.float32)
+    out, status = _host_item_csr(src, dst, N, attr)
+    assert status == 0
+    E = len(src)
+    np.testing.assert_array_equal(out["row_ptr"][:N + 1], z[case + "/row_ptr"])
+    np.testing.assert_array_equal(out["perm"][:E], z[case + "/perm"])
+    np.testing.assert_array_equal(out["src"][:E], z[case + "/src_csr"])
+    np.testing.assert_array_equal(out["dst"][:E], z[case + "/dst_csr"])
+    np.testing.assert_array_equal(out["attr"][:E], attr[z[case + "/perm"]])
+    rp, perm, s_csr, d_csr = onp.coo_to_csr(src, dst, N)
+    np.testing.assert_array_equal(out["row_ptr"][:N + 1], rp)
+    np.testing.assert_array_equal(out["perm"][:E], perm)
+
+
+def test_item_csr_host_segments_and_status_flags(golden_dir):
+    z = np.load(os.path.join(golden_dir, "integer_ops.npz"))
+    bb, P = z["seg/bbox_idx"], int(z["seg/P"])
+    out, status = _host_item_csr(np.array([0, 1]), np.array([1, 0]), len(bb), bbox_idx=bb, P=P)
+    assert status == 0
+    np.testing.assert_array_equal(out["seg_ptr"][:P + 1], z["seg/seg_ptr"])
+    np.testing.assert_array_equal(out["node_seg"][:len(bb)], bb.astype(np.int32))
+    # the device kernels' flags, on the host: ids outside [0, N) are clamped and reported; unsorted bbox_idx reported
+    out, status = _host_item_csr(np.array([0, 9]), np.array([1, 0]), 3, bbox_idx=np.array([0, 0, 0]), P=1)
+    assert status & yv.ops.STATUS_EDGE_RANGE and out["src"][:2].max() <= 2
+    _, status = _host_item_csr(np.array([0]), np.array([1]), 3, bbox_idx=np.array([0, 1, 0]), P=2)
+    assert status & yv.ops.STATUS_SEG_UNSORTED
+    _, status = _host_item_csr(np.array([0]), np.array([1]), 3, bbox_idx=np.array([0, 1, 5]), P=2)
+    assert status & yv.ops.STATUS_SEG_RANGE
+    item = yv.Data(x=torch.zeros(3, 5), pos=torch.zeros(3, 2), edge=torch.tensor([[0, 7]]), e_attr=torch.zeros(1, 4),
+                   bbox_idx=torch.tensor([0, 0, 0]), bbox=torch.zeros(1, 4), labels=torch.zeros(1, dtype=torch.long))
+    with pytest.raises(IndexError):
+        yv.item_csr(item)
+
+
+def test_collate_csr_pack_equals_csr_of_the_collated_batch(golden_dir):
+    """Block-diagonal merge: the items' CSRs concatenated with offsets == the CSR of the reference-collated, fixed-up
+    batch (tests/golden/collate.npz is the output of the reference's OWN collate + fix-up loop), bit for bit; and
+    yolat_collate_pack == torch.cat of every key."""
+    z = np.load(os.path.join(golden_dir, "collate.npz"))
+    keys = ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "labels")
+    items = [yv.Data(**{k: torch.from_numpy(z["item%d/%s" % (i, k)].copy()) for k in keys}) for i in range(3)]
+    cs = [yv.item_csr(it) for it in items]
+    assert yv.item_csr(items[0]) is cs[0]                        # cached on the item
+    Nt, Et, Pt = (sum(c[k] for c in cs) for k in ("N", "E", "P"))
+    i32 = lambda n: np.zeros(n, dtype=np.int32)
+    out = dict(row_ptr=i32(Nt + 1), src=i32(Et), dst=i32(Et), attr=np.zeros((Et, 4), np.float32), seg_ptr=i32(Pt + 1),
+               node_seg=i32(Nt))
+    arr = (_lib.ItemCsr * 3)(*[c["struct"] for c in cs])
+    _lib.check(_lib.lib.yolat_collate_csr_pack(arr, 3, out["row_ptr"].ctypes.data, out["src"].ctypes.data,
+                                               out["dst"].ctypes.data, out["attr"].ctypes.data, out["seg_ptr"].ctypes.data,
+                                               out["node_seg"].ctypes.data), "yolat_collate_csr_pack")
+    # reference: the CSR of the golden batch (edge already offset-fixed by the reference's loop)
+    be, ba, bb = z["batch/edge"], z["batch/e_attr"], z["batch/bbox_idx"]
+    want, status = _host_item_csr(be[:, 0], be[:, 1], Nt, ba, bbox_idx=bb, P=Pt)
+    assert status == 0
+    for k in ("row_ptr", "src", "dst", "attr", "seg_ptr", "node_seg"):
+        n = out[k].shape[0]
+        np.testing.assert_array_equal(out[k], want[k][:n], err_msg=k)
+    rp, perm, s_csr, d_csr = onp.coo_to_csr(be[:, 0], be[:, 1], Nt)
+    np.testing.assert_array_equal(out["row_ptr"], rp)
+    np.testing.assert_array_equal(out["src"], s_csr)
+    np.testing.assert_array_equal(out["seg_ptr"], onp.segment_ptr(bb, Pt))
+    # yolat_collate_pack: every key of every item back to back
+    buf = np.zeros(4096, np.uint8)
+    spans = (_lib.Span * (len(keys) * 3))()
+    foff = (ctypes.c_int64 * len(keys))()
+    off = 0
+    for f, k in enumerate(keys):
+        foff[f] = off
+        for i, it in enumerate(items):
+            spans[f * 3 + i].ptr, spans[f * 3 + i].bytes = it[k].data_ptr(), it[k].numel() * it[k].element_size()
+        off += z["batch/" + k].nbytes if k != "edge" else sum(it[k].numel() * 8 for it in items)
+    _lib.check(_lib.lib.yolat_collate_pack(buf.ctypes.data, foff, spans, len(keys), 3), "yolat_collate_pack")
+    for f, k in enumerate(keys):
+        want_k = np.concatenate([it[k].numpy() for it in items], 0)
+        got = buf[foff[f]:foff[f] + want_k.nbytes].view(want_k.dtype).reshape(want_k.shape)
+        np.testing.assert_array_equal(got, want_k, err_msg=k)

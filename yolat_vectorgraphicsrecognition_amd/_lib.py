@@ -54,6 +54,30 @@ class ModelEvalBf16(ctypes.Structure):
                 [(n, c_p) for n in ("Wf_fold", "Wfs_fold", "tf_fold", "tfs_fold")])
 
 
+class Span(ctypes.Structure):
+    """yolat_span"""
+    _fields_ = [("ptr", c_p), ("bytes", c_i64)]
+
+
+class ItemCsr(ctypes.Structure):
+    """yolat_item_csr"""
+    _fields_ = [("N", c_i64), ("E", c_i64), ("P", c_i64), ("row_ptr", c_p), ("src", c_p), ("dst", c_p), ("attr", c_p),
+                ("seg_ptr", c_p), ("node_seg", c_p)]
+
+
+YOLAT_MAX_KEYS = 8
+
+
+class ItemDesc(ctypes.Structure):
+    """yolat_item_desc"""
+    _fields_ = [("n_keys", c_i64), ("key", Span * YOLAT_MAX_KEYS), ("rows", c_i64 * YOLAT_MAX_KEYS), ("csr", ItemCsr)]
+
+
+class GraphCsr(ctypes.Structure):
+    """yolat_graph_csr"""
+    _fields_ = [("row_ptr", c_p), ("src", c_p), ("dst", c_p), ("attr", c_p), ("seg_ptr", c_p), ("node_seg", c_p)]
+
+
 # name -> (restype, argtypes); order mirrors include/yolat_hip.h
 SIGNATURES = {
     "yolat_abi_version": (c_int, []),
@@ -192,6 +216,15 @@ SIGNATURES = {
     "yolat_proposals_get": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_proposals_window_counts": (c_int, [c_p, c_p, c_p]),
     "yolat_proposals_free": (None, [c_p]),
+    "yolat_collate_pack": (c_int, [c_p, c_p, ctypes.POINTER(Span), c_i64, c_i64]),
+    "yolat_item_csr_host": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
+                                     c_p]),
+    "yolat_collate_csr_pack": (c_int, [ctypes.POINTER(ItemCsr), c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "yolat_collate_batch": (c_int, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_forward_eval_csr": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, ctypes.POINTER(GraphCsr), c_i64, c_i64,
+                                        c_i64, c_p, c_i64, c_p, c_sz, c_p]),
+    "yolat_forward_eval_bf16_csr": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, ctypes.POINTER(GraphCsr), c_i64,
+                                             c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p]),
     "yolat_edge_uv_mlp2_mean_eval_bf16": (c_int, [c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p,
                                                    c_i64, c_p, c_i64, c_int, c_p]),
     "yolat_forward_eval_bf16_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEvalBf16), c_i64, c_i64, c_i64]),

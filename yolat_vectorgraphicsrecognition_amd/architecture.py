@@ -131,6 +131,11 @@ class SparseCADGCN(nn.Module):
         """H2D of the tensors forward reads (arch:107-115), cached on the batch object so a second
         forward on the same batch (predict, epochs over a cached batch) re-uses them; the device-side
         CSR / segment structure is added lazily for the training path (the eval plan builds its own)."""
+        pre = data.__dict__.get("_yolat_graph") if hasattr(data, "__dict__") else None
+        if pre is not None:
+            # the batch carries a prepared graph (data.collate_to_device(csr=True)); x / bbox are device tensors already
+            x = data.x if data.x.dtype == torch.float32 else data.x.float()
+            return {"x": x, "bbox": data.bbox, "g": pre, "prepared": True}
         cache = getattr(data, "_yolat_stage", None)
         key = (data.x.data_ptr(), data.x._version, data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
                data.bbox_idx._version, data.e_attr.data_ptr(), data.e_attr._version, data.bbox.data_ptr(),
@@ -173,7 +178,10 @@ class SparseCADGCN(nn.Module):
             if ug is not None:
                 plan.use_graph = ug
             self._yolat_plan = plan          # the plan of the most recent forward (status checks)
-            pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])
+            if st.get("prepared"):
+                pred_cls = plan.run_prepared(st["x"], st["g"])
+            else:
+                pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])
             st["plan_status"] = plan
         else:
             st = self._stage(data)

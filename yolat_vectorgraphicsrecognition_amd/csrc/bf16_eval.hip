@@ -705,11 +705,36 @@ extern "C" size_t yolat_forward_eval_bf16_workspace_bytes(const yolat_model_eval
   return carve_h(mh->base, N, E, P, nullptr).bytes;
 }
 
+static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx, const int64_t* edge,
+                                  int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                                  int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                  size_t workspace_bytes, int32_t* status, yolat_stream_t stream, const yolat_graph_csr* g);
+
 extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
                                        const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
                                        const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, float* logits,
                                        int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
                                        yolat_stream_t stream) {
+  return forward_eval_bf16_impl(mh, x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, logits, ld_logits,
+                                workspace, workspace_bytes, status, stream, nullptr);
+}
+
+extern "C" int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
+                                           const yolat_graph_csr* g, int64_t N, int64_t E, int64_t P, float* logits,
+                                           int64_t ld_logits, void* workspace, size_t workspace_bytes,
+                                           yolat_stream_t stream) {
+  if (!g || !g->row_ptr || !g->seg_ptr || !g->node_seg || (E > 0 && (!g->src || !g->dst || !g->attr)))
+    return YOLAT_E_INVALID;
+  int32_t unused_status = 0;
+  return forward_eval_bf16_impl(mh, x, ldx, nullptr, 0, 0, nullptr, reinterpret_cast<const int64_t*>(g->node_seg), N, E, P,
+                                logits, ld_logits, workspace, workspace_bytes, &unused_status, stream, g);
+}
+
+static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx, const int64_t* edge,
+                                  int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                                  int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                  size_t workspace_bytes, int32_t* status, yolat_stream_t stream,
+                                  const yolat_graph_csr* g) {
   if (!x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0) return YOLAT_E_INVALID;
   YL_TRY(model_ok(mh));
   if (N > (1LL << 23) || E > (1LL << 29)) return YOLAT_E_UNSUPPORTED;     // 32-bit element offsets in the gathers
@@ -717,6 +742,11 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
   const yolat_model_eval* m = mh->base;
   PlanH p = carve_h(m, N, E, P, workspace);
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
+  if (g != nullptr) {                 // prepared graph (collate.hip): the caller's arrays, never written here
+    p.row_ptr = const_cast<int*>(g->row_ptr); p.src = const_cast<int*>(g->src); p.dst = const_cast<int*>(g->dst);
+    p.attr = const_cast<float*>(g->attr); p.seg_ptr = const_cast<int*>(g->seg_ptr);
+    p.node_seg = const_cast<int*>(g->node_seg);
+  }
   hipStream_t st = (hipStream_t)stream;
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
   const int lo = m->n_blocks - m->n_blocks_out;
@@ -736,8 +766,15 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
     a.euv.Y = nullptr; a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
     a.euv.scale = mh->uv_scale[0]; a.euv.shift = mh->uv_shift[0];
     a.en.Y = nullptr; a.en.Yh = s_slot(0); a.en.ldy = ld_slot(0);
+    if (g != nullptr) {
+      const dim3 grid(yl_cdiv(N, 64), 4);
+      if (cv0.Cin <= 16) hipLaunchKernelGGL(k_gemm_nt_node3<16>, grid, dim3(256), 0, st, a);
+      else hipLaunchKernelGGL(k_gemm_nt_node3<32>, grid, dim3(256), 0, st, a);
+      YL_LAUNCH_CHECK();
+    } else {
     YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
                                  p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, false, stream));
+    }
   });
   for (int l = 0; l < m->n_blocks; ++l) {
     const yolat_conv_eval& cv = m->conv[l];

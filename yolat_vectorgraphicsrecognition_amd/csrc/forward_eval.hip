@@ -159,7 +159,20 @@ extern "C" size_t yolat_forward_eval_workspace_bytes(const yolat_model_eval* m, 
 static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t ldx, const int64_t* edge,
                              int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                              int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
-                             size_t workspace_bytes, int32_t* status, bool primed, yolat_stream_t stream);
+                             size_t workspace_bytes, int32_t* status, bool primed, yolat_stream_t stream,
+                             const yolat_graph_csr* g = nullptr);
+
+// The forward on a prepared device graph (collate.hip: the batch's CSR merged from the items' cached CSRs, one H2D copy):
+// no COO -> CSR conversion, the first layer's node side as its own launch.
+extern "C" int yolat_forward_eval_csr(const yolat_model_eval* m, const float* x, int64_t ldx, const yolat_graph_csr* g,
+                                      int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                      size_t workspace_bytes, yolat_stream_t stream) {
+  if (!g || !g->row_ptr || !g->seg_ptr || !g->node_seg || (E > 0 && (!g->src || !g->dst || !g->attr)))
+    return YOLAT_E_INVALID;
+  int32_t unused_status = 0;
+  return forward_eval_impl(m, x, ldx, nullptr, 0, 0, nullptr, reinterpret_cast<const int64_t*>(g->node_seg), N, E, P, logits,
+                           ld_logits, workspace, workspace_bytes, &unused_status, false, stream, g);
+}
 
 extern "C" int yolat_forward_eval(const yolat_model_eval* m, const float* x, int64_t ldx,
                                   const int64_t* edge, int64_t stride_e, int64_t stride_c,
@@ -186,7 +199,8 @@ extern "C" int yolat_forward_eval_primed(const yolat_model_eval* m, const float*
 static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t ldx, const int64_t* edge,
                              int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                              int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
-                             size_t workspace_bytes, int32_t* status, bool primed, yolat_stream_t stream) {
+                             size_t workspace_bytes, int32_t* status, bool primed, yolat_stream_t stream,
+                             const yolat_graph_csr* g) {
   if (!m || !x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0)
     return YOLAT_E_INVALID;
   if (m->n_blocks < 1 || m->n_blocks > YOLAT_MAX_LAYERS || m->n_blocks_out < 1 ||
@@ -194,6 +208,11 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
     return YOLAT_E_INVALID;
   Plan p = carve(m, N, E, P, workspace);
   if (p.bytes > workspace_bytes) return YOLAT_E_INVALID;
+  if (g != nullptr) {                 // prepared graph: the kernels read the caller's arrays (never written here)
+    p.row_ptr = const_cast<int*>(g->row_ptr); p.src = const_cast<int*>(g->src); p.dst = const_cast<int*>(g->dst);
+    p.attr = const_cast<float*>(g->attr); p.seg_ptr = const_cast<int*>(g->seg_ptr);
+    p.node_seg = const_cast<int*>(g->node_seg);
+  }
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D);
   const int lo = m->n_blocks - m->n_blocks_out;
 
@@ -202,14 +221,15 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
   // The node side of layer 0 (UV products, root Linear, node-branch Linear) reads only x: its GEMM tiles are
   // co-scheduled with the last, latency-bound pre-processing launch instead of being a launch of their own.
   const yolat_conv_eval& cv0 = m->conv[0];
-  const bool node0_in_prep = C == 64 && cv0.Wuv != nullptr && cv0.Wc4 != nullptr;
+  const bool node0_ok = C == 64 && cv0.Wuv != nullptr && cv0.Wc4 != nullptr;
+  const bool node0_in_prep = node0_ok && g == nullptr;
   const bool fold0 = cv0.Wuvf && cv0.uvb && cv0.Wc4f && cv0.t2f;
   // One launch per conv layer (small graphs on the <= 16-node tiles, every layer factorised + folded, packed next-layer
   // weights present): layer l's edge launch computes layer l + 1's UV / root rows for its own nodes and, in extra
   // workgroups, layer l + 1's node branch (EdgeNext, common.hpp) — k_gemm_nt_node3 is not launched at all.
   // YOLAT_NODE_CHAIN=0: node side as a launch per layer.
   static const bool chain_on = []() { const char* v = getenv("YOLAT_NODE_CHAIN"); return !(v && v[0] == '0'); }();
-  bool chain_mode = chain_on && node0_in_prep && fold0 && E > 0 && m->n_blocks >= 2 && p.UV2 != nullptr &&
+  bool chain_mode = chain_on && node0_ok && fold0 && E > 0 && m->n_blocks >= 2 && p.UV2 != nullptr &&
                     yl_edge_tile_groups(N, E) == 1;
   for (int l = 1; l < m->n_blocks && chain_mode; ++l) {
     const yolat_conv_eval& c = m->conv[l];
@@ -228,7 +248,7 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
              prep_node_uv(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p, status, x, ldx, cv0.Cin,
                           fold0 ? cv0.Wuvf : cv0.Wuv, fold0 ? cv0.uvb : nullptr, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn,
                           cv0.tn, C, f0, ld0, s0, ld0, primed, stream));
-  } else {
+  } else if (g == nullptr) {
   YL_STAGE("graph_prep[csr+attr+segments]", 0, 16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N,
            yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src,
                                  p.dst, p.attr, p.seg_ptr, p.node_seg, p.work, status, nullptr, primed, stream));

@@ -15,6 +15,8 @@ Mirrors what the reference's callers hand to ``SparseCADGCN.forward(data, slices
 """
 from itertools import product
 
+import ctypes
+
 import numpy as np
 import torch
 
@@ -113,32 +115,169 @@ def fixup_offsets(data, slices):
 # .cuda() copies of architecture3cc_rpn_gp_iter2.py:107-115)
 # --------------------------------------------------------------------------------------
 
+ctypes_i64 = ctypes.c_int64
 _DEVICE_KEYS = ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "stat_feats", "labels")
+_CSR_SKIP = ("edge", "e_attr", "bbox_idx")       # replaced by the prepared graph in csr mode
 _PINNED = {}
 
 
-def collate_to_device(data_list, device="cuda"):
+def item_csr(item):
+    """The destination-sorted (CSR) form of ONE dataset item, computed once by the library's host code
+    (``yolat_item_csr_host``: the host twin of the device-side ``yolat_graph_prepare``) and cached on the item — a dataset
+    item's graph never changes (the reference caches its proposals the same way, Datasets/graph_dict3.py:924-929).
+    Raises like ``Graph.check_status`` on ids outside [0, N) / an unsorted ``bbox_idx``."""
+    c = item.__dict__.get("_yolat_csr")
+    if c is not None:
+        return c
+    from ._lib import lib, check
+    edge, e_attr, bidx = item.edge, item.e_attr.contiguous(), item.bbox_idx.contiguous()
+    if edge.dtype != torch.long or bidx.dtype != torch.long or e_attr.dtype != torch.float32:
+        raise TypeError("item_csr: edge / bbox_idx must be int64 and e_attr float32 (Datasets/graph_dict3.py:1049-1066)")
+    N, E = int(item.x.shape[0]), int(edge.shape[0])
+    P = int(item.bbox.shape[0])
+    i32 = lambda n: np.empty(max(n, 1), dtype=np.int32)
+    c = {"N": N, "E": E, "P": P, "row_ptr": i32(N + 1), "perm": i32(E), "src": i32(E), "dst": i32(E),
+         "attr": np.empty((max(E, 1), 4), dtype=np.float32), "seg_ptr": i32(P + 1), "node_seg": i32(N)}
+    status = np.zeros(1, dtype=np.int32)
+    check(lib.yolat_item_csr_host(edge.data_ptr(), edge.stride(0), edge.stride(1) if edge.dim() == 2 else 1,
+                                  e_attr.data_ptr(), bidx.data_ptr(), E, N, P, c["row_ptr"].ctypes.data,
+                                  c["perm"].ctypes.data, c["src"].ctypes.data, c["dst"].ctypes.data, c["attr"].ctypes.data,
+                                  c["seg_ptr"].ctypes.data, c["node_seg"].ctypes.data, status.ctypes.data),
+          "yolat_item_csr_host")
+    from . import ops
+    st = int(status[0])
+    if st & ops.STATUS_EDGE_RANGE:
+        raise IndexError("edge_index contains a node id outside [0, N)")
+    if st & ops.STATUS_SEG_UNSORTED:
+        raise ValueError("bbox_idx is not non-decreasing")
+    if st & ops.STATUS_SEG_RANGE:
+        raise IndexError("bbox_idx contains a proposal id outside [0, P)")
+    from ._lib import ItemCsr
+    c["struct"] = ItemCsr(N, E, P, c["row_ptr"].ctypes.data, c["src"].ctypes.data, c["dst"].ctypes.data,
+                          c["attr"].ctypes.data, c["seg_ptr"].ctypes.data, c["node_seg"].ctypes.data)
+    item.__dict__["_yolat_csr"] = c
+    return c
+
+
+def _item_desc(item, ship):
+    """The cached yolat_item_desc of a dataset item: pointers / sizes of its dense arrays in `ship` order + its CSR."""
+    d = item.__dict__.get("_yolat_desc")
+    if d is not None and d[0] == ship:
+        return d[1]
+    from ._lib import ItemDesc
+    if len(ship) > 8:
+        raise ValueError("collate_to_device(csr=True) ships at most 8 dense keys")
+    c = item_csr(item)
+    desc = ItemDesc()
+    desc.n_keys = len(ship)
+    keep = []
+    for f, k in enumerate(ship):
+        t = item[k]
+        if not t.is_contiguous():
+            t = t.contiguous()
+        keep.append(t)
+        desc.key[f].ptr, desc.key[f].bytes = t.data_ptr(), t.numel() * t.element_size()
+        desc.rows[f] = t.shape[0]
+    desc.csr = c["struct"]
+    item.__dict__["_yolat_desc"] = (ship, desc, keep)
+    return desc
+
+
+_ZERO_STATUS = {}
+
+
+def _collate_csr(data_list, device, tkeys, ship, batch, slices):
+    """csr mode of collate_to_device: ONE native call (yolat_collate_batch) lays out, packs and merges."""
+    from . import ops
+    from ._lib import lib, check
+    first = data_list[0]
+    B, nk = len(data_list), len(ship)
+    ptrs = (ctypes.c_void_p * B)(*[ctypes.addressof(_item_desc(it, ship)) for it in data_list])
+    off = (ctypes_i64 * (nk + 6))()
+    tot = (ctypes_i64 * 4)()
+    sl = np.empty((nk, B + 1), dtype=np.int64)
+    slot = _PINNED["next"] = 1 - _PINNED.get("next", 1)
+    pin, ev = _PINNED.get(("buf", slot)), _PINNED.get(("ev", slot))
+    if ev is not None:
+        ev.synchronize()
+    for attempt in range(2):
+        cap = pin.numel() if pin is not None else 0
+        check(lib.yolat_collate_batch(ptrs, B, pin.data_ptr() if pin is not None else None, cap, off,
+                                      ctypes.addressof(tot), sl.ctypes.data, ctypes.addressof(tot) + 8), "yolat_collate_batch")
+        if tot[0] <= cap:
+            break
+        pin = _PINNED[("buf", slot)] = torch.empty(int(tot[0] * 1.5), dtype=torch.uint8).pin_memory()
+    total, Nt, Et, Pt = int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3])
+    dbuf = torch.empty(total, dtype=torch.uint8, device=device)
+    dbuf.copy_(pin[:total], non_blocking=True)                  # the one H2D copy
+    if ev is None:
+        ev = _PINNED[("ev", slot)] = torch.cuda.Event()
+    ev.record()
+    typed = {}
+
+    def view(o, dtype, shape):
+        b = typed.get(dtype)
+        if b is None:
+            b = typed[dtype] = dbuf.view(dtype)
+        es = b.element_size()
+        n = 1
+        for d_ in shape:
+            n *= d_
+        return b[o // es:o // es + n].view(shape)
+
+    for f, k in enumerate(ship):
+        t = first[k]
+        batch[k] = view(off[f], t.dtype, (int(sl[f, B]),) + tuple(t.shape[1:]))
+        slices[k] = torch.from_numpy(sl[f])
+    # the keys that are not shipped still get their slices (train.py:141-147 builds them for every key)
+    for k in tkeys:
+        if k not in slices:
+            ends = np.zeros(B + 1, dtype=np.int64)
+            np.cumsum([it[k].shape[0] for it in data_list], out=ends[1:])
+            slices[k] = torch.from_numpy(ends)
+    Ee = max(Et, 1)
+    g = ops.Graph.from_arrays(Nt, Et, Pt, view(off[nk], torch.int32, (Nt + 1,)), view(off[nk + 1], torch.int32, (Ee,)),
+                              view(off[nk + 2], torch.int32, (Ee,)), view(off[nk + 3], torch.float32, (Ee, 4)),
+                              view(off[nk + 4], torch.int32, (Pt + 1,)), view(off[nk + 5], torch.int32, (Nt,)))
+    batch.__dict__["_yolat_graph"] = g
+    batch._device_buffer = dbuf
+    return batch, slices
+
+
+def collate_to_device(data_list, device="cuda", csr=False):
     """List of per-image ``Data`` (CPU tensors) -> (batched ``Data`` of CUDA tensors, ``slices``).
 
     Same result as ``collate`` + ``fixup_offsets`` + ``.cuda()`` of every tensor, but: the items' arrays are
-    packed into ONE pinned staging buffer, moved with ONE asynchronous H2D copy, the batched tensors are
-    views of that single device buffer, and the per-image index offsets are added by one device kernel
-    (``yolat_fixup_offsets``) instead of Python loops over the images.  Non-tensor keys (``roots`` ...)
-    and ``slices`` are assembled on the host exactly like ``collate`` does."""
+    packed into ONE pinned staging buffer by ONE native call (``yolat_collate_pack``, GIL released), moved with ONE
+    asynchronous H2D copy, the batched tensors are views of that single device buffer, and the per-image index
+    offsets are added by one device kernel (``yolat_fixup_offsets``) instead of Python loops over the images.
+    Non-tensor keys (``roots`` ...) and ``slices`` are assembled on the host exactly like ``collate`` does.
+
+    ``csr=True``: the batch carries a PREPARED graph instead of ``edge`` / ``e_attr`` / ``bbox_idx``: every item's
+    destination-sorted form is computed once (``item_csr``, cached on the item) and the batch's form is their
+    concatenation with the offsets added (``yolat_collate_csr_pack``; bit-identical to rebuilding it on the device from
+    the collated COO list).  ``SparseCADGCN.forward`` then skips the COO -> CSR conversion.  The raw ``edge`` /
+    ``e_attr`` / ``bbox_idx`` tensors are not shipped (``slices`` still describes them)."""
     from . import ops
-    from ._lib import lib, check
+    from ._lib import lib, check, Span
     keys = data_list[0].keys
-    tkeys = [k for k in keys if isinstance(data_list[0][k], torch.Tensor) and data_list[0][k].dim() > 0 and k in _DEVICE_KEYS]
+    first = data_list[0]
+    tkeys = [k for k in keys if isinstance(first[k], torch.Tensor) and first[k].dim() > 0 and k in _DEVICE_KEYS]
     rest = [k for k in keys if k not in tkeys]
     B = len(data_list)
-    # host-side assembly of everything that is not a device tensor, and of the slices
-    host_items = [data_list[0].__class__(**{k: it[k] for k in rest}) for it in data_list] if rest else None
+    batch = first.__class__()
     slices = {}
-    for k in tkeys:
-        sizes = [int(it[k].shape[0]) for it in data_list]
-        slices[k] = torch.tensor(np.concatenate([[0], np.cumsum(sizes)]), dtype=torch.long)
-    batch = data_list[0].__class__()
+    ship = [k for k in tkeys if not (csr and k in _CSR_SKIP)]
+    if csr:
+        _collate_csr(data_list, device, tkeys, tuple(ship), batch, slices)
+    else:
+        for k in tkeys:
+            ends = np.zeros(B + 1, dtype=np.int64)
+            np.cumsum([it[k].shape[0] for it in data_list], out=ends[1:])
+            slices[k] = torch.from_numpy(ends)
+    # host-side assembly of everything that is not a device tensor
     if rest:
+        host_items = [first.__class__(**{k: it[k] for k in rest}) for it in data_list]
         hb, hs = collate(host_items)
         for k in rest:
             batch[k] = hb[k]
@@ -148,21 +287,25 @@ def collate_to_device(data_list, device="cuda"):
             if "edge" in k and isinstance(batch[k], torch.Tensor) and batch[k].dtype == torch.long:
                 for i in range(B):
                     batch[k][int(slices[k][i]):int(slices[k][i + 1])] += node_slices[i]
-    # layout of the packed buffer (256-byte aligned fields) + the 4 small index tables of the fix-up
-    tables = {"edge_ptr": slices["edge"], "node_ptr": slices["pos"] if "pos" in slices else slices["x"],
-              "node_off": (slices["pos"] if "pos" in slices else slices["x"])[:-1],
-              "prop_off": slices["labels"][:-1] if "labels" in slices else slices["bbox"][:-1]}
+    if csr:
+        return batch, slices
+    node_ptr = slices["pos"] if "pos" in slices else slices["x"]
+    # layout of the packed buffer (256-byte aligned fields)
     fields, off = [], 0
-    for k in tkeys:
-        first = data_list[0][k]
-        shape = (int(slices[k][-1]),) + tuple(first.shape[1:])
-        nbytes = int(np.prod(shape)) * first.element_size()
-        fields.append((k, first.dtype, shape, off, nbytes))
+
+    def field(name, dtype, shape, esize):
+        nonlocal off
+        nbytes = int(np.prod(shape)) * esize
+        fields.append((name, dtype, shape, off, nbytes))
         off = (off + nbytes + 255) // 256 * 256
+
+    for k in ship:
+        field(k, first[k].dtype, (int(slices[k][-1]),) + tuple(first[k].shape[1:]), first[k].element_size())
+    n_pack = len(fields)
+    tables = {"edge_ptr": slices["edge"], "node_ptr": node_ptr, "node_off": node_ptr[:-1],
+              "prop_off": slices["labels"][:-1] if "labels" in slices else slices["bbox"][:-1]}
     for k, t in tables.items():
-        nbytes = t.numel() * 8
-        fields.append((k, torch.int64, (t.numel(),), off, nbytes))
-        off = (off + nbytes + 255) // 256 * 256
+        field(k, torch.int64, (t.numel(),), 8)
     total = max(off, 256)
     # two pinned staging buffers used alternately; a buffer is only re-packed after the H2D copy that last read
     # it has completed (event recorded right after that copy)
@@ -172,19 +315,25 @@ def collate_to_device(data_list, device="cuda"):
         ev.synchronize()
     if pin is None or pin.numel() < total:
         pin = _PINNED[("buf", slot)] = torch.empty(int(total * 1.5), dtype=torch.uint8).pin_memory()
+    base = pin.data_ptr()
     dbuf = torch.empty(total, dtype=torch.uint8, device=device)
-    pin_np = pin.numpy()                       # plain memcpy per item (torch.cat / copy_ wake a thread pool per call)
-    for k, dtype, shape, o, nbytes in fields:
-        if not nbytes:
-            continue
-        if k in tables:
-            pin_np[o:o + nbytes] = tables[k].numpy().view(np.uint8).reshape(-1)
-            continue
-        pos = o
-        for it in data_list:
-            src = it[k].contiguous().numpy().view(np.uint8).reshape(-1)
-            pin_np[pos:pos + src.size] = src
-            pos += src.size
+    # ONE native call moves every shipped key of every item (torch.cat / copy_ wake a thread pool per call)
+    spans = (Span * (n_pack * B))()
+    foff = (ctypes_i64 * n_pack)()
+    keep = []
+    for f, (k, dtype, shape, o, nbytes) in enumerate(fields[:n_pack]):
+        foff[f] = o
+        for i, it in enumerate(data_list):
+            t = it[k]
+            if not t.is_contiguous():
+                t = t.contiguous()
+                keep.append(t)
+            sp = spans[f * B + i]
+            sp.ptr, sp.bytes = t.data_ptr(), t.numel() * t.element_size()
+    check(lib.yolat_collate_pack(base, foff, spans, n_pack, B), "yolat_collate_pack")
+    pin_np = pin.numpy()
+    for k, dtype, shape, o, nbytes in fields[n_pack:]:
+        pin_np[o:o + nbytes] = tables[k].numpy().view(np.uint8).reshape(-1)
     dbuf.copy_(pin[:total], non_blocking=True)                  # the one H2D copy
     ev = _PINNED.get(("ev", slot))
     if ev is None:
@@ -193,7 +342,7 @@ def collate_to_device(data_list, device="cuda"):
     dv = {}
     for k, dtype, shape, o, nbytes in fields:
         dv[k] = dbuf[o:o + nbytes].view(dtype).view(shape)
-    for k in tkeys:
+    for k in ship:
         batch[k] = dv[k]
     E, N = dv["edge"].shape[0], dv["bbox_idx"].shape[0]
     check(lib.yolat_fixup_offsets(dv["edge"].data_ptr(), E, dv["edge_ptr"].data_ptr(), dv["bbox_idx"].data_ptr(), N,

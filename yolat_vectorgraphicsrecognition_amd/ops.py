@@ -81,12 +81,32 @@ def _ld(t):
 # graph pre-processing
 # ---------------------------------------------------------------------------------------------
 
+_ZERO_STATUS = {}
+
+
 class Graph(object):
     """Device-resident integer structure of one batch (CSR by destination, optional CSC by source,
     proposal segments).  Owned by the caller / cached on the batch object."""
 
     __slots__ = ("N", "E", "P", "row_ptr", "perm", "src", "dst", "attr", "col_ptr", "slots",
                  "seg_ptr", "node_seg", "status", "_work", "_inv_deg")
+
+    @classmethod
+    def from_arrays(cls, N, E, P, row_ptr, src, dst, attr, seg_ptr, node_seg, perm=None):
+        """A Graph over device arrays prepared elsewhere (data.collate_to_device(csr=True): the batch's CSR merged on
+        the host from the items' cached CSRs and shipped with the batch).  The ids were validated where the arrays
+        were built, so the status word is zero."""
+        g = cls()
+        g._inv_deg = None
+        g.N, g.E, g.P = int(N), int(E), int(P)
+        g.row_ptr, g.src, g.dst, g.attr, g.seg_ptr, g.node_seg, g.perm = row_ptr, src, dst, attr, seg_ptr, node_seg, perm
+        g.col_ptr = g.slots = None
+        g._work = None
+        st = _ZERO_STATUS.get(row_ptr.device)          # shared, never written for a prepared graph
+        if st is None:
+            st = _ZERO_STATUS[row_ptr.device] = torch.zeros(1, dtype=torch.int32, device=row_ptr.device)
+        g.status = st
+        return g
 
     def inv_deg(self):
         """[N] fp32 1 / max(in-degree, 1) (the factor of the mean aggregation's backward), built once per graph."""

@@ -272,6 +272,42 @@ class EvalPlan(object):
                 return out
         return self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
 
+    def run_prepared(self, x, g):
+        """The forward on a prepared device graph (ops.Graph; yolat_forward_eval_csr / _bf16_csr): no COO -> CSR
+        conversion inside the call.  (hipGraph replay of this path was measured and dropped: batches arrive in fresh
+        allocations, so captured graphs rarely match — 4.3 k vs 6.2 k graphs/s H2D-inclusive at cfg 2.)"""
+        key = self._version_key()
+        if key != self._key:
+            self._build()
+            self._key = key
+            self._graphs.clear()
+        N, E, P = g.N, g.E, g.P
+        if self._desc_h is not None:
+            need = int(lib.yolat_forward_eval_bf16_workspace_bytes(ctypes.byref(self._desc_h), N, E, P))
+        else:
+            need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=x.device)
+            self._graphs.clear()
+        self._primed = None
+        return self._launch_prepared(x, g)
+
+    def _launch_prepared(self, x, g):
+        from ._lib import GraphCsr
+        N, E, P = g.N, g.E, g.P
+        gc = GraphCsr(g.row_ptr.data_ptr(), g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), g.seg_ptr.data_ptr(),
+                      g.node_seg.data_ptr())
+        logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
+        if self._desc_h is not None:
+            check(lib.yolat_forward_eval_bf16_csr(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x), ctypes.byref(gc),
+                                                  N, E, P, logits.data_ptr(), logits.stride(0), self._ws.data_ptr(),
+                                                  self._ws.numel(), ops._stream()), "yolat_forward_eval_bf16_csr")
+        else:
+            check(lib.yolat_forward_eval_csr(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x), ctypes.byref(gc), N, E, P,
+                                             logits.data_ptr(), logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
+                                             ops._stream()), "yolat_forward_eval_csr")
+        return logits
+
     def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
         if self._desc_h is not None:
