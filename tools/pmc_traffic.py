@@ -2,7 +2,7 @@
 pass and a --pmc WRITE_SIZE pass of `bench.py --config C --streams 1`): per eval-plan stage the KiB fetched / written
 per launch, the summary files they came from and a digest of the kernel sources they were measured on (bench.py
 reports `traffic: null` + "STALE" when the sources change afterwards).
-usage: python tools/pmc_traffic.py <cfg> <fetch.txt> <write.txt> <committed-name-prefix>"""
+usage: python tools/pmc_traffic.py <cfg> <fetch.txt> <write.txt> <committed-name-prefix> [bf16]"""
 import hashlib
 import json
 import os
@@ -22,6 +22,15 @@ STAGES = {
     "edge_uv_mlp2_mean+node_uv_next[E x (U+V+attr) -> 64 -> 64 -> mean; N x 64 -> 128+64+64]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "with_next"),
     "node_uv[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_gemm_nt_node3", [CS + "common.hpp", CS + "dense.hip"], "all"),
     "graph_prep[csr+attr+segments] + node_uv[layer 0]": ("k_prep_rows_node3", [CS + "common.hpp", CS + "graph.hip"], "all"),
+}
+
+
+# bf16-storage forward (bf16_eval.hip YL_HSTAGE names; round 3)
+STAGES_BF16 = {
+    "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_chain_h", [CS + "common.hpp", CS + "edge_chain.hip"], "all"),
+    "fusion_gemm_bf16+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_hfusion_rows8<128", [CS + "common.hpp", CS + "segmax.hpp", CS + "fusion_h8.hip"], "all"),
+    "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_hgemm_node3", [CS + "common.hpp", CS + "bf16_eval.hip"], "all"),
+    "graph_prep[csr+attr+segments] + node_uv[layer 0, bf16 out]": ("k_prep_rows_node3", [CS + "common.hpp", CS + "graph.hip"], "all"),
 }
 
 
@@ -65,14 +74,15 @@ def select(table, kern, pick):
 
 def main():
     cfg, fetch, write, prefix = sys.argv[1:5]
+    stages = STAGES_BF16 if (len(sys.argv) > 5 and sys.argv[5] == "bf16") else STAGES
     f, w = parse(fetch), parse(write)
     path = os.path.join(REPO, "profiles", "pmc_traffic.json")
     table = json.load(open(path)) if os.path.exists(path) else {}
     ent = table.setdefault("cfg%s" % cfg, {})
     for stage in list(ent):
-        if stage not in STAGES:
+        if stage not in STAGES and stage not in STAGES_BF16:
             del ent[stage]
-    for stage, (kern, srcs, pick) in STAGES.items():
+    for stage, (kern, srcs, pick) in stages.items():
         fs, ws = select(f, kern, pick), select(w, kern, pick)
         if fs is None or ws is None:
             ent.pop(stage, None)
