@@ -216,7 +216,7 @@ extern "C" size_t yolat_fusion_pool_train_work_elems(int64_t N, int64_t K, int64
   const size_t fwd = colsum + gram + keys + wsplit;
   // backward: GM[P*F] | column partials | sparse-dW partials | small vectors / matrices
   const size_t bwd = (size_t)P * F + 2 * (size_t)yl_cdiv(P, 128) * F + 64 * (size_t)F * K + 4 * F + 2 * K * K +
-                     (size_t)F * K + yolat_linear_bwd_w_work_elems(F, K, K) + 64;
+                     (size_t)F * K + yolat_linear_bwd_w_work_elems(F, K, K) + 64 + (size_t)F * K + 64;
   return (fwd > bwd ? fwd : bwd) + 64;
 }
 
@@ -539,6 +539,151 @@ static __global__ void __launch_bounds__(THREADS) k_fus_da_sparse(const float* _
   }
 }
 
+// ------------------------------------------------------------------------------------------------
+// The same sparse input gradient on the bf16 matrix cores (round 3).  Why: k_fus_da_sparse streams ALL of W through the
+// LDS of every 32-row workgroup (2.8 GB of L2 -> LDS traffic at N = 175 k for a 512 KB weight) and walks a match mask
+// per row and 32-column chunk: 358 us at cfg 3, the largest kernel of the training step.
+//     dA[rows, 0:128] += M . W,   M[r, c] = GM[p(r), c] if arg[p(r), c] == r else 0      ([rows, F], one entry per column
+// and proposal) is a GEMM whose A operand is BUILT in registers from arg / GM (8 consecutive columns per lane: one
+// compare + select per element) and split into two bf16 terms, against W^T pre-split once per step into two bf16 terms
+// (k_wt_split2): three products a_h b_h + a_h b_m + a_m b_h per 16 columns reproduce the fp32 product to 2^-16 — the
+// gradient tolerance is 2e-4 — with fp32 accumulation in a fixed order (deterministic).  A 512-thread workgroup owns 256
+// rows; W^T's two planes and the arg / GM entries of the workgroup's (~10) proposals stream through double-buffered LDS
+// tiles of CH columns (W once per 256 rows: 0.35 GB).  Measured at cfg 3 (N = 175 k, P = 8000): 358 -> 174 us (CH = 32,
+// two workgroups per CU); the matrix-core time of the 4.2 M MFMAs is 62 us.
+// ------------------------------------------------------------------------------------------------
+typedef __bf16 ft_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned ft_u32x4 __attribute__((ext_vector_type(4)));
+
+// WT_h / WT_m [K][F] bf16:  W[c][k] = h + m + O(2^-16)   (h = top 8 significand bits, m = the next 8; truncation)
+static __global__ void k_wt_split2(const float* __restrict__ W, int F, int K, unsigned short* __restrict__ WTh,
+                                   unsigned short* __restrict__ WTm) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;          // (k, c), c fastest
+  if (i >= F * K) return;
+  const int k = i / F, c = i - k * F;
+  const float x = W[(long)c * K + k];
+  const unsigned hb = __float_as_uint(x) & 0xFFFF0000u;
+  const float r = x - __uint_as_float(hb);
+  WTh[i] = (unsigned short)(hb >> 16);
+  WTm[i] = (unsigned short)(__float_as_uint(r) >> 16);
+}
+
+template <int CH>
+static __global__ void __launch_bounds__(512, (CH == 32 ? 4 : 2)) k_fus_da_mfma(const unsigned short* __restrict__ WTh,
+                                                          const unsigned short* __restrict__ WTm, int F,
+                                                          const int* __restrict__ node_seg, int P,
+                                                          const float* __restrict__ GM, const int* __restrict__ arg,
+                                                          int N, float* dA, long ldda) {
+  constexpr int RS = CH + 8;                              // CH columns per LDS chunk, row stride (bf16)
+  constexpr int NPL = 32, PS = CH + 4;                    // proposals whose arg / GM chunk is staged in LDS, row stride
+  constexpr int WPT = 2 * 128 * (CH / 8) / 512;           // 16-byte W^T pieces per thread (2 planes x 128 k rows)
+  constexpr int SQN = CH / 4;                             // arg / GM staging: column quads per proposal
+  __shared__ __attribute__((aligned(16))) unsigned short Ws[2][2][128 * RS];     // [buffer][plane][k row][c]
+  __shared__ __attribute__((aligned(16))) int argS[2][NPL * PS];
+  __shared__ __attribute__((aligned(16))) float gmS[2][NPL * PS];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int R0 = blockIdx.x * 256;
+  const int row = R0 + wave * 32 + l31;
+  const int rowc = yl_min(row, N - 1);
+  const int p_first = node_seg[R0];
+  const int pl = node_seg[rowc] - p_first;                // this row's proposal, local to the workgroup
+  const bool in_lds = pl < NPL;                           // (256 rows hold ~10 proposals; beyond 32: straight from L2)
+  const long pbase = (long)(p_first + pl) * F + 8 * lhi;
+  const int myrow = row < N ? row : -1;
+  // staging roles: W^T pieces (2 planes x 128 k rows x CH/8 pieces); arg / GM: thread = (proposal, 4 columns)
+  const int sp = tid / SQN, sq = tid % SQN;
+  const bool stager = sp < NPL;
+  const long sbase = (long)yl_min(p_first + sp, P - 1) * F + 4 * sq;
+  auto load_w = [&](int c0, ft_u32x4* rw, int4& ra, float4& rg) {
+#pragma unroll
+    for (int t = 0; t < WPT; ++t) {
+      const int i = tid + 512 * t, plane = i / (128 * (CH / 8)), r = (i / (CH / 8)) & 127, pc = i % (CH / 8);
+      rw[t] = *reinterpret_cast<const ft_u32x4*>((plane ? WTm : WTh) + (long)r * F + c0 + 8 * pc);
+    }
+    ra = *reinterpret_cast<const int4*>(arg + sbase + c0);
+    rg = *reinterpret_cast<const float4*>(GM + sbase + c0);
+  };
+  auto store_w = [&](int buf, const ft_u32x4* rw, const int4& ra, const float4& rg) {
+#pragma unroll
+    for (int t = 0; t < WPT; ++t) {
+      const int i = tid + 512 * t, plane = i / (128 * (CH / 8)), r = (i / (CH / 8)) & 127, pc = i % (CH / 8);
+      *reinterpret_cast<ft_u32x4*>(&Ws[buf][plane][r * RS + 8 * pc]) = rw[t];
+    }
+    if (stager) {
+      *reinterpret_cast<int4*>(&argS[buf][sp * PS + 4 * sq]) = ra;
+      *reinterpret_cast<float4*>(&gmS[buf][sp * PS + 4 * sq]) = rg;
+    }
+  };
+  f32x16 acc[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+  ft_u32x4 rw[WPT];
+  int4 ra;
+  float4 rg;
+  load_w(0, rw, ra, rg);
+  store_w(0, rw, ra, rg);
+  __syncthreads();
+  const int nch = F / CH;
+  for (int ch = 0; ch < nch; ++ch) {
+    const int buf = ch & 1;
+    if (ch + 1 < nch) load_w((ch + 1) * CH, rw, ra, rg);
+#pragma unroll
+    for (int ks = 0; ks < CH / 16; ++ks) {
+      // ---- A fragments of this k step: M[row, c] = GM[p, c] where arg[p, c] == row, in two bf16 terms
+      int4 a0, a1;
+      float4 g0, g1;
+      if (in_lds) {
+        const int* ap = &argS[buf][pl * PS + 16 * ks + 8 * lhi];
+        const float* gp = &gmS[buf][pl * PS + 16 * ks + 8 * lhi];
+        a0 = *reinterpret_cast<const int4*>(ap); a1 = *reinterpret_cast<const int4*>(ap + 4);
+        g0 = *reinterpret_cast<const float4*>(gp); g1 = *reinterpret_cast<const float4*>(gp + 4);
+      } else {
+        const long o = pbase + ch * CH + 16 * ks;
+        a0 = *reinterpret_cast<const int4*>(arg + o); a1 = *reinterpret_cast<const int4*>(arg + o + 4);
+        g0 = *reinterpret_cast<const float4*>(GM + o); g1 = *reinterpret_cast<const float4*>(GM + o + 4);
+      }
+      const int av[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+      const float gv[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      unsigned ph[4], pm[4];
+#pragma unroll
+      for (int i = 0; i < 4; ++i) {
+        const float x0 = av[2 * i] == myrow ? gv[2 * i] : 0.f, x1 = av[2 * i + 1] == myrow ? gv[2 * i + 1] : 0.f;
+        const unsigned h0 = __float_as_uint(x0) & 0xFFFF0000u, h1 = __float_as_uint(x1) & 0xFFFF0000u;
+        const float m0 = x0 - __uint_as_float(h0), m1 = x1 - __uint_as_float(h1);
+        ph[i] = __builtin_amdgcn_perm(h1, h0, 0x07060302u);
+        pm[i] = __builtin_amdgcn_perm(__float_as_uint(m1), __float_as_uint(m0), 0x07060302u);
+      }
+      const ft_u32x4 qh = {ph[0], ph[1], ph[2], ph[3]}, qm = {pm[0], pm[1], pm[2], pm[3]};
+      const ft_bf16x8 Ah = __builtin_bit_cast(ft_bf16x8, qh), Am = __builtin_bit_cast(ft_bf16x8, qm);
+      const unsigned short* bh = &Ws[buf][0][l31 * RS + 16 * ks + 8 * lhi];
+      const unsigned short* bm = &Ws[buf][1][l31 * RS + 16 * ks + 8 * lhi];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const ft_bf16x8 Bh = *reinterpret_cast<const ft_bf16x8*>(bh + 32 * j * RS);
+        const ft_bf16x8 Bm = *reinterpret_cast<const ft_bf16x8*>(bm + 32 * j * RS);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Am, Bh, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bm, acc[j], 0, 0, 0);
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Ah, Bh, acc[j], 0, 0, 0);
+      }
+    }
+    if (ch + 1 < nch) store_w(buf ^ 1, rw, ra, rg);
+    __syncthreads();
+  }
+  // dA += acc   (C layout: lane = column, register = row)
+  const int rb = R0 + wave * 32 + 4 * lhi;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int rr = rb + (r & 3) + 8 * (r >> 2);
+    if (rr < N) {
+      float* o = dA + (long)rr * ldda + l31;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[32 * j] += acc[j][r];
+    }
+  }
+}
+
 static __global__ void k_row_scale(const float* __restrict__ W, const float* s, long elems, int K, float* out) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < elems) out[i] = s[i / K] * W[i];
@@ -622,7 +767,21 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
   // 3. input gradient: sparse scatter term, then  dA += (A - mean_A) . (-Q) - u   with Q = W^T diag(q2) W
   static int da_threads = -1;
   if (da_threads < 0) { const char* e = getenv("YOLAT_FUS_DA_THREADS"); da_threads = e ? atoi(e) : 256; }   // measured at N = 175 k: 256 -> 3.78, 512 -> 3.75, 1024 -> 3.86 ms per cfg-3 step (not the W re-staging: the walk)
-  if (da_threads == 1024)
+  static int da_mfma = -1, da_ch = -1;
+  if (da_mfma < 0) { const char* e = getenv("YOLAT_FUS_DA_MFMA"); da_mfma = e ? atoi(e) : 1; }
+  if (da_ch < 0) { const char* e = getenv("YOLAT_FUS_DA_CH"); da_ch = e ? atoi(e) : 32; }
+  if (da_mfma && F % 64 == 0 && F >= 64) {
+    unsigned short* WTh = reinterpret_cast<unsigned short*>(take((size_t)F * K / 2 + 8));
+    unsigned short* WTm = reinterpret_cast<unsigned short*>(take((size_t)F * K / 2 + 8));
+    hipLaunchKernelGGL(k_wt_split2, dim3(yl_cdiv(F * K, 256)), dim3(256), 0, st, W, (int)F, (int)K, WTh, WTm);
+    YL_LAUNCH_CHECK();
+    if (da_ch == 64)
+      hipLaunchKernelGGL(k_fus_da_mfma<64>, dim3(yl_cdiv(N, 256)), dim3(512), 0, st, WTh, WTm, (int)F, node_seg, (int)P, GM,
+                         sv.arg, (int)N, dA, (long)ldda);
+    else
+      hipLaunchKernelGGL(k_fus_da_mfma<32>, dim3(yl_cdiv(N, 256)), dim3(512), 0, st, WTh, WTm, (int)F, node_seg, (int)P, GM,
+                         sv.arg, (int)N, dA, (long)ldda);
+  } else if (da_threads == 1024)
     hipLaunchKernelGGL((k_fus_da_sparse<8, 1024>), dim3(yl_cdiv(N, 128)), dim3(1024), 0, st, W, (int)K, (int)F, node_seg, GM,
                        sv.arg, (int)N, dA, (long)ldda);
   else if (da_threads == 512)

@@ -260,7 +260,11 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         dA1 = torch.empty(E, C, dtype=H1.dtype, device=dev)
         bn1_done = False
         one_kernel = C == 64 and nn3.in_features == 64 and nn3.weight.is_contiguous()
-        if (FUSED_BN_CSR_BWD and C % 4 == 0 and d_f.stride(0) % 4 == 0
+        # the fused kernels read the parameter / coefficient vectors with 16-byte loads: views of a flat parameter buffer
+        # start wherever the preceding parameters end, so the alignment is part of the gate (else: the materialising path)
+        aligned = all(t.data_ptr() % 16 == 0 for t in (nn3.weight, d_f, H1, H2, c1[0], c1[1], c1[2], c1[3], c2[0], c2[1],
+                                                       c2[2], c2[3]))
+        if (FUSED_BN_CSR_BWD and aligned and C % 4 == 0 and d_f.stride(0) % 4 == 0
                 and (H1.dtype == torch.float32 or one_kernel)):
             # the gradient w.r.t. H2 (mean aggregation -> ReLU -> BatchNorm backward) is formed inside its two consumers
             # instead of being written and re-read: 5 instead of 11 passes over [E,C] (bn_csr.hip)

@@ -106,6 +106,12 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
     o2n = np.cumsum(not_control) - 1
     if edge.size and (~not_control[edge.reshape(-1)]).any():
         raise KeyError("an edge references a control point")          # o2n[e[0]] in the reference
+    # (the reference looks every id up in its o2n dict, graph_dict3.py:337-356: a control-point id anywhere raises KeyError)
+    if edge_super.size and (~not_control[edge_super.reshape(-1)]).any():
+        raise KeyError("a super edge references a control point")
+    for cluster in cc:
+        if len(cluster) and (~not_control[np.asarray(cluster, dtype=np.int64)]).any():
+            raise KeyError("a connected component contains a control point")
     edge = o2n[edge.reshape(-1, 2)] if edge.size else np.zeros((0, 2), np.int64)
     edge_super = o2n[edge_super.reshape(-1, 2)] if edge_super.size else np.zeros((0, 2), np.int64)
     cc = [[int(o2n[i]) for i in cluster] for cluster in cc]
