@@ -587,7 +587,9 @@ static __global__ void __launch_bounds__(512, (CH == 32 ? 4 : 2)) k_fus_da_mfma(
   const int rowc = yl_min(row, N - 1);
   const int p_first = node_seg[R0];
   const int pl = node_seg[rowc] - p_first;                // this row's proposal, local to the workgroup
-  const bool in_lds = pl < NPL;                           // (256 rows hold ~10 proposals; beyond 32: straight from L2)
+  // (256 rows hold ~10 proposals; a WAVE with a row beyond the 32 staged proposals reads arg / GM straight from L2 —
+  // wave-uniform, so that the common path carries no masked-off global loads: they were 256 of a wave's 449 vector loads)
+  const bool in_lds = __builtin_amdgcn_ballot_w64(pl >= NPL) == 0ull;
   const long pbase = (long)(p_first + pl) * F + 8 * lhi;
   const int myrow = row < N ? row : -1;
   // staging roles: W^T pieces (2 planes x 128 k rows x CH/8 pieces); arg / GM: thread = (proposal, 4 columns)
