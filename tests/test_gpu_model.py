@@ -315,8 +315,10 @@ def test_train_step_fused_fusion_block_matches_materialising_schedule():
     for n in ga:
         scale = max(float(gb[n].abs().max()), 1e-8)
         err = float((ga[n] - gb[n]).abs().max())
-        # biases in front of a BatchNorm have mathematically zero gradient: only an absolute bound applies
-        assert err <= 2e-4 * scale + 2e-6 * gmax, (n, err, scale)
+        # biases in front of a BatchNorm have mathematically zero gradient: only an absolute bound applies — the level
+        # of the sums' rounding noise.  The sparse input gradient of the fused block runs on two-term bf16 splits
+        # (k_fus_da_mfma: 2^-16 per term instead of 2^-24), which shows in these noise sums: measured 4e-6 * gmax
+        assert err <= 2e-4 * scale + 1e-5 * gmax, (n, err, scale)
     for n in ba:
         if ba[n].is_floating_point():
             np.testing.assert_allclose(ba[n].cpu().numpy(), bb[n].cpu().numpy(), rtol=1e-4, atol=1e-6, err_msg=n)
