@@ -235,6 +235,31 @@ def test_linear_backward_ops(M, K, N):
     close(dW2, dY.double().T @ a2 + dY.double().T @ A.double(), msg="dW prologue+acc")
 
 
+@pytest.mark.parametrize("M,K,N", [(4100, 1896, 520), (8000, 2304, 512)])
+def test_linear_bwd_w_wide_weight_takes_the_bf16x6_gemm(M, K, N):
+    """dW of a wide Linear with many rows (the classifier's first layer at P = 8000) runs as transpose + pack +
+    yolat_gemm_x6 (gemm_x6.hip); M not a multiple of 16 and a ragged last tile in both output dimensions; compared with the
+    fp64 product at fp32-GEMM accuracy, bit-identical reruns (fixed split-K order), db from the transpose tiles."""
+    yv = _yv()
+    g = torch.Generator().manual_seed(M + N)
+    A = torch.relu(torch.randn(M, K, generator=g))            # pooled activations are non-negative and sparse-ish
+    dY = torch.randn(M, N, generator=g) * torch.rand(1, N, generator=g)
+    Ad, dYd = A.cuda(), dY.cuda()
+    dW, db = torch.full((N, K), 7.0).cuda(), torch.full((N,), 7.0).cuda()
+    yv.ops.linear_bwd_w(dYd, Ad, dW, db)
+    want = dYd.double().T @ Ad.double()
+    scale = float(want.abs().max())
+    assert float((dW.double() - want).abs().max()) <= 2e-6 * scale
+    close(db, dYd.double().sum(0), msg="db")
+    dW2, db2 = torch.empty_like(dW), torch.empty_like(db)
+    yv.ops.linear_bwd_w(dYd, Ad, dW2, db2)
+    assert torch.equal(dW, dW2) and torch.equal(db, db2)
+    # the accumulating form keeps the split-row fp32 kernel: same result to rounding
+    dW3 = torch.zeros_like(dW)
+    yv.ops.linear_bwd_w(dYd, Ad, dW3, None, accumulate=True)
+    assert float((dW3.double() - want).abs().max()) <= 2e-5 * scale
+
+
 @pytest.mark.parametrize("M,C,relu", [(50, 64, True), (1000, 64, True), (300, 1024, True), (45, 512, False)])
 def test_bn_relu_backward(M, C, relu):
     yv = _yv()

@@ -213,9 +213,17 @@ extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64
   return launch_gemm_nt<DenseOp, TransOp, true>(a, b, ep, M, Nout, K, (hipStream_t)stream);
 }
 
+// gemm_x6.hip: the weight gradient of a wide Linear on the bf16x6 GEMM
+bool yl_bwd_w_x6_ok(int64_t M, int64_t Nout, int64_t K);
+size_t yl_bwd_w_x6_work_elems(int64_t M, int64_t Nout, int64_t K);
+int yl_bwd_w_x6(const float* dY, int64_t lddy, int64_t M, int64_t Nout, const float* A, int64_t lda, int64_t K, float* dW,
+                int64_t lddw, float* db, int accumulate_db, float* work, hipStream_t st);
+
 extern "C" size_t yolat_linear_bwd_w_work_elems(int64_t M, int64_t Nout, int64_t K) {
   TnPlan p = yl_tn_plan(M, Nout, K);
-  return (size_t)p.S * (size_t)(Nout * K + Nout);
+  const size_t tn = (size_t)p.S * (size_t)(Nout * K + Nout);
+  if (yl_bwd_w_x6_ok(M, Nout, K)) { const size_t x = yl_bwd_w_x6_work_elems(M, Nout, K); return x > tn ? x : tn; }
+  return tn;
 }
 
 extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int64_t Nout,
@@ -229,6 +237,10 @@ extern "C" int yolat_linear_bwd_w(const float* dY, int64_t lddy, int64_t M, int6
   if ((a_scale == nullptr) != (a_shift == nullptr)) return YOLAT_E_INVALID;
   if (a_relu && !a_scale) return YOLAT_E_INVALID;
   hipStream_t st = (hipStream_t)stream;
+  // a wide weight with many rows (the classifier's first layer): the bf16x6 matrix-core GEMM, 16-byte aligned operands
+  if (a_scale == nullptr && !accumulate && yl_bwd_w_x6_ok(M, Nout, K) && lda % 4 == 0 && yl_aligned16(A) &&
+      yl_aligned16(partial))
+    return yl_bwd_w_x6(dY, lddy, M, Nout, A, lda, K, dW, lddw, db, 0, partial, st);
   TnPlan p = yl_tn_plan(M, Nout, K);
   DenseOp y = yl_dense(dY, lddy, M, Nout);
   float* dbpart = db ? partial + (size_t)p.S * Nout * K : nullptr;

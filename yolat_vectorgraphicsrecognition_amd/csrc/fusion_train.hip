@@ -32,6 +32,7 @@
   } while (0)
 
 constexpr int CS_ROWS = 512;    // rows per column-sum workgroup
+constexpr int FB_NG = 256;      // upper bound of the row-block groups (= partial slabs) of the sparse weight gradient
 
 // partial[rb][k] = sum of A[r][k] over the rb-th block of CS_ROWS rows; 64 columns x 4 row lanes per WG
 static __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict__ A, long lda, long N, int K,
@@ -215,7 +216,7 @@ extern "C" size_t yolat_fusion_pool_train_work_elems(int64_t N, int64_t K, int64
   const size_t wsplit = (3 * (size_t)F * K + 1) / 2 + 8;                      // bf16 split of W (bf16x6 forward GEMM)
   const size_t fwd = colsum + gram + keys + wsplit;
   // backward: GM[P*F] | column partials | sparse-dW partials | small vectors / matrices
-  const size_t bwd = (size_t)P * F + 2 * (size_t)yl_cdiv(P, 128) * F + 64 * (size_t)F * K + 4 * F + 2 * K * K +
+  const size_t bwd = (size_t)P * F + 2 * (size_t)yl_cdiv(P, 128) * F + (size_t)FB_NG * F * K + 4 * F + 2 * K * K +
                      (size_t)F * K + yolat_linear_bwd_w_work_elems(F, K, K) + 64 + (size_t)F * K + 64;
   return (fwd > bwd ? fwd : bwd) + 64;
 }
@@ -321,7 +322,6 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
 // backward
 // =================================================================================================
 constexpr int FB_PROWS = 128;   // proposals per column-partial workgroup
-constexpr int FB_NG = 64;       // row-block groups (= partial slabs) of the sparse weight gradient
 
 // Per column: partial sums over a chunk of proposals of the masked gradient g and g*xhat; GM = scale*g.
 static __global__ void __launch_bounds__(256) k_fus_cols_partial(const float* __restrict__ gZ, long ldg,
@@ -378,11 +378,11 @@ static __global__ void k_fus_cols_final(const float* partial, int PB, int F, flo
 // Sparse weight gradient: partial[g][c][k] = sum over the row blocks of group g of GM[p,c] * A[arg[p,c], k].
 // One workgroup = 128 columns x one group of 64-row blocks; the block's A rows are staged in LDS, thread
 // (column, k-half) keeps 64 accumulators.  Fixed iteration order -> deterministic.
-static __global__ void __launch_bounds__(256) k_fus_dw_sparse(const float* __restrict__ A, long lda, int N, int K,
+static __global__ void __launch_bounds__(256, 3) k_fus_dw_sparse(const float* __restrict__ A, long lda, int N, int K,
                                                        const int* __restrict__ node_seg,
                                                        const float* __restrict__ GM, const int* __restrict__ arg,
                                                        int F, int blocks_per_group, float* partial) {
-  constexpr int LDA = 132;
+  constexpr int LDA = 136;       // the two lanes of a column read 32 adjacent bytes; rows 8 banks apart
   __shared__ __attribute__((aligned(16))) float As[64 * LDA];
   const int tid = threadIdx.x;
   const int cl = tid >> 1, kh = tid & 1;
@@ -395,34 +395,66 @@ static __global__ void __launch_bounds__(256) k_fus_dw_sparse(const float* __res
   const int nb = (N + 63) / 64;
   const int b0 = blockIdx.y * blocks_per_group;
   const int b1 = (b0 + blocks_per_group < nb) ? b0 + blocks_per_group : nb;
-  for (int b = b0; b < b1; ++b) {
-    const int R0 = b * 64, R1 = (R0 + 64 < N) ? R0 + 64 : N;
-    __syncthreads();
+  // software pipeline: the A rows of block b+1 and the (arg, GM) entries of its first four proposals are in flight
+  // while block b is walked (a workgroup is otherwise a chain of exposed global-load latencies: 43 blocks x 3.7 us)
+  float4 nxt[8];
+  int pf_n = 0, pl_n = -1, a_n[4];
+  float g_n[4];
 #pragma unroll
-    for (int t = 0; t < 8; ++t) {        // 64 rows x 32 float4
-      const int i = tid + t * 256;
-      const int r = yl_min(R0 + (i >> 5), N - 1);
-      *reinterpret_cast<float4*>(As + (i >> 5) * LDA + 4 * (i & 31)) =
-          *reinterpret_cast<const float4*>(A + (long)r * lda + 4 * (i & 31));
+  for (int t = 0; t < 8; ++t) nxt[t] = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { a_n[j] = 0; g_n[j] = 0.f; }
+  for (int b = b0 - 1; b < b1; ++b) {      // iteration b0 - 1 only fetches
+    const int R0 = b * 64, R1 = (R0 + 64 < N) ? R0 + 64 : N;
+    const bool live = b >= b0;
+    const int pf = pf_n, pl = pl_n;
+    int a[4];
+    float g[4];
+    if (live) {
+      __syncthreads();
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {
+        const int i = tid + t * 256;
+        *reinterpret_cast<float4*>(As + (i >> 5) * LDA + 4 * (i & 31)) = nxt[t];
+      }
+      __syncthreads();
     }
-    __syncthreads();
-    const int pf = node_seg[R0], pl = node_seg[R1 - 1];
-    for (int p = pf; p <= pl; p += 4) {  // 4 proposals' (arg, GM) loaded together
-      int a[4];
-      float g[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { a[j] = a_n[j]; g[j] = g_n[j]; }
+    {                                      // block b + 1 (past the group's end: a clamped, unused reload)
+      const int Rn0 = yl_min(b + 1, nb - 1) * 64, Rn1 = (Rn0 + 64 < N) ? Rn0 + 64 : N;
+#pragma unroll
+      for (int t = 0; t < 8; ++t) {        // 64 rows x 32 float4
+        const int i = tid + t * 256;
+        const int r = yl_min(Rn0 + (i >> 5), N - 1);
+        nxt[t] = *reinterpret_cast<const float4*>(A + (long)r * lda + 4 * (i & 31));
+      }
+      pf_n = node_seg[Rn0];
+      pl_n = node_seg[Rn1 - 1];
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        const int pj = yl_min(p + j, pl);
-        a[j] = arg[(long)pj * F + cc];
-        g[j] = GM[(long)pj * F + cc];
+        const int pj = yl_min(pf_n + j, pl_n);
+        a_n[j] = arg[(long)pj * F + cc];
+        g_n[j] = GM[(long)pj * F + cc];
+      }
+    }
+    if (!live) continue;
+    for (int p = pf; p <= pl; p += 4) {  // 4 proposals' (arg, GM) together; the first four came with the prefetch
+      if (p != pf) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int pj = yl_min(p + j, pl);
+          a[j] = arg[(long)pj * F + cc];
+          g[j] = GM[(long)pj * F + cc];
+        }
       }
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
         if (p + j <= pl && a[j] >= R0 && a[j] < R1 && g[j] != 0.f) {
-          const float* row = As + (a[j] - R0) * LDA + kh * 64;
+          const float* row = As + (a[j] - R0) * LDA + 4 * kh;      // k = 8 q + 4 kh + (0..3)
 #pragma unroll
           for (int q = 0; q < 16; ++q) {
-            const float4 v = *reinterpret_cast<const float4*>(row + 4 * q);
+            const float4 v = *reinterpret_cast<const float4*>(row + 8 * q);
             acc[4 * q + 0] = fmaf(g[j], v.x, acc[4 * q + 0]);
             acc[4 * q + 1] = fmaf(g[j], v.y, acc[4 * q + 1]);
             acc[4 * q + 2] = fmaf(g[j], v.z, acc[4 * q + 2]);
@@ -433,10 +465,10 @@ static __global__ void __launch_bounds__(256) k_fus_dw_sparse(const float* __res
     }
   }
   if (c_ok) {
-    float* o = partial + ((long)blockIdx.y * F + c) * K + kh * 64;
+    float* o = partial + ((long)blockIdx.y * F + c) * K + 4 * kh;
 #pragma unroll
     for (int q = 0; q < 16; ++q)
-      *reinterpret_cast<float4*>(o + 4 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
+      *reinterpret_cast<float4*>(o + 8 * q) = make_float4(acc[4 * q], acc[4 * q + 1], acc[4 * q + 2], acc[4 * q + 3]);
   }
 }
 
@@ -758,7 +790,9 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
   YL_LAUNCH_CHECK();
   // 2. weight gradient: sparse gather term + the two rank-structured dense terms
   const int nb = yl_cdiv(N, 64);
-  const int bpg = yl_cdiv(nb, FB_NG);
+  static int dw_ng = -1;
+  if (dw_ng < 0) { const char* e = getenv("YOLAT_FUS_DW_NG"); dw_ng = e ? atoi(e) : 64; if (dw_ng < 1 || dw_ng > FB_NG) dw_ng = 64; }
+  const int bpg = yl_cdiv(nb, dw_ng);
   const int ng = yl_cdiv(nb, bpg);
   hipLaunchKernelGGL(k_fus_dw_sparse, dim3(yl_cdiv(F, 128), ng), dim3(256), 0, st, A, (long)lda, (int)N, (int)K,
                      node_seg, GM, sv.arg, (int)F, bpg, dwpart);

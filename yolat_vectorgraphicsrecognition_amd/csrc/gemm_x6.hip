@@ -233,8 +233,9 @@ __global__ void k_gemm_x6_reduce(const float* __restrict__ partial, int S, long 
 
 // W [N, K] fp32 (optionally scaled per row) -> packed[ct][ks][part][gx_slot(col, k half)]; columns beyond N are zero
 // transposed != 0: W is given as [K, N] row-major (the GEMM's weight is its transpose: dX = dY . W of a Linear)
+// kvalid: k indices at or beyond it read as zero (the transposed form of a matrix whose row count is not a multiple of 16)
 __global__ void k_gemm_x6_pack(const float* __restrict__ W, long ldw, int N, int K, const float* __restrict__ row_scale,
-                               int transposed, yl_bf16_t* __restrict__ packed) {
+                               int transposed, int kvalid, yl_bf16_t* __restrict__ packed) {
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;          // (ct, ks, col j, k half)
   const int nks = K >> 4, tn = (N + GX_BN - 1) / GX_BN;
   if (i >= (long)tn * nks * GX_BN * 2) return;
@@ -244,10 +245,11 @@ __global__ void k_gemm_x6_pack(const float* __restrict__ W, long ldw, int N, int
   const int n = ct * GX_BN + j;
   float x[8];
 #pragma unroll
-  for (int e = 0; e < 8; ++e)
-    x[e] = n < N ? (transposed ? W[(long)(16 * ks + 8 * half + e) * ldw + n] : W[(long)n * ldw + 16 * ks + 8 * half + e]) *
-                       (row_scale ? row_scale[n] : 1.f)
-                 : 0.f;
+  for (int e = 0; e < 8; ++e) {
+    const int k = 16 * ks + 8 * half + e;
+    x[e] = (n < N && k < kvalid) ? (transposed ? W[(long)k * ldw + n] : W[(long)n * ldw + k]) * (row_scale ? row_scale[n] : 1.f)
+                                 : 0.f;
+  }
   fx_bf16x8 h, m, l;
   fx_split8(x, h, m, l);
   yl_bf16_t* o = packed + ((long)ct * nks + ks) * (3 * GX_PART) + gx_slot(j, half);
@@ -260,7 +262,7 @@ __global__ void k_gemm_x6_pack(const float* __restrict__ W, long ldw, int N, int
 int gx_splits(long M, long N, long K) {
   const long tiles = yl_cdiv(M, GX_BM) * yl_cdiv(N, GX_BN), nst = yl_cdiv(K / 16, GX_KS);
   if (tiles >= 128) return 1;
-  long s = yl_cdiv(256, tiles);
+  long s = 256 / tiles;                 // one workgroup per CU (147 KB of LDS): more than 256 would run in two rounds
   if (s > nst / 2) s = nst / 2;
   return s < 1 ? 1 : (int)s;
 }
@@ -271,13 +273,13 @@ extern "C" size_t yolat_gemm_x6_packed_elems(int64_t N, int64_t K) {
 }
 // packed: yolat_gemm_x6_packed_elems(N, K) bfloat16 values, 16-byte aligned; K % 16 == 0.  Once per weight version.
 static int gx_pack(const float* W, int64_t ldw, int64_t N, int64_t K, const float* row_scale, int transposed,
-                   uint16_t* packed, yolat_stream_t stream) {
+                   uint16_t* packed, yolat_stream_t stream, int64_t kvalid = -1) {
   if (N <= 0 || K <= 0 || !W || !packed || ldw < (transposed ? N : K) || N >= (1LL << 31) - GX_BN || K >= (1LL << 31))
     return YOLAT_E_INVALID;
   if (K % 16 != 0 || !yl_aligned16(packed)) return YOLAT_E_UNSUPPORTED;
   const long items = (long)yl_cdiv(N, GX_BN) * (K / 16) * GX_BN * 2;
   hipLaunchKernelGGL(k_gemm_x6_pack, dim3((unsigned)yl_cdiv(items, 256)), dim3(256), 0, (hipStream_t)stream, W, (long)ldw,
-                     (int)N, (int)K, row_scale, transposed, reinterpret_cast<yl_bf16_t*>(packed));
+                     (int)N, (int)K, row_scale, transposed, (int)(kvalid < 0 ? K : kvalid), reinterpret_cast<yl_bf16_t*>(packed));
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -339,4 +341,90 @@ static int gx_run(const float* A, int64_t lda, int64_t M, int64_t K, const uint1
                      shift, relu, out, (long)ldo);
   YL_LAUNCH_CHECK();
   return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of a wide Linear on the same kernel (round 3):  dW [Nout, K] = dY [M, Nout]^T . A [M, K],  db = column
+// sums of dY (torch.nn.Linear's backward; the per-proposal classifier's first layer, architecture3cc_rpn_gp_iter2.py:91,
+// 127: M = P proposals, K = 2304, Nout = 512).  Both operands have the reduction index M as their ROW index, so dY is
+// transposed into the GEMM's row operand ([Nout, Mp], Mp = M rounded up to 16, zero filled; its 64-row tiles also give the
+// column sums, reduced in a fixed order) and A is packed as the "weight given transposed" (yolat_gemm_x6_pack_t's form).
+// Replaces the split-row fp32 v_mfma_f32_32x32x2 kernel (k_gemm_tn: 231 us at P = 8000).
+// ------------------------------------------------------------------------------------------------
+namespace {
+// out [C][ldo] = in [R][C]^T for the 64 x 64 tile (blockIdx.x: row tile, blockIdx.y: column tile); colpart [row tile][C] =
+// the tile's column sums, rows ascending
+__global__ void __launch_bounds__(256) k_x6_transpose_colsum(const float* __restrict__ in, long ldi, int R, int C,
+                                                             float* __restrict__ out, long ldo, int Rp,
+                                                             float* __restrict__ colpart) {
+  __shared__ float t[64][65];
+  const int r0 = blockIdx.x * 64, c0 = blockIdx.y * 64, tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = r0 + ty + 4 * i, c = c0 + tx;
+    t[ty + 4 * i][tx] = (r < R && c < C) ? in[(long)r * ldi + c] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = c0 + ty + 4 * i, r = r0 + tx;
+    if (c < C && r < Rp) out[(long)c * ldo + r] = t[tx][ty + 4 * i];
+  }
+  if (colpart != nullptr && threadIdx.x < 64 && c0 + tx < C) {
+    float s = 0.f;
+#pragma unroll 8
+    for (int i = 0; i < 64; ++i) s += t[i][tx];
+    colpart[(long)blockIdx.x * C + c0 + tx] = s;
+  }
+}
+// db[c] (+)= sum over the T row tiles: 64 columns x 16 tile lanes per workgroup, lane q sums tiles q, q + 16, ... and the
+// sixteen lane sums are added in lane order (fixed order: deterministic)
+__global__ void __launch_bounds__(1024) k_x6_colsum_final(const float* __restrict__ colpart, int T, int C,
+                                                          float* __restrict__ db, int accumulate) {
+  __shared__ float part[16][64];
+  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
+  float s = 0.f;
+  if (c < C)
+    for (int t = q; t < T; t += 16) s += colpart[(long)t * C + c];
+  part[q][cx] = s;
+  __syncthreads();
+  if (q == 0 && c < C) {
+    float v = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v += part[j][cx];
+    db[c] = accumulate ? db[c] + v : v;
+  }
+}
+inline size_t gx_al4(size_t n) { return (n + 3) / 4 * 4; }
+}  // namespace
+
+// worthwhile and possible for this shape?  (the split path pays two extra passes over the operands)
+bool yl_bwd_w_x6_ok(int64_t M, int64_t Nout, int64_t K) {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("YOLAT_BWD_W_X6"); on = e ? atoi(e) : 1; }
+  return on && M >= 2048 && Nout >= 128 && K >= 128 && (double)M * (double)Nout * (double)K >= 4.0e9 && M < (1LL << 30);
+}
+size_t yl_bwd_w_x6_work_elems(int64_t M, int64_t Nout, int64_t K) {
+  const int64_t Mp = (M + 15) / 16 * 16;
+  return gx_al4((size_t)Nout * Mp) + gx_al4((yolat_gemm_x6_packed_elems(K, Mp) + 1) / 2) +
+         gx_al4(yolat_gemm_x6_work_elems(Nout, K, Mp)) + gx_al4((size_t)yl_cdiv(M, 64) * Nout);
+}
+int yl_bwd_w_x6(const float* dY, int64_t lddy, int64_t M, int64_t Nout, const float* A, int64_t lda, int64_t K, float* dW,
+                int64_t lddw, float* db, int accumulate_db, float* work, hipStream_t st) {
+  const int64_t Mp = (M + 15) / 16 * 16;
+  float* dYT = work;
+  uint16_t* packed = reinterpret_cast<uint16_t*>(dYT + gx_al4((size_t)Nout * Mp));
+  float* gwork = reinterpret_cast<float*>(packed) + gx_al4((yolat_gemm_x6_packed_elems(K, Mp) + 1) / 2);
+  float* colpart = gwork + gx_al4(yolat_gemm_x6_work_elems(Nout, K, Mp));
+  const int T = yl_cdiv(M, 64);
+  hipLaunchKernelGGL(k_x6_transpose_colsum, dim3((unsigned)yl_cdiv(Mp, 64), (unsigned)yl_cdiv(Nout, 64)), dim3(256), 0, st, dY,
+                     (long)lddy, (int)M, (int)Nout, dYT, (long)Mp, (int)Mp, db ? colpart : (float*)nullptr);
+  YL_LAUNCH_CHECK();
+  if (db) {
+    hipLaunchKernelGGL(k_x6_colsum_final, dim3((unsigned)yl_cdiv(Nout, 64)), dim3(1024), 0, st, colpart, T, (int)Nout, db,
+                       accumulate_db);
+    YL_LAUNCH_CHECK();
+  }
+  { const int rc = gx_pack(A, lda, K, Mp, nullptr, 1, packed, (yolat_stream_t)st, M); if (rc != 0) return rc; }
+  return gx_run(dYT, Mp, Nout, Mp, packed, nullptr, 0, K, dW, lddw, gwork, nullptr, (yolat_stream_t)st);
 }
