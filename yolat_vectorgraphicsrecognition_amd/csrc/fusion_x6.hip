@@ -80,7 +80,10 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
   constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / 512;   // 16-byte chunks of one W tile, per thread
   static_assert(CHUNKS % 512 == 0, "W tile / thread mismatch");
-  __shared__ __attribute__((aligned(16))) yl_bf16_t Ws[2][3 * 64 * RS];
+  constexpr int TK = 64, TS = TK + 4;                       // the prologue's transposition tile: [32 rows][TK + 4] floats per wave
+  constexpr int SMEM_W = 2 * 3 * 64 * RS * 2, SMEM_T = 8 * 32 * TS * 4;
+  __shared__ __attribute__((aligned(16))) char smem[SMEM_W > SMEM_T ? SMEM_W : SMEM_T];
+  yl_bf16_t (*Ws)[3 * 64 * RS] = reinterpret_cast<yl_bf16_t (*)[3 * 64 * RS]>(smem);
   __shared__ int seg_s[256];
   const int tid = threadIdx.x;
   // the small problem's workgroups come first (padded to a multiple of 8 so that the big problem keeps its
@@ -142,22 +145,37 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int row0 = rt * 256 + wave * 32;
-  // ---- this wave's 32 rows of A, split once
+  // ---- this wave's 32 rows of A, split once.  Loaded row by row (a row's 64 floats of the pass = 16 lanes x 16 bytes:
+  // whole cache lines per instruction, eight loads in flight) and turned into the MFMA operand order (lane = row, 8
+  // consecutive k) through a [32][TK + 4] fp32 tile in LDS — the weights' buffers, not yet in use.  (Reading the operand
+  // order straight from memory, every lane its own row, as a chain of dependent 16-byte loads was 126 of the kernel's
+  // 350 us at N = 200 k: profiles/r03_fusion_x6_ablation.txt.)
   fx_bf16x8 Ah[KS], Am[KS], Al[KS];
   {
-    const float* ap = A + (long)yl_min(row0 + l31, N - 1) * P.lda + 8 * lhi;
+    float* T = reinterpret_cast<float*>(smem) + wave * (32 * TS);
+    const int lr = lane >> 4, lc = (lane & 15) * 4;
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) {
-      const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * ks);
-      const float4 a1 = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
-      float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-      if (P.a_scale != nullptr) {
-        const float* sp = P.a_scale + 16 * ks + 8 * lhi;
-        const float* hp = P.a_shift + 16 * ks + 8 * lhi;
+    for (int q = 0; q < KD / TK; ++q) {
+      float4 v[8];
 #pragma unroll
-        for (int e = 0; e < 8; ++e) x[e] = fmaxf(fmaf(x[e], sp[e], hp[e]), P.a_floor);
+      for (int i = 0; i < 8; ++i)
+        v[i] = *reinterpret_cast<const float4*>(A + (long)yl_min(row0 + 4 * i + lr, N - 1) * P.lda + TK * q + lc);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(T + (4 * i + lr) * TS + lc) = v[i];
+#pragma unroll
+      for (int u = 0; u < TK / 16; ++u) {
+        const int ks = (TK / 16) * q + u;
+        const float4 a0 = *reinterpret_cast<const float4*>(T + l31 * TS + 16 * u + 8 * lhi);
+        const float4 a1 = *reinterpret_cast<const float4*>(T + l31 * TS + 16 * u + 8 * lhi + 4);
+        float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        if (P.a_scale != nullptr) {
+          const float* sp = P.a_scale + 16 * ks + 8 * lhi;
+          const float* hp = P.a_shift + 16 * ks + 8 * lhi;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) x[e] = fmaxf(fmaf(x[e], sp[e], hp[e]), P.a_floor);
+        }
+        fx_split8(x, Ah[ks], Am[ks], Al[ks]);
       }
-      fx_split8(x, Ah[ks], Am[ks], Al[ks]);
     }
   }
   const bool pooling = P.seg != nullptr;
@@ -195,6 +213,7 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   // shifts of the first tile; later tiles: fetched one tile ahead, BEFORE that tile's W loads, so that no wait on
   // them ever sits behind younger loads or the epilogue's atomics (vmcnt retires in order)
   float t0 = P.tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = P.tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
+  __syncthreads();                                          // every wave is done with its transposition tile
   store_w(0, rw);
   __syncthreads();
   for (int j = 0; j < ngl; ++j) {
