@@ -556,6 +556,47 @@ def test_launch_merging_of_the_small_graph_forward(tmp_path):
         assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max())
 
 
+def test_strict_fp32_switch_runs_the_fp32_mfma_kernels_and_agrees(tmp_path):
+    """YOLAT_STRICT_FP32=1 (csrc/x6.hpp, common.hpp yl_strict_fp32, plan._x6_on): one switch that takes every GEMM of the fp32
+    mode off the bf16x6 emulation — eval forward at a size where the emulated kernels are the default for the edge stage
+    (E >= 131072), the node side (N >= 65536), the fusion block and the classifier (P >= 1024), and one train step.  The
+    two modes differ by summation order only; an Inf in the input propagates IEEE-style (no finite logits for that graph's
+    proposals) in strict mode."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = (
+        "import sys, torch\n"
+        "sys.path.insert(0, %r); sys.path.insert(0, %r)\n"
+        "import golden_util as gu\n"
+        "import yolat_vectorgraphicsrecognition_amd as yv\n"
+        "data, slices = yv.synth_batch(1, 21, num_proposals=1100, nodes_lo=62, nodes_hi=62, edges_per_proposal=130)\n"
+        "optkw = dict(n_classes=9, n_blocks=2, n_blocks_out=2)\n"
+        "model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 3).cuda().eval()\n"
+        "with torch.no_grad():\n"
+        "    logits = model(data, slices)[0].cpu()\n"
+        "model.check_last_status()\n"
+        "small, ss = yv.synth_batch(2, 9, num_proposals=60, nodes_lo=4, nodes_hi=20, edge_factor=1.5, augmented=True)\n"
+        "m2 = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 4).cuda()\n"
+        "tr = yv.Trainer(m2, yv.Opt(), lr=1e-3, weight_decay=1e-5)\n"
+        "loss = float(tr.step(small, ss))\n"
+        "torch.save(dict(logits=logits, loss=loss, grad=tr.flat.grad.cpu(), shape=(data.x.shape[0], data.edge.shape[0])),\n"
+        "           sys.argv[1])\n" % (root, os.path.join(root, "tests")))
+    got = {}
+    for tag, env in (("default", {}), ("strict", {"YOLAT_STRICT_FP32": "1"})):
+        out = str(tmp_path / ("strict_%s.pt" % tag))
+        subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, **env), timeout=600)
+        got[tag] = torch.load(out)
+    N, E = got["default"]["shape"]
+    assert N >= 65536 and E >= 131072
+    a, b = got["default"]["logits"], got["strict"]["logits"]
+    assert torch.isfinite(a).all() and torch.isfinite(b).all() and not torch.equal(a, b)     # different kernels ran
+    assert float((a - b).abs().max()) <= 1e-5 * float(b.abs().max())
+    assert abs(got["default"]["loss"] - got["strict"]["loss"]) <= 1e-5 * abs(got["strict"]["loss"])
+    ga, gb = got["default"]["grad"], got["strict"]["grad"]
+    assert float(gb.abs().max()) > 0 and float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
+
+
 def test_primed_workspace_forwards_equal_self_contained_forwards():
     """plan.EvalPlan skips the memset of the CSR-build counters when its workspace was last used by a forward of the same
     shape (yolat_forward_eval_primed: every forward leaves the counters zero).  A sequence that repeats and alternates

@@ -28,6 +28,14 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 static inline int yl_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 static inline bool yl_aligned16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+// YOLAT_STRICT_FP32=1: every GEMM of the fp32 mode runs on the fp32-input MFMA kernels (v_mfma_f32_32x32x2_f32) instead
+// of the bf16x6 emulation (x6.hpp) — the one switch for strict-parity runs (IEEE Inf / NaN propagation, fp32 MFMA
+// summation order); the Python side (plan.py, ops.py) reads the same variable.
+static inline bool yl_strict_fp32() {
+  static int v = -1;
+  if (v < 0) { const char* e = getenv("YOLAT_STRICT_FP32"); v = (e && e[0] == '1') ? 1 : 0; }
+  return v != 0;
+}
 
 __device__ __forceinline__ int yl_min(int a, int b) { return a < b ? a : b; }
 // a*b rounded on its own: the empty asm keeps the compiler from contracting it with a following add into an

@@ -872,7 +872,7 @@ static int edge_env_variant() {
 int yl_edge_tile_groups(int64_t N, int64_t E) {
   if (N <= 0 || E <= 0) return 0;
   const int ev = edge_env_variant();
-  const int variant = ev != 0 ? ev : (E >= 131072 ? YOLAT_EDGE_WS_X6 : YOLAT_EDGE_TILES);
+  const int variant = ev != 0 ? ev : (E >= 131072 ? (yl_strict_fp32() ? YOLAT_EDGE_WS_F32 : YOLAT_EDGE_WS_X6) : YOLAT_EDGE_TILES);
   if (variant != YOLAT_EDGE_TILES) return 0;
   return edge_tile_npt(N, E) <= 16 ? 1 : 4;
 }
@@ -907,7 +907,7 @@ int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t
   // the persistent kernel addresses UV / attr / the index arrays with 32-bit byte offsets
   const bool ws_ok = yl_aligned16(W2) && E >= 64 && N * ld_uv * 4 < (1LL << 32) && E * 16 < (1LL << 32);
   if (variant == YOLAT_EDGE_AUTO) {
-    variant = env_variant != 0 ? env_variant : (E >= 131072 ? YOLAT_EDGE_WS_X6 : YOLAT_EDGE_TILES);
+    variant = env_variant != 0 ? env_variant : (E >= 131072 ? (yl_strict_fp32() ? YOLAT_EDGE_WS_F32 : YOLAT_EDGE_WS_X6) : YOLAT_EDGE_TILES);
     if (!ws_ok) variant = YOLAT_EDGE_TILES;
   } else if (variant != YOLAT_EDGE_TILES && !ws_ok) {
     return YOLAT_E_UNSUPPORTED;

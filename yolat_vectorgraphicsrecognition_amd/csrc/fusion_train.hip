@@ -290,7 +290,7 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
   // K in {64, 128}: as an fp32 GEMM emulated with six bf16 MFMA products on the rows kernel (fusion_x6.hip; the weight
   // split lives behind the keys in `work`)
   static int use_x6 = -1;
-  if (use_x6 < 0) { const char* e = getenv("YOLAT_FUSION_TRAIN_X6"); use_x6 = (e && e[0] == '0') ? 0 : 1; }
+  if (use_x6 < 0) { const char* e = getenv("YOLAT_FUSION_TRAIN_X6"); use_x6 = ((e && e[0] == '0') || yl_strict_fp32()) ? 0 : 1; }
   int x6rc = YOLAT_E_UNSUPPORTED;
   if (use_x6 && bias != nullptr) {
     uint16_t* wsplit = reinterpret_cast<uint16_t*>(((uintptr_t)(keys + (size_t)P * F) + 15) & ~(uintptr_t)15);

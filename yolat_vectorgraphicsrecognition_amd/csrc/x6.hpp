@@ -2,6 +2,18 @@
 // split of fp32 values.  x = h + m + l with h = the top 8 significand bits of x, m the next 8, l the last 8
 // (truncation splits: every term is exactly representable in bfloat16); six of the nine products a_i * b_j — all but
 // the three O(2^-24) ones — reproduce the fp32 product to ~3e-7 relative with fp32 accumulation.
+//
+// Non-finite and tiny inputs.  The split is exact for every finite x whose three terms are normal or zero.  It is NOT a
+// drop-in for an IEEE fp32 product at the edges of the format:
+//   * x = +-Inf: h = +-Inf, m = hm - h = Inf - Inf = NaN — an Inf operand turns its output row / column into NaN where a
+//     true fp32 GEMM would give +-Inf (or NaN only against a zero); NaN stays NaN.  The model's activations are finite
+//     (BatchNorm'd features, bounded Bezier attributes); yolat_check_last_status-style input checks do not look at values.
+//   * |x| < 2^-110 or so: the low terms underflow bfloat16's normal range only when x itself is within 2^16 of the
+//     smallest normal fp32 (bf16 shares fp32's exponent range), i.e. products that are far below fp32's own rounding of
+//     any sum they enter.
+// Strict-parity runs select the fp32-input MFMA kernels everywhere with ONE switch, YOLAT_STRICT_FP32=1 (common.hpp
+// yl_strict_fp32; plan.py / ops.py read the same variable): IEEE propagation and the fp32 MFMA summation order, at the
+// fp32 vector-ALU rate (DESIGN.md "fp32 MFMA and the vector ALU").
 #pragma once
 #include "common.hpp"
 

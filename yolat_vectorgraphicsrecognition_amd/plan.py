@@ -17,6 +17,14 @@ from ._lib import lib, check, ModelEval, ModelEvalBf16, YOLAT_MAX_LAYERS
 PRIMED_WS = os.environ.get("YOLAT_PRIMED_WS", "1") != "0"
 
 
+def _x6_on(name, default="1"):
+    """A bf16x6-emulated stage of the fp32 plan: its own switch, and off as a whole under YOLAT_STRICT_FP32=1
+    (csrc/x6.hpp: strict IEEE propagation / fp32 MFMA summation order)."""
+    if os.environ.get("YOLAT_STRICT_FP32", "0") == "1":
+        return False
+    return os.environ.get(name, default) == "1"
+
+
 def _fold(bn, dev):
     coef = torch.empty(2, bn.num_features, dtype=torch.float32, device=dev)
     ops.bn_eval_coeffs(bn, coef[0], coef[1])
@@ -117,7 +125,7 @@ class EvalPlan(object):
                         tnx = torch.cat([uvb, cv.lin_r.bias.detach()], 0).contiguous()
                         keep += [wnx, tnx]
                         c.Wnx, c.tnx = wnx.data_ptr(), tnx.data_ptr()
-                    if (cv.in_channels == 64 and C == 64 and os.environ.get("YOLAT_NODE_X6", "1") != "0"
+                    if (cv.in_channels == 64 and C == 64 and _x6_on("YOLAT_NODE_X6")
                             and cv.lin_r.bias is not None):
                         # node side on the bf16x6 rows kernel (yolat_node_uv_eval_x6): [Wuvf ; Wr] stacked and split,
                         # shifts [uvb ; br]; node branch with its BatchNorm scale folded into the weight rows
@@ -144,7 +152,7 @@ class EvalPlan(object):
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
         Dk = fb[0].in_features
-        x6 = (self.precision == "fp32" and os.environ.get("YOLAT_FUSION_X6", "1") != "0" and Dk in (64, 128)
+        x6 = (self.precision == "fp32" and _x6_on("YOLAT_FUSION_X6") and Dk in (64, 128)
               and d.F % 64 == 0)
 
         def split3(lin, fold):
@@ -176,7 +184,7 @@ class EvalPlan(object):
         c2fold = keep[-1]
         d.Wc3, d.bc3 = ptr(m3[0].weight), ptr(m3[0].bias)
         # prediction_cls.0 (P x 2304 -> 512) on the LDS-tiled bf16x6 GEMM (yolat_gemm_x6)
-        if (self.precision == "fp32" and os.environ.get("YOLAT_CLS1_X6", "1") != "0" and m1[0].in_features % 16 == 0):
+        if (self.precision == "fp32" and _x6_on("YOLAT_CLS1_X6") and m1[0].in_features % 16 == 0):
             lin = m1[0]
             rows, cols = lin.out_features, lin.in_features
             packed = torch.empty(lib.yolat_gemm_x6_packed_elems(rows, cols), dtype=torch.bfloat16, device=dev)
@@ -189,7 +197,7 @@ class EvalPlan(object):
         # classifier layers for the skinny bf16x6 kernel (yolat_linear_x6): all three or none.  Off by default: measured
         # equal to the fp32 split-K kernel at P = 400 (20.8 vs 21.2 us for cls1; operands streamed from L2 straight
         # into registers make it L1-bandwidth bound, profiles/r02_linear_x6_skinny.txt) and slower beyond.
-        if (self.precision == "fp32" and os.environ.get("YOLAT_CLS_X6", "0") == "1"
+        if (self.precision == "fp32" and _x6_on("YOLAT_CLS_X6", "0")
                 and all(l[0].in_features % 16 == 0 for l in (m1, m2, m3))):
             for i, (l, fold) in enumerate(((m1, c1fold), (m2, c2fold), (m3, None))):
                 lin = l[0]
