@@ -859,6 +859,43 @@ def test_factorised_edge_layer_matches_unfactorised(N, E, Cin):
     assert torch.isnan(got[:, 64:]).all()
 
 
+@pytest.mark.parametrize("N,Cin,ldx", [(32768, 5, 5), (50001, 5, 8), (40007, 8, 8), (33000, 3, 3)])
+def test_node_uv_eval_first_layer_stream_kernel(N, Cin, ldx):
+    """yolat_node_uv_eval with K = in_channels <= 8 on a large graph (N >= 32768) takes the output-stream kernel
+    (dense.hip k_node3_smallk: one wave per row, lane = 4 output columns): UV = x.Wuv^T + uv_bias, root = x.Wr^T + br, node
+    branch = relu((s.Wn^T + bn)*sn + tn), against fp64 and — at one row below the threshold — against the MFMA tiles."""
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    tg = torch.Generator().manual_seed(N + Cin)
+    xb = torch.randn(N, ldx, generator=tg).cuda()
+    sb = torch.randn(N, ldx, generator=tg).cuda()
+    x, s_in = xb[:, :Cin], sb[:, :Cin]
+    wuv = (torch.randn(128, Cin, generator=tg) / Cin ** 0.5).cuda()
+    Wr = (torch.randn(64, Cin, generator=tg) / Cin ** 0.5).cuda()
+    Wn = (torch.randn(64, Cin, generator=tg) / Cin ** 0.5).cuda()
+    uvb, br, bn = [(torch.randn(n, generator=tg) * 0.3).cuda() for n in (128, 64, 64)]
+    sn, tn = (torch.rand(64, generator=tg) - 0.2).cuda(), (torch.randn(64, generator=tg) * 0.2).cuda()
+    st = torch.cuda.current_stream().cuda_stream
+
+    def run(n):
+        UV = torch.full((n, 128), float("nan")).cuda()
+        big = torch.full((n, 192), float("nan")).cuda()            # root and node branch as column slices (ld 192)
+        f_out, s_out = big[:, :64], big[:, 64:128]
+        check(lib.yolat_node_uv_eval(x.data_ptr(), ldx, s_in.data_ptr(), ldx, n, Cin, wuv.data_ptr(), uvb.data_ptr(),
+                                     Wr.data_ptr(), br.data_ptr(), Wn.data_ptr(), bn.data_ptr(), sn.data_ptr(),
+                                     tn.data_ptr(), 64, UV.data_ptr(), 128, f_out.data_ptr(), 192, s_out.data_ptr(), 192, st))
+        return UV, f_out, s_out, big
+    UV, f_out, s_out, big = run(N)
+    xd, sd = x.double(), s_in.double()
+    close(UV, xd @ wuv.double().T + uvb.double(), msg="UV")
+    close(f_out, xd @ Wr.double().T + br.double(), msg="root")
+    close(s_out, torch.relu((sd @ Wn.double().T + bn.double()) * sn.double() + tn.double()), msg="node branch")
+    assert torch.isnan(big[:, 128:]).all()                          # nothing written past the two slices
+    # the MFMA tiles on the first 32767 rows (below the threshold): same values up to the summation order
+    UV2, f2, s2, _ = run(32767)
+    for a_, b_ in ((UV, UV2), (f_out, f2), (s_out, s2)):
+        assert float((a_[:32767] - b_).abs().max()) <= 2e-6 * float(b_.abs().max())
+
+
 @pytest.mark.parametrize("N,E", [(6, 7), (70, 300), (1000, 4000), (500, 9001), (2500, 3000), (9000, 54000),
                                  (40000, 9000), (30000, 140000)])
 def test_fused_edge_mean_is_bit_identical_to_edge_kernel_plus_csr_mean(N, E):

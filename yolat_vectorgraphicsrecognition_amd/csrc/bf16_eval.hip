@@ -766,7 +766,9 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
     a.euv.Y = nullptr; a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
     a.euv.scale = mh->uv_scale[0]; a.euv.shift = mh->uv_shift[0];
     a.en.Y = nullptr; a.en.Yh = s_slot(0); a.en.ldy = ld_slot(0);
-    if (g != nullptr) {
+    if (g != nullptr && yl_node3_smallk_ok(a)) {
+      YL_TRY(yl_node3_smallk(a, st));
+    } else if (g != nullptr) {
       const dim3 grid(yl_cdiv(N, 64), 4);
       if (cv0.Cin <= 16) hipLaunchKernelGGL(k_gemm_nt_node3<16>, grid, dim3(256), 0, st, a);
       else hipLaunchKernelGGL(k_gemm_nt_node3<32>, grid, dim3(256), 0, st, a);

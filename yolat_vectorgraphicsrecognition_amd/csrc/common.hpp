@@ -672,6 +672,99 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
                      int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr, const float* br,
                      const float* Wn, const float* bn, const float* sn, const float* tn, int64_t C, float* UV,
                      int64_t ld_uv, float* f_out, int64_t ld_fo, float* s_out, int64_t ld_so);
+// ------------------------------------------------------------------------------------------------
+// Node side of the FIRST conv layer of a large graph as an output stream (launcher: dense.hip yl_node3_smallk).  K = in_channels = 5 raw Bezier features -> 256 outputs per node
+// (UV [N, 128], root [N, 64], node branch [N, 64]; architecture3cc_rpn_gp_iter2.py:110-113 with torch_vertex.py:319-337
+// factorised): with K <= 8 there is nothing for the matrix cores to do, the launch is a 100 - 200 MB output stream.  One
+// wave owns 8 consecutive rows per step, lane = four consecutive output columns with their weights in registers (4 x K
+// fma per row), 16-byte (fp32) / 8-byte (bf16) stores that cover whole cache lines; the next step's inputs are in
+// flight during the stores.  Same epilogue arithmetic as wave_epilogue (bias, scale / shift, ReLU, bf16 = nearest even);
+// the sum over k runs in ascending order.  (The 64x64 MFMA tiles of k_gemm_nt_node3, one load -> LDS -> MFMA -> store
+// chain per 16 KB of output, needed 57 - 65 us at N = 200 k and 80 - 90 us together with the CSR emission they were
+// co-scheduled with; this kernel 51 us fp32 / 43 us bf16 beside a 21 us emission launch.)
+// ------------------------------------------------------------------------------------------------
+constexpr int N3_KMAX = 8, N3_ROWS = 32;           // rows per workgroup iteration (4 waves x 8 consecutive rows)
+__device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb, int rows_per_wg) {
+  // per wave: the 8 rows x K inputs of both sources, written by lane (row u = lane / 8, k = lane % 8) and read back as
+  // two uniform-address (broadcast) 16-byte reads per row
+  __shared__ __attribute__((aligned(16))) float xs[4][2][64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int C = a.C, Cin = a.Cin, N = a.N;
+  const int c4 = 4 * lane;
+  const int prob = c4 < 2 * C ? 0 : (c4 < 3 * C ? 1 : 2);
+  const int col = prob == 0 ? c4 : (prob == 1 ? c4 - 2 * C : c4 - 3 * C);
+  const float* __restrict__ wp = prob == 0 ? a.wuv.p : (prob == 1 ? a.wr.p : a.wn.p);
+  const long ldw = prob == 0 ? a.wuv.ld : (prob == 1 ? a.wr.ld : a.wn.ld);
+  const float* bias = prob == 0 ? a.euv.bias : (prob == 1 ? a.er.bias : a.en.bias);
+  const float* scale = prob == 0 ? a.euv.scale : (prob == 1 ? a.er.scale : a.en.scale);
+  const float* shift = prob == 0 ? a.euv.shift : (prob == 1 ? a.er.shift : a.en.shift);
+  const int relu = prob == 0 ? a.euv.relu : (prob == 1 ? a.er.relu : a.en.relu);
+  float* Y = prob == 0 ? a.euv.Y : (prob == 1 ? a.er.Y : a.en.Y);
+  unsigned short* Yh = prob == 0 ? a.euv.Yh : (prob == 1 ? a.er.Yh : a.en.Yh);
+  const long ldy = prob == 0 ? a.euv.ldy : (prob == 1 ? a.er.ldy : a.en.ldy);
+  float w[4][N3_KMAX], b[4], sc[4], sh[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+#pragma unroll
+    for (int k = 0; k < N3_KMAX; ++k) w[j][k] = k < Cin ? wp[(long)(col + j) * ldw + k] : 0.f;
+    b[j] = bias ? bias[col + j] : 0.f;
+    sc[j] = scale ? scale[col + j] : 1.f;
+    sh[j] = scale ? shift[col + j] : 0.f;
+  }
+  const float floor = relu ? 0.f : -INFINITY;
+  const int r0 = vb * rows_per_wg, r1 = yl_min(r0 + rows_per_wg, N);
+  const int lu = lane >> 3, lk = lane & 7;
+  const bool k_ok = lk < Cin;
+  const float* __restrict__ fp = a.af.p + lk;
+  const float* __restrict__ sp = a.as.p + lk;
+  const long ldf = a.af.ld, lds_ = a.as.ld;
+  float* mine_w0 = &xs[wave][0][lane];
+  float* mine_w1 = &xs[wave][1][lane];
+  const float* mine = xs[wave][prob == 2 ? 1 : 0];
+  int r = r0 + 8 * wave;
+  float fa = 0.f, sa = 0.f;
+  if (r < r1 && k_ok) {
+    const long row = yl_min(r + lu, N - 1);
+    fa = fp[row * ldf]; sa = sp[row * lds_];
+  }
+  for (; r < r1; r += N3_ROWS) {
+    *mine_w0 = fa; *mine_w1 = sa;
+    const int rn = r + N3_ROWS;
+    if (rn < r1 && k_ok) {                       // next iteration's inputs: in flight during this one's stores
+      const long row = yl_min(rn + lu, N - 1);
+      fa = fp[row * ldf]; sa = sp[row * lds_];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float4 x0 = *reinterpret_cast<const float4*>(mine + 8 * u);
+      const float4 x1 = *reinterpret_cast<const float4*>(mine + 8 * u + 4);
+      const float x[8] = {x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w};
+      float v[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        float acc = 0.f;
+#pragma unroll
+        for (int k = 0; k < N3_KMAX; ++k) acc = fmaf(x[k], w[j][k], acc);
+        v[j] = fmaxf(fmaf(acc + b[j], sc[j], sh[j]), floor);
+      }
+      const int row = r + u;
+      if (row < r1) {
+        if (Yh != nullptr) {
+          uint2 o;
+          o.x = yl_pack_bf16(v[0], v[1]); o.y = yl_pack_bf16(v[2], v[3]);
+          *reinterpret_cast<uint2*>(Yh + (long)row * ldy + col) = o;
+        } else {
+          *reinterpret_cast<float4*>(Y + (long)row * ldy + col) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+      }
+    }
+  }
+}
+
+// the node side of the first conv layer (K = in_channels <= 8) of a large graph as an output stream (dense.hip)
+int yl_node3_smallk_rows(const NodeUv& a);
+bool yl_node3_smallk_ok(const NodeUv& a);
+int yl_node3_smallk(const NodeUv& a, hipStream_t st);
 // training-mode fusion GEMM with the key64 pooling epilogue on the bf16x6 rows kernel (fusion_x6.hip)
 int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const float* W, const float* bias, long F,
                             const float* sgn, const int* node_seg, unsigned long long* keys, uint16_t* wsplit,

@@ -155,6 +155,38 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
   return 0;
 }
 
+// Node side of the first conv layer of a large graph as an output stream: launcher of common.hpp's node3_smallk_body
+namespace {
+__global__ void __launch_bounds__(256) k_node3_smallk(NodeUv a, int rows_per_wg) {
+  node3_smallk_body(a, blockIdx.x, rows_per_wg);
+}
+bool n3_epi_ok(const Epilogue& e) {
+  if (e.accumulate || e.stats || e.seg || e.pool || e.key64 || e.agg) return false;
+  if ((e.scale == nullptr) != (e.shift == nullptr)) return false;
+  if (e.Yh != nullptr) return e.ldy % 4 == 0 && (((uintptr_t)e.Yh) & 7) == 0;
+  return e.Y != nullptr && e.ldy % 4 == 0 && yl_aligned16(e.Y);
+}
+}  // namespace
+
+// the stream kernel applies (large N, tiny K, C = 64, plain operands, 16-byte aligned outputs)
+bool yl_node3_smallk_ok(const NodeUv& a) {
+  static int min_rows = -1;
+  if (min_rows < 0) { const char* e = getenv("YOLAT_NODE3_SMALLK_MIN_ROWS"); min_rows = e ? atoi(e) : 32768; }
+  return a.C == 64 && a.Cin >= 1 && a.Cin <= N3_KMAX && a.N >= min_rows && !a.af.scale && !a.as.scale &&
+         n3_epi_ok(a.euv) && n3_epi_ok(a.er) && n3_epi_ok(a.en);
+}
+// rows per workgroup: ~8 workgroups per CU; every workgroup re-loads its lanes' 4 x K weights once
+int yl_node3_smallk_rows(const NodeUv& a) {
+  const int rows_per_wg = yl_cdiv(a.N, 2048);
+  return yl_cdiv(rows_per_wg, N3_ROWS) * N3_ROWS;
+}
+int yl_node3_smallk(const NodeUv& a, hipStream_t st) {
+  const int rows_per_wg = yl_node3_smallk_rows(a);
+  hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, rows_per_wg)), dim3(256), 0, st, a, rows_per_wg);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 extern "C" int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* s_in, int64_t ld_s, int64_t N,
                                   int64_t Cin, const float* Wuv, const float* uv_bias, const float* Wr,
                                   const float* br, const float* Wn, const float* bn, const float* sn, const float* tn,
@@ -164,6 +196,7 @@ extern "C" int yolat_node_uv_eval(const float* f_in, int64_t ld_f, const float* 
   const int rc = yl_build_node_uv(&a, f_in, ld_f, s_in, ld_s, N, Cin, Wuv, uv_bias, Wr, br, Wn, bn, sn, tn, C, UV, ld_uv,
                                   f_out, ld_fo, s_out, ld_so);
   if (rc != 0) return rc;
+  if (yl_node3_smallk_ok(a)) return yl_node3_smallk(a, (hipStream_t)stream);
   const dim3 grid(yl_cdiv(N, 64), 4);
   if (Cin <= 16) hipLaunchKernelGGL(k_gemm_nt_node3<16>, grid, dim3(256), 0, (hipStream_t)stream, a);
   else hipLaunchKernelGGL(k_gemm_nt_node3<32>, grid, dim3(256), 0, (hipStream_t)stream, a);

@@ -445,6 +445,16 @@ int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_
     YL_LAUNCH_CHECK();
   }
   const int rows_blocks = yl_cdiv(E > n1 ? E : n1, 256);
+  if (extra != nullptr && yl_node3_smallk_ok(*extra)) {
+    // large graph: the K = in_channels node side is an output stream of its own (common.hpp node3_smallk_body), not tiles
+    // of this launch.  (Riding in the COUNTING launch instead, interleaved with its blocks, was measured: the stream slows
+    // the returning atomics down — fp32 38.8 + 51 us as two launches, 109 us as one; bf16 34.6 + 43.5 vs 75.)
+    hipLaunchKernelGGL(k_prep_rows, dim3(rows_blocks), dim3(256), 0, st, local, btot, (int)N, (int)E, items, src32, dst32,
+                       reinterpret_cast<const float4*>(e_attr), row_ptr, perm, src_csr, dst_csr,
+                       reinterpret_cast<float4*>(attr_csr));
+    YL_LAUNCH_CHECK();
+    return yl_node3_smallk(*extra, st);
+  }
   if (extra != nullptr) {
     const unsigned total = (unsigned)rows_blocks + 4u * (unsigned)yl_cdiv(extra->N, 64);
     if (extra->Cin <= 16)
