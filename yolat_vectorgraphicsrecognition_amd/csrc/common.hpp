@@ -677,63 +677,83 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
 // (UV [N, 128], root [N, 64], node branch [N, 64]; architecture3cc_rpn_gp_iter2.py:110-113 with torch_vertex.py:319-337
 // factorised): with K <= 8 there is nothing for the matrix cores to do, the launch is a 100 - 200 MB output stream.  One
 // wave owns 8 consecutive rows per step, lane = four consecutive output columns with their weights in registers (4 x K
-// fma per row), 16-byte (fp32) / 8-byte (bf16) stores that cover whole cache lines; the next step's inputs are in
-// flight during the stores.  Same epilogue arithmetic as wave_epilogue (bias, scale / shift, ReLU, bf16 = nearest even);
-// the sum over k runs in ascending order.  (The 64x64 MFMA tiles of k_gemm_nt_node3, one load -> LDS -> MFMA -> store
-// chain per 16 KB of output, needed 57 - 65 us at N = 200 k and 80 - 90 us together with the CSR emission they were
-// co-scheduled with; this kernel 51 us fp32 / 43 us bf16 beside a 21 us emission launch.)
+// fma per row), 16-byte (fp32) / 8-byte (bf16) stores that cover whole cache lines.  Same epilogue arithmetic as wave_epilogue (bias, scale / shift, ReLU, bf16 = nearest even);
+// the sum over k runs in ascending order.  Measured at N = 200 k (tools/exp/node3_bench.py): 39 us for the 205 MB of
+// fp32 outputs = 5.3 TB/s, against 6.8 - 7.8 TB/s of a plain fill on this part (tools/exp/stream_bw.py) and 57 - 65 us
+// for the 64x64 MFMA tiles of k_gemm_nt_node3 (one load -> LDS -> MFMA -> store chain per 16 KB of output; 80 - 90 us
+// together with the CSR emission they were co-scheduled with).  With the stores switched off the kernel runs 22 us
+// (its ~44 vector-ALU operations per row), with the FMAs switched off 45: the store stream is the bound.
 // ------------------------------------------------------------------------------------------------
-constexpr int N3_KMAX = 8, N3_ROWS = 32;           // rows per workgroup iteration (4 waves x 8 consecutive rows)
-__device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb, int rows_per_wg) {
-  // per wave: the 8 rows x K inputs of both sources, written by lane (row u = lane / 8, k = lane % 8) and read back as
-  // two uniform-address (broadcast) 16-byte reads per row
-  __shared__ __attribute__((aligned(16))) float xs[4][2][64];
+constexpr int N3_KMAX = 8, N3_ROWS = 32, N3_ITERS = 4;        // 4 waves x 8 consecutive rows per step, steps per workgroup
+__device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
+  // ALL inputs of the workgroup's 128 rows are fetched up front into LDS (lane (row u = lane / 8, k = lane % 8) of the
+  // row's wave; read back as two uniform-address 16-byte reads per row), so that the row loop holds no load: on this
+  // ISA loads and stores share one in-order counter, and a load issued behind the previous step's stores made every
+  // step wait for those stores' acknowledgements (51 -> 44 us).
+  __shared__ __attribute__((aligned(16))) float xs[N3_ITERS][4][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = a.C, Cin = a.Cin, N = a.N;
+  const int r0 = vb * (N3_ROWS * N3_ITERS), r1 = yl_min(r0 + N3_ROWS * N3_ITERS, N);
   const int c4 = 4 * lane;
   const int prob = c4 < 2 * C ? 0 : (c4 < 3 * C ? 1 : 2);
   const int col = prob == 0 ? c4 : (prob == 1 ? c4 - 2 * C : c4 - 3 * C);
-  const float* __restrict__ wp = prob == 0 ? a.wuv.p : (prob == 1 ? a.wr.p : a.wn.p);
-  const long ldw = prob == 0 ? a.wuv.ld : (prob == 1 ? a.wr.ld : a.wn.ld);
-  const float* bias = prob == 0 ? a.euv.bias : (prob == 1 ? a.er.bias : a.en.bias);
-  const float* scale = prob == 0 ? a.euv.scale : (prob == 1 ? a.er.scale : a.en.scale);
-  const float* shift = prob == 0 ? a.euv.shift : (prob == 1 ? a.er.shift : a.en.shift);
   const int relu = prob == 0 ? a.euv.relu : (prob == 1 ? a.er.relu : a.en.relu);
   float* Y = prob == 0 ? a.euv.Y : (prob == 1 ? a.er.Y : a.en.Y);
   unsigned short* Yh = prob == 0 ? a.euv.Yh : (prob == 1 ? a.er.Yh : a.en.Yh);
   const long ldy = prob == 0 ? a.euv.ldy : (prob == 1 ? a.er.ldy : a.en.ldy);
+  const int lu = lane >> 3, lk = lane & 7;
+  float fa[N3_ITERS], sa[N3_ITERS];
+#pragma unroll
+  for (int it = 0; it < N3_ITERS; ++it) {
+    // (clamped addresses + select, here and for the weights below: a load under a condition becomes a branch with
+    // its own wait, and the kernel's start was a chain of ~30 such round trips)
+    const long row = yl_min(r0 + N3_ROWS * it + 8 * wave + lu, N - 1);
+    const int kc = yl_min(lk, Cin - 1);
+    const float f = a.af.p[row * a.af.ld + kc], g = a.as.p[row * a.as.ld + kc];
+    fa[it] = lk < Cin ? f : 0.f;
+    sa[it] = lk < Cin ? g : 0.f;
+  }
+  // the 256 weight rows (5 KB) and per-column constants: one row / one column per thread, through LDS.  (Every lane
+  // fetching its own 4 x K weights straight from memory touched 64 different cache lines per load instruction, in
+  // every one of 1563 workgroups: 44 -> 39 us.)
+  __shared__ __attribute__((aligned(16))) float wl[256][N3_KMAX];
+  __shared__ float cl[3][256];
+  {
+    const int t = threadIdx.x;                              // virtual column t of [UV | root | node branch]
+    const int tp = t < 2 * C ? 0 : (t < 3 * C ? 1 : 2);
+    const int tc = tp == 0 ? t : (tp == 1 ? t - 2 * C : t - 3 * C);
+    const float* __restrict__ twp = tp == 0 ? a.wuv.p : (tp == 1 ? a.wr.p : a.wn.p);
+    const long tld = tp == 0 ? a.wuv.ld : (tp == 1 ? a.wr.ld : a.wn.ld);
+    const float* tb = tp == 0 ? a.euv.bias : (tp == 1 ? a.er.bias : a.en.bias);
+    const float* ts = tp == 0 ? a.euv.scale : (tp == 1 ? a.er.scale : a.en.scale);
+    const float* th = tp == 0 ? a.euv.shift : (tp == 1 ? a.er.shift : a.en.shift);
+    float wr_[N3_KMAX];
+#pragma unroll
+    for (int k = 0; k < N3_KMAX; ++k) wr_[k] = twp[(long)tc * tld + yl_min(k, Cin - 1)];
+    const float vb_ = (tb ? tb : twp)[tb ? tc : 0], vs_ = (ts ? ts : twp)[ts ? tc : 0], vh_ = (ts ? th : twp)[ts ? tc : 0];
+#pragma unroll
+    for (int k = 0; k < N3_KMAX; ++k) wl[t][k] = k < Cin ? wr_[k] : 0.f;
+    cl[0][t] = tb ? vb_ : 0.f;
+    cl[1][t] = ts ? vs_ : 1.f;
+    cl[2][t] = ts ? vh_ : 0.f;
+  }
+#pragma unroll
+  for (int it = 0; it < N3_ITERS; ++it) { xs[it][wave][0][lane] = fa[it]; xs[it][wave][1][lane] = sa[it]; }
+  __syncthreads();
   float w[4][N3_KMAX], b[4], sc[4], sh[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
-#pragma unroll
-    for (int k = 0; k < N3_KMAX; ++k) w[j][k] = k < Cin ? wp[(long)(col + j) * ldw + k] : 0.f;
-    b[j] = bias ? bias[col + j] : 0.f;
-    sc[j] = scale ? scale[col + j] : 1.f;
-    sh[j] = scale ? shift[col + j] : 0.f;
+    const float4 w0 = *reinterpret_cast<const float4*>(&wl[c4 + j][0]), w1 = *reinterpret_cast<const float4*>(&wl[c4 + j][4]);
+    w[j][0] = w0.x; w[j][1] = w0.y; w[j][2] = w0.z; w[j][3] = w0.w;
+    w[j][4] = w1.x; w[j][5] = w1.y; w[j][6] = w1.z; w[j][7] = w1.w;
+    b[j] = cl[0][c4 + j]; sc[j] = cl[1][c4 + j]; sh[j] = cl[2][c4 + j];
   }
   const float floor = relu ? 0.f : -INFINITY;
-  const int r0 = vb * rows_per_wg, r1 = yl_min(r0 + rows_per_wg, N);
-  const int lu = lane >> 3, lk = lane & 7;
-  const bool k_ok = lk < Cin;
-  const float* __restrict__ fp = a.af.p + lk;
-  const float* __restrict__ sp = a.as.p + lk;
-  const long ldf = a.af.ld, lds_ = a.as.ld;
-  float* mine_w0 = &xs[wave][0][lane];
-  float* mine_w1 = &xs[wave][1][lane];
-  const float* mine = xs[wave][prob == 2 ? 1 : 0];
-  int r = r0 + 8 * wave;
-  float fa = 0.f, sa = 0.f;
-  if (r < r1 && k_ok) {
-    const long row = yl_min(r + lu, N - 1);
-    fa = fp[row * ldf]; sa = sp[row * lds_];
-  }
-  for (; r < r1; r += N3_ROWS) {
-    *mine_w0 = fa; *mine_w1 = sa;
-    const int rn = r + N3_ROWS;
-    if (rn < r1 && k_ok) {                       // next iteration's inputs: in flight during this one's stores
-      const long row = yl_min(rn + lu, N - 1);
-      fa = fp[row * ldf]; sa = sp[row * lds_];
-    }
+#pragma unroll 1
+  for (int it = 0; it < N3_ITERS; ++it) {
+    const float* mine = xs[it][wave][prob == 2 ? 1 : 0];
+    const int rb = r0 + N3_ROWS * it + 8 * wave;
+    if (rb >= r1) break;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
       const float4 x0 = *reinterpret_cast<const float4*>(mine + 8 * u);
@@ -747,7 +767,7 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb, int r
         for (int k = 0; k < N3_KMAX; ++k) acc = fmaf(x[k], w[j][k], acc);
         v[j] = fmaxf(fmaf(acc + b[j], sc[j], sh[j]), floor);
       }
-      const int row = r + u;
+      const int row = rb + u;
       if (row < r1) {
         if (Yh != nullptr) {
           uint2 o;

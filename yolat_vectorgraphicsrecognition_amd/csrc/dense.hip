@@ -157,8 +157,8 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
 
 // Node side of the first conv layer of a large graph as an output stream: launcher of common.hpp's node3_smallk_body
 namespace {
-__global__ void __launch_bounds__(256) k_node3_smallk(NodeUv a, int rows_per_wg) {
-  node3_smallk_body(a, blockIdx.x, rows_per_wg);
+__global__ void __launch_bounds__(256) k_node3_smallk(NodeUv a) {
+  node3_smallk_body(a, blockIdx.x);
 }
 bool n3_epi_ok(const Epilogue& e) {
   if (e.accumulate || e.stats || e.seg || e.pool || e.key64 || e.agg) return false;
@@ -175,14 +175,9 @@ bool yl_node3_smallk_ok(const NodeUv& a) {
   return a.C == 64 && a.Cin >= 1 && a.Cin <= N3_KMAX && a.N >= min_rows && !a.af.scale && !a.as.scale &&
          n3_epi_ok(a.euv) && n3_epi_ok(a.er) && n3_epi_ok(a.en);
 }
-// rows per workgroup: ~8 workgroups per CU; every workgroup re-loads its lanes' 4 x K weights once
-int yl_node3_smallk_rows(const NodeUv& a) {
-  const int rows_per_wg = yl_cdiv(a.N, 2048);
-  return yl_cdiv(rows_per_wg, N3_ROWS) * N3_ROWS;
-}
+int yl_node3_smallk_rows(const NodeUv&) { return N3_ROWS * N3_ITERS; }
 int yl_node3_smallk(const NodeUv& a, hipStream_t st) {
-  const int rows_per_wg = yl_node3_smallk_rows(a);
-  hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, rows_per_wg)), dim3(256), 0, st, a, rows_per_wg);
+  hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);
   YL_LAUNCH_CHECK();
   return 0;
 }
