@@ -169,7 +169,7 @@ class SparseCADGCN(nn.Module):
             # one plan (folded weights, workspace, status word) per launch stream: independent forwards
             # issued on different streams overlap on the GPU (no kernel of a 10k-node graph fills 256 CUs)
             plans = self.__dict__.setdefault("_yolat_plans", {})
-            sid = torch.cuda.current_stream().cuda_stream
+            sid = ops._stream()
             plan = plans.get(sid)
             if plan is None:
                 from .plan import EvalPlan

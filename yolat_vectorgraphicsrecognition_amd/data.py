@@ -16,6 +16,7 @@ Mirrors what the reference's callers hand to ``SparseCADGCN.forward(data, slices
 from itertools import product
 
 import ctypes
+import os
 
 import numpy as np
 import torch
@@ -184,6 +185,8 @@ def _item_desc(item, ship):
 
 
 _ZERO_STATUS = {}
+# opt-in: measured 5.86 k -> 6.07 k graphs/s at cfg 2 — the Python stream context costs what the overlap gains
+_COPY_STREAM_ON = os.environ.get("YOLAT_H2D_COPY_STREAM", "0") == "1"
 
 
 def _collate_csr(data_list, device, tkeys, ship, batch, slices):
@@ -208,11 +211,27 @@ def _collate_csr(data_list, device, tkeys, ship, batch, slices):
             break
         pin = _PINNED[("buf", slot)] = torch.empty(int(tot[0] * 1.5), dtype=torch.uint8).pin_memory()
     total, Nt, Et, Pt = int(tot[0]), int(tot[1]), int(tot[2]), int(tot[3])
-    dbuf = torch.empty(total, dtype=torch.uint8, device=device)
-    dbuf.copy_(pin[:total], non_blocking=True)                  # the one H2D copy
     if ev is None:
         ev = _PINNED[("ev", slot)] = torch.cuda.Event()
-    ev.record()
+    if _COPY_STREAM_ON:
+        # YOLAT_H2D_COPY_STREAM=1: the H2D copy on its own stream, so that batch i + 1 crosses PCIe while batch i's forward
+        # runs (on one stream the 1.3 MB copy of cfg 2 — ~65 us with its launch — and the 100 us forward alternate).  The buffer is allocated
+        # in the copy stream's pool and handed to the consumer's stream: record_stream() keeps the allocator from
+        # re-using it before that stream is done with it.
+        cur = ops.current_stream_object()
+        cs = _PINNED.get("copy_stream")
+        if cs is None:
+            cs = _PINNED["copy_stream"] = torch.cuda.Stream(device=device)
+        with torch.cuda.stream(cs):
+            dbuf = torch.empty(total, dtype=torch.uint8, device=device)
+            dbuf.copy_(pin[:total], non_blocking=True)          # the one H2D copy
+            ev.record(cs)
+        cur.wait_event(ev)
+        dbuf.record_stream(cur)
+    else:
+        dbuf = torch.empty(total, dtype=torch.uint8, device=device)
+        dbuf.copy_(pin[:total], non_blocking=True)              # the one H2D copy
+        ev.record(ops.current_stream_object())
     typed = {}
 
     def view(o, dtype, shape):
@@ -232,13 +251,14 @@ def _collate_csr(data_list, device, tkeys, ship, batch, slices):
     # the keys that are not shipped still get their slices (train.py:141-147 builds them for every key)
     for k in tkeys:
         if k not in slices:
-            ends = np.zeros(B + 1, dtype=np.int64)
-            np.cumsum([it[k].shape[0] for it in data_list], out=ends[1:])
-            slices[k] = torch.from_numpy(ends)
-    Ee = max(Et, 1)
-    g = ops.Graph.from_arrays(Nt, Et, Pt, view(off[nk], torch.int32, (Nt + 1,)), view(off[nk + 1], torch.int32, (Ee,)),
-                              view(off[nk + 2], torch.int32, (Ee,)), view(off[nk + 3], torch.float32, (Ee, 4)),
-                              view(off[nk + 4], torch.int32, (Pt + 1,)), view(off[nk + 5], torch.int32, (Nt,)))
+            if B == 1:
+                slices[k] = torch.tensor([0, first[k].shape[0]], dtype=torch.int64)
+            else:
+                ends = np.zeros(B + 1, dtype=np.int64)
+                np.cumsum([it[k].shape[0] for it in data_list], out=ends[1:])
+                slices[k] = torch.from_numpy(ends)
+    # the merged CSR stays six offsets into the device buffer until somebody asks for the arrays (ops.PackedGraph)
+    g = ops.PackedGraph.from_buffer(dbuf, [off[nk + i] for i in range(6)], Nt, Et, Pt)
     batch.__dict__["_yolat_graph"] = g
     batch._device_buffer = dbuf
     return batch, slices

@@ -303,8 +303,7 @@ class EvalPlan(object):
     def _launch_prepared(self, x, g):
         from ._lib import GraphCsr
         N, E, P = g.N, g.E, g.P
-        gc = GraphCsr(g.row_ptr.data_ptr(), g.src.data_ptr(), g.dst.data_ptr(), g.attr.data_ptr(), g.seg_ptr.data_ptr(),
-                      g.node_seg.data_ptr())
+        gc = GraphCsr(*g.device_pointers())
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
         if self._desc_h is not None:
             check(lib.yolat_forward_eval_bf16_csr(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x), ctypes.byref(gc),
