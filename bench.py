@@ -870,8 +870,10 @@ def main():
         for k in ("roots",):
             if hasattr(cpu_item, k):
                 delattr(cpu_item, k)
-        nh = min(args.steps, 100)
-        for _ in range(5):
+        # 200 hand-overs after 20 untimed ones whatever --steps is (30 ms): with the driver's --steps 20 the first
+        # iterations (allocator and pinned-buffer growth, plan for the new stream) were a visible part of the figure
+        nh = 200
+        for _ in range(20):
             b, sl = yv.collate_to_device([cpu_item])
             with torch.no_grad():
                 model(b, sl)
@@ -886,7 +888,7 @@ def main():
         # the same with the item's destination-sorted form cached on the item (data.item_csr: computed once per dataset
         # item by the library's host code) and merged into the batch's by offset-add at collate time (csr=True): the
         # forward skips the COO -> CSR conversion, the staging buffer carries int32 CSR arrays instead of int64 COO
-        for _ in range(5):
+        for _ in range(20):
             b, sl = yv.collate_to_device([cpu_item], csr=True)
             with torch.no_grad():
                 model(b, sl)

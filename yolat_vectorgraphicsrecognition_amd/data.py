@@ -222,10 +222,15 @@ def _collate_csr(data_list, device, tkeys, ship, batch, slices):
         cs = _PINNED.get("copy_stream")
         if cs is None:
             cs = _PINNED["copy_stream"] = torch.cuda.Stream(device=device)
-        with torch.cuda.stream(cs):
+        # (torch.cuda.stream(cs) as a context manager costs ~25 us of Python per use; the two calls it ends in, 2)
+        _set = torch._C._cuda_setStream
+        _set(stream_id=cs.stream_id, device_index=cs.device_index, device_type=cs.device_type)
+        try:
             dbuf = torch.empty(total, dtype=torch.uint8, device=device)
             dbuf.copy_(pin[:total], non_blocking=True)          # the one H2D copy
             ev.record(cs)
+        finally:
+            _set(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
         cur.wait_event(ev)
         dbuf.record_stream(cur)
     else:
