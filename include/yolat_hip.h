@@ -630,6 +630,12 @@ int yolat_forward_eval_bf16(const yolat_model_eval_bf16* m, const float* x, int6
                             int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                             int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                             size_t workspace_bytes, int32_t* status, yolat_stream_t stream);
+/* yolat_forward_eval_bf16 under the contract of yolat_forward_eval_primed (workspace last used by the same call shape on
+ * the same stream: the counter memset is skipped) */
+int yolat_forward_eval_bf16_primed(const yolat_model_eval_bf16* m, const float* x, int64_t ldx, const int64_t* edge,
+                                   int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                                   int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                   size_t workspace_bytes, int32_t* status, yolat_stream_t stream);
 /* the same forward on a prepared device graph (yolat_graph_csr above) */
 int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* m, const float* x, int64_t ldx, const yolat_graph_csr* g,
                                 int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,

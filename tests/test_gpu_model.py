@@ -597,14 +597,16 @@ def test_strict_fp32_switch_runs_the_fp32_mfma_kernels_and_agrees(tmp_path):
     assert float(gb.abs().max()) > 0 and float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
 
 
-def test_primed_workspace_forwards_equal_self_contained_forwards():
+@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+def test_primed_workspace_forwards_equal_self_contained_forwards(precision):
     """plan.EvalPlan skips the memset of the CSR-build counters when its workspace was last used by a forward of the same
-    shape (yolat_forward_eval_primed: every forward leaves the counters zero).  A sequence that repeats and alternates
+    shape (yolat_forward_eval_primed / yolat_forward_eval_bf16_primed: every forward leaves the counters zero).  A sequence that repeats and alternates
     batch shapes on ONE plan must give, bit for bit, what the self-contained calls give; the status word stays clean."""
     import yolat_vectorgraphicsrecognition_amd as yv
     from yolat_vectorgraphicsrecognition_amd import plan as plan_mod
     optkw = dict(n_classes=9, n_blocks=2, n_blocks_out=2)
     model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 5).cuda().eval()
+    model.set_eval_precision(precision)
     batches = [yv.synth_batch(2, 40 + i, num_proposals=25 + 10 * (i % 2), nodes_lo=2, nodes_hi=24, n_classes=9)
                for i in range(3)]
     order = [0, 0, 0, 1, 1, 0, 2, 2, 1, 1, 1]

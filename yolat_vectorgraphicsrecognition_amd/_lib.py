@@ -230,6 +230,8 @@ SIGNATURES = {
     "yolat_forward_eval_bf16_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEvalBf16), c_i64, c_i64, c_i64]),
     "yolat_forward_eval_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_forward_eval_bf16_primed": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
+                                        c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
 }
 
 

@@ -708,7 +708,8 @@ extern "C" size_t yolat_forward_eval_bf16_workspace_bytes(const yolat_model_eval
 static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx, const int64_t* edge,
                                   int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                                   int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
-                                  size_t workspace_bytes, int32_t* status, yolat_stream_t stream, const yolat_graph_csr* g);
+                                  size_t workspace_bytes, int32_t* status, yolat_stream_t stream, const yolat_graph_csr* g,
+                                  bool primed = false);
 
 extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
                                        const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
@@ -717,6 +718,18 @@ extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const fl
                                        yolat_stream_t stream) {
   return forward_eval_bf16_impl(mh, x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, logits, ld_logits,
                                 workspace, workspace_bytes, status, stream, nullptr);
+}
+
+// The same forward for a caller that vouches for the workspace: its previous use was yolat_forward_eval_bf16 /
+// _bf16_primed with the same m layout, N, E and P on the same stream (every forward leaves the CSR-build counters zero,
+// so the memset launch is skipped — the contract of yolat_forward_eval_primed).
+extern "C" int yolat_forward_eval_bf16_primed(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
+                                              const int64_t* edge, int64_t stride_e, int64_t stride_c,
+                                              const float* e_attr, const int64_t* bbox_idx, int64_t N, int64_t E,
+                                              int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                              size_t workspace_bytes, int32_t* status, yolat_stream_t stream) {
+  return forward_eval_bf16_impl(mh, x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, logits, ld_logits,
+                                workspace, workspace_bytes, status, stream, nullptr, true);
 }
 
 extern "C" int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
@@ -734,7 +747,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
                                   int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                                   int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                                   size_t workspace_bytes, int32_t* status, yolat_stream_t stream,
-                                  const yolat_graph_csr* g) {
+                                  const yolat_graph_csr* g, bool primed) {
   if (!x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0) return YOLAT_E_INVALID;
   YL_TRY(model_ok(mh));
   if (N > (1LL << 23) || E > (1LL << 29)) return YOLAT_E_UNSUPPORTED;     // 32-bit element offsets in the gathers
@@ -775,7 +788,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
       YL_LAUNCH_CHECK();
     } else {
     YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
-                                 p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, false, stream));
+                                 p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, primed, stream));
     }
   });
   for (int l = 0; l < m->n_blocks; ++l) {

@@ -318,11 +318,19 @@ class EvalPlan(object):
     def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
         if self._desc_h is not None:
-            check(lib.yolat_forward_eval_bf16(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x),
-                                              ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
-                                              ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
-                                              logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
-                                              self._status.data_ptr(), ops._stream()), "yolat_forward_eval_bf16")
+            stream = ops._stream()
+            capturing = torch.cuda.is_current_stream_capturing()
+            key = (self._ws.data_ptr(), self._desc_key, N, E, P, stream, "bf16")
+            primed = PRIMED_WS and not capturing and self._primed == key
+            self._primed = None
+            fn = lib.yolat_forward_eval_bf16_primed if primed else lib.yolat_forward_eval_bf16
+            check(fn(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x),
+                     ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
+                     ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
+                     logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
+                     self._status.data_ptr(), stream), "yolat_forward_eval_bf16")
+            if not capturing:
+                self._primed = key
             return logits
         # the workspace is this plan's own: when its previous use was a forward of the same shape on the same stream,
         # the CSR-build counters are already zero (yolat_forward_eval_primed: no memset launch).  A hipGraph capture
