@@ -159,9 +159,13 @@ __device__ __forceinline__ void hgemm_tile(const AL& A, const HOp& B, const Epil
     __syncthreads();
   }
   static_assert(TM <= 2 && TN <= 2, "epilogue expansion covers up to 2x2 sub-tiles");
+  // the operand tiles are dead after the loop's closing barrier: every wave stages its stores in its own 4.5 KB of them
+  static_assert(HTileSmem<TM, TN>::elems * 2 >= 4 * 32 * YL_STAGE_LD * 4, "LDS too small for the store staging");
+  float* stage = reinterpret_cast<float*>(smem) + wave * (32 * YL_STAGE_LD);
 #define YL_EPI(i, j)                                                                                                 \
   if constexpr ((i) < TM && (j) < TN)                                                                                \
-    wave_epilogue(acc[i][j], row0 + (wm * TM + (i)) * 32, col0 + (wn * TN + (j)) * 32 + l31, lhi, ep, M, N, pre[i][j]);
+    wave_epilogue(acc[i][j], row0 + (wm * TM + (i)) * 32, col0 + (wn * TN + (j)) * 32 + l31, lhi, ep, M, N, pre[i][j], \
+                  stage);
   YL_EPI(0, 0) YL_EPI(0, 1) YL_EPI(1, 0) YL_EPI(1, 1)
 #undef YL_EPI
 }

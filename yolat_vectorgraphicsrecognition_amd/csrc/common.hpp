@@ -352,8 +352,19 @@ __device__ __forceinline__ void wave_epilogue_segmax(const f32x16& acc, int col,
     atomicMax(reinterpret_cast<int*>(ep.pool + (long)cur_seg * ep.ldpool + col), __float_as_int(cur));
 }
 
+// stage (optional): this wave's private [32][YL_STAGE_LD] fp32 region of LDS (free once the K loop's last barrier has
+// passed).  The plain stores of a full 32 x 32 sub-tile then go row-major through it: every lane writes 16 bytes, one
+// instruction covers 8 rows x 128 bytes (fp32) — instead of 4 bytes per lane and 2 rows x 128 bytes per instruction in
+// the accumulator layout, 4x the store instructions for the same bytes.
+constexpr int YL_STAGE_LD = 36;
+__device__ __forceinline__ bool yl_stage_ok(const Epilogue& ep, int row_base, int col_base, int M, int N) {
+  if (row_base + 32 > M || col_base + 32 > N) return false;
+  if (ep.Yh != nullptr) return ep.ldy % 8 == 0 && (((uintptr_t)ep.Yh) & 15) == 0;
+  return ep.ldy % 4 == 0 && (((uintptr_t)ep.Y) & 15) == 0;
+}
 __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col, int lhi,
-                                              const Epilogue& ep, int M, int N, const EpiPre& pre) {
+                                              const Epilogue& ep, int M, int N, const EpiPre& pre,
+                                              float* stage = nullptr) {
   const bool col_ok = col < N;
   const int cc = col_ok ? col : N - 1;
   if (ep.bias != nullptr) {
@@ -418,6 +429,23 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
     int sgs[16];
     yl_tile_segs(pre.segv, lhi, sgs);
     wave_epilogue_segmax(acc, col, ep, N, pre.sc, pre.sh, sgs);
+    return;
+  }
+  if (ep.Yh != nullptr && stage != nullptr && yl_stage_ok(ep, row_base, col - (int)(threadIdx.x & 31), M, N)) {
+    const int l31s = threadIdx.x & 31, lane = threadIdx.x & 63, col_base = col - l31s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * YL_STAGE_LD + l31s] = fmaxf(fmaf(acc[r], sc, sh), floor);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int chunk = lane + 64 * t, R = chunk >> 2, c = (chunk & 3) * 8;
+      const float4 x0 = *reinterpret_cast<const float4*>(stage + R * YL_STAGE_LD + c);
+      const float4 x1 = *reinterpret_cast<const float4*>(stage + R * YL_STAGE_LD + c + 4);
+      uint4 o;
+      o.x = yl_pack_bf16(x0.x, x0.y); o.y = yl_pack_bf16(x0.z, x0.w);
+      o.z = yl_pack_bf16(x1.x, x1.y); o.w = yl_pack_bf16(x1.z, x1.w);
+      *reinterpret_cast<uint4*>(ep.Yh + (long)(row_base + R) * ep.ldy + col_base + c) = o;
+    }
     return;
   }
   if (ep.Yh != nullptr) {
@@ -490,6 +518,19 @@ __device__ __forceinline__ void wave_epilogue(f32x16 acc, int row_base, int col,
 #pragma unroll
     for (int r = 0; r < 16; ++r) old[r] = 0.f;
   }
+  if (stage != nullptr && yl_stage_ok(ep, row_base, col - (int)(threadIdx.x & 31), M, N)) {
+    const int l31s = threadIdx.x & 31, lane = threadIdx.x & 63, col_base = col - l31s;
+#pragma unroll
+    for (int r = 0; r < 16; ++r)
+      stage[((r & 3) + 8 * (r >> 2) + 4 * lhi) * YL_STAGE_LD + l31s] = fmaxf(fmaf(acc[r], sc, sh), floor) + old[r];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int chunk = lane + 64 * t, R = chunk >> 3, c = (chunk & 7) * 4;
+      *reinterpret_cast<float4*>(ep.Y + (long)(row_base + R) * ep.ldy + col_base + c) =
+          *reinterpret_cast<const float4*>(stage + R * YL_STAGE_LD + c);
+    }
+    return;
+  }
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
@@ -517,7 +558,9 @@ __device__ __forceinline__ void gemm_nt_tile(const AL& A, const BL& B, const Epi
   constexpr int KQ = BK / 4;
   constexpr int NA = (BM * KQ) / 256, NB = (BN * KQ) / 256;   // float4 loads per thread per tile
   static_assert((BM * KQ) % 256 == 0 && (BN * KQ) % 256 == 0, "tile/thread mismatch");
-  __shared__ float smem[(BM + BN) * LD];
+  // (at least the 4 x [32][YL_STAGE_LD] floats of the epilogue's store staging, which re-uses the operand tiles)
+  constexpr int SMEM = (BM + BN) * LD > 4 * 32 * YL_STAGE_LD ? (BM + BN) * LD : 4 * 32 * YL_STAGE_LD;
+  __shared__ __attribute__((aligned(16))) float smem[SMEM];
   float* As = smem;
   float* Bs = smem + BM * LD;
 
@@ -618,7 +661,8 @@ __device__ __forceinline__ void gemm_nt_tile(const AL& A, const BL& B, const Epi
   static_assert(TM <= 2 && TN <= 2, "epilogue expansion covers up to 2x2 sub-tiles");
 #define YL_EPI(i, j)                                                                                              \
   if constexpr ((i) < TM && (j) < TN)                                                                             \
-    wave_epilogue(acc[i][j], row0 + wm * WM + (i) * 32, col0 + wn * WN + (j) * 32 + l31, lhi, ep, M, N, pre[i][j]);
+    wave_epilogue(acc[i][j], row0 + wm * WM + (i) * 32, col0 + wn * WN + (j) * 32 + l31, lhi, ep, M, N, pre[i][j], \
+                  smem + wave * (32 * YL_STAGE_LD));
   YL_EPI(0, 0) YL_EPI(0, 1) YL_EPI(1, 0) YL_EPI(1, 1)
 #undef YL_EPI
 }
