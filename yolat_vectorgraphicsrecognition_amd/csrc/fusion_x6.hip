@@ -85,6 +85,10 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   __shared__ __attribute__((aligned(16))) char smem[SMEM_W > SMEM_T ? SMEM_W : SMEM_T];
   yl_bf16_t (*Ws)[3 * 64 * RS] = reinterpret_cast<yl_bf16_t (*)[3 * 64 * RS]>(smem);
   __shared__ int seg_s[256];
+  constexpr int FX_STG_LD = 36;
+  // per-wave staging tile of the plain-store epilogue — KD = 64 only (node side, training Linear): the KD = 128 kernel
+  // sits at 248 registers and spilled with it
+  __shared__ __attribute__((aligned(16))) float st_s[KD == 64 ? 8 * 32 * FX_STG_LD : 4];
   const int tid = threadIdx.x;
   // the small problem's workgroups come first (padded to a multiple of 8 so that the big problem keeps its
   // id % 8 = XCD alignment): they start with the first round of workgroups instead of forming a tail
@@ -307,6 +311,24 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
       const unsigned long old = (unsigned long)(second ? P.ldo2 : P.ldo);
       const int cb = second ? 64 * P.ct2 : 0;
       const float lo = P.relu ? 0.f : -INFINITY;
+      // full tile, 16-byte aligned rows: the two 32 x 32 blocks go row-major through this wave's staging tile, so that
+      // every lane stores 16 bytes and one instruction covers 8 rows x 128 bytes (in the accumulator layout a store
+      // instruction is 4 bytes per lane, 2 rows x 128 bytes: 4x the instructions for the node side's 205 MB)
+      if (KD == 64 && row0 + 32 <= N && ct * 64 + 64 <= F && (old & 3) == 0 && ((uintptr_t)ob & 15) == 0) {
+        float* stg = st_s + wave * (32 * FX_STG_LD);
+#pragma unroll
+        for (int blk = 0; blk < 2; ++blk) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r)
+            stg[((r & 3) + 8 * (r >> 2) + 4 * lhi) * FX_STG_LD + l31] = fmaxf(blk == 0 ? acc0[r] : acc1[r], lo);
+#pragma unroll
+          for (int t = 0; t < 4; ++t) {
+            const int chunk = lane + 64 * t, R = chunk >> 3, c = (chunk & 7) * 4;
+            *reinterpret_cast<float4*>(ob + (unsigned long)(row0 + R) * old - cb + ct * 64 + 32 * blk + c) =
+                *reinterpret_cast<const float4*>(stg + R * FX_STG_LD + c);
+          }
+        }
+      } else
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const unsigned row = rb + (r & 3) + 8 * (r >> 2);
