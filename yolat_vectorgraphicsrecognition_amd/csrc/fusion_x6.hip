@@ -75,20 +75,26 @@ struct FxProb {
 
 // RIDER = false: the rider argument is never read (an instantiation that reads it keeps more kernel arguments live:
 // 75 -> 121 spilled SGPRs, and the cfg-5 fusion launch went 332 -> 365 us until the two were separated)
+// Threads per workgroup (32 rows per wave).  K = 128 (fusion blocks): 512 threads = 256 rows, one workgroup per CU (248
+// registers, 105 KB of LDS).  K = 64 (node side, training Linear: one to three column tiles per workgroup, store-heavy):
+// 256 threads = 128 rows and 75 KB of LDS, so that TWO workgroups share a CU and one's prologue / stores run under the
+// other's MFMAs.
+template <int KD> struct FxShape { static constexpr int T = KD == 64 ? 256 : 512, ROWS = T / 2; };
 template <int KD, bool RIDER = false>
-__global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1, PoolRider rider) {
+__global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0, FxProb p1, PoolRider rider) {
+  constexpr int T = FxShape<KD>::T, NWAVE = T / 64;
   constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
-  constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / 512;   // 16-byte chunks of one W tile, per thread
-  static_assert(CHUNKS % 512 == 0, "W tile / thread mismatch");
+  constexpr int CHUNKS = 3 * 64 * CPR, NW = CHUNKS / T;     // 16-byte chunks of one W tile, per thread
+  static_assert(CHUNKS % T == 0, "W tile / thread mismatch");
   constexpr int TK = 64, TS = TK + 4;                       // the prologue's transposition tile: [32 rows][TK + 4] floats per wave
-  constexpr int SMEM_W = 2 * 3 * 64 * RS * 2, SMEM_T = 8 * 32 * TS * 4;
+  constexpr int SMEM_W = 2 * 3 * 64 * RS * 2, SMEM_T = NWAVE * 32 * TS * 4;
   __shared__ __attribute__((aligned(16))) char smem[SMEM_W > SMEM_T ? SMEM_W : SMEM_T];
   yl_bf16_t (*Ws)[3 * 64 * RS] = reinterpret_cast<yl_bf16_t (*)[3 * 64 * RS]>(smem);
-  __shared__ int seg_s[256];
+  __shared__ int seg_s[T / 2];
   constexpr int FX_STG_LD = 36;
   // per-wave staging tile of the plain-store epilogue — KD = 64 only (node side, training Linear): the KD = 128 kernel
   // sits at 248 registers and spilled with it
-  __shared__ __attribute__((aligned(16))) float st_s[KD == 64 ? 8 * 32 * FX_STG_LD : 4];
+  __shared__ __attribute__((aligned(16))) float st_s[KD == 64 ? NWAVE * 32 * FX_STG_LD : 4];
   const int tid = threadIdx.x;
   // the small problem's workgroups come first (padded to a multiple of 8 so that the big problem keeps its
   // id % 8 = XCD alignment): they start with the first round of workgroups instead of forming a tail
@@ -98,7 +104,7 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   // pooled rows that nothing in this launch reads)
   if constexpr (RIDER) {
     if (id >= n1p + p0.tm * p0.groups) {
-      yl_pool_rider(rider, id - (n1p + p0.tm * p0.groups), rider.blocks, tid, 512);
+      yl_pool_rider(rider, id - (n1p + p0.tm * p0.groups), rider.blocks, tid, T);
       return;
     }
   }
@@ -148,7 +154,7 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   if (ngl <= 0) return;
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
-  const int row0 = rt * 256 + wave * 32;
+  const int row0 = rt * (T / 2) + wave * 32;
   // ---- this wave's 32 rows of A, split once.  Loaded row by row (a row's 64 floats of the pass = 16 lanes x 16 bytes:
   // whole cache lines per instruction, eight loads in flight) and turned into the MFMA operand order (lane = row, 8
   // consecutive k) through a [32][TK + 4] fp32 tile in LDS — the weights' buffers, not yet in use.  (Reading the operand
@@ -156,7 +162,7 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   // 350 us at N = 200 k: profiles/r03_fusion_x6_ablation.txt.)
   fx_bf16x8 Ah[KS], Am[KS], Al[KS];
   {
-    float* T = reinterpret_cast<float*>(smem) + wave * (32 * TS);
+    float* Tt = reinterpret_cast<float*>(smem) + wave * (32 * TS);
     const int lr = lane >> 4, lc = (lane & 15) * 4;
 #pragma unroll
     for (int q = 0; q < KD / TK; ++q) {
@@ -165,12 +171,12 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
       for (int i = 0; i < 8; ++i)
         v[i] = *reinterpret_cast<const float4*>(A + (long)yl_min(row0 + 4 * i + lr, N - 1) * P.lda + TK * q + lc);
 #pragma unroll
-      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(T + (4 * i + lr) * TS + lc) = v[i];
+      for (int i = 0; i < 8; ++i) *reinterpret_cast<float4*>(Tt + (4 * i + lr) * TS + lc) = v[i];
 #pragma unroll
       for (int u = 0; u < TK / 16; ++u) {
         const int ks = (TK / 16) * q + u;
-        const float4 a0 = *reinterpret_cast<const float4*>(T + l31 * TS + 16 * u + 8 * lhi);
-        const float4 a1 = *reinterpret_cast<const float4*>(T + l31 * TS + 16 * u + 8 * lhi + 4);
+        const float4 a0 = *reinterpret_cast<const float4*>(Tt + l31 * TS + 16 * u + 8 * lhi);
+        const float4 a1 = *reinterpret_cast<const float4*>(Tt + l31 * TS + 16 * u + 8 * lhi + 4);
         float x[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
         if (P.a_scale != nullptr) {
           const float* sp = P.a_scale + 16 * ks + 8 * lhi;
@@ -191,16 +197,16 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
   }
   const int* segs = seg_s + wave * 32;
   const yl_bf16_t* const wparts[3] = {small ? p1.Wh : p0.Wh, small ? p1.Wm : p0.Wm, small ? p1.Wl : p0.Wl};
-  // W tile pieces: thread tid moves 16-byte piece (tid + 512 t) of the [3][64][KD] tile; 64 * CPR is a multiple of
-  // 512, so the part (hi / mid / lo) of piece t is a compile-time constant
-  constexpr int PER = 64 * CPR / 512;                       // pieces per thread and part
-  static_assert((64 * CPR) % 512 == 0, "part boundary inside a thread's pieces");
+  // W tile pieces: thread tid moves 16-byte piece (tid + T t) of the [3][64][KD] tile; 64 * CPR is a multiple of
+  // T, so the part (hi / mid / lo) of piece t is a compile-time constant
+  constexpr int PER = 64 * CPR / T;                         // pieces per thread and part
+  static_assert((64 * CPR) % T == 0, "part boundary inside a thread's pieces");
   const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
   auto load_w = [&](int ct, fx_u32x4* rw) {
 #pragma unroll
     for (int t = 0; t < NW; ++t) {
       const int part = t / PER;
-      const unsigned r = wr0 + (unsigned)(t % PER) * (512 / CPR);
+      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
       rw[t] = *reinterpret_cast<const fx_u32x4*>(wparts[part] + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
     }
   };
@@ -208,7 +214,7 @@ __global__ void __launch_bounds__(512, 2) k_fusion_rows_x6(FxProb p0, FxProb p1,
 #pragma unroll
     for (int t = 0; t < NW; ++t) {
       const int part = t / PER;
-      const unsigned r = wr0 + (unsigned)(t % PER) * (512 / CPR);
+      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
       *reinterpret_cast<fx_u32x4*>(&Ws[buf][part * 64 * RS + r * RS + wk]) = rw[t];
     }
   };
@@ -399,8 +405,9 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
   p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1; p0.key64 = nullptr; p0.sgn = nullptr; p0.a_scale = nullptr; p0.a_shift = nullptr; p0.a_floor = 0.f; p0.stats = nullptr;
   p1.A = S; p1.lda = lds; p1.N = (int)P; p1.Wh = Wsh; p1.Wm = Wsm; p1.Wl = Wsl; p1.tfold = tsfold; p1.seg = nullptr;
   p1.out = Ys; p1.ldo = ldys; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = (int)F; p1.relu = 1; p1.key64 = nullptr; p1.sgn = nullptr; p1.a_scale = nullptr; p1.a_shift = nullptr; p1.a_floor = 0.f; p1.stats = nullptr;
-  p0.tm = yl_cdiv(N, 256);
-  p1.tm = yl_cdiv(P, 256);
+  const int rows_wg = D == 64 ? FxShape<64>::ROWS : FxShape<128>::ROWS, wg_round = D == 64 ? 512 : 256;
+  p0.tm = yl_cdiv(N, rows_wg);
+  p1.tm = yl_cdiv(P, rows_wg);
   p1.groups = tn; p1.ng = 1;
   const long n1 = (((long)p1.tm * tn + 7) & ~7L);
   int best_g = 1;
@@ -408,7 +415,7 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
   for (int g = 1; g <= tn; g *= 2) {
     const int ng = yl_cdiv(tn, g);
     const long wgs = (long)p0.tm * yl_cdiv(tn, ng) + n1;
-    const double cost = (double)((wgs + 255) / 256) * (1.0 + ng);
+    const double cost = (double)((wgs + wg_round - 1) / wg_round) * (1.0 + ng);
     if (cost < best) { best = cost; best_g = g; }
   }
   if (forced > 0) best_g = forced < tn ? forced : tn;
@@ -420,11 +427,11 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (pr.blocks > 0) {
-    if (D == 128) hipLaunchKernelGGL((k_fusion_rows_x6<128, true>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
-    else hipLaunchKernelGGL((k_fusion_rows_x6<64, true>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+    if (D == 128) hipLaunchKernelGGL((k_fusion_rows_x6<128, true>), dim3((unsigned)total), dim3(FxShape<128>::T), 0, st, p0, p1, pr);
+    else hipLaunchKernelGGL((k_fusion_rows_x6<64, true>), dim3((unsigned)total), dim3(FxShape<64>::T), 0, st, p0, p1, pr);
   } else {
-    if (D == 128) hipLaunchKernelGGL((k_fusion_rows_x6<128>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
-    else hipLaunchKernelGGL((k_fusion_rows_x6<64>), dim3((unsigned)total), dim3(512), 0, st, p0, p1, pr);
+    if (D == 128) hipLaunchKernelGGL((k_fusion_rows_x6<128>), dim3((unsigned)total), dim3(FxShape<128>::T), 0, st, p0, p1, pr);
+    else hipLaunchKernelGGL((k_fusion_rows_x6<64>), dim3((unsigned)total), dim3(FxShape<64>::T), 0, st, p0, p1, pr);
   }
   YL_LAUNCH_CHECK();
   return 0;
@@ -458,13 +465,14 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
   p0.out = nullptr; p0.ldo = F; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 0;
   p0.key64 = keys; p0.sgn = sgn;
   p0.a_scale = nullptr; p0.a_shift = nullptr; p0.a_floor = 0.f; p0.stats = nullptr;
-  p0.tm = yl_cdiv(N, 256);
+  const int rows_wg = K == 64 ? FxShape<64>::ROWS : FxShape<128>::ROWS, wg_round = K == 64 ? 512 : 256;
+  p0.tm = yl_cdiv(N, rows_wg);
   int best_g = 1;
   double best = 1e300;
   for (int g = 1; g <= tn; g *= 2) {
     const int ng = yl_cdiv(tn, g);
     const long wgs = (long)p0.tm * yl_cdiv(tn, ng);
-    const double cost = (double)((wgs + 255) / 256) * (1.0 + ng);
+    const double cost = (double)((wgs + wg_round - 1) / wg_round) * (1.0 + ng);
     if (cost < best) { best = cost; best_g = g; }
   }
   p0.ng = yl_cdiv(tn, best_g);
@@ -474,8 +482,8 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
   const long total = (long)p0.tm * p0.groups;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
+  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(FxShape<128>::T), 0, st, p0, p1, PoolRider{});
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(FxShape<64>::T), 0, st, p0, p1, PoolRider{});
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -503,14 +511,14 @@ extern "C" int yolat_linear_fwd_rows_x6(const float* A, int64_t lda, int64_t M, 
   p0.out = Y; p0.ldo = ldy; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)Nout; p0.relu = 0;
   p0.key64 = nullptr; p0.sgn = nullptr;
   p0.a_scale = a_scale; p0.a_shift = a_shift; p0.a_floor = a_relu ? 0.f : -INFINITY; p0.stats = stats;
-  p0.tm = yl_cdiv(M, 256); p0.groups = 1; p0.ng = tn;
+  p0.tm = yl_cdiv(M, K == 64 ? FxShape<64>::ROWS : FxShape<128>::ROWS); p0.groups = 1; p0.ng = tn;
   p1 = p0;
   p1.tm = 0; p1.groups = 1; p1.ng = 1;
   const long total = (long)p0.tm;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
-  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
-  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1, PoolRider{});
+  if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(FxShape<128>::T), 0, st, p0, p1, PoolRider{});
+  else hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(FxShape<64>::T), 0, st, p0, p1, PoolRider{});
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -537,13 +545,13 @@ extern "C" int yolat_node_uv_eval_x6(const float* f_in, int64_t ld_f, const floa
   p0.out = UV; p0.ldo = ld_uv; p0.out2 = f_out; p0.ldo2 = ld_fo; p0.ct2 = 2; p0.F = 192; p0.relu = 0;
   p0.key64 = nullptr; p0.sgn = nullptr; p1.key64 = nullptr; p1.sgn = nullptr;
   p0.a_scale = p0.a_shift = p1.a_scale = p1.a_shift = nullptr; p0.a_floor = p1.a_floor = 0.f; p0.stats = p1.stats = nullptr; p1.a_scale = nullptr; p1.a_shift = nullptr; p1.a_floor = 0.f; p1.stats = nullptr;
-  p0.tm = yl_cdiv(N, 256); p0.groups = 1; p0.ng = 3;
+  p0.tm = yl_cdiv(N, FxShape<64>::ROWS); p0.groups = 1; p0.ng = 3;
   p1.A = s_in; p1.lda = ld_s; p1.N = (int)N; p1.Wh = Wn_h; p1.Wm = Wn_m; p1.Wl = Wn_l; p1.tfold = tn_fold; p1.seg = nullptr;
   p1.out = s_out; p1.ldo = ld_so; p1.out2 = nullptr; p1.ldo2 = 0; p1.ct2 = 1 << 30; p1.F = 64; p1.relu = 1;
-  p1.tm = yl_cdiv(N, 256); p1.groups = 1; p1.ng = 1;
+  p1.tm = yl_cdiv(N, FxShape<64>::ROWS); p1.groups = 1; p1.ng = 1;
   const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L);
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
-  hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(512), 0, (hipStream_t)stream, p0, p1, PoolRider{});
+  hipLaunchKernelGGL(k_fusion_rows_x6<64>, dim3((unsigned)total), dim3(FxShape<64>::T), 0, (hipStream_t)stream, p0, p1, PoolRider{});
   YL_LAUNCH_CHECK();
   return 0;
 }
