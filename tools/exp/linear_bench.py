@@ -15,12 +15,18 @@ def bench(M, K, N, pro, stats):
         ops.linear_fwd(A, W, b, Y, a_pro=(sc, sh) if pro else None, a_relu=pro, stats=st)
     for _ in range(3): run()
     torch.cuda.synchronize()
+    Ad = A.double()
+    if pro:
+        Ad = torch.relu(Ad * sc.double() + sh.double())
+    want = Ad @ W.double().T + b.double()
+    err = float((Y.double() - want).abs().max() / want.abs().max())
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record()
     for _ in range(20): run()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) / 20 * 1e3
     mb = (M * K + M * N) * 4 / 1e6
-    print("ABL=%s M=%d K=%d N=%d pro=%d stats=%d: %.1f us  (%.0f MB -> %.2f TB/s)" % (os.environ.get("YOLAT_GEMM_ABL", "0"), M, K, N, pro, stats, us, mb, mb / us / 1e6 * 1e6 / 1e6))
+    print("rows_gemm=%s M=%d K=%d N=%d pro=%d stats=%d: %.1f us  (%.0f MB -> %.2f TB/s)  max err %.1e"
+          % (os.environ.get("YOLAT_ROWS_GEMM", "1"), M, K, N, pro, stats, us, mb, mb / us, err))
 for M, K, N, pro, stats in ((174512, 64, 64, 0, 0), (174512, 64, 128, 0, 0), (174512, 64, 128, 1, 1), (212511, 64, 64, 1, 1)):
     bench(M, K, N, pro, stats)
