@@ -826,7 +826,6 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
 }
 
 // the node side of the first conv layer (K = in_channels <= 8) of a large graph as an output stream (dense.hip)
-int yl_node3_smallk_rows(const NodeUv& a);
 bool yl_node3_smallk_ok(const NodeUv& a);
 int yl_node3_smallk(const NodeUv& a, hipStream_t st);
 // training-mode fusion GEMM with the key64 pooling epilogue on the bf16x6 rows kernel (fusion_x6.hip)

@@ -175,7 +175,6 @@ bool yl_node3_smallk_ok(const NodeUv& a) {
   return a.C == 64 && a.Cin >= 1 && a.Cin <= N3_KMAX && a.N >= min_rows && !a.af.scale && !a.as.scale &&
          n3_epi_ok(a.euv) && n3_epi_ok(a.er) && n3_epi_ok(a.en);
 }
-int yl_node3_smallk_rows(const NodeUv&) { return N3_ROWS * N3_ITERS; }
 int yl_node3_smallk(const NodeUv& a, hipStream_t st) {
   hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);
   YL_LAUNCH_CHECK();
