@@ -32,6 +32,8 @@
   } while (0)
 
 constexpr int CS_ROWS = 512;    // rows per column-sum workgroup
+constexpr int FB_PROWS = 32;    // proposals per column-partial workgroup (128: one workgroup per CU at P = 8000, 12 KB of loads
+                                // in flight per CU — 64 us for 131 MB)
 constexpr int FB_NG = 256;      // upper bound of the row-block groups (= partial slabs) of the sparse weight gradient
 
 // partial[rb][k] = sum of A[r][k] over the rb-th block of CS_ROWS rows; 64 columns x 4 row lanes per WG
@@ -216,7 +218,7 @@ extern "C" size_t yolat_fusion_pool_train_work_elems(int64_t N, int64_t K, int64
   const size_t wsplit = (3 * (size_t)F * K + 1) / 2 + 8;                      // bf16 split of W (bf16x6 forward GEMM)
   const size_t fwd = colsum + gram + keys + wsplit;
   // backward: GM[P*F] | column partials | sparse-dW partials | small vectors / matrices
-  const size_t bwd = (size_t)P * F + 2 * (size_t)yl_cdiv(P, 128) * F + (size_t)FB_NG * F * K + 4 * F + 2 * K * K +
+  const size_t bwd = (size_t)P * F + 2 * (size_t)yl_cdiv(P, FB_PROWS) * F + (size_t)FB_NG * F * K + 4 * F + 2 * K * K +
                      (size_t)F * K + yolat_linear_bwd_w_work_elems(F, K, K) + 64 + (size_t)F * K + 64;
   return (fwd > bwd ? fwd : bwd) + 64;
 }
@@ -321,7 +323,6 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
 // =================================================================================================
 // backward
 // =================================================================================================
-constexpr int FB_PROWS = 128;   // proposals per column-partial workgroup
 
 // Per column: partial sums over a chunk of proposals of the masked gradient g and g*xhat; GM = scale*g.
 static __global__ void __launch_bounds__(256) k_fus_cols_partial(const float* __restrict__ gZ, long ldg,
@@ -358,15 +359,26 @@ static __global__ void __launch_bounds__(256) k_fus_cols_partial(const float* __
   partial[((long)blockIdx.y * 2 + 1) * F + c] = sx;
 }
 
-static __global__ void k_fus_cols_final(const float* partial, int PB, int F, float invN, const float* coef, float* dgamma,
-                                 float* dbeta, float* dbias, float* q1, float* nq2) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= F) return;
+// 64 columns x 16 chunk lanes per workgroup: lane q sums the chunks q, q + 16, ... (ascending), the sixteen lane sums are
+// added in lane order — fixed order, deterministic
+static __global__ void __launch_bounds__(1024) k_fus_cols_final(const float* partial, int PB, int F, float invN,
+                                                                const float* coef, float* dgamma, float* dbeta, float* dbias,
+                                                                float* q1, float* nq2) {
+  __shared__ float part[2][16][64];
+  const int cx = threadIdx.x & 63, q = threadIdx.x >> 6, c = blockIdx.x * 64 + cx;
   float sg = 0.f, sx = 0.f;
-  for (int b = 0; b < PB; ++b) {
-    sg += partial[((long)b * 2 + 0) * F + c];
-    sx += partial[((long)b * 2 + 1) * F + c];
-  }
+  if (c < F)
+    for (int b = q; b < PB; b += 16) {
+      sg += partial[((long)b * 2 + 0) * F + c];
+      sx += partial[((long)b * 2 + 1) * F + c];
+    }
+  part[0][q][cx] = sg;
+  part[1][q][cx] = sx;
+  __syncthreads();
+  if (q != 0 || c >= F) return;
+  sg = 0.f; sx = 0.f;
+#pragma unroll
+  for (int j = 0; j < 16; ++j) { sg += part[0][j][cx]; sx += part[1][j][cx]; }
   dbeta[c] = sg;
   dgamma[c] = sx;
   if (dbias) dbias[c] = 0.f;
@@ -785,7 +797,7 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
   hipLaunchKernelGGL(k_fus_cols_partial, dim3(yl_cdiv(F, 256), PB), dim3(256), 0, st, gZ, (long)ldg, sv.zstar, sv.arg,
                      (long)P, (int)F, (int)N, coef, GM, colpart);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_fus_cols_final, dim3(yl_cdiv(F, 64)), dim3(64), 0, st, colpart, PB, (int)F, 1.f / (float)N, coef,
+  hipLaunchKernelGGL(k_fus_cols_final, dim3(yl_cdiv(F, 64)), dim3(1024), 0, st, colpart, PB, (int)F, 1.f / (float)N, coef,
                      dgamma, dbeta, dbias, q1, nq2);
   YL_LAUNCH_CHECK();
   // 2. weight gradient: sparse gather term + the two rank-structured dense terms
