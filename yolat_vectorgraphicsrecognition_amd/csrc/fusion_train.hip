@@ -32,8 +32,14 @@
   } while (0)
 
 constexpr int CS_ROWS = 512;    // rows per column-sum workgroup
+constexpr int FB_GRAM_S = 512;  // row slabs (= partial products) of the centered Gram matrix
 constexpr int FB_PROWS = 32;    // proposals per column-partial workgroup (128: one workgroup per CU at P = 8000, 12 KB of loads
                                 // in flight per CU — 64 us for 131 MB)
+// partial area of the Gram stage: the TN GEMM's plan or FB_GRAM_S slabs of K x K
+static inline size_t fus_gram_elems(int64_t N, int64_t K) {
+  const size_t a = yolat_linear_bwd_w_work_elems(N, K, K), b = (size_t)FB_GRAM_S * K * K;
+  return a > b ? a : b;
+}
 constexpr int FB_NG = 256;      // upper bound of the row-block groups (= partial slabs) of the sparse weight gradient
 
 // partial[rb][k] = sum of A[r][k] over the rb-th block of CS_ROWS rows; 64 columns x 4 row lanes per WG
@@ -213,7 +219,7 @@ extern "C" size_t yolat_fusion_pool_train_saved_elems(int64_t K, int64_t F, int6
 
 extern "C" size_t yolat_fusion_pool_train_work_elems(int64_t N, int64_t K, int64_t F, int64_t P) {
   const size_t colsum = (size_t)yl_cdiv(N, CS_ROWS) * K;
-  const size_t gram = yolat_linear_bwd_w_work_elems(N, K, K);
+  const size_t gram = fus_gram_elems(N, K);
   const size_t keys = 2 * (size_t)P * F + 4;                                  // 64-bit keys
   const size_t wsplit = (3 * (size_t)F * K + 1) / 2 + 8;                      // bf16 split of W (bf16x6 forward GEMM)
   const size_t fwd = colsum + gram + keys + wsplit;
@@ -239,7 +245,7 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
   float* colpart = work;
   float* grampart = colpart + (size_t)yl_cdiv(N, CS_ROWS) * K;
   unsigned long long* keys =
-      reinterpret_cast<unsigned long long*>(grampart + (yolat_linear_bwd_w_work_elems(N, K, K) + 1) / 2 * 2);
+      reinterpret_cast<unsigned long long*>(grampart + (fus_gram_elems(N, K) + 1) / 2 * 2);
   if (((uintptr_t)keys & 7) != 0) keys = reinterpret_cast<unsigned long long*>((char*)keys + 4);
 
   // 1. column sums of A (fixed-order two-level reduction)
@@ -259,10 +265,10 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
     // 32 rows and feeds 64 MFMAs per wave between barriers; the generic TN GEMM — 64 x 64 output tiles, 16 MFMAs per
     // wave and stage — was latency bound: 234 us at N = 174 k)
     int S = (int)yl_cdiv(N, 32 * 8);                    // >= 256 rows per workgroup
-    if (S > 256) S = 256;                               // one workgroup per CU; fits the TN GEMM's partial area
+    if (S > FB_GRAM_S) S = FB_GRAM_S;                   // two workgroups per CU: one's loads under the other's MFMAs (66 -> 4x us)
     const int rows_per = (int)yl_cdiv(yl_cdiv(N, S), 32) * 32;
     S = (int)yl_cdiv(N, rows_per);
-    if ((size_t)S * K * K > yolat_linear_bwd_w_work_elems(N, K, K)) return YOLAT_E_INVALID;
+    if ((size_t)S * K * K > fus_gram_elems(N, K)) return YOLAT_E_INVALID;
     hipLaunchKernelGGL(k_gram128, dim3(S), dim3(256), 0, st, A, (long)lda, (long)N, sv.negmean, rows_per, grampart);
     YL_LAUNCH_CHECK();
     hipLaunchKernelGGL(k_reduce_splits, dim3(yl_cdiv(K * K, 32)), dim3(256), 0, st, grampart, (long)(K * K), S, sv.G,
