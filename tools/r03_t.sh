@@ -10,4 +10,4 @@ timeout 600 rocprofv3 --kernel-trace --stats -d $R/gpurun_out/$n --output-format
 f=$(find $R/gpurun_out/$n -name "*.db" | head -1)
 python $R/tools/rocpd_stats.py $f > $R/gpurun_out/$n.txt
 rm -rf $R/gpurun_out/$n
-grep "k_reduce_slabs\|k_fusion_bn_stats\|dispatches" $R/gpurun_out/$n.txt | cut -c1-150
+grep "k_bn_merge\|k_bn_finalize\|dispatches" $R/gpurun_out/$n.txt | cut -c1-150

@@ -328,21 +328,26 @@ extern "C" int yolat_linear_bwd_w_h(const uint16_t* dY, int64_t lddy, int64_t M,
 }
 
 // ------------------------------------------------------------------------------------------------
-// BatchNorm1d statistics (training mode): Chan merge of the 32-row (sum, M2) partials in fp64.
-// Level 1: workgroup g merges a contiguous range of row groups (64 columns x 16 partitions per
-// workgroup) into one (n, mean, M2) triple per column.  Level 2: one workgroup merges the level-1
-// triples in order and emits mean / invstd / scale / shift and the running-stat update.
-// Every merge order is fixed => deterministic.
+// BatchNorm1d statistics (training mode) from the 32-row (sum, M2-about-the-group-mean) partials the GEMM epilogues
+// write, reduced in fp64.  Level 1: workgroup g reduces a contiguous range of row groups (64 columns x 16 partitions per
+// workgroup) to one triple per column.  Level 2: one workgroup adds the level-1 triples in order and emits mean / invstd /
+// scale / shift and the running-stat update.  Every summation order is fixed => deterministic.
+// The triple is (n, S = sum x, R = sum x^2) with the group's contribution to R = M2_g + S_g^2 / cnt_g, so that reducing
+// is three fp64 additions per partial; M2 = R - S^2 / n once at the end.  (The pairwise Chan update it replaces needs
+// three fp64 divisions per merge, ~1200 cycles each on this part: a chain of 31 of them made every BatchNorm finalize a
+// 9 - 15 us launch.)  In fp64 the cancellation in R - S^2 / n costs a relative error of the variance of about
+// 2^-53 (1 + mean^2 / var): below fp32 resolution unless |mean| > 10^4 standard deviations.
 // ------------------------------------------------------------------------------------------------
 #define BN_L1_MAX 128
 struct Chan { double n, mean, m2; };
-__device__ __forceinline__ void chan_merge(Chan& a, double nb, double mb, double m2b) {
-  if (nb == 0.0) return;
-  const double delta = mb - a.mean;
-  const double tot = a.n + nb;
-  a.mean += delta * (nb / tot);
-  a.m2 += m2b + delta * delta * (a.n * nb / tot);
-  a.n = tot;
+// (n, S, R = sum x^2) -> (n, mean, M2)
+__device__ __forceinline__ Chan bn_chan(double n, double S, double R) {
+  Chan a;
+  a.n = n;
+  a.mean = n > 0.0 ? S / n : 0.0;
+  const double m2 = R - S * a.mean;
+  a.m2 = m2 > 0.0 ? m2 : 0.0;
+  return a;
 }
 
 __device__ __forceinline__ void bn_emit(const Chan& a, int c, const float* gamma, const float* beta, float* running_mean,
@@ -381,31 +386,41 @@ __global__ void __launch_bounds__(1024) k_bn_merge_l1(const float2* stats, long 
   const long per = (g1 - g0 + 15) / 16;
   long b0 = g0 + part * per, b1 = b0 + per;
   if (b1 > g1) b1 = g1;
-  Chan a; a.n = 0.0; a.mean = 0.0; a.m2 = 0.0;
+  double an = 0.0, as = 0.0, ar = 0.0;
   if (c < C) {
-    for (long b = b0; b < b1; ++b) {
-      const float2 t = stats[b * C + c];
-      long cnt = M - b * 32;
-      if (cnt > 32) cnt = 32;
-      chan_merge(a, (double)cnt, (double)t.x / (double)cnt, (double)t.y);
+    for (long b = b0; b < b1; b += 8) {                     // 8 loads in flight, added in order
+      float2 t[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) t[k] = stats[(b + k < b1 ? b + k : b1 - 1) * C + c];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (b + k < b1) {
+          long cnt = M - (b + k) * 32;
+          if (cnt > 32) cnt = 32;
+          const double sg = (double)t[k].x;
+          an += (double)cnt;
+          as += sg;
+          ar += (double)t[k].y + (cnt == 32 ? sg * sg * 0.03125 : sg * sg / (double)cnt);
+        }
+      }
     }
   }
-  s_n[part][cl] = a.n; s_mean[part][cl] = a.mean; s_m2[part][cl] = a.m2;
+  s_n[part][cl] = an; s_mean[part][cl] = as; s_m2[part][cl] = ar;
   __syncthreads();
   if (part == 0 && c < C) {
-    for (int p = 1; p < 16; ++p) chan_merge(a, s_n[p][cl], s_mean[p][cl], s_m2[p][cl]);
+    for (int p = 1; p < 16; ++p) { an += s_n[p][cl]; as += s_mean[p][cl]; ar += s_m2[p][cl]; }
     if (FINAL) {
-      bn_emit(a, c, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+      bn_emit(bn_chan(an, as, ar), c, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale,
+              shift);
     } else {
       double* o = l1 + ((long)blockIdx.y * C + c) * 3;
-      o[0] = a.n; o[1] = a.mean; o[2] = a.m2;
+      o[0] = an; o[1] = as; o[2] = ar;
     }
   }
 }
 
-// 64 columns x 16 partitions per workgroup: partition p merges a contiguous range of the level-1 triples in order,
-// partition 0 then merges the 16 partials in order (a single thread per column walked up to 128 triples, two fp64
-// divisions each: 35 us of pure latency per BatchNorm at E = 1.2 M)
+// 64 columns x 16 partitions per workgroup: partition p adds a contiguous range of the level-1 triples in order,
+// partition 0 then adds the 16 partials in order
 __global__ void __launch_bounds__(1024) k_bn_finalize_l2(const double* l1, int G, int C, const float* gamma,
                                                          const float* beta, float* running_mean, float* running_var,
                                                          float momentum, float eps, float* save_mean,
@@ -415,18 +430,25 @@ __global__ void __launch_bounds__(1024) k_bn_finalize_l2(const double* l1, int G
   const int c = blockIdx.x * 64 + cl;
   const int per = (G + 15) / 16;
   const int g0 = part * per, g1 = yl_min(G, g0 + per);
-  Chan a; a.n = 0.0; a.mean = 0.0; a.m2 = 0.0;
+  double an = 0.0, as = 0.0, ar = 0.0;
   if (c < C) {
-    for (int g = g0; g < g1; ++g) {
-      const double* o = l1 + ((long)g * C + c) * 3;
-      chan_merge(a, o[0], o[1], o[2]);
+    for (int g = g0; g < g1; g += 4) {                       // 12 loads in flight, added in order
+      double v[4][3];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        const double* o = l1 + ((long)(g + k < g1 ? g + k : g1 - 1) * C + c) * 3;
+        v[k][0] = o[0]; v[k][1] = o[1]; v[k][2] = o[2];
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (g + k < g1) { an += v[k][0]; as += v[k][1]; ar += v[k][2]; }
     }
   }
-  s_n[part][cl] = a.n; s_mean[part][cl] = a.mean; s_m2[part][cl] = a.m2;
+  s_n[part][cl] = an; s_mean[part][cl] = as; s_m2[part][cl] = ar;
   __syncthreads();
   if (part != 0 || c >= C) return;
-  for (int p = 1; p < 16; ++p) chan_merge(a, s_n[p][cl], s_mean[p][cl], s_m2[p][cl]);
-  bn_emit(a, c, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
+  for (int p = 1; p < 16; ++p) { an += s_n[p][cl]; as += s_mean[p][cl]; ar += s_m2[p][cl]; }
+  bn_emit(bn_chan(an, as, ar), c, gamma, beta, running_mean, running_var, momentum, eps, save_mean, save_invstd, scale, shift);
 }
 
 static inline void bn_l1_plan(long M, long* nb, long* G, long* per_wg) {
