@@ -193,6 +193,34 @@ def test_linear_stats_and_bn_finalize(M, C, K):
     close(bn_d.running_var, ref_bn.running_var, msg="running_var")
 
 
+@pytest.mark.parametrize("M,mean,std", [(70000, 300.0, 0.02), (8000, -50.0, 1e-3), (300000, 0.0, 5.0), (33, 1e3, 0.1)])
+def test_bn_finalize_offset_data(M, mean, std):
+    """The BatchNorm statistics are reduced as (n, sum, sum of squares) in fp64 (dense.hip: the per-32-row partials carry M2
+    about their own group mean, so only the between-group part meets the cancellation in R - S^2 / n): columns whose mean
+    is up to 5e4 standard deviations away from zero must still give the batch variance to fp32 accuracy, on both reduction
+    levels (M > 8192 rows) and on the single-level path."""
+    yv = _yv()
+    C = 64
+    g = torch.Generator().manual_seed(M)
+    cols = torch.linspace(0.5, 1.5, C)
+    Y0 = (torch.randn(M, C, generator=g, dtype=torch.float64) * (std * cols) + mean * cols).float()
+    eye = torch.eye(C).cuda()
+    bn = torch.nn.BatchNorm1d(C).cuda()
+    Y = torch.empty(M, C).cuda()
+    stats = yv.ops.stats_buffer(M, C, "cuda")
+    yv.ops.linear_fwd(Y0.cuda(), eye, None, Y, stats=stats)            # Y = Y0 exactly; the epilogue writes the partials
+    assert torch.equal(Y.cpu(), Y0)
+    coef = torch.empty(4, C).cuda()
+    yv.ops.bn_finalize(stats, M, bn, coef[0], coef[1], coef[2], coef[3])
+    yd = Y0.double()
+    want_mean = yd.mean(0)
+    want_var = yd.var(0, unbiased=False)
+    got_var = 1.0 / coef[3].double().cpu() ** 2 - 1e-5
+    assert float(((coef[2].double().cpu() - want_mean).abs() / (want_mean.abs() + want_var.sqrt())).max()) <= 2e-7
+    # fp32 partials (M2 of 32 rows about their group mean) bound the accuracy, not the fp64 reduction
+    assert float(((got_var - want_var).abs() / (want_var + 1e-5)).max()) <= 2e-3
+
+
 def test_bn_eval_coeffs():
     yv = _yv()
     bn = torch.nn.BatchNorm1d(70)
