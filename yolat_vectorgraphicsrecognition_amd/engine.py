@@ -80,9 +80,14 @@ class GradSink(object):
 # BatchNorm coefficient helpers
 # ---------------------------------------------------------------------------------------------
 
-def _bn_train(stats, M, bn, dev):
+def _bn_train(stats, M, bn, dev, coef_out=None):
+    """Returns the four coefficient vectors (scale, shift, mean, invstd), indexable 0..3.  ``coef_out`` = (scale, shift)
+    destinations the caller wants them in (slices of a wider vector: the concatenated prologue of the per-proposal mean
+    over the node branches) — written there directly instead of copied afterwards."""
     C = bn.num_features
     coef = torch.empty(4, C, dtype=torch.float32, device=dev)   # scale, shift, mean, invstd
+    if coef_out is not None:
+        coef = (coef_out[0], coef_out[1], coef[2], coef[3])
     ops.bn_finalize(stats, M, bn, coef[0], coef[1], coef[2], coef[3])
     if bn.num_batches_tracked is not None:
         _PENDING_NBT.append(bn.num_batches_tracked)
@@ -118,7 +123,7 @@ def _bn_eval(bn, dev):
 # Linear (+ BatchNorm1d + ReLU)
 # ---------------------------------------------------------------------------------------------
 
-def lbr_fwd(a, lin, bn, relu, training, out=None):
+def lbr_fwd(a, lin, bn, relu, training, out=None, coef_out=None):
     """a: Lazy input [M,K].  Returns (Lazy output, saved).  ``out`` optionally names the [M,C]
     destination (may be a column slice of a wider buffer)."""
     A = a.t
@@ -134,7 +139,7 @@ def lbr_fwd(a, lin, bn, relu, training, out=None):
             raise ValueError("BatchNorm1d in training mode needs at least one row")
         stats = ops.stats_buffer(M, C, dev)
         ops.linear_fwd(A, lin.weight, lin.bias, y, a_pro=a.pro, a_relu=a.relu, stats=stats)
-        coef = _bn_train(stats, M, bn, dev)
+        coef = _bn_train(stats, M, bn, dev, coef_out)
         sv["coef"] = coef
         return Lazy(y, coef[0], coef[1], relu), sv
     coef = _bn_eval(bn, dev)
@@ -197,7 +202,7 @@ def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inp
 FUSED_BN_CSR_BWD = os.environ.get("YOLAT_FUSED_BN_CSR_BWD", "1") != "0"
 
 
-def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False):
+def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False, node_coef_out=None):
     """x [N,Cin] materialised; xn Lazy [N,Cin]; out_f / out_s: [N,C] destinations (or None).
     Returns (f tensor, s Lazy, saved)."""
     nn0, bn1, nn3, bn4 = conv.nn[0], conv.nn[1], conv.nn[3], conv.nn[4]
@@ -234,7 +239,7 @@ def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False):
             ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, o_pro=(c1[0], c1[1]), o_relu=True)
             ops.linear_fwd(H1, nn3.weight, nn3.bias, H2, o_pro=(c2[0], c2[1]), o_relu=True)
             ops.csr_mean_fwd(H2, g, out_f, accumulate=True)
-    s, sv_n = lbr_fwd(xn, conv.mlp_node[0], conv.mlp_node[1], True, training, out=out_s)
+    s, sv_n = lbr_fwd(xn, conv.mlp_node[0], conv.mlp_node[1], True, training, out=out_s, coef_out=node_coef_out)
     sv["node"] = sv_n
     return out_f, s, sv
 
@@ -339,10 +344,10 @@ def model_fwd(model, g, x, training):
         slot = l - lo
         of = feats[:, slot * C:(slot + 1) * C] if slot >= 0 else None
         os_ = fsup[:, slot * C:(slot + 1) * C] if slot >= 0 else None
-        f, s, sv_c = conv_fwd(conv, g, f, s, of, os_, training, half=training and half)
-        if training and slot >= 0:
-            sup_coef[0, slot * C:(slot + 1) * C].copy_(s.scale)
-            sup_coef[1, slot * C:(slot + 1) * C].copy_(s.shift)
+        # the node branch's BatchNorm coefficients of an output layer land in their slice of sup_coef (no copies)
+        nco = ((sup_coef[0, slot * C:(slot + 1) * C], sup_coef[1, slot * C:(slot + 1) * C])
+               if training and slot >= 0 else None)
+        f, s, sv_c = conv_fwd(conv, g, f, s, of, os_, training, half=training and half, node_coef_out=nco)
         sv["convs"].append(sv_c)
 
     Z = _empty(P, 2 * (F + D), dev)     # [max(fusion) | max(feats) | fusion_super | mean(sup)]  (arch:127)

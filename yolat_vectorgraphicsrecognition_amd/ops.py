@@ -239,14 +239,19 @@ def build_graph(edge, e_attr, bbox_idx, num_nodes, num_proposals):
     g.perm = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     g.src = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
     g.dst = torch.empty(max(E, 1), dtype=torch.int32, device=dev)
-    g.status = torch.zeros(1, dtype=torch.int32, device=dev)
     g.attr = torch.empty(max(E, 1), 4, dtype=torch.float32, device=dev)
     g.seg_ptr = g.node_seg = None
     if bbox_idx is not None:
         # zero-initialised: with a malformed (unsorted) bbox_idx the kernels flag STATUS_SEG_UNSORTED and the
-        # pointers stay inside [0, N] whatever the write order, so every downstream kernel is memory-safe
-        g.seg_ptr = torch.zeros(P + 1, dtype=torch.int32, device=dev)
-        g.node_seg = torch.zeros(max(N, 1), dtype=torch.int32, device=dev)
+        # pointers stay inside [0, N] whatever the write order, so every downstream kernel is memory-safe.
+        # (status word, segment pointers and node segments as slices of ONE zeroed buffer: one fill, not three)
+        n_seg = (P + 1 + 3) // 4 * 4
+        z = torch.zeros(4 + n_seg + max(N, 1), dtype=torch.int32, device=dev)
+        g.status = z[0:1]
+        g.seg_ptr = z[4:4 + P + 1]
+        g.node_seg = z[4 + n_seg:4 + n_seg + max(N, 1)]
+    else:
+        g.status = torch.zeros(1, dtype=torch.int32, device=dev)
     if E > 0:
         if e_attr.shape[0] != E or e_attr.shape[1] != 4:
             raise ValueError("e_attr must be [E,4]")
