@@ -86,7 +86,7 @@ class _ModelFn(torch.autograd.Function):
             raise RuntimeError("backward through an eval-mode SparseCADGCN is not supported by the HIP path")
         model = ctx.model
         flat = getattr(model, "_yolat_flat", None)
-        dl = dlogits.contiguous().clone()
+        dl = dlogits.contiguous()          # read only: the logits layer has no BatchNorm, nothing below writes into it
         sv, g, params = ctx.sv, ctx.g, ctx.params
         ctx.released = True
         ctx.sv = ctx.g = None           # one backward per forward (as retain_graph=False means): release the activations now
