@@ -129,12 +129,12 @@ __global__ void __launch_bounds__(1024) k_bn_csr_finalize(const float2* part, lo
   if (b1 > nb) b1 = nb;
   double a = 0.0, b = 0.0;
   if (c < C)
-    for (long i = b0; i < b1; i += 8) {
-      float2 t[8];
+    for (long i = b0; i < b1; i += 16) {                    // 16 loads in flight (E = 1.2 M: 147 partials per partition)
+      float2 t[16];
 #pragma unroll
-      for (int k = 0; k < 8; ++k) t[k] = part[(i + k < b1 ? i + k : b1 - 1) * C + c];
+      for (int k = 0; k < 16; ++k) t[k] = part[(i + k < b1 ? i + k : b1 - 1) * C + c];
 #pragma unroll
-      for (int k = 0; k < 8; ++k)
+      for (int k = 0; k < 16; ++k)
         if (i + k < b1) { a += (double)t[k].x; b += (double)t[k].y; }
     }
   s1s[p][cl] = a; s2s[p][cl] = b;
