@@ -597,6 +597,38 @@ def test_strict_fp32_switch_runs_the_fp32_mfma_kernels_and_agrees(tmp_path):
     assert float(gb.abs().max()) > 0 and float((ga - gb).abs().max()) <= 1e-4 * float(gb.abs().max())
 
 
+def test_weight_gradients_on_the_side_stream_are_bit_identical():
+    """engine._on_side: the weight gradients of the Linears run on a second stream beside the input-gradient chain
+    (ordered by events, inputs kept alive with record_stream, joined before the gradient exchange / the end of the
+    backward).  Same kernels on the same data: losses and every gradient must equal the single-stream step bit for bit,
+    over several steps and batch shapes (the allocator recycles blocks between them)."""
+    import yolat_vectorgraphicsrecognition_amd as yv
+    from yolat_vectorgraphicsrecognition_amd import engine
+    batches = [yv.synth_batch(2, 70 + i, num_proposals=40 + 25 * i, nodes_lo=3, nodes_hi=30, edge_factor=1.4, augmented=True)
+               for i in range(3)]
+
+    def run(side):
+        old = engine.SIDE_STREAM
+        engine.SIDE_STREAM = side
+        try:
+            model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 11).cuda()
+            tr = yv.Trainer(model, yv.Opt(), lr=1e-3, weight_decay=1e-5)
+            out = []
+            for i in (0, 1, 2, 1, 0, 2):
+                data, slices = batches[i]
+                data._yolat_stage = None
+                loss = float(tr.step(data, slices))
+                out.append((loss, tr.flat.grad.clone()))
+            torch.cuda.synchronize()
+            return out, tr.flat.param.clone()
+        finally:
+            engine.SIDE_STREAM = old
+    (a, pa), (b, pb) = run(False), run(True)
+    for (la, ga), (lb, gb) in zip(a, b):
+        assert la == lb and torch.equal(ga, gb)
+    assert torch.equal(pa, pb)
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_primed_workspace_forwards_equal_self_contained_forwards(precision):
     """plan.EvalPlan skips the memset of the CSR-build counters when its workspace was last used by a forward of the same

@@ -171,6 +171,49 @@ def _drop_p(mlp):
     return float(last.p) if last.__class__.__name__.startswith("Dropout") else 0.0
 
 
+# ---------------------------------------------------------------------------------------------
+# Weight gradients on a second stream
+# ---------------------------------------------------------------------------------------------
+# In a Linear's backward dW = dY^T . A and dX = dY . W depend on the same dY and on nothing of each other, and nothing
+# in the rest of the backward reads dW: it is only consumed by the gradient exchange / Adam.  Both are tall-skinny
+# launches far from saturating the chip, so dW goes to a side stream — ordered after everything issued
+# so far on the current stream by an event — and runs beside the dX chain; the streams join before the first consumer
+# (model_bwd: the head bucket's all-reduce, the end of the backward).  Tensors handed to the side stream are marked
+# with record_stream so that the caching allocator does not recycle them while it still reads them.
+SIDE_STREAM = os.environ.get("YOLAT_BWD_SIDE_STREAM", "1") != "0"
+_SIDE = {}
+
+
+def _on_side(fn, keep):
+    if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
+        return fn()
+    cur = ops.current_stream_object()
+    ent = _SIDE.get(cur.device_index)
+    if ent is None:
+        ent = _SIDE[cur.device_index] = {"stream": torch.cuda.Stream(device=cur.device), "dirty": False}
+    side = ent["stream"]
+    side.wait_stream(cur)
+    _set = torch._C._cuda_setStream
+    _set(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
+    try:
+        fn()
+    finally:
+        _set(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
+    for t in keep:
+        if t is not None:
+            t.record_stream(side)
+    ent["dirty"] = True
+
+
+def _join_side():
+    """The current stream waits for the weight-gradient work issued so far."""
+    cur = ops.current_stream_object()
+    ent = _SIDE.get(cur.device_index)
+    if ent is not None and ent["dirty"]:
+        cur.wait_stream(ent["stream"])
+        ent["dirty"] = False
+
+
 def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inplace=True):
     """dz: gradient w.r.t. the block's (post-activation) output [M,C].  Writes parameter gradients
     into ``sink``; returns the gradient w.r.t. the block's *post-prologue* input (i.e. w.r.t. the
@@ -187,7 +230,8 @@ def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inp
             raise NotImplementedError("Linear+ReLU without BatchNorm is not on the reference path")
         dy = dz
     db = sink.get(lin.bias) if lin.bias is not None else None
-    ops.linear_bwd_w(dy, a.t, sink.get(lin.weight), db, a_pro=a.pro, a_relu=a.relu)
+    dW = sink.get(lin.weight)
+    _on_side(lambda: ops.linear_bwd_w(dy, a.t, dW, db, a_pro=a.pro, a_relu=a.relu), (dy, a.t, a.scale, a.shift))
     if not need_dx:
         return None
     dx = _empty(M, lin.in_features, dev) if dx_out is None else dx_out
@@ -256,7 +300,8 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
     # node branch
     dxn = lbr_bwd(sv["node"], d_s, sink, dx_out=dxn, dx_accumulate=dxn_acc, need_dx=need_dx)
     # root term
-    ops.linear_bwd_w(d_f, x, sink.get(conv.lin_r.weight), sink.get(conv.lin_r.bias))
+    dWr, dbr = sink.get(conv.lin_r.weight), sink.get(conv.lin_r.bias)
+    _on_side(lambda: ops.linear_bwd_w(d_f, x, dWr, dbr), (d_f, x))
     if need_dx:
         dx = _empty(N, Cin, dev) if dx is None else dx
         ops.linear_fwd_wt(d_f, conv.lin_r.weight, dx, accumulate=dx_acc)
@@ -422,6 +467,7 @@ def model_bwd(model, g, sv, dlogits, sink):
         ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)
         lbr_bwd(sv["fus"], d_fus, sink, dx_out=d_feats, dx_accumulate=True)
     if sink.on_head_done is not None:
+        _join_side()                                                  # the head bucket's gradients are complete
         sink.on_head_done()
     # conv layers, last to first
     d_f_next, d_s_next = None, None      # grads flowing into layer l's outputs from layer l+1
@@ -443,4 +489,5 @@ def model_bwd(model, g, sv, dlogits, sink):
                 acc = True
         d_f_next, d_s_next = conv_bwd(sv["convs"][l], g, d_f, d_s, sink, dx=dx, dx_acc=acc, dxn=dxn,
                                       dxn_acc=acc, need_dx=need_dx)
+    _join_side()                                                      # every gradient is complete on the caller's stream
     return sink
