@@ -345,7 +345,7 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
                                      and nn0.bias is not None):
             # per-node sums of dH1 + N-row dense algebra instead of the gathered E-row GEMMs (pays when E >> N)
             ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), sink.get(nn0.bias),
-                                         dx=dx if need_dx else None, dx_accumulate=True)
+                                         dx=dx if need_dx else None, dx_accumulate=True, side=_on_side)
         else:
             ops.edge_lin1_bwd_w(dA1, x, g, sink.get(nn0.weight), sink.get(nn0.bias))
             if need_dx:

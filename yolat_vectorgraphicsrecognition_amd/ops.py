@@ -516,7 +516,7 @@ def split_w1(W1, Cin):
     return wuv, wc4
 
 
-def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=False, wuv=None):
+def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=False, wuv=None, side=None):
     """Backward of the first edge Linear through the per-node products (see yolat_edge_uv_sums): writes dW1, db1 and,
     when `dx` is given, (accumulates) the gradient w.r.t. the node features.  C = 64; pays when E >> N."""
     N, Cin = x.shape
@@ -532,12 +532,19 @@ def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=Fal
     else:
         check(lib.yolat_edge_uv_sums(_f(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
                                      g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums")
-    dwuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
-    linear_bwd_w(dUV, x, dwuv)
-    dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
-    linear_bwd_w(dH1, g.attr, dwc4, db1)
-    check(lib.yolat_conv_merge_dw1(dwuv.data_ptr(), dwc4.data_ptr(), Cin, C, _f(dW1), _ld(dW1), 0, _stream()),
-          "yolat_conv_merge_dw1")
+    def weight_grads():
+        dwuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
+        linear_bwd_w(dUV, x, dwuv)
+        dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
+        linear_bwd_w(dH1, g.attr, dwc4, db1)
+        check(lib.yolat_conv_merge_dw1(dwuv.data_ptr(), dwc4.data_ptr(), Cin, C, _f(dW1), _ld(dW1), 0, _stream()),
+              "yolat_conv_merge_dw1")
+    # `side` (engine._on_side): the three weight-gradient launches on a second stream, beside the dx GEMM below and
+    # whatever the caller issues next — nothing in the backward reads dW1 / db1
+    if side is not None:
+        side(weight_grads, (dUV, x, dH1, g.attr))
+    else:
+        weight_grads()
     if dx is not None:
         linear_fwd_wt(dUV, wuv, dx, accumulate=dx_accumulate)
     return dW1
