@@ -413,6 +413,18 @@ int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t N, int64_t 
                                 const int32_t* node_seg, const int32_t* seg_ptr, int64_t P, const float* gZ,
                                 int64_t ldg, float* dW, float* dbias, float* dgamma, float* dbeta, float* dA,
                                 int64_t ldda, float* work, yolat_stream_t stream);
+/* the same backward in parts (bit mask) for a caller that overlaps the weight gradient with the input gradient on a
+ * second stream: _COLS (dgamma, dbeta and the coefficient vectors in `work` that both other parts read) must be complete
+ * before _DW (dW) and _DA (dA +=), which touch disjoint regions of `work`; yolat_fusion_pool_train_bwd = all three      */
+#define YOLAT_FUS_BWD_COLS 1
+#define YOLAT_FUS_BWD_DW 2
+#define YOLAT_FUS_BWD_DA 4
+#define YOLAT_FUS_BWD_ALL 7
+int yolat_fusion_pool_train_bwd_parts(const float* A, int64_t lda, int64_t N, int64_t K, const float* W,
+                                      const float* gamma, int64_t F, const float* coef, const float* saved,
+                                      const int32_t* node_seg, const int32_t* seg_ptr, int64_t P, const float* gZ,
+                                      int64_t ldg, float* dW, float* dbias, float* dgamma, float* dbeta, float* dA,
+                                      int64_t ldda, float* work, int parts, yolat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
  * Loss and optimiser

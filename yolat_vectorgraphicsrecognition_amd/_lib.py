@@ -94,6 +94,8 @@ SIGNATURES = {
                                              c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
     "yolat_fusion_pool_train_bwd": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p,
                                              c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p]),
+    "yolat_fusion_pool_train_bwd_parts": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_p,
+                                                   c_i64, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_int, c_p]),
     "yolat_expand_ranges": (c_int, [c_p, c_p, c_i64, c_i64, c_p, c_p]),
     "yolat_subgraph_work_elems": (c_sz, [c_i64, c_i64]),
     "yolat_subgraph_reindex": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),

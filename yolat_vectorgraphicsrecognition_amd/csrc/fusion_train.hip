@@ -786,7 +786,21 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
                                            const float* gZ, int64_t ldg, float* dW, float* dbias, float* dgamma,
                                            float* dbeta, float* dA, int64_t ldda, float* work,
                                            yolat_stream_t stream) {
+  return yolat_fusion_pool_train_bwd_parts(A, lda, N, K, W, gamma, F, coef, saved, node_seg, seg_ptr, P, gZ, ldg, dW, dbias,
+                                           dgamma, dbeta, dA, ldda, work, YOLAT_FUS_BWD_ALL, stream);
+}
+
+// The same backward in parts (bit mask), for a caller that runs the weight gradient beside the input gradient on a second
+// stream: YOLAT_FUS_BWD_COLS (the per-column reductions: dgamma, dbeta and the coefficient vectors both other parts read)
+// must be complete — stream order or an event — before _DW and _DA, which write disjoint regions of `work`.
+extern "C" int yolat_fusion_pool_train_bwd_parts(const float* A, int64_t lda, int64_t N, int64_t K, const float* W,
+                                                 const float* gamma, int64_t F, const float* coef, const float* saved,
+                                                 const int32_t* node_seg, const int32_t* seg_ptr, int64_t P,
+                                                 const float* gZ, int64_t ldg, float* dW, float* dbias, float* dgamma,
+                                                 float* dbeta, float* dA, int64_t ldda, float* work, int parts,
+                                                 yolat_stream_t stream) {
   (void)gamma; (void)seg_ptr;
+  if ((parts & ~YOLAT_FUS_BWD_ALL) != 0 || parts == 0) return YOLAT_E_INVALID;
   if (N <= 0 || K <= 0 || F <= 0 || P <= 0 || !A || !W || !coef || !saved || !node_seg || !gZ || !dW || !dgamma ||
       !dbeta || !dA || !work)
     return YOLAT_E_INVALID;
@@ -809,13 +823,16 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
   float* tnpart = take(yolat_linear_bwd_w_work_elems(F, K, K));
 
   // 1. per-column reductions over the P*F sparse entries: dbeta, dgamma and the coefficient vectors
+  if (parts & YOLAT_FUS_BWD_COLS) {
   hipLaunchKernelGGL(k_fus_cols_partial, dim3(yl_cdiv(F, 256), PB), dim3(256), 0, st, gZ, (long)ldg, sv.zstar, sv.arg,
                      (long)P, (int)F, (int)N, coef, GM, colpart);
   YL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_fus_cols_final, dim3(yl_cdiv(F, 64)), dim3(1024), 0, st, colpart, PB, (int)F, 1.f / (float)N, coef,
                      dgamma, dbeta, dbias, q1, nq2);
   YL_LAUNCH_CHECK();
+  }
   // 2. weight gradient: sparse gather term + the two rank-structured dense terms
+  if (parts & YOLAT_FUS_BWD_DW) {
   const int nb = yl_cdiv(N, 64);
   static int dw_ng = -1;
   if (dw_ng < 0) { const char* e = getenv("YOLAT_FUS_DW_NG"); dw_ng = e ? atoi(e) : 64; if (dw_ng < 1 || dw_ng > FB_NG) dw_ng = 64; }
@@ -827,6 +844,8 @@ extern "C" int yolat_fusion_pool_train_bwd(const float* A, int64_t lda, int64_t 
   hipLaunchKernelGGL(k_fus_dw_finish, dim3(yl_cdiv(F * K, 256)), dim3(256), 0, st, dwpart, ng, (long)(F * K), (int)K, q1,
                      nq2, sv.sumA, sv.T, dW);
   YL_LAUNCH_CHECK();
+  }
+  if (!(parts & YOLAT_FUS_BWD_DA)) return 0;
   // 3. input gradient: sparse scatter term, then  dA += (A - mean_A) . (-Q) - u   with Q = W^T diag(q2) W
   static int da_threads = -1;
   if (da_threads < 0) { const char* e = getenv("YOLAT_FUS_DA_THREADS"); da_threads = e ? atoi(e) : 256; }   // measured at N = 175 k: 256 -> 3.78, 512 -> 3.75, 1024 -> 3.86 ms per cfg-3 step (not the W re-staging: the walk)

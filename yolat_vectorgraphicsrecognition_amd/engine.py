@@ -461,7 +461,7 @@ def model_bwd(model, g, sv, dlogits, sink):
         lin, bn = sv["fus"]["lin"], sv["fus"]["bn"]
         ops.fusion_pool_train_bwd(sv["fus"], g, dZ[:, 0:F], sink.get(lin.weight),
                                   sink.get(lin.bias) if lin.bias is not None else None, sink.get(bn.weight),
-                                  sink.get(bn.bias), d_feats)
+                                  sink.get(bn.bias), d_feats, side=_on_side)
     else:
         d_fus = _empty(N, F, dev)
         ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)

@@ -795,15 +795,25 @@ def fusion_pool_train_fwd(A, lin, bn, g, Z):
     return {"A": A, "lin": lin, "bn": bn, "coef": coef, "saved": saved, "work": work}
 
 
-def fusion_pool_train_bwd(sv, g, gZ, dW, dbias, dgamma, dbeta, dA):
+def fusion_pool_train_bwd(sv, g, gZ, dW, dbias, dgamma, dbeta, dA, side=None):
+    """`side` (engine._on_side): the weight gradient (sparse gather + finish, ~140 us at cfg 3) on a second stream
+    beside the input gradient; the per-column reductions both read run first on the caller's stream."""
     A, lin = sv["A"], sv["lin"]
     N, K = A.shape
     F = lin.out_features
-    check(lib.yolat_fusion_pool_train_bwd(_f(A), _ld(A), N, K, _f(lin.weight), _f(sv["bn"].weight), F, _f(sv["coef"]),
-                                          _f(sv["saved"]), g.node_seg.data_ptr(), g.seg_ptr.data_ptr(), g.P,
-                                          _f(gZ, "gZ"), _ld(gZ), _f(dW), _f(dbias, "dbias", True), _f(dgamma),
-                                          _f(dbeta), _f(dA), _ld(dA), _f(sv["work"]), _stream()),
-          "yolat_fusion_pool_train_bwd")
+
+    def part(mask):
+        check(lib.yolat_fusion_pool_train_bwd_parts(_f(A), _ld(A), N, K, _f(lin.weight), _f(sv["bn"].weight), F,
+                                                    _f(sv["coef"]), _f(sv["saved"]), g.node_seg.data_ptr(),
+                                                    g.seg_ptr.data_ptr(), g.P, _f(gZ, "gZ"), _ld(gZ), _f(dW),
+                                                    _f(dbias, "dbias", True), _f(dgamma), _f(dbeta), _f(dA), _ld(dA),
+                                                    _f(sv["work"]), mask, _stream()), "yolat_fusion_pool_train_bwd")
+    if side is None:
+        part(7)
+        return
+    part(1)
+    side(lambda: part(2), (A, gZ, sv["saved"], sv["work"], sv["coef"], g.node_seg))
+    part(4)
 
 
 # ---------------------------------------------------------------------------------------------
