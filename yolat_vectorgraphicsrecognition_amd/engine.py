@@ -196,17 +196,31 @@ def _on_side(fn, keep):
     _set = torch._C._cuda_setStream
     _set(stream_id=side.stream_id, device_index=side.device_index, device_type=side.device_type)
     try:
-        fn()
+        res = fn()
     finally:
         _set(stream_id=cur.stream_id, device_index=cur.device_index, device_type=cur.device_type)
     for t in keep:
         if t is not None:
             t.record_stream(side)
     ent["dirty"] = True
+    return res
+
+
+def _adopt(*tensors):
+    """Tensors allocated while the side stream was current (its allocator pool) that live on into work of the current
+    stream: tell the allocator."""
+    if not SIDE_STREAM:
+        return
+    cur = ops.current_stream_object()
+    for t in tensors:
+        if isinstance(t, (tuple, list)):
+            _adopt(*t)
+        elif t is not None:
+            t.record_stream(cur)
 
 
 def _join_side():
-    """The current stream waits for the weight-gradient work issued so far."""
+    """The current stream waits for the side-stream work issued so far."""
     cur = ops.current_stream_object()
     ent = _SIDE.get(cur.device_index)
     if ent is not None and ent["dirty"]:
@@ -283,7 +297,15 @@ def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False, node_coef_out=N
             ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, o_pro=(c1[0], c1[1]), o_relu=True)
             ops.linear_fwd(H1, nn3.weight, nn3.bias, H2, o_pro=(c2[0], c2[1]), o_relu=True)
             ops.csr_mean_fwd(H2, g, out_f, accumulate=True)
-    s, sv_n = lbr_fwd(xn, conv.mlp_node[0], conv.mlp_node[1], True, training, out=out_s, coef_out=node_coef_out)
+    # node branch (mlp_node: Linear + BatchNorm + ReLU on the previous layer's node branch): independent of this layer's
+    # edge side and read again only by the next layer's node branch and, at the very end, by the per-proposal mean — in
+    # training it runs on the side stream beside the following edge-side kernels (model_fwd joins before the mean)
+    if training:
+        s, sv_n = _on_side(lambda: lbr_fwd(xn, conv.mlp_node[0], conv.mlp_node[1], True, training, out=out_s,
+                                           coef_out=node_coef_out), (xn.t, xn.scale, xn.shift))
+        _adopt(sv_n["y"], sv_n.get("coef"))
+    else:
+        s, sv_n = lbr_fwd(xn, conv.mlp_node[0], conv.mlp_node[1], True, training, out=out_s, coef_out=node_coef_out)
     sv["node"] = sv_n
     return out_f, s, sv
 
@@ -414,6 +436,7 @@ def model_fwd(model, g, x, training):
     # super branch: per-proposal mean, then fusion_block_super                        (arch:65-69)
     sup = Z[:, 2 * F + D:2 * F + 2 * D]
     if training:
+        _join_side()                     # the node branches (fsup, sup_coef) were computed on the side stream
         ops.segment_mean_fwd(fsup, g, sup, x_pro=(sup_coef[0], sup_coef[1]), x_relu=True)
     else:
         ops.segment_mean_fwd(fsup, g, sup)
