@@ -319,8 +319,11 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
     N, Cin = x.shape
     C = nn0.out_features
     dev = x.device
-    # node branch
-    dxn = lbr_bwd(sv["node"], d_s, sink, dx_out=dxn, dx_accumulate=dxn_acc, need_dx=need_dx)
+    # node branch: its backward chain (BatchNorm+ReLU backward, dW, dX) feeds nothing but the previous layer's node branch,
+    # so across the layers it forms a chain of its own: on the side stream, beside the edge-side backward below
+    svn, dxn_dst = sv["node"], dxn
+    dxn = _on_side(lambda: lbr_bwd(svn, d_s, sink, dx_out=dxn_dst, dx_accumulate=dxn_acc, need_dx=need_dx), (d_s,))
+    _adopt(dxn)
     # root term
     dWr, dbr = sink.get(conv.lin_r.weight), sink.get(conv.lin_r.bias)
     _on_side(lambda: ops.linear_bwd_w(d_f, x, dWr, dbr), (d_f, x))
