@@ -529,11 +529,18 @@ def _timed_loop(fn, budget_s, lo=5, hi=200, warm=5):
     torch.cuda.synchronize()
     one = max(time.perf_counter() - t0, 1e-5)
     n = int(max(lo, min(hi, budget_s / one)))
-    t0 = time.perf_counter()
-    for _ in range(n):
-        fn()
-    torch.cuda.synchronize()
-    return (time.perf_counter() - t0) / n, n
+    # four timed chunks, the median chunk's mean: one allocator growth or host hiccup inside the region does not end up
+    # in the figure (a whole slow region still does)
+    chunk = max(1, n // 4)
+    means = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        for _ in range(chunk):
+            fn()
+        torch.cuda.synchronize()
+        means.append((time.perf_counter() - t0) / chunk)
+    means.sort()
+    return 0.5 * (means[1] + means[2]), 4 * chunk
 
 
 def eval_config_record(yv, gu, cfg, precision, budget_s=4.0):
