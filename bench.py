@@ -217,17 +217,46 @@ def roofline_entry(summary, cfg=None, precision="fp32", shape=None):
     return r
 
 
+def utilisation_view(r):
+    """Sub-record form of a roofline entry: `frac` is a UTILISATION figure that cannot exceed what
+    the hardware did, everything priced on work the kernel never moved or issued is named `credit_*`.
+      bound hbm : frac = counter traffic / t / 8 TB/s when a PMC pass exists for the stage (`hbm_frac_counters`), else the
+                  bytes the kernel has to move (`executed_bytes`) / t / 8 TB/s; `credit_b_agg_of_hbm_peak` = SURVEY 8(d)'s
+                  algorithmic bytes of the unfactorised reference op / t / 8 TB/s (the figure north_star's ">= 50 % HBM
+                  roofline on the sparse aggregation" is quoted on; it credits the factorisation and the fusion).
+      bound mfma: frac = flops ISSUED on the pipe they are issued to / that pipe's dense peak (`frac_executed_pipe`);
+                  `credit_algorithmic_of_fp32_peak` = algorithmic fp32 flops / t / fp32-MFMA peak (may exceed 1 for a
+                  GEMM emulated with six bf16 products)."""
+    r = dict(r)
+    t = r["avg_launch_us"] * 1e-6
+    alg = r.pop("frac")
+    r.pop("frac_algorithmic", None)
+    if r["bound"] == "hbm":
+        r["credit_b_agg_of_hbm_peak"] = alg
+        r["hbm_frac_counters"] = (r["traffic"] / t / (PEAK_HBM_GBS * 1e9)) if r.get("traffic") else None
+        must = r.get("executed_bytes", r.get("algorithmic_bytes", 0.0)) / t / (PEAK_HBM_GBS * 1e9)
+        r["frac"] = r["hbm_frac_counters"] if r["hbm_frac_counters"] is not None else min(must, alg)
+        r["frac_kind"] = ("HBM bytes by PMC counters / t / 8 TB/s" if r["hbm_frac_counters"] is not None else
+                          "bytes the kernel must move / t / 8 TB/s (no PMC pass for this stage)")
+    else:
+        r["credit_algorithmic_of_fp32_peak"] = alg
+        r["frac"] = r["frac_executed_pipe"]
+        r["frac_kind"] = "flops issued / dense peak of the pipe they are issued to (%s)" % r.get("executed_pipe", "")
+    r["achieved_note"] = "`achieved` is algorithmic work / t (credit); `frac` is the utilisation figure"
+    return r
+
+
 def _runs_as_bf16x6(label, precision, shape):
     """Which stages of the fp32 eval plan execute their GEMM as six exact-split bf16 MFMA products (x6.hpp)."""
     if precision != "fp32" or shape is None:
         return False
     N, E, P = shape
     if label.startswith("fusion_gemm+segmax"):
-        return os.environ.get("YOLAT_FUSION_X6", "1") != "0"
+        return os.environ.get("YOLAT_STRICT_FP32", "0") != "1"
     if label.startswith("edge_uv_mlp2_mean"):
         return E >= 131072
     if label.startswith("cls1"):
-        return P >= 1024 and os.environ.get("YOLAT_CLS1_X6", "1") != "0"
+        return P >= 1024 and os.environ.get("YOLAT_STRICT_FP32", "0") != "1"
     if label.startswith("node_uv"):
         return N >= 65536
     return False
@@ -304,7 +333,7 @@ def fusion_stage_roofline(summary, cfg, precision):
            "frac": ach / PEAK_MFMA_F32_TFLOPS, "avg_launch_us": rec["ms_avg"] * 1e3,
            "algorithmic_flops": rec["flops"], "algorithmic_bytes": rec["bytes"]}
     out["traffic"], out["traffic_source"] = pmc_traffic(label, cfg)
-    if precision == "fp32" and os.environ.get("YOLAT_FUSION_X6", "1") != "0":
+    if precision == "fp32" and os.environ.get("YOLAT_STRICT_FP32", "0") != "1":
         x = 6.0 * rec["flops"]
         out["executed"] = {"bf16_mfma_flops": x, "bf16_TFLOPs": x / t / 1e12,
                            "frac_of_dense_bf16_peak": x / t / 1e12 / PEAK_MFMA_BF16_TFLOPS,
@@ -559,14 +588,14 @@ def eval_config_record(yv, gu, cfg, precision, budget_s=4.0):
 
     lat, n = _timed_loop(one, budget_s)
     table = plan_profile(one, 20)
-    roof = roofline_entry(table, str(cfg), precision, (N, E, P))
+    roof = utilisation_view(roofline_entry(table, str(cfg), precision, (N, E, P)))
     stages = {k: round(v["ms_avg"] * 1e3, 1) for k, v in sorted(table.items(), key=lambda kv: -kv[1]["ms_total"])}
     priced = {}
     for k, v in table.items():
         if v["ms_avg"] * 1e3 >= 20.0:
             e = executed_pricing(k, v, precision, (N, E, P))
-            priced[k] = {"us": round(v["ms_avg"] * 1e3, 1), "frac_algorithmic": round(e["frac_algorithmic"], 3),
-                         "frac_executed_pipe": round(e["frac_executed_pipe"], 3), "executed_pipe": e["executed_pipe"]}
+            priced[k] = {"us": round(v["ms_avg"] * 1e3, 1), "frac": round(e["frac_executed_pipe"], 3),
+                         "credit_algorithmic": round(e["frac_algorithmic"], 3), "executed_pipe": e["executed_pipe"]}
     total_fl = sum(v["flops"] * v["calls"] for v in table.values()) / 20.0
     del model
     return {"workload": "cfg%s eval forward, %s" % (cfg, "fp32" if precision == "fp32" else
@@ -671,7 +700,11 @@ def single_rank_nccl_dp_record(yv, gu, steps=10):
         params = {}
         for mode in ("nccl_exchange", "local"):
             model = gu.fill_state_(yv.SparseCADGCN(opt), 0).cuda()
-            tr = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5, force_exchange=(mode == "nccl_exchange"))
+            # exchange_premul = 2: the buckets are doubled before their all-reduce and halved by Adam (exact), so that
+            # `bit_identical_to_local_step` can only hold if every gradient was in its bucket when the exchange was
+            # issued — SUM over one rank alone is the identity and would hide a missing join (tests/test_gpu_dist.py)
+            tr = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5, force_exchange=(mode == "nccl_exchange"),
+                            exchange_premul=(2.0 if mode == "nccl_exchange" else None))
 
             def step():
                 data._yolat_stage = None
@@ -698,6 +731,8 @@ def single_rank_nccl_dp_record(yv, gu, steps=10):
                 "ms_per_step": out["nccl_exchange"] * 1e3, "ms_per_step_without_exchange": out["local"] * 1e3,
                 "graphs_per_sec": n_graphs / out["nccl_exchange"],
                 "bit_identical_to_local_step": bool(torch.equal(params["nccl_exchange"], params["local"])),
+                "exchange_is_identity": False,
+                "exchange_note": "buckets x2 on the compute stream before each all-reduce, Adam grad_scale 1/2",
                 "allreduce_alone_ms": t_ar * 1e3,
                 "collective": "2 async SUM all-reduces per step (fusion+classifier bucket during the conv backward, "
                               "conv bucket after it) over %s" % dist.get_backend()}
@@ -1023,6 +1058,29 @@ def main():
             line["op_breakdown_us"] = {k: round(v["ms_total"] / max(min(args.steps, 50), 1) * 1e3, 2) for k, v in top}
             line["gpu_us_per_step_sum_of_stages"] = round(sum(v["ms_total"] for v in op_table.values()) /
                                                           max(min(args.steps, 50), 1) * 1e3, 1)
+        # flat scalars of every sub-record as the LAST ~600 characters of the line (the driver keeps the line's tail)
+        def pick(d, *path):
+            for k in path:
+                if not isinstance(d, dict) or k not in d or d[k] is None:
+                    return None
+                d = d[k]
+            return round(d, 4) if isinstance(d, float) else d
+        line["summary"] = {
+            "graphs_per_sec": round(line["value"], 1), "ms_per_forward": pick(line, "ms_per_forward"),
+            "train_cfg3_ms": pick(line, "train_cfg3", "ms_per_step"), "cfg5_fp32_ms": pick(line, "cfg5_fp32", "ms_per_forward"),
+            "cfg5_bf16_ms": pick(line, "cfg5_bf16", "ms_per_forward"),
+            "train_cfg5_fp32_ms": pick(line, "train_cfg5_fp32", "ms_per_step"),
+            "train_cfg5_bf16_ms": pick(line, "train_cfg5_bf16", "ms_per_step"),
+            "csr_merged_ms": pick(line, "csr_merged_mode", "ms_per_forward_resident"),
+            "csr_merged_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec"),
+            "h2d_inclusive_gps": pick(line, "h2d_inclusive_graphs_per_sec"), "multi_stream_gps": pick(line, "multi_stream", "value"),
+            "floorplans_ms": pick(line, "floorplans_sized", "ms_per_forward"),
+            "floorplans_x_cpu": pick(line, "floorplans_sized", "speedup_vs_cpu_one_at_a_time"),
+            "predict_ms": pick(line, "predict", "ms_per_call"), "dp1_nccl_ms": pick(line, "train_dp_single_rank_nccl", "ms_per_step"),
+            "dp1_bit_identical": pick(line, "train_dp_single_rank_nccl", "bit_identical_to_local_step"),
+            "cpu_gps": pick(line, "cpu_baseline", "value"), "roofline_frac": pick(line, "roofline", "frac"),
+            "roofline_frac_executed": pick(line, "roofline", "frac_executed_pipe"),
+            "agg_hbm_frac": pick(line, "roofline_aggregation", "frac")}
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(line) + "\n").encode())
     if world > 1:

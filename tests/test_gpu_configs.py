@@ -158,8 +158,7 @@ def test_cfg3_full_size_train_step_matches_oracle_and_is_deterministic():
     rlogits, rloss = _oracle_train(ref, optkw, data)
     assert abs(float(runs[0][1]) - float(rloss)) <= RTOL_FWD * abs(float(rloss))
     assert float((runs[0][0].cpu() - rlogits).abs().max()) <= 5e-4 * float(rlogits.abs().max())
-    _grad_check(runs[0][2], ref, 5e-3, "cfg 3")
-    # ... and every tensor at its own scale against the float64 oracle (floor = that tensor's fp32-vs-fp64 oracle gap)
+    # every tensor at its own scale against the float64 oracle (floor = that tensor's fp32-vs-fp64 oracle gap)
     g32 = {n: p.grad.detach().double() for n, p in ref.named_parameters()}
     _, _, g64 = _oracle_grads(optkw, 33, data, torch.float64)
     _grad_check_per_tensor(runs[0][2], g64, g32, 5e-3, "cfg 3")
@@ -188,7 +187,6 @@ def test_cfg4_diagrams_batch_train_step_matches_oracle():
     _, rloss = _oracle_train(ref, optkw, data)
     assert abs(float(loss) - float(rloss)) <= RTOL_FWD * abs(float(rloss))
     hip_grads = {n: tr.flat.grad_views[id(p)] for n, p in model.named_parameters()}
-    _grad_check(hip_grads, ref, 5e-3, "cfg 4")
     g32 = {n: p.grad.detach().double() for n, p in ref.named_parameters()}
     _, _, g64 = _oracle_grads(optkw, 44, data, torch.float64)
     _grad_check_per_tensor(hip_grads, g64, g32, 5e-3, "cfg 4")
@@ -286,6 +284,18 @@ def test_cfg5_full_size_train_step_matches_oracle():
     data._yolat_stage = None
     l16 = yv.DetectionLoss(opt)(m16(data, slices), data)["loss"]
     assert abs(float(l16.detach()) - float(l64)) <= 2e-3 * abs(float(l64))
+    # ... and every gradient tensor of the bf16-storage step against the float64 ORACLE at its own scale (the oracle's own
+    # sensitivity to a bf16-sized input perturbation + a stated bf16 term: tests/test_gpu_bf16.py)
+    from test_gpu_bf16 import bf16_grads_vs_fp64_oracle, _perturb_x
+    l16.backward()
+    g16 = {n: p.grad.detach().clone() for n, p in m16.named_parameters()}
+    x0 = data.x
+    data.x = _perturb_x(data)
+    try:
+        _, _, g64p = _oracle_grads(optkw, 55, data, torch.float64)
+    finally:
+        data.x = x0
+    bf16_grads_vs_fp64_oracle(g16, g64, g64p, "cfg 5, bf16 storage")
 
 
 def test_cfg5_train_step_is_deterministic_finite_and_block_diagonal():

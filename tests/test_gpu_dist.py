@@ -100,9 +100,18 @@ def _nccl_worker(rank, world, port, outdir):
     import golden_util as gu
     opt = yv.Opt()
     res = {}
-    for mode in ("exchange", "local"):
+    from yolat_vectorgraphicsrecognition_amd import engine
+    # "big": large enough (N ~ 90 k) that the side stream's weight-gradient kernels of the fusion block are still running
+    # when the host has already enqueued what follows the backward's head — the situation the join exists for
+    batches = {"small": _batch(yv, 0),
+               "big": yv.synth_batch(4, 47, num_proposals=1000, nodes_lo=4, nodes_hi=40, edge_factor=1.5, augmented=True)}
+    for mode in ("exchange", "local", "premul", "premul_fault", "local_big"):
         model = gu.fill_state_(yv.SparseCADGCN(opt), 61).cuda()
-        tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5, force_exchange=(mode == "exchange"))
+        # premul: the buckets are doubled before their all-reduce, Adam halves them (exact) — the exchange is no longer
+        # an identity; premul_fault: the same with the head bucket's exchange issued before its gradients exist
+        engine._FAULT_EARLY_HEAD_EXCHANGE = (mode == "premul_fault")
+        tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5, force_exchange=(not mode.startswith("local")),
+                        exchange_premul=(2.0 if mode.startswith("premul") else None))
         assert tr.flat.conv_end > 0                       # the two-bucket branch is the one that runs
         fired = []
         if mode == "exchange":
@@ -112,7 +121,7 @@ def _nccl_worker(rank, world, port, outdir):
                 fired.append((int(t.numel()), bool(k.get("async_op", False))))
                 return real(t, *a, **k)
             dist.all_reduce = spy
-        data, slices = _batch(yv, 0)
+        data, slices = batches["big" if mode.startswith("premul") or mode == "local_big" else "small"]
         losses = []
         for _ in range(3):
             data._yolat_stage = None
@@ -123,9 +132,12 @@ def _nccl_worker(rank, world, port, outdir):
             # per step: bucket 1 (fusion + classifier) from inside the backward, bucket 2 (conv layers) after it
             assert len(fired) == 6 and all(a for _, a in fired), fired
             assert fired[0][0] == tr.flat.numel - tr.flat.conv_end and fired[1][0] == tr.flat.conv_end, fired
+        engine._FAULT_EARLY_HEAD_EXCHANGE = False
         res[mode] = (tr.flat.param.cpu().numpy().copy(), np.array(losses))
     np.savez(os.path.join(outdir, "nccl.npz"), p_ex=res["exchange"][0], p_lo=res["local"][0],
-             l_ex=res["exchange"][1], l_lo=res["local"][1], backend=np.array(dist.get_backend()))
+             l_ex=res["exchange"][1], l_lo=res["local"][1], p_pm=res["premul"][0], l_pm=res["premul"][1],
+             p_pf=res["premul_fault"][0], p_lb=res["local_big"][0], l_lb=res["local_big"][1],
+             backend=np.array(dist.get_backend()))
     dist.destroy_process_group()
 
 
@@ -133,11 +145,23 @@ def test_dp_exchange_over_rccl_in_a_one_rank_group_equals_the_local_step(tmp_pat
     """The exchange branch of Trainer.step (async all-reduce fired from inside the backward, second bucket, wait, Adam
     with the 1/world scale) over the `nccl` backend = librccl, in a process group of ONE rank on the one GPU: the
     collective runs on RCCL's own stream, ordered against the HIP kernels' stream by events — the ordering gloo's
-    host-staged path never exercises.  SUM over one rank is the identity, so parameters and losses must be
-    bit-identical to the step without the exchange."""
+    host-staged path never exercises.  (1) SUM over one rank is the identity: parameters and losses bit-identical to the
+    step without the exchange.  (2) The identity cannot see an exchange issued too early, so the same step runs with
+    Trainer(exchange_premul=2): every bucket is doubled on the compute stream right before its all-reduce and Adam halves
+    it — exact in fp32, still bit-identical, but only if every gradient was in its bucket at that point.  (3) The check
+    can fail: with the head bucket's exchange issued before its gradients exist (engine._FAULT_EARLY_HEAD_EXCHANGE: the
+    program-order form of a missing wait; a removed stream join alone does not reproduce on demand, see engine.py) the
+    gradients land after the doubling and the parameters differ."""
     port = _free_port()
     mp.spawn(_nccl_worker, args=(1, port, str(tmp_path)), nprocs=1, join=True)
     r = np.load(tmp_path / "nccl.npz")
     assert str(r["backend"]) == "nccl"
     np.testing.assert_array_equal(r["l_ex"], r["l_lo"])
     np.testing.assert_array_equal(r["p_ex"], r["p_lo"])
+    # a NON-identity exchange (buckets doubled on the compute stream in front of the all-reduce, halved by Adam: exact in
+    # fp32): still bit-identical — every gradient was in its bucket when the exchange was issued ...
+    np.testing.assert_array_equal(r["l_pm"], r["l_lb"])
+    np.testing.assert_array_equal(r["p_pm"], r["p_lb"])
+    # ... and the check can FAIL: with the head bucket's exchange issued at the start of the backward
+    # (engine._FAULT_EARLY_HEAD_EXCHANGE) its gradients land after the doubling and the parameters differ
+    assert not np.array_equal(r["p_pf"], r["p_lb"]), "the exchange-ordering check did not see an exchange issued too early"

@@ -522,7 +522,10 @@ def test_launch_merging_of_the_small_graph_forward(tmp_path):
     tile epilogue on 16x16x4 MFMAs, the node branch in extra workgroups).  The switches are read once per process,
     hence child processes:
       YOLAT_POOL_RIDERS=0   same arithmetic in the same order -> logits bit-identical to the default;
-      YOLAT_NODE_CHAIN=0    the node side as its own launch on 32x32x2 MFMAs -> equal up to fp32 summation grouping.
+      YOLAT_NODE_CHAIN=0    the node side as its own launch on 32x32x2 MFMAs -> equal up to fp32 summation grouping;
+      YOLAT_PREP_SMALL=0    the graph preparation in four launches instead of one (graph.hip k_prep_small); the first layer's
+                            node side then rides as 64 x 64 MFMA tiles instead of the K <= 8 vector-ALU rows -> equal up to
+                            fp32 summation grouping.
     cfg 2, a one-block model, and a 4-block model that concatenates only its last two layers."""
     import subprocess
     import sys
@@ -546,14 +549,16 @@ def test_launch_merging_of_the_small_graph_forward(tmp_path):
         "    model.check_last_status()\n"
         "torch.save(outs, sys.argv[1])\n" % (root, os.path.join(root, "tests")))
     got = {}
-    for tag, env in (("default", {}), ("no_riders", {"YOLAT_POOL_RIDERS": "0"}), ("no_chain", {"YOLAT_NODE_CHAIN": "0"})):
+    for tag, env in (("default", {}), ("no_riders", {"YOLAT_POOL_RIDERS": "0"}), ("no_chain", {"YOLAT_NODE_CHAIN": "0"}),
+                     ("four_launch_prep", {"YOLAT_PREP_SMALL": "0"})):
         out = str(tmp_path / ("logits_%s.pt" % tag))
         subprocess.run([sys.executable, "-c", script, out], check=True, env=dict(os.environ, **env), timeout=600)
         got[tag] = torch.load(out)
-    for a, b, c in zip(got["default"], got["no_riders"], got["no_chain"]):
-        assert a.shape == b.shape == c.shape and torch.isfinite(a).all()
+    for a, b, c, d in zip(got["default"], got["no_riders"], got["no_chain"], got["four_launch_prep"]):
+        assert a.shape == b.shape == c.shape == d.shape and torch.isfinite(a).all()
         assert torch.equal(a, b)
         assert float((a - c).abs().max()) <= 2e-6 * float(c.abs().max())
+        assert float((a - d).abs().max()) <= 2e-6 * float(d.abs().max())
 
 
 def test_strict_fp32_switch_runs_the_fp32_mfma_kernels_and_agrees(tmp_path):

@@ -64,12 +64,15 @@ def test_coo_to_csr_and_csc_match_fixture(golden_dir, transposed):
         np.testing.assert_array_equal(g.attr[:E].cpu().numpy(), attr.cpu().numpy()[z["csr_%s/perm" % tag]])
 
 
-@pytest.mark.parametrize("N,E", [(20000, 90001), (20000, 140001), (70000, 100000), (300, 20000), (4097, 4096)])
+@pytest.mark.parametrize("N,E", [(20000, 90001), (20000, 140001), (70000, 100000), (300, 20000), (4097, 4096),
+                                 (45000, 98000), (1, 7), (33, 1)])
 def test_csr_large_random_matches_numpy_and_properties(N, E):
-    """Both forms of yolat_graph_prepare (graph.hip): the 3-launch one for small graphs (N + 1 <= 16 * 4096 and
-    E <= 131072: ticket scan, row emitted by the thread that completes it, wave-cooperative rows above 16 items) and
-    the 5-launch one above that, against numpy's stable argsort.  (300, 20000): every row is a heavy row, one of them
-    holds 3000 edges (above the LDS-staged row length)."""
+    """Both forms of yolat_graph_prepare (graph.hip) against numpy's stable argsort: the ONE-launch form for small graphs
+    (k_prep_small: E <= 98304 and at most 256 rows per workgroup — every workgroup walks the whole edge list for its own
+    destination rows, no exchange between workgroups) and the four-launch form above that (count / scan / fill /
+    rank-and-emit).  (300, 20000) and the skewed (20000, 90001): workgroups whose rows hold more than 4096 edges take the
+    kernel's ORDERED path (two more walks, stable rank from per-wave counters + lane masks); one row holds 3000 edges.
+    (1, 7): one node, every edge a self loop; (33, 1): a single edge."""
     yv = _yv()
     rng = np.random.default_rng(5)
     src = rng.integers(0, N, size=E).astype(np.int64)
@@ -90,6 +93,19 @@ def test_csr_large_random_matches_numpy_and_properties(N, E):
     src_csr = src[order]
     order2 = np.argsort(src_csr, kind="stable")
     np.testing.assert_array_equal(g.slots.cpu().numpy(), order2.astype(np.int32))
+
+
+def test_graph_prepare_four_launch_form_on_small_graphs():
+    """YOLAT_PREP_SMALL=0 (graph.hip, read once per process): the four-launch form of yolat_graph_prepare at the sizes
+    where the one-launch kernel is the default — the integer tests of this file again in a child process."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-q", "-x",
+                        "-k", "(csr or segment_ptr or edge_range) and not four_launch"],
+                       env=dict(os.environ, YOLAT_PREP_SMALL="0"), cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
 
 
 def test_edge_range_violation_is_flagged():

@@ -200,3 +200,63 @@ def test_predict_slicing_rejects_edge_leaving_the_subset():
     data.edge[int(se[0]), 1] = outside
     with pytest.raises(KeyError):
         build_subset(data, sp, se, sb)
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_scatter_semantics_second_opinion_from_torch_reductions(seed):
+    """torch_scatter / PyG are absent from this image (parity of the gather / mean / max core is pinned on
+    the published semantics only).  torch ships two INDEPENDENT implementations of the same published reductions —
+    Tensor.scatter_reduce (include_self=False) and torch.segment_reduce — so the oracle's restatement
+    (oracle_torch.scatter: sum -> count.clamp(1) -> divide; max with untouched rows = 0, first row wins a tie, gradient to
+    the arg row) is held against them on exactly the cases the restatement could get wrong: empty segments (leading,
+    inner, trailing via dim_size), duplicate indices, exact ties, all-negative segments, a single-row segment.
+    Does not replace the missing third-party pin; it is the only independent check available here."""
+    g = torch.Generator().manual_seed(seed)
+    P, C = 9, 5
+    # sorted segment ids with empty segments 0, 4 and 8 (trailing: only reachable through dim_size)
+    counts = torch.tensor([0, 3, 1, 6, 0, 2, 4, 1, 0])
+    index = torch.repeat_interleave(torch.arange(P), counts)
+    N = int(counts.sum())
+    src = torch.randn(N, C, generator=g, dtype=torch.float64)
+    src[4:10, 1] = src[4, 1]                    # an exact 6-way tie: all of segment 3 (rows 4..9)
+    src[index == 5] = -src[index == 5].abs() - 1.0       # an all-negative segment: max must stay negative, not clamp to 0
+    perm = torch.randperm(N, generator=g)       # the edge-side call (propagate) sees UNSORTED destinations
+    for idx, s in ((index, src), (index[perm], src[perm])):
+        ours_mean = orc.scatter(s, idx, dim=0, dim_size=P, reduce="mean")
+        ours_max = orc.scatter(s, idx, dim=0, dim_size=P, reduce="max")
+        ours_sum = orc.scatter(s, idx, dim=0, dim_size=P, reduce="sum")
+        ix = idx.view(-1, 1).expand(-1, C)
+        z = torch.zeros(P, C, dtype=torch.float64)
+        ref_sum = z.scatter_reduce(0, ix, s, "sum", include_self=False)
+        ref_mean = z.scatter_reduce(0, ix, s, "mean", include_self=False)      # untouched rows keep the 0 they held
+        ref_max = z.scatter_reduce(0, ix, s, "amax", include_self=False)
+        torch.testing.assert_close(ours_sum, ref_sum, rtol=1e-14, atol=1e-14)
+        torch.testing.assert_close(ours_mean, ref_mean, rtol=1e-14, atol=1e-14)
+        assert torch.equal(ours_max, ref_max)
+        assert torch.all(ours_max[[0, 4, 8]] == 0) and torch.all(ours_mean[[0, 4, 8]] == 0)
+        assert torch.all(ours_max[5] < 0)
+    # the sorted (pooling) call against segment_reduce on lengths.  Non-empty segments must agree exactly; an EMPTY
+    # segment is where the libraries differ by design: segment_reduce returns its identity (-inf / nan), torch_scatter
+    # leaves the zero the output was created with (SURVEY.md App. B) — which is what the oracle restates
+    seg_mean = torch.segment_reduce(src, "mean", lengths=counts, axis=0)
+    seg_max = torch.segment_reduce(src, "max", lengths=counts, axis=0)
+    ours_max = orc.scatter(src, index, dim=0, dim_size=P, reduce="max")
+    ne = counts > 0
+    torch.testing.assert_close(orc.scatter(src, index, dim=0, dim_size=P, reduce="mean")[ne], seg_mean[ne],
+                               rtol=1e-14, atol=1e-14)
+    assert torch.equal(ours_max[ne], seg_max[ne])
+    assert torch.all(torch.isinf(seg_max[~ne])) and torch.all(ours_max[~ne] == 0)
+    # no dim_size: rows = index.max() + 1 (architecture3cc_rpn_gp_iter2.py:67,122 pass none) -> the trailing empty one is gone
+    assert orc.scatter(src, index, dim=0, reduce="max").shape[0] == 8
+    # backward of max: the whole gradient of a tied column goes to ONE row, the first in input order; amax's own backward
+    # splits it evenly over the tied rows — a documented difference of torch's op, which is why the oracle does not use it
+    s1 = src.clone().requires_grad_(True)
+    orc.scatter(s1, index, dim=0, dim_size=P, reduce="max").sum().backward()
+    tie = s1.grad[4:10, 1]
+    assert float(tie[0]) == 1.0 and float(tie[1:].abs().sum()) == 0.0
+    s2 = src.clone().requires_grad_(True)
+    torch.zeros(P, C, dtype=torch.float64).scatter_reduce(0, index.view(-1, 1).expand(-1, C), s2, "amax",
+                                                          include_self=False).sum().backward()
+    untied = torch.ones(N, dtype=torch.bool); untied[4:10] = False
+    assert torch.equal(s1.grad[untied], s2.grad[untied])          # outside exact ties both route identically
+    assert abs(float(s2.grad[4:10, 1].sum()) - 1.0) < 1e-12        # ... and inside one the mass is the same, split differently

@@ -574,12 +574,6 @@ static int yl_edge_uv_mlp2_mean_bf16_impl(const u16* UV, long ld_uv, const int* 
                                           const int* row_ptr, long N, long E, const float* Wc4, const float* s1,
                                           const u16* W2f, const float* t2f, const float* root, long ld_r, u16* f_out,
                                           long ld_fo, int variant, hipStream_t st) {
-  static int env_variant = -1;
-  if (env_variant < 0) {
-    const char* e = getenv("YOLAT_HEDGE_VARIANT");
-    env_variant = (e && (e[0] == '1' || e[0] == '2')) ? e[0] - '0' : 0;
-  }
-  if (variant == 0) variant = env_variant;
   // the chained kernel walks the EDGE list: it needs enough edges to fill 2048 waves and pays per finished node
   if (variant == 0) variant = (E >= 131072 && E >= 2 * N) ? 2 : 1;
   if (variant == 2) {
@@ -677,8 +671,8 @@ int model_ok(const yolat_model_eval_bf16* mh) {
 template <class AL>
 int launch_hgemm(const AL& A, const HOp& B, const Epilogue& ep, long M, long N, long K, hipStream_t st) {
   if (K % 64 != 0 || M <= 0 || N <= 0) return YOLAT_E_UNSUPPORTED;
-  static const int wide = getenv("YOLAT_HGEMM_WIDE") ? atoi(getenv("YOLAT_HGEMM_WIDE")) : 1;   // 64x128 tiles once they still fill the GPU (cfg 5 classifier 1: 55 -> 45 us)
-  if (wide && N % 128 == 0 && (long)yl_cdiv(M, 64) * (N / 128) >= 256)
+  // 64x128 tiles once they still fill the GPU (cfg 5 classifier 1: 55 -> 45 us)
+  if (N % 128 == 0 && (long)yl_cdiv(M, 64) * (N / 128) >= 256)
     hipLaunchKernelGGL((k_hgemm<1, 2, AL>), dim3(yl_cdiv(M, 64), N / 128), dim3(256), 0, st, A, B, ep, (int)M, (int)N,
                        (int)K);
   else
@@ -815,7 +809,9 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
       });
     }
     snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
-    YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * (2.0 * C * 2.0 + 16.0 + 8.0) + 4.0 * N * C + 2.0 * N * C + 4.0 * N, {
+    // bytes: SURVEY.md 8(d) B_agg(l) of the UNFACTORISED layer at 2 bytes per feature element,
+    // E ((2 Cin + 4) s + 2 * 4) + N C s — the credit figure; what the kernel has to move is priced in bench.py
+    YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * ((2.0 * cv.Cin + 4.0) * 2.0 + 8.0) + 2.0 * N * C, {
       YL_TRY(yl_edge_uv_mlp2_mean_bf16_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.s1, mh->W2[l],
                                             mh->t2f[l], p.root, C, f_slot(l), ld_slot(l), 0, st));
     });
@@ -839,8 +835,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
     e1.bias = m->bfs; e1.scale = m->sfs; e1.shift = m->tfs; e1.relu = 1; e1.Y = p.Z + F + D; e1.ldy = ZW;
     const int tm1 = yl_cdiv(P, 64), tn1 = yl_cdiv(F, 64);
     const long n1p = ((long)tm1 * tn1 + 7) & ~7L;
-    static const int h8 = getenv("YOLAT_HFUSION8") ? atoi(getenv("YOLAT_HFUSION8")) : 1;
-    if (h8 && (D == 64 || D == 128) && mh->Wf_fold && mh->Wfs_fold && mh->tf_fold && mh->tfs_fold) {
+    if ((D == 64 || D == 128) && mh->Wf_fold && mh->Wfs_fold && mh->tf_fold && mh->tfs_fold) {
       // A-in-registers rows kernel on the BatchNorm-folded weights (fusion_h8.hip)
       YL_TRY(yl_hfusion_rows8(p.feats, D, N, D, mh->Wf_fold, mh->tf_fold, p.node_seg, p.Z, ZW, F, p.Z + 2 * F + D, ZW, P,
                               mh->Wfs_fold, mh->tfs_fold, p.Z + F + D, ZW, st));
@@ -852,8 +847,6 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
       // (x 1) / 161 us (x 4); cfg 2 (N = 10k): 8 groups 16.1 us, 16 groups 16.8 us, 2 groups 21.2 us
       bool big = false;
       long min_wgs = 1024;
-      if (const char* e = getenv("YOLAT_HFUSION_TM")) big = e[0] == '2';          // tuning hooks
-      if (const char* e = getenv("YOLAT_HFUSION_WGS")) min_wgs = atol(e);
       const int tm0 = yl_cdiv(N, big ? 128 : 64);
       int groups = 4;
       while ((long)tm0 * groups < min_wgs && groups < tn) groups *= 2;

@@ -729,15 +729,19 @@ int yl_build_node_uv(NodeUv* a, const float* f_in, int64_t ld_f, const float* s_
 // (its ~44 vector-ALU operations per row), with the FMAs switched off 45: the store stream is the bound.
 // ------------------------------------------------------------------------------------------------
 constexpr int N3_KMAX = 8, N3_ROWS = 32, N3_ITERS = 4;        // 4 waves x 8 consecutive rows per step, steps per workgroup
+// WAVES waves per workgroup (8 consecutive rows per wave and step), ITERS steps: the 256-thread stream kernel is <4, 4>,
+// the node-side workgroups of the one-launch graph preparation (graph.hip k_prep_small, 1024 threads) are <16, 1>
+template <int WAVES = 4, int ITERS = N3_ITERS>
 __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
+  constexpr int ROWS = 8 * WAVES;
   // ALL inputs of the workgroup's 128 rows are fetched up front into LDS (lane (row u = lane / 8, k = lane % 8) of the
   // row's wave; read back as two uniform-address 16-byte reads per row), so that the row loop holds no load: on this
   // ISA loads and stores share one in-order counter, and a load issued behind the previous step's stores made every
   // step wait for those stores' acknowledgements (51 -> 44 us).
-  __shared__ __attribute__((aligned(16))) float xs[N3_ITERS][4][2][64];
+  __shared__ __attribute__((aligned(16))) float xs[ITERS][WAVES][2][64];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int C = a.C, Cin = a.Cin, N = a.N;
-  const int r0 = vb * (N3_ROWS * N3_ITERS), r1 = yl_min(r0 + N3_ROWS * N3_ITERS, N);
+  const int r0 = vb * (ROWS * ITERS), r1 = yl_min(r0 + ROWS * ITERS, N);
   const int c4 = 4 * lane;
   const int prob = c4 < 2 * C ? 0 : (c4 < 3 * C ? 1 : 2);
   const int col = prob == 0 ? c4 : (prob == 1 ? c4 - 2 * C : c4 - 3 * C);
@@ -746,12 +750,12 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
   unsigned short* Yh = prob == 0 ? a.euv.Yh : (prob == 1 ? a.er.Yh : a.en.Yh);
   const long ldy = prob == 0 ? a.euv.ldy : (prob == 1 ? a.er.ldy : a.en.ldy);
   const int lu = lane >> 3, lk = lane & 7;
-  float fa[N3_ITERS], sa[N3_ITERS];
+  float fa[ITERS], sa[ITERS];
 #pragma unroll
-  for (int it = 0; it < N3_ITERS; ++it) {
+  for (int it = 0; it < ITERS; ++it) {
     // (clamped addresses + select, here and for the weights below: a load under a condition becomes a branch with
     // its own wait, and the kernel's start was a chain of ~30 such round trips)
-    const long row = yl_min(r0 + N3_ROWS * it + 8 * wave + lu, N - 1);
+    const long row = yl_min(r0 + ROWS * it + 8 * wave + lu, N - 1);
     const int kc = yl_min(lk, Cin - 1);
     const float f = a.af.p[row * a.af.ld + kc], g = a.as.p[row * a.as.ld + kc];
     fa[it] = lk < Cin ? f : 0.f;
@@ -762,7 +766,7 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
   // every one of 1563 workgroups: 44 -> 39 us.)
   __shared__ __attribute__((aligned(16))) float wl[256][N3_KMAX];
   __shared__ float cl[3][256];
-  {
+  if (threadIdx.x < 256) {
     const int t = threadIdx.x;                              // virtual column t of [UV | root | node branch]
     const int tp = t < 2 * C ? 0 : (t < 3 * C ? 1 : 2);
     const int tc = tp == 0 ? t : (tp == 1 ? t - 2 * C : t - 3 * C);
@@ -782,7 +786,7 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
     cl[2][t] = ts ? vh_ : 0.f;
   }
 #pragma unroll
-  for (int it = 0; it < N3_ITERS; ++it) { xs[it][wave][0][lane] = fa[it]; xs[it][wave][1][lane] = sa[it]; }
+  for (int it = 0; it < ITERS; ++it) { xs[it][wave][0][lane] = fa[it]; xs[it][wave][1][lane] = sa[it]; }
   __syncthreads();
   float w[4][N3_KMAX], b[4], sc[4], sh[4];
 #pragma unroll
@@ -794,9 +798,9 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
   }
   const float floor = relu ? 0.f : -INFINITY;
 #pragma unroll 1
-  for (int it = 0; it < N3_ITERS; ++it) {
+  for (int it = 0; it < ITERS; ++it) {
     const float* mine = xs[it][wave][prob == 2 ? 1 : 0];
-    const int rb = r0 + N3_ROWS * it + 8 * wave;
+    const int rb = r0 + ROWS * it + 8 * wave;
     if (rb >= r1) break;
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -827,6 +831,7 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
 
 // the node side of the first conv layer (K = in_channels <= 8) of a large graph as an output stream (dense.hip)
 bool yl_node3_smallk_ok(const NodeUv& a);
+bool yl_node3_smallk_shape_ok(const NodeUv& a);
 int yl_node3_smallk(const NodeUv& a, hipStream_t st);
 // training-mode fusion GEMM with the key64 pooling epilogue on the bf16x6 rows kernel (fusion_x6.hip)
 int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const float* W, const float* bias, long F,

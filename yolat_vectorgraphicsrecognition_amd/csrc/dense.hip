@@ -169,11 +169,12 @@ bool n3_epi_ok(const Epilogue& e) {
 }  // namespace
 
 // the stream kernel applies (large N, tiny K, C = 64, plain operands, 16-byte aligned outputs)
-bool yl_node3_smallk_ok(const NodeUv& a) {
-  static int min_rows = -1;
-  if (min_rows < 0) { const char* e = getenv("YOLAT_NODE3_SMALLK_MIN_ROWS"); min_rows = e ? atoi(e) : 32768; }
-  return a.C == 64 && a.Cin >= 1 && a.Cin <= N3_KMAX && a.N >= min_rows && !a.af.scale && !a.as.scale &&
-         n3_epi_ok(a.euv) && n3_epi_ok(a.er) && n3_epi_ok(a.en);
+bool yl_node3_smallk_shape_ok(const NodeUv& a) {       // what node3_smallk_body can compute at all (any N)
+  return a.C == 64 && a.Cin >= 1 && a.Cin <= N3_KMAX && !a.af.scale && !a.as.scale && n3_epi_ok(a.euv) &&
+         n3_epi_ok(a.er) && n3_epi_ok(a.en);
+}
+bool yl_node3_smallk_ok(const NodeUv& a) {             // ... and where it beats the 64 x 64 MFMA tiles as a launch of its own
+  return a.N >= 32768 && yl_node3_smallk_shape_ok(a);
 }
 int yl_node3_smallk(const NodeUv& a, hipStream_t st) {
   hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);

@@ -856,23 +856,13 @@ static long edge_tile_npt(long N, long E) {
   long npt = (56 * N) / E;
   const long npt2 = (112 * N) / E < 16 ? (112 * N) / E : 16;
   if (npt2 >= 2 * npt - 2 && N / (npt2 > 0 ? npt2 : 1) >= 8192) npt = npt2;
-  if (const char* e = getenv("YOLAT_EDGE_NPT")) npt = atol(e);     // tuning hook
   if (npt < 1) npt = 1;
   if (npt > 64) npt = 64;
   return npt;
 }
-static int edge_env_variant() {
-  static int env_variant = -1;
-  if (env_variant < 0) {
-    const char* e = getenv("YOLAT_EDGE_VARIANT");
-    env_variant = (e && e[0] >= '1' && e[0] <= '3') ? e[0] - '0' : 0;
-  }
-  return env_variant;
-}
 int yl_edge_tile_groups(int64_t N, int64_t E) {
   if (N <= 0 || E <= 0) return 0;
-  const int ev = edge_env_variant();
-  const int variant = ev != 0 ? ev : (E >= 131072 ? (yl_strict_fp32() ? YOLAT_EDGE_WS_F32 : YOLAT_EDGE_WS_X6) : YOLAT_EDGE_TILES);
+  const int variant = E >= 131072 ? (yl_strict_fp32() ? YOLAT_EDGE_WS_F32 : YOLAT_EDGE_WS_X6) : YOLAT_EDGE_TILES;
   if (variant != YOLAT_EDGE_TILES) return 0;
   return edge_tile_npt(N, E) <= 16 ? 1 : 4;
 }
@@ -896,18 +886,11 @@ int yl_edge_uv_mlp2_mean_eval_impl(const float* UV, int64_t ld_uv, const int32_t
     return YOLAT_E_UNSUPPORTED;
   // folded form: layer 1's bias / BatchNorm already applied to UV and Wc4 by the caller, layer 2's bias inside t2
   const bool fold = b1 == nullptr && s1 == nullptr && b2 == nullptr;
-  // YOLAT_EDGE_VARIANT (1..3) overrides the automatic choice, YOLAT_EDGE_WGS the number of persistent workgroups
-  // (bench A/B hooks; an explicit `variant` argument always wins)
-  const int env_variant = edge_env_variant();
-  static long ws_wgs = -1;
-  if (ws_wgs < 0) {
-    const char* w = getenv("YOLAT_EDGE_WGS");
-    ws_wgs = (w && atol(w) > 0) ? atol(w) : 512;
-  }
+  const long ws_wgs = 512;            // persistent workgroups of the wave-specialised kernels: two per CU
   // the persistent kernel addresses UV / attr / the index arrays with 32-bit byte offsets
   const bool ws_ok = yl_aligned16(W2) && E >= 64 && N * ld_uv * 4 < (1LL << 32) && E * 16 < (1LL << 32);
   if (variant == YOLAT_EDGE_AUTO) {
-    variant = env_variant != 0 ? env_variant : (E >= 131072 ? (yl_strict_fp32() ? YOLAT_EDGE_WS_F32 : YOLAT_EDGE_WS_X6) : YOLAT_EDGE_TILES);
+    variant = E >= 131072 ? (yl_strict_fp32() ? YOLAT_EDGE_WS_F32 : YOLAT_EDGE_WS_X6) : YOLAT_EDGE_TILES;
     if (!ws_ok) variant = YOLAT_EDGE_TILES;
   } else if (variant != YOLAT_EDGE_TILES && !ws_ok) {
     return YOLAT_E_UNSUPPORTED;

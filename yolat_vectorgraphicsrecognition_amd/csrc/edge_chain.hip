@@ -401,33 +401,18 @@ int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr
                        const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
                        const float* s1, const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
                        uint16_t* f_out, int64_t ld_fo, hipStream_t st) {
-  static long wgs = -1;
-  if (wgs < 0) {
-    const char* e = getenv("YOLAT_HCHAIN_WGS");
-    wgs = (e && atol(e) > 0) ? atol(e) : 768;
-  }
+  const long wgs = 768;        // measured: 256 / 512 / 768 / 1024 workgroups 63 / 52 / 49 / 62 us at cfg 5
   const long streams = 8 * wgs;
   long chunk = ((E + streams - 1) / streams + 15) / 16 * 16;
   if (chunk < 16) chunk = 16;
   // every node must fall into some wave's node range: the last wave's range ends at N by construction
   const long need = (E + 2 * chunk - 1) / (2 * chunk);           // waves that own at least one chunk boundary < E
   const long grid = (need + 3) / 4 > 0 ? (need + 3) / 4 : 1;
-  static int abl = -1;
-  if (abl < 0) abl = getenv("YOLAT_HCHAIN_ABL") ? atoi(getenv("YOLAT_HCHAIN_ABL")) : 0;
 #define EC_LAUNCH(A)                                                                                                    \
   hipLaunchKernelGGL(k_edge_chain_h<A>, dim3((unsigned)grid), dim3(256), 0, st, UV, (unsigned)ld_uv, src_csr, dst_csr,    \
                      attr_csr, row_ptr, (int)N, (int)E, (int)chunk, Wc4, s1, W2f, t2f, root, (unsigned)ld_r, f_out,       \
                      (unsigned)ld_fo)
-  switch (abl) {
-    case 1: EC_LAUNCH(1); break;
-    case 2: EC_LAUNCH(2); break;
-    case 3: EC_LAUNCH(3); break;
-    case 4: EC_LAUNCH(4); break;
-    case 5: EC_LAUNCH(5); break;
-    case 6: EC_LAUNCH(6); break;
-    case 7: EC_LAUNCH(7); break;
-    default: EC_LAUNCH(0); break;
-  }
+  EC_LAUNCH(0);       // (template argument: the phase-ablation variants behind profiles/r03_edge_chain_bf16_ablation.txt)
 #undef EC_LAUNCH
   YL_LAUNCH_CHECK();
   return 0;

@@ -260,8 +260,7 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
   static const bool riders_on = []() { const char* v = getenv("YOLAT_POOL_RIDERS"); return !(v && v[0] == '0'); }();
   const bool fusion_x6 = m->Wf_hi && m->Wf_mid && m->Wf_lo && m->tf_fold && m->Wfs_hi && m->Wfs_mid && m->Wfs_lo &&
                          m->tfs_fold && (D == 64 || D == 128) && F % 64 == 0 && (long)P * ZW < (1LL << 32);
-  static const long rider_items = []() { const char* v = getenv("YOLAT_POOL_RIDER_ITEMS"); return v ? atol(v) : (1L << 20); }();
-  const bool small_pool = riders_on && (long)P * (F + 2 * D) <= rider_items;
+  const bool small_pool = riders_on && (long)P * (F + 2 * D) <= (1L << 20);
   PoolRider ride_a{}, ride_b{};
   ride_a.feats = ride_b.feats = p.feats; ride_a.fsup = ride_b.fsup = p.fsup; ride_a.ld = ride_b.ld = D;
   ride_a.D = ride_b.D = (int)D; ride_a.F = ride_b.F = (int)F; ride_a.P = ride_b.P = (int)P;
@@ -333,8 +332,10 @@ static int forward_eval_impl(const yolat_model_eval* m, const float* x, int64_t 
                      C, C, C, 2 * C, C, C);
           else
             snprintf(nm, sizeof nm, "edge_uv_mlp2_mean[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
+          // bytes: SURVEY.md 8(d) B_agg(l) of the UNFACTORISED layer, E ((2 Cin + 4) 4 + 2 * 4) + N C 4 — the credit figure
+          // (what the kernel has to move is priced in bench.py executed_pricing)
           YL_STAGE(nm, 2.0 * E * (4.0 * C + C * C) + (with_next ? 8.0 * N * C * C : 0.0),
-                   E * (2.0 * C * 4.0 + 16.0 + 8.0) + 8.0 * N * C + (with_next ? 4.0 * (N * C + 4.0 * N * C) : 0.0),
+                   E * ((2.0 * cv.Cin + 4.0) * 4.0 + 8.0) + 4.0 * N * C + (with_next ? 4.0 * (N * C + 4.0 * N * C) : 0.0),
                    fold ? yl_edge_uv_mlp2_mean_eval_impl(uv_l, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4f,
                                                          nullptr, nullptr, nullptr, cv.W2, nullptr, cv.s2, cv.t2f, C,
                                                          f_out, ld_out, YOLAT_EDGE_AUTO, rd, &rode,

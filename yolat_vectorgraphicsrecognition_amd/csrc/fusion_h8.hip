@@ -196,8 +196,7 @@ int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const
       // 32 sixteen-tile workgroups 93 us for the launch)
       groups = 1;
       while ((long)tm * groups * 2 <= 128 && groups * 2 <= tn) groups *= 2;
-      if (const char* e = getenv("YOLAT_H8_GROUPS1")) { const int g = atoi(e); if (g >= 1 && g <= tn) groups = g; }
-    } else if (const char* e = getenv("YOLAT_H8_GROUPS")) { const int g = atoi(e); if (g >= 1 && g <= tn) groups = g; }
+    }
     ng = yl_cdiv(tn, groups);
     groups = yl_cdiv(tn, ng);
   };

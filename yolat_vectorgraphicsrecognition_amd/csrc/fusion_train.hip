@@ -40,7 +40,7 @@ static inline size_t fus_gram_elems(int64_t N, int64_t K) {
   const size_t a = yolat_linear_bwd_w_work_elems(N, K, K), b = (size_t)FB_GRAM_S * K * K;
   return a > b ? a : b;
 }
-constexpr int FB_NG = 256;      // upper bound of the row-block groups (= partial slabs) of the sparse weight gradient
+constexpr int FB_NG = 64;       // row-block groups (= partial slabs) of the sparse weight gradient
 
 // partial[rb][k] = sum of A[r][k] over the rb-th block of CS_ROWS rows; 64 columns x 4 row lanes per WG
 static __global__ void __launch_bounds__(256) k_colsum_partial(const float* __restrict__ A, long lda, long N, int K,
@@ -306,8 +306,7 @@ extern "C" int yolat_fusion_pool_train_fwd(const float* A, int64_t lda, int64_t 
   if (hipMemsetAsync(keys, 0, sizeof(unsigned long long) * (size_t)P * F, st) != hipSuccess) return YOLAT_E_INVALID;
   // K in {64, 128}: as an fp32 GEMM emulated with six bf16 MFMA products on the rows kernel (fusion_x6.hip; the weight
   // split lives behind the keys in `work`)
-  static int use_x6 = -1;
-  if (use_x6 < 0) { const char* e = getenv("YOLAT_FUSION_TRAIN_X6"); use_x6 = ((e && e[0] == '0') || yl_strict_fp32()) ? 0 : 1; }
+  const int use_x6 = yl_strict_fp32() ? 0 : 1;
   int x6rc = YOLAT_E_UNSUPPORTED;
   if (use_x6 && bias != nullptr) {
     uint16_t* wsplit = reinterpret_cast<uint16_t*>(((uintptr_t)(keys + (size_t)P * F) + 15) & ~(uintptr_t)15);
@@ -834,8 +833,7 @@ extern "C" int yolat_fusion_pool_train_bwd_parts(const float* A, int64_t lda, in
   // 2. weight gradient: sparse gather term + the two rank-structured dense terms
   if (parts & YOLAT_FUS_BWD_DW) {
   const int nb = yl_cdiv(N, 64);
-  static int dw_ng = -1;
-  if (dw_ng < 0) { const char* e = getenv("YOLAT_FUS_DW_NG"); dw_ng = e ? atoi(e) : 64; if (dw_ng < 1 || dw_ng > FB_NG) dw_ng = 64; }
+  const int dw_ng = FB_NG;
   const int bpg = yl_cdiv(nb, dw_ng);
   const int ng = yl_cdiv(nb, bpg);
   hipLaunchKernelGGL(k_fus_dw_sparse, dim3(yl_cdiv(F, 128), ng), dim3(256), 0, st, A, (long)lda, (int)N, (int)K,
@@ -847,11 +845,10 @@ extern "C" int yolat_fusion_pool_train_bwd_parts(const float* A, int64_t lda, in
   }
   if (!(parts & YOLAT_FUS_BWD_DA)) return 0;
   // 3. input gradient: sparse scatter term, then  dA += (A - mean_A) . (-Q) - u   with Q = W^T diag(q2) W
-  static int da_threads = -1;
-  if (da_threads < 0) { const char* e = getenv("YOLAT_FUS_DA_THREADS"); da_threads = e ? atoi(e) : 256; }   // measured at N = 175 k: 256 -> 3.78, 512 -> 3.75, 1024 -> 3.86 ms per cfg-3 step (not the W re-staging: the walk)
-  static int da_mfma = -1, da_ch = -1;
-  if (da_mfma < 0) { const char* e = getenv("YOLAT_FUS_DA_MFMA"); da_mfma = e ? atoi(e) : 1; }
-  if (da_ch < 0) { const char* e = getenv("YOLAT_FUS_DA_CH"); da_ch = e ? atoi(e) : 32; }
+  const int da_threads = 256;   // measured at N = 175 k: 256 -> 3.78, 512 -> 3.75, 1024 -> 3.86 ms per cfg-3 step (not the W re-staging: the walk)
+  // the matrix-core form splits the operands into TWO bf16 terms (three products, 2^-16 per product): not under
+  // YOLAT_STRICT_FP32, which promises fp32 arithmetic / IEEE propagation for every GEMM of the fp32 mode
+  const int da_mfma = yl_strict_fp32() ? 0 : 1, da_ch = 32;
   if (da_mfma && F % 64 == 0 && F >= 64) {
     unsigned short* WTh = reinterpret_cast<unsigned short*>(take((size_t)F * K / 2 + 8));
     unsigned short* WTm = reinterpret_cast<unsigned short*>(take((size_t)F * K / 2 + 8));

@@ -397,9 +397,6 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
   // workgroups; a workgroup costs one prologue (load + split of its 256 rows of A, measured ~ one column tile's time)
   // plus its column tiles.  Pick the power-of-two split with the fewest (rounds x workgroup cost); the small problem
   // always gets the finest split (its few row tiles must not become the longest workgroups).
-  // YOLAT_FUSION_X6_GROUPS=g forces the split of the pooled problem (experiments).
-  static int forced = -1;
-  if (forced < 0) { const char* e = getenv("YOLAT_FUSION_X6_GROUPS"); forced = e ? atoi(e) : 0; }
   FxProb p0, p1;
   p0.A = A; p0.lda = lda; p0.N = (int)N; p0.Wh = Wh; p0.Wm = Wm; p0.Wl = Wl; p0.tfold = tfold; p0.seg = node_seg;
   p0.out = pool; p0.ldo = ldpool; p0.out2 = nullptr; p0.ldo2 = 0; p0.ct2 = 1 << 30; p0.F = (int)F; p0.relu = 1; p0.key64 = nullptr; p0.sgn = nullptr; p0.a_scale = nullptr; p0.a_shift = nullptr; p0.a_floor = 0.f; p0.stats = nullptr;
@@ -418,7 +415,6 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
     const double cost = (double)((wgs + wg_round - 1) / wg_round) * (1.0 + ng);
     if (cost < best) { best = cost; best_g = g; }
   }
-  if (forced > 0) best_g = forced < tn ? forced : tn;
   p0.ng = yl_cdiv(tn, best_g);
   p0.groups = yl_cdiv(tn, p0.ng);
   PoolRider pr{};

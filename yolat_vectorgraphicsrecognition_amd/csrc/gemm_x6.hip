@@ -400,9 +400,7 @@ inline size_t gx_al4(size_t n) { return (n + 3) / 4 * 4; }
 
 // worthwhile and possible for this shape?  (the split path pays two extra passes over the operands)
 bool yl_bwd_w_x6_ok(int64_t M, int64_t Nout, int64_t K) {
-  static int on = -1;
-  if (on < 0) { const char* e = getenv("YOLAT_BWD_W_X6"); on = e ? atoi(e) : 1; if (yl_strict_fp32()) on = 0; }
-  return on && M >= 2048 && Nout >= 128 && K >= 128 && (double)M * (double)Nout * (double)K >= 4.0e9 && M < (1LL << 30);
+  return !yl_strict_fp32() && M >= 2048 && Nout >= 128 && K >= 128 && (double)M * (double)Nout * (double)K >= 4.0e9 && M < (1LL << 30);
 }
 size_t yl_bwd_w_x6_work_elems(int64_t M, int64_t Nout, int64_t K) {
   const int64_t Mp = (M + 15) / 16 * 16;

@@ -399,6 +399,250 @@ __global__ void __launch_bounds__(256) k_prep_rows_node3(const int* local, const
   node_uv_tile<BK>(a, t >> 2, t & 3);
 }
 
+// ------------------------------------------------------------------------------------------------
+// One-launch graph preparation for SMALL graphs (k_prep_small).  At E = 40 k the four launches above are ~5 us of
+// dependent latency each (24 us of a 117 us forward) and every in-launch hand-off between workgroups costs as much as a
+// launch boundary on this part (8 XCDs with private L2s: DESIGN.md Appendix R).  So this kernel has NO communication
+// between workgroups at all: workgroup b owns the destination rows [b R, (b+1) R) and finds their edges by reading the
+// WHOLE edge list itself (E x 16 bytes through its L1: ~4 us at E = 40 k, the price of the scheme and the reason it is
+// for small graphs only):
+//   walk   wave w reads the edge range [w E/16, (w+1) E/16), 64 edges per step, eight steps of loads in flight:
+//          below += [dst < r0]; an OWNED edge (r0 <= dst < r1) bumps its row's counter (LDS atomic, no return) and is
+//          appended to a list in LDS (one slot allocation per eight steps)
+//   sums   base = row_ptr[r0] = the workgroup's total of `below`; exclusive scan of the row counters -> row_ptr
+//   group  list -> row buckets (LDS cursor per row; any order)
+//   rank   every bucket entry counts the entries of its row with a smaller edge id — the stable order of the
+//          reference's index_select / scatter (rows are a handful of edges) — and emits perm / src / dst / attr at
+//          base + rowstart + rank
+// A workgroup whose rows hold more than PS_CAP edges (skewed graphs) takes the ORDERED path instead: two more walks of
+// the edge list in ascending edge order per wave.  Rank of an owned edge among the lanes of its step with the same
+// destination: every owned lane ORs its lane bit into the wave's 64-bit word of that row (commutative: independent of
+// the order the lanes are served in) and reads the word back = the match mask of its key; rank = wave's running row
+// counter + popcount(mask below me).  First walk: per-wave row counts; exclusive prefix over the waves; second walk:
+// emit at base + rowstart + prefix + rank.  No sort, O(E) per workgroup whatever the degrees.
+// Proposal segments (k_prep_count's second half) and the node side of the first conv layer (K = in_channels <= 8:
+// node3_smallk_body) in extra workgroups of the same launch.  Bit-exact with the four-launch form (tests/test_gpu_ops.py).
+// ------------------------------------------------------------------------------------------------
+#define PS_T 1024
+#define PS_NW (PS_T / 64)
+#define PS_RMAX 256
+#define PS_CAP 4096
+#define PS_PF 8
+#define PS_NODE_ITERS 2
+struct PrepSmall {
+  const int64_t* edge; long se, sc; const float4* attr; const int64_t* bbox; long P;
+  int E, N, R, nprep, nseg;
+  int* row_ptr; int* perm; int* src_csr; int* dst_csr; float4* attr_csr; int* seg_ptr; int* node_seg; int* status;
+};
+
+__device__ __forceinline__ void ps_emit(const PrepSmall& g, int e, int d, int pos) {
+  int64_t s = g.edge[(long)e * g.se];
+  const float4 av = g.attr[e];
+  if (s < 0 || s >= g.N) {
+    atomicOr(g.status, YOLAT_STATUS_EDGE_RANGE);
+    s = s < 0 ? 0 : g.N - 1;
+  }
+  g.perm[pos] = e;
+  g.src_csr[pos] = (int)s;
+  g.dst_csr[pos] = d;
+  g.attr_csr[pos] = av;
+}
+
+// MODE 0: below + row counters + list;  1: per-wave row counters (ordered);  2: ordered emit (cw = running counters)
+template <int MODE>
+__device__ __forceinline__ void ps_walk(const PrepSmall& g, int r0, int r1, int* rowcnt, int* cw, unsigned long long* mw,
+                                        int* list_n, unsigned* list, int& below, int base, const int* rowstart) {
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  const unsigned long long lt = (1ull << lane) - 1ull;
+  const int per = ((g.E + PS_NW * 64 - 1) / (PS_NW * 64)) * 64;
+  const int wb = w * per, we = yl_min(wb + per, g.E);
+  for (int eb = wb; eb < we; eb += 64 * PS_PF) {
+    int64_t dv[PS_PF];
+#pragma unroll
+    for (int j = 0; j < PS_PF; ++j) {
+      const int e = yl_min(eb + 64 * j + lane, g.E - 1);
+      dv[j] = g.edge[(long)e * g.se + g.sc];
+    }
+    if (MODE == 0) {
+      unsigned long long om[PS_PF];
+      int nown = 0;
+#pragma unroll
+      for (int j = 0; j < PS_PF; ++j) {
+        const bool valid = eb + 64 * j + lane < we;
+        const int d = dv[j] < 0 ? 0 : (dv[j] >= g.N ? g.N - 1 : (int)dv[j]);
+        below += (valid && d < r0) ? 1 : 0;
+        om[j] = __ballot(valid && d >= r0 && d < r1);
+        nown += __popcll(om[j]);
+      }
+      if (nown == 0) continue;                                    // wave-uniform
+      int s0 = 0;
+      if (lane == 0) s0 = atomicAdd(list_n, nown);
+      s0 = __builtin_amdgcn_readfirstlane(s0);
+#pragma unroll
+      for (int j = 0; j < PS_PF; ++j) {
+        if ((om[j] >> lane) & 1ull) {
+          const int dl = (dv[j] < 0 ? 0 : (dv[j] >= g.N ? g.N - 1 : (int)dv[j])) - r0, slot = s0 + __popcll(om[j] & lt);
+          atomicAdd(&rowcnt[dl], 1);
+          if (dv[j] < 0 || dv[j] >= g.N) atomicOr(g.status, YOLAT_STATUS_EDGE_RANGE);
+          if (slot < PS_CAP) list[slot] = (unsigned)(eb + 64 * j + lane) | ((unsigned)dl << 20);
+        }
+        s0 += __popcll(om[j]);
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < PS_PF; ++j) {
+        const int e = eb + 64 * j + lane;
+        const int d = dv[j] < 0 ? 0 : (dv[j] >= g.N ? g.N - 1 : (int)dv[j]);
+        const bool own = e < we && d >= r0 && d < r1;
+        if (__ballot(own) == 0ull) continue;                      // wave-uniform
+        const int dl = own ? d - r0 : 0;
+        const int c = cw[dl];
+        if (own) atomicOr(&mw[dl], 1ull << lane);
+        const unsigned long long m = mw[dl];                      // after every lane's OR (LDS serves a wave in order)
+        if (own && (m & lt) == 0ull) {                            // the group's lowest lane
+          cw[dl] = c + __popcll(m);
+          mw[dl] = 0ull;
+        }
+        if (MODE == 2 && own) ps_emit(g, e, d, base + rowstart[dl] + c + __popcll(m & lt));
+      }
+    }
+  }
+}
+
+__global__ void __launch_bounds__(PS_T) k_prep_small(PrepSmall g, NodeUv a, int with_node) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if ((int)blockIdx.x >= g.nprep + g.nseg) {
+    if (with_node) node3_smallk_body<PS_NW, PS_NODE_ITERS>(a, blockIdx.x - g.nprep - g.nseg);
+    return;
+  }
+  if ((int)blockIdx.x >= g.nprep) {
+    // proposal segments: thread t owns the boundary between rows t - 1 and t (as k_prep_count)
+    const int t = (blockIdx.x - g.nprep) * PS_T + tid;
+    if (t > g.N) return;
+    long prev = (t == 0) ? -1 : g.bbox[t - 1];
+    long cur = (t == g.N) ? g.P : g.bbox[t];
+    if (t < g.N) {
+      if (cur < 0 || cur >= g.P) { atomicOr(g.status, YOLAT_STATUS_SEG_RANGE); cur = cur < 0 ? 0 : g.P - 1; }
+      g.node_seg[t] = (int)cur;
+    }
+    if (prev >= g.P) prev = g.P - 1;
+    if (prev < -1) prev = -1;
+    if (cur < prev) atomicOr(g.status, YOLAT_STATUS_SEG_UNSORTED);
+    else for (long p = prev + 1; p <= cur; ++p) g.seg_ptr[p] = t;
+    return;
+  }
+  // one pool, two layouts (the whole launch is sized by this role: below 80 KB two workgroups share a CU, so the
+  // segment / node-side workgroups run beside the CSR ones instead of queueing behind them):
+  //   list path     list[PS_CAP] | grp[PS_CAP]            (edge id | local row << 20)
+  //   ordered path  msk[PS_NW][PS_RMAX] (64-bit) | cnt[PS_NW][PS_RMAX]
+  __shared__ unsigned long long pool[PS_NW * PS_RMAX + PS_NW * PS_RMAX / 2];
+  static_assert(2 * PS_CAP * sizeof(unsigned) <= sizeof(unsigned long long) * PS_NW * PS_RMAX, "list + grp fit the mask area");
+  unsigned* list = reinterpret_cast<unsigned*>(pool);
+  unsigned* grp = list + PS_CAP;
+  unsigned long long (*msk)[PS_RMAX] = reinterpret_cast<unsigned long long (*)[PS_RMAX]>(pool);
+  int (*cnt)[PS_RMAX] = reinterpret_cast<int (*)[PS_RMAX]>(pool + PS_NW * PS_RMAX);
+  __shared__ int rowcnt[PS_RMAX], cur[PS_RMAX], rowstart[PS_RMAX];
+  __shared__ int wbelow[PS_NW], wtot[PS_RMAX / 64], list_n;
+  const int r0 = blockIdx.x * g.R, r1 = yl_min(r0 + g.R, g.N);
+  const bool last = (int)blockIdx.x == g.nprep - 1;
+  if (tid < PS_RMAX) { rowcnt[tid] = 0; cur[tid] = 0; }
+  if (tid == 0) list_n = 0;
+  __syncthreads();
+  int below = 0;
+  ps_walk<0>(g, r0, r1, rowcnt, nullptr, nullptr, &list_n, list, below, 0, nullptr);
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) below += __shfl_down(below, off);
+  if (lane == 0) wbelow[w] = below;
+  __syncthreads();
+  // exclusive scan of the row counters
+  const int rt = tid < PS_RMAX ? rowcnt[tid] : 0;
+  int incl = rt;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int nb = __shfl_up(incl, off);
+    if (lane >= off) incl += nb;
+  }
+  if (tid < PS_RMAX && lane == 63) wtot[w] = incl;
+  int base = 0;
+#pragma unroll
+  for (int v = 0; v < PS_NW; ++v) base += wbelow[v];
+  const int n_list = list_n;
+  __syncthreads();
+  if (tid < PS_RMAX) {
+    int off = 0;
+#pragma unroll
+    for (int v = 0; v < PS_RMAX / 64; ++v) off += (v < w) ? wtot[v] : 0;
+    rowstart[tid] = off + incl - rt;
+    if (r0 + tid < r1) g.row_ptr[r0 + tid] = base + off + incl - rt;
+    if (last && tid == PS_RMAX - 1) g.row_ptr[g.N] = base + off + incl;
+  }
+  if (n_list <= PS_CAP) {
+    // the gathers of the entries this thread will emit go out now (cold lines: the longest latency left), under the
+    // grouping phases
+    static_assert(PS_CAP == 4 * PS_T, "four list entries per thread, spelled out");
+    __syncthreads();
+    for (int i = tid; i < n_list; i += PS_T) {
+      const unsigned en = list[i];
+      const int dl = (int)(en >> 20);
+      grp[rowstart[dl] + atomicAdd(&cur[dl], 1)] = en;
+    }
+    __syncthreads();
+    // all gathers first (cold lines: the longest latency left; clamped, unconditional), then rank + store
+    if (n_list > 0) {
+      const int lastv = n_list - 1;
+      auto emit_k = [&](int i, unsigned en, int64_t sv, float a0, float a1, float a2, float a3) {
+        if (i >= n_list) return;
+        const int dl = (int)(en >> 20), b = rowstart[dl], n = rowcnt[dl];
+        int r = 0;
+        for (int u = 0; u < n; ++u) r += (grp[b + u] < en) ? 1 : 0;   // same row: the comparison is on the edge id
+        if (sv < 0 || sv >= g.N) { atomicOr(g.status, YOLAT_STATUS_EDGE_RANGE); sv = sv < 0 ? 0 : g.N - 1; }
+        const int pos = base + b + r;
+        g.perm[pos] = (int)(en & 0xFFFFFu);
+        g.src_csr[pos] = (int)sv;
+        g.dst_csr[pos] = r0 + dl;
+        g.attr_csr[pos] = make_float4(a0, a1, a2, a3);
+      };
+#define PS_G(k)                                                                        \
+      const unsigned en##k = list[yl_min(tid + (k) * PS_T, lastv)];                    \
+      const int64_t sx##k = g.edge[(long)(en##k & 0xFFFFFu) * g.se];                   \
+      const float4 ax##k = g.attr[en##k & 0xFFFFFu];
+      PS_G(0) PS_G(1) PS_G(2) PS_G(3)
+#undef PS_G
+      emit_k(tid, en0, sx0, ax0.x, ax0.y, ax0.z, ax0.w);
+      emit_k(tid + PS_T, en1, sx1, ax1.x, ax1.y, ax1.z, ax1.w);
+      emit_k(tid + 2 * PS_T, en2, sx2, ax2.x, ax2.y, ax2.z, ax2.w);
+      emit_k(tid + 3 * PS_T, en3, sx3, ax3.x, ax3.y, ax3.z, ax3.w);
+    }
+  } else {
+    __syncthreads();
+    for (int i = tid; i < PS_NW * PS_RMAX; i += PS_T) { (&cnt[0][0])[i] = 0; (&msk[0][0])[i] = 0ull; }
+    __syncthreads();
+    int unused = 0;
+    ps_walk<1>(g, r0, r1, nullptr, cnt[w], msk[w], nullptr, nullptr, unused, 0, nullptr);
+    __syncthreads();
+    if (tid < PS_RMAX) {
+      int run = 0;
+#pragma unroll
+      for (int v = 0; v < PS_NW; ++v) { const int t = cnt[v][tid]; cnt[v][tid] = run; run += t; }
+    }
+    __syncthreads();
+    ps_walk<2>(g, r0, r1, nullptr, cnt[w], msk[w], nullptr, nullptr, unused, base, rowstart);
+  }
+}
+
+// rows per workgroup of k_prep_small, or 0 when the four-launch form is the one to use.  Every workgroup reads all E
+// edges: worth it while that is a few microseconds per workgroup and the whole grid is resident at once.
+static int prep_small_rows(int64_t N, int64_t E, int other_blocks) {
+  static const bool on = []() { const char* e = getenv("YOLAT_PREP_SMALL"); return !(e && e[0] == '0'); }();
+  if (!on || E > 98304) return 0;
+  const int wgs = 250 - other_blocks;            // one workgroup per CU (16 waves), the whole grid resident at once
+  if (wgs < 16) return 0;
+  int R = yl_cdiv(N, wgs);
+  if (R < 16) R = 16;
+  if (R > PS_RMAX) return 0;
+  return R;
+}
+
 extern "C" size_t yolat_graph_work_elems(int64_t N, int64_t E) {
   return (size_t)(2 * (((N + 1) + 63) / 64 * 64) + 4 * E + (N + 1) / PREP_BLK + 16);
 }
@@ -424,6 +668,23 @@ int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_
   int* dst32 = src32 + E;
   int* rank = dst32 + E;
   int* items = rank + E;
+  // small graphs: everything in ONE launch (k_prep_small), no counters to zero
+  const int node_blocks = extra ? yl_cdiv(extra->N, 8 * PS_NW * PS_NODE_ITERS) : 0;
+  const int seg_blocks = bbox_idx ? yl_cdiv(N + 1, PS_T) : 0;
+  const int Rs = (extra == nullptr || yl_node3_smallk_shape_ok(*extra)) ? prep_small_rows(N, E, node_blocks + seg_blocks) : 0;
+  if (Rs > 0) {
+    PrepSmall g;
+    g.edge = edge; g.se = (long)stride_e; g.sc = (long)stride_c; g.attr = reinterpret_cast<const float4*>(e_attr);
+    g.bbox = bbox_idx; g.P = (long)P; g.E = (int)E; g.N = (int)N; g.R = Rs; g.nprep = yl_cdiv(N, Rs);
+    g.nseg = seg_blocks;
+    g.row_ptr = row_ptr; g.perm = perm; g.src_csr = src_csr; g.dst_csr = dst_csr;
+    g.attr_csr = reinterpret_cast<float4*>(attr_csr); g.seg_ptr = seg_ptr; g.node_seg = node_seg; g.status = status;
+    NodeUv none{};
+    hipLaunchKernelGGL(k_prep_small, dim3(g.nprep + g.nseg + node_blocks), dim3(PS_T), 0, st, g, extra ? *extra : none,
+                       extra ? 1 : 0);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   // primed: the caller vouches that the counters are zero (left so by the previous call with this shape on this buffer)
   // (a kernel, not hipMemsetAsync: the eval plan may be captured into a hipGraph, and ROCm 7.2's memset graph node
   // faulted — "write access to a read-only page", gigabytes away from every buffer of the graph — after a few dozen

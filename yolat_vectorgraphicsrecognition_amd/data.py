@@ -185,8 +185,9 @@ def _item_desc(item, ship):
 
 
 _ZERO_STATUS = {}
-# opt-in: measured 5.86 k -> 6.07 k graphs/s at cfg 2 — the Python stream context costs what the overlap gains
-_COPY_STREAM_ON = os.environ.get("YOLAT_H2D_COPY_STREAM", "0") == "1"
+# module flag (no environment switch): measured 5.86 k -> 6.07 k graphs/s at cfg 2 — the Python stream context costs what
+# the overlap gains, so the separate copy stream stays off
+_COPY_STREAM_ON = False
 
 
 def _collate_csr(data_list, device, tkeys, ship, batch, slices):
@@ -214,7 +215,7 @@ def _collate_csr(data_list, device, tkeys, ship, batch, slices):
     if ev is None:
         ev = _PINNED[("ev", slot)] = torch.cuda.Event()
     if _COPY_STREAM_ON:
-        # YOLAT_H2D_COPY_STREAM=1: the H2D copy on its own stream, so that batch i + 1 crosses PCIe while batch i's forward
+        # (_COPY_STREAM_ON) the H2D copy on its own stream, so that batch i + 1 crosses PCIe while batch i's forward
         # runs (on one stream the 1.3 MB copy of cfg 2 — ~65 us with its launch — and the 100 us forward alternate).  The buffer is allocated
         # in the copy stream's pool and handed to the consumer's stream: record_stream() keeps the allocator from
         # re-using it before that stream is done with it.

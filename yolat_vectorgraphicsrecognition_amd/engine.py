@@ -21,12 +21,13 @@ import torch
 from . import ops
 
 # training-mode fusion block + max pooling without the [N, 1024] activation (csrc/fusion_train.hip);
-# YOLAT_FUSED_FUSION_TRAIN=0 selects the materialising schedule (kept as the cross-check in the tests)
-FACTORISED_TRAIN = os.environ.get("YOLAT_FACTORISED_TRAIN", "1") != "0"
+# FUSED_FUSION_TRAIN = False selects the materialising schedule (kept as the cross-check in the tests)
+# (module flags, flipped in-process by the tests that cross-check the schedules against each other; no environment switches)
+FACTORISED_TRAIN = True
 # edges per node from which the factorised first edge Linear is used (forward / backward chosen separately)
-FACT_FWD_RATIO = float(os.environ.get("YOLAT_FACT_FWD_RATIO", "2.0"))
-FACT_BWD_RATIO = float(os.environ.get("YOLAT_FACT_BWD_RATIO", "1.0"))     # measured: cfg 3 (E = 1.2 N) 3.77 -> 3.66 ms, cfg 4 3.63 -> 3.53 ms
-FUSED_FUSION_TRAIN = os.environ.get("YOLAT_FUSED_FUSION_TRAIN", "1") != "0"
+FACT_FWD_RATIO = 2.0
+FACT_BWD_RATIO = 1.0     # measured: cfg 3 (E = 1.2 N) 3.77 -> 3.66 ms, cfg 4 3.63 -> 3.53 ms
+FUSED_FUSION_TRAIN = True
 
 
 class Lazy(object):
@@ -180,7 +181,7 @@ def _drop_p(mlp):
 # so far on the current stream by an event — and runs beside the dX chain; the streams join before the first consumer
 # (model_bwd: the head bucket's all-reduce, the end of the backward).  Tensors handed to the side stream are marked
 # with record_stream so that the caching allocator does not recycle them while it still reads them.
-SIDE_STREAM = os.environ.get("YOLAT_BWD_SIDE_STREAM", "1") != "0"
+SIDE_STREAM = True           # module flag (tests/test_gpu_model.py flips it: both schedules bit-identical)
 _SIDE = {}
 
 
@@ -217,6 +218,15 @@ def _adopt(*tensors):
             _adopt(*t)
         elif t is not None:
             t.record_stream(cur)
+
+
+# Fault injection for tests/test_gpu_dist.py ONLY: issue the head bucket's exchange at the START of the backward, before
+# any of its gradients exists — the program-order form of "the exchange does not wait for the gradients".  (Removing the
+# join in front of the exchange alone does not reproduce on demand: measured with the side stream held back by 10 ms per
+# submission, the step stayed bit-identical — the caching allocator's device-wide synchronisations, whenever a block
+# recorded on the side stream cannot be reused yet, serialise the two streams in practice.  The join stays: correctness
+# must not depend on that.)
+_FAULT_EARLY_HEAD_EXCHANGE = False
 
 
 def _join_side():
@@ -257,7 +267,7 @@ def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inp
 # AttrRelativeEdgeConvGlobalPool2
 # ---------------------------------------------------------------------------------------------
 
-FUSED_BN_CSR_BWD = os.environ.get("YOLAT_FUSED_BN_CSR_BWD", "1") != "0"
+FUSED_BN_CSR_BWD = True
 
 
 def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False, node_coef_out=None):
@@ -469,6 +479,8 @@ def model_bwd(model, g, sv, dlogits, sink):
     net = model.cls_net
     N, P, C, F, D, L, lo = sv["dims"]
     dev = dlogits.device
+    if sink.on_head_done is not None and _FAULT_EARLY_HEAD_EXCHANGE:
+        sink.on_head_done()                                           # (tests only: see _FAULT_EARLY_HEAD_EXCHANGE)
     sv1, sv2, sv3 = sv["cls"]
     d2 = lbr_bwd(sv3, dlogits, sink)
     if sv.get("drop") is not None:
@@ -492,7 +504,7 @@ def model_bwd(model, g, sv, dlogits, sink):
         d_fus = _empty(N, F, dev)
         ops.segment_max_bwd(dZ[:, 0:F], sv["arg_fus"], g, d_fus)
         lbr_bwd(sv["fus"], d_fus, sink, dx_out=d_feats, dx_accumulate=True)
-    if sink.on_head_done is not None:
+    if sink.on_head_done is not None and not _FAULT_EARLY_HEAD_EXCHANGE:
         _join_side()                                                  # the head bucket's gradients are complete
         sink.on_head_done()
     # conv layers, last to first

@@ -278,11 +278,11 @@ def stats_buffer(M, C, device):
 
 # YOLAT_STRICT_FP32=1: no bf16x6-emulated GEMM anywhere (csrc/x6.hpp; the C side reads the same variable)
 STRICT_FP32 = os.environ.get("YOLAT_STRICT_FP32", "0") == "1"
-X6_TRAIN_GEMM = os.environ.get("YOLAT_TRAIN_X6_GEMM", "1") != "0" and not STRICT_FP32
+X6_TRAIN_GEMM = not STRICT_FP32          # module flag (tests/test_gpu_ops.py flips it)
 # the many-row training Linear on the bf16x6 rows kernel: measured EQUAL to the fp32-MFMA tiles (201 vs 199 us for
 # [1.2 M, 64] -> [1.2 M, 64]: one 8-wave workgroup per CU, its load -> split -> MFMA -> store chain is not overlapped
 # with a neighbour's), so it stays opt-in
-X6_TRAIN_ROWS = os.environ.get("YOLAT_TRAIN_ROWS_X6", "0") == "1" and not STRICT_FP32
+X6_TRAIN_ROWS = False                    # module flag (tests/test_gpu_ops.py flips it)
 
 
 def linear_fwd(A, W, bias, Y, a_pro=None, a_relu=False, o_pro=None, o_relu=False,

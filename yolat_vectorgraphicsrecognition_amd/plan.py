@@ -13,16 +13,18 @@ from . import ops
 from ._lib import lib, check, ModelEval, ModelEvalBf16, YOLAT_MAX_LAYERS
 
 # skip the memset of the CSR-build counters when the plan's workspace was last used by a forward of the same shape
-# (yolat_forward_eval_primed, include/yolat_hip.h); YOLAT_PRIMED_WS=0: always the self-contained call
-PRIMED_WS = os.environ.get("YOLAT_PRIMED_WS", "1") != "0"
+# (yolat_forward_eval_primed, include/yolat_hip.h); module flag, False: always the self-contained call
+# (tests/test_gpu_model.py runs both)
+PRIMED_WS = True
 
 
-def _x6_on(name, default="1"):
-    """A bf16x6-emulated stage of the fp32 plan: its own switch, and off as a whole under YOLAT_STRICT_FP32=1
-    (csrc/x6.hpp: strict IEEE propagation / fp32 MFMA summation order)."""
+def _x6_on(default=True):
+    """A bf16x6-emulated stage of the fp32 plan: off as a whole under YOLAT_STRICT_FP32=1 (csrc/x6.hpp: strict IEEE
+    propagation / fp32 MFMA summation order) — the one switch; `default` False = a stage that measured no faster than its
+    fp32-MFMA form and stays off."""
     if os.environ.get("YOLAT_STRICT_FP32", "0") == "1":
         return False
-    return os.environ.get(name, default) == "1"
+    return bool(default)
 
 
 def _fold(bn, dev):
@@ -50,7 +52,7 @@ class EvalPlan(object):
         self._graphs = {}
         self._primed = None        # (workspace, descriptor build, N, E, P, stream) of the last completed direct launch
         self._desc_key = 0
-        self.use_graph = os.environ.get("YOLAT_HIP_GRAPH", "0") == "1"
+        self.use_graph = False      # model.use_hip_graphs(True) turns the captured-graph replay on
 
     def _version_key(self):
         return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(), ops.weight_epoch())
@@ -104,9 +106,9 @@ class EvalPlan(object):
                   "yolat_conv_split_w1")
             keep += [wuv, wc4]
             wuvs.append(wuv)
-            if self.precision == "bf16" or os.environ.get("YOLAT_EDGE_FACTORISED", "1") != "0":
+            if True:
                 c.Wuv, c.Wc4 = wuv.data_ptr(), wc4.data_ptr()
-                if self.precision == "fp32" and os.environ.get("YOLAT_EDGE_FOLD", "1") != "0":
+                if self.precision == "fp32":
                     # folded form of the layer (once per weight version; elementwise on [C]-sized tensors): nn.1's
                     # folded BatchNorm (s1, t1) and the bias b1 move into the per-node products and the attr weights,
                     # b2 into the shift of nn.4 — the per-edge arithmetic shrinks to
@@ -125,7 +127,7 @@ class EvalPlan(object):
                         tnx = torch.cat([uvb, cv.lin_r.bias.detach()], 0).contiguous()
                         keep += [wnx, tnx]
                         c.Wnx, c.tnx = wnx.data_ptr(), tnx.data_ptr()
-                    if (cv.in_channels == 64 and C == 64 and _x6_on("YOLAT_NODE_X6")
+                    if (cv.in_channels == 64 and C == 64 and _x6_on()
                             and cv.lin_r.bias is not None):
                         # node side on the bf16x6 rows kernel (yolat_node_uv_eval_x6): [Wuvf ; Wr] stacked and split,
                         # shifts [uvb ; br]; node branch with its BatchNorm scale folded into the weight rows
@@ -152,7 +154,7 @@ class EvalPlan(object):
         d.Wf, d.bf = ptr(fb[0].weight), ptr(fb[0].bias)
         d.sf, d.tf = folded(fb[1])
         Dk = fb[0].in_features
-        x6 = (self.precision == "fp32" and _x6_on("YOLAT_FUSION_X6") and Dk in (64, 128)
+        x6 = (self.precision == "fp32" and _x6_on() and Dk in (64, 128)
               and d.F % 64 == 0)
 
         def split3(lin, fold):
@@ -184,7 +186,7 @@ class EvalPlan(object):
         c2fold = keep[-1]
         d.Wc3, d.bc3 = ptr(m3[0].weight), ptr(m3[0].bias)
         # prediction_cls.0 (P x 2304 -> 512) on the LDS-tiled bf16x6 GEMM (yolat_gemm_x6)
-        if (self.precision == "fp32" and _x6_on("YOLAT_CLS1_X6") and m1[0].in_features % 16 == 0):
+        if (self.precision == "fp32" and _x6_on() and m1[0].in_features % 16 == 0):
             lin = m1[0]
             rows, cols = lin.out_features, lin.in_features
             packed = torch.empty(lib.yolat_gemm_x6_packed_elems(rows, cols), dtype=torch.bfloat16, device=dev)
@@ -197,7 +199,7 @@ class EvalPlan(object):
         # classifier layers for the skinny bf16x6 kernel (yolat_linear_x6): all three or none.  Off by default: measured
         # equal to the fp32 split-K kernel at P = 400 (20.8 vs 21.2 us for cls1; operands streamed from L2 straight
         # into registers make it L1-bandwidth bound, profiles/r02_linear_x6_skinny.txt) and slower beyond.
-        if (self.precision == "fp32" and _x6_on("YOLAT_CLS_X6", "0")
+        if (self.precision == "fp32" and _x6_on(False)
                 and all(l[0].in_features % 16 == 0 for l in (m1, m2, m3))):
             for i, (l, fold) in enumerate(((m1, c1fold), (m2, c2fold), (m3, None))):
                 lin = l[0]

@@ -215,7 +215,7 @@ def allreduce_mean_(flat_grad):
 
 class Trainer(object):
     def __init__(self, model, opt, lr=2.5e-4, weight_decay=1e-5, precision=None, check_inputs_every=0,
-                 force_exchange=None):
+                 force_exchange=None, exchange_premul=None):
         self.model = model
         if precision is not None:
             model.set_train_precision(precision)
@@ -231,9 +231,13 @@ class Trainer(object):
         self.exchange_gradients = True      # False: skip the all-reduce (bench.py: cost of the exchange after overlap)
         # run the exchange branch (async bucket from inside backward, second bucket, wait) in a process group of ONE
         # rank as well: exercises the RCCL stream ordering on a single GPU (tests/test_gpu_dist.py, bench.py)
-        if force_exchange is None:
-            force_exchange = os.environ.get("YOLAT_FORCE_DP", "0") == "1"
         self.force_exchange = bool(force_exchange)
+        # exchange_premul = c: every gradient bucket is multiplied by c on the compute stream right before its
+        # all-reduce and Adam's grad_scale carries 1 / (world c) — with c a power of two the step is bit-identical to the
+        # plain one, but a gradient that lands in the bucket AFTER the exchange was issued (a missing join with the
+        # side stream of the backward) stays unscaled and changes the result.  It makes the ordering of the exchange
+        # observable in a process group of ONE rank, where SUM is the identity (tests/test_gpu_dist.py).
+        self.exchange_premul = None if exchange_premul is None else float(exchange_premul)
 
     def step(self, data, slices=None):
         """One training step on this rank's batch.  Returns the (device) loss tensor."""
@@ -246,17 +250,24 @@ class Trainer(object):
         exchange = self.exchange_gradients and grouped and (world > 1 or self.force_exchange)
         if not exchange:
             world = 1
+        premul = self.exchange_premul if exchange else None
+
+        def reduce_(bucket, async_op):
+            if premul is not None:
+                bucket.mul_(premul)
+            return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=async_op)
+
         if exchange and self.flat.conv_end > 0:
             # bucket 1 (fusion blocks + classifier, 93 % of the bytes) is all-reduced while the conv layers'
             # backward still runs; bucket 2 (conv layers) after the backward
             handles = []
             tail = self.flat.grad[self.flat.conv_end:]
-            self.flat.on_head_done = lambda: handles.append(dist.all_reduce(tail, op=dist.ReduceOp.SUM, async_op=True))
+            self.flat.on_head_done = lambda: handles.append(reduce_(tail, True))
             try:
                 loss.backward()
             finally:
                 self.flat.on_head_done = None
-            handles.append(dist.all_reduce(self.flat.grad[:self.flat.conv_end], op=dist.ReduceOp.SUM, async_op=True))
+            handles.append(reduce_(self.flat.grad[:self.flat.conv_end], True))
             for h in handles:
                 h.wait()
             scale = 1.0 / world
@@ -264,8 +275,10 @@ class Trainer(object):
             loss.backward()
             scale = 1.0
             if exchange:
-                dist.all_reduce(self.flat.grad, op=dist.ReduceOp.SUM)
+                reduce_(self.flat.grad, False)
                 scale = 1.0 / world
+        if premul is not None:
+            scale /= premul
         if self._steps == 0 or (self.check_inputs_every > 0 and self._steps % self.check_inputs_every == 0):
             self.model.check_last_status()      # raises before the update is applied
         self._steps += 1
