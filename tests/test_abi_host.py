@@ -223,6 +223,42 @@ def test_reference_checkpoint_with_numpy_best_value_and_optimizer_state_loads_fr
         assert torch.equal(model.state_dict()[k], v), k
 
 
+class _Evil(object):
+    def __reduce__(self):
+        return (os.system, ("echo pwned > /dev/null",))
+
+
+def test_reference_checkpoint_loader_does_not_unpickle_arbitrary_objects(tmp_path):
+    """Reference checkpoints are third-party downloads: load_reference_checkpoint(path) uses torch's safe unpickler (numpy's
+    scalar reconstructors allow-listed, previous test) and REFUSES a file whose pickle would call into arbitrary code;
+    only trust_pickle=True takes the full unpickler."""
+    import yolat_vectorgraphicsrecognition_amd as yv
+    model = yv.SparseCADGCN(yv.Opt())
+    path = str(tmp_path / "evil.pth")
+    torch.save({"epoch": 1, "state_dict": model.state_dict(), "best_value": _Evil()}, path)
+    with pytest.raises(RuntimeError, match="safe unpickler"):
+        yv.load_reference_checkpoint(yv.SparseCADGCN(yv.Opt()), path)
+    epoch, _ = yv.load_reference_checkpoint(yv.SparseCADGCN(yv.Opt()), path, trust_pickle=True)
+    assert epoch == 1
+
+
+def test_item_csr_cache_is_rebuilt_when_the_item_changes():
+    """data.item_csr caches the destination-sorted form ON the dataset item; an in-place edit or a re-assignment of the
+    arrays it was computed from (edge / e_attr / bbox_idx) must invalidate the entry, not ship a stale graph."""
+    import yolat_vectorgraphicsrecognition_amd as yv
+    from yolat_vectorgraphicsrecognition_amd import data as ydata
+    item, _ = yv.synth_batch(1, 5, num_proposals=6, nodes_lo=4, nodes_hi=9)
+    c0 = ydata.item_csr(item)
+    assert ydata.item_csr(item) is c0                          # unchanged item: the cached entry
+    attr0 = c0["attr"].copy()
+    item.e_attr.mul_(2.0)                                      # in place (an augmentation)
+    c1 = ydata.item_csr(item)
+    assert c1 is not c0 and np.array_equal(c1["attr"], 2.0 * attr0)
+    item.edge = item.edge.flip(1).contiguous()                 # re-assigned: every edge reversed
+    c2 = ydata.item_csr(item)
+    assert c2 is not c1 and np.array_equal(np.sort(c2["dst"][:c2["E"]]), np.sort(c1["src"][:c1["E"]]))
+
+
 # ---------------------------------------------------------------------------------------------
 # native host side of the batch hand-over (csrc/collate.hip; SURVEY.md section 8 f.2)
 # ---------------------------------------------------------------------------------------------

@@ -204,6 +204,9 @@ class SparseCADGCN(nn.Module):
         slice_image_bbox, None)``.  The host walks the proposal tree; node / edge re-indexing and the
         gathers are device kernels (`ops.extract_subgraph`); both forwards run through the HIP path."""
         from .data import select_tree_ranges, interleave_root_child
+        if getattr(data, "_yolat_graph", None) is not None and not all(k in data.keys for k in ("edge", "e_attr", "bbox_idx")):
+            raise ValueError("predict() cuts sub-graphs out of the raw edge list: batches from collate_to_device(csr=True) "
+                             "carry the prepared CSR only and support forward() — collate with csr=False for predict()")
         # the whole batch goes to the device once; both sub-batches are cut out of it by integer kernels
         # (csrc/subgraph.hip) — the host only walks the proposal tree (O(#tree nodes))
         dev = {k: getattr(data, k).cuda(non_blocking=True) for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox",

@@ -122,13 +122,25 @@ _CSR_SKIP = ("edge", "e_attr", "bbox_idx")       # replaced by the prepared grap
 _PINNED = {}
 
 
+def _source_key(item, names):
+    """(data_ptr, version counter, shape) of the tensors a cache entry was computed from: an in-place edit (augmentation,
+    normalisation) or a re-assignment of any of them invalidates the entry — the same rule `_stage` applies to the
+    non-csr path."""
+    out = []
+    for k in names:
+        t = item[k] if k in item.keys else None
+        out.append(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)))
+    return tuple(out)
+
+
 def item_csr(item):
     """The destination-sorted (CSR) form of ONE dataset item, computed once by the library's host code
     (``yolat_item_csr_host``: the host twin of the device-side ``yolat_graph_prepare``) and cached on the item — a dataset
     item's graph never changes (the reference caches its proposals the same way, Datasets/graph_dict3.py:924-929).
     Raises like ``Graph.check_status`` on ids outside [0, N) / an unsorted ``bbox_idx``."""
     c = item.__dict__.get("_yolat_csr")
-    if c is not None:
+    key = _source_key(item, ("edge", "e_attr", "bbox_idx", "x", "bbox"))
+    if c is not None and c.get("key") == key:
         return c
     from ._lib import lib, check
     edge, e_attr, bidx = item.edge, item.e_attr.contiguous(), item.bbox_idx.contiguous()
@@ -156,14 +168,17 @@ def item_csr(item):
     from ._lib import ItemCsr
     c["struct"] = ItemCsr(N, E, P, c["row_ptr"].ctypes.data, c["src"].ctypes.data, c["dst"].ctypes.data,
                           c["attr"].ctypes.data, c["seg_ptr"].ctypes.data, c["node_seg"].ctypes.data)
+    c["key"] = key
     item.__dict__["_yolat_csr"] = c
+    item.__dict__.pop("_yolat_desc", None)        # the descriptor points into the previous CSR arrays
     return c
 
 
 def _item_desc(item, ship):
     """The cached yolat_item_desc of a dataset item: pointers / sizes of its dense arrays in `ship` order + its CSR."""
     d = item.__dict__.get("_yolat_desc")
-    if d is not None and d[0] == ship:
+    key = _source_key(item, tuple(ship) + ("edge", "e_attr", "bbox_idx"))
+    if d is not None and d[0] == ship and len(d) > 3 and d[3] == key:
         return d[1]
     from ._lib import ItemDesc
     if len(ship) > 8:
@@ -180,7 +195,7 @@ def _item_desc(item, ship):
         desc.key[f].ptr, desc.key[f].bytes = t.data_ptr(), t.numel() * t.element_size()
         desc.rows[f] = t.shape[0]
     desc.csr = c["struct"]
-    item.__dict__["_yolat_desc"] = (ship, desc, keep)
+    item.__dict__["_yolat_desc"] = (ship, desc, keep, key)
     return desc
 
 

@@ -153,16 +153,43 @@ class FlatAdam(torch.optim.Optimizer):
         self.step_count = steps.pop() if steps else 0
 
 
-def load_reference_checkpoint(model, checkpoint, optimizer=None, strict=True):
+def _load_checkpoint_file(path, trust_pickle):
+    """torch.load of a reference-format checkpoint WITHOUT arbitrary unpickling: weights_only=True with the handful of
+    numpy reconstructors a reference checkpoint needs allow-listed (`best_value` is a numpy.float64, train.py:311,508).
+    Only `trust_pickle=True` (or YOLAT_TRUST_PICKLE=1 — checkpoints are third-party downloads) falls back to the full
+    unpickler."""
+    import numpy as np
+    allow = [np.dtype, np.float64, np.float32, np.int64, np.ndarray]
+    for name in ("scalar", "_reconstruct"):
+        for mod in ((getattr(np, "_core", None),) if hasattr(np, "_core") else (getattr(np, "core", None),)):
+            fn = getattr(getattr(mod, "multiarray", None), name, None) if mod is not None else None
+            if fn is not None and fn not in allow:
+                allow.append(fn)
+    for tname in ("Float64DType", "Float32DType", "Int64DType"):
+        t = getattr(getattr(np, "dtypes", None), tname, None)
+        if t is not None:
+            allow.append(t)
+    try:
+        with torch.serialization.safe_globals(allow):
+            return torch.load(path, map_location="cpu", weights_only=True)
+    except Exception as exc:
+        if trust_pickle or os.environ.get("YOLAT_TRUST_PICKLE", "0") == "1":
+            return torch.load(path, map_location="cpu", weights_only=False)
+        raise RuntimeError("checkpoint %r does not load with the safe unpickler (%s: %s); pass trust_pickle=True only for "
+                           "files you trust — full unpickling executes code from the file" %
+                           (path, type(exc).__name__, exc)) from exc
+
+
+def load_reference_checkpoint(model, checkpoint, optimizer=None, strict=True, trust_pickle=False):
     """Load a checkpoint in the reference's format (cad_recognition/train.py:313-321: {'epoch', 'state_dict',
     'optimizer_state_dict', 'scheduler_state_dict', 'best_value'}) into the HIP modules: the same `module.` prefix
     fix-up as utils/ckpt_util.py:51-64 (checkpoints saved from a multi-GPU wrapper), then load_state_dict — the
     parameter / buffer names are the reference's.  `checkpoint`: a path or the loaded dict.
     Returns (epoch, best_value)."""
     if not isinstance(checkpoint, dict):
-        # reference checkpoints are full pickles (train.py:313-321): `best_value` is a numpy.float64 (train.py:311,508),
-        # next to optimizer / scheduler dicts — torch >= 2.6's default weights_only=True refuses them
-        checkpoint = torch.load(checkpoint, map_location="cpu", weights_only=False)
+        # reference checkpoints (train.py:313-321) carry `best_value` as a numpy.float64 (train.py:311,508) next to
+        # optimizer / scheduler dicts: torch's safe unpickler with numpy's scalar reconstructors allow-listed
+        checkpoint = _load_checkpoint_file(checkpoint, trust_pickle)
     sd = checkpoint["state_dict"] if "state_dict" in checkpoint else checkpoint
     own_multi = next(iter(model.state_dict())).startswith("module.")
     ckpt_multi = next(iter(sd)).startswith("module.")
