@@ -732,6 +732,15 @@ int yolat_bn_relu_bwd_apply(const void* dZ, int64_t lddz, const void* Y, int64_t
                             const float* save_mean, const float* save_invstd, const float* scale, const float* shift,
                             int relu, const float* coef, void* dY, int64_t lddy, int half, yolat_stream_t stream);
 
+/* Training backward of the factorised first edge Linear, the part that reads the edge attributes (torch_vertex.py:331,
+ * gconv.nn.0 restricted to its 4 attr inputs):  dWc4 [C, 4] = dH1^T . attr,  db1 [C] = column sums of dH1 (NULL: skipped).
+ * dH1 [E, C] fp32 (half = 0) or bfloat16 (half != 0), rows in CSR order like attr_csr [E, 4].  One streaming pass + a
+ * fixed-order reduction of per-workgroup partials (deterministic); `work`: yolat_edge_attr_dw_work_elems(E) floats.
+ * C == 64, ldh % 4 == 0, dH1 16-byte (bf16: 8-byte) aligned.                                                        */
+size_t yolat_edge_attr_dw_work_elems(int64_t E);
+int yolat_edge_attr_dw(const void* dH1, int64_t ldh, int half, const float* attr_csr, int64_t E, int64_t C, float* dWc4,
+                       float* db1, float* work, yolat_stream_t stream);
+
 /* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
  * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).
  * ~3e-7 relative to the fp32 product, deterministic (few rows: K is split over workgroups and the fp32 partials are

@@ -1460,3 +1460,33 @@ def test_linear_fwd_gemm_x6_stats_path_matches_fp32_kernel(M, K, N):
     close(cb[3], (1 / torch.sqrt(ref.var(0, unbiased=False) + 1e-5)).float(), rtol=1e-4, atol=1e-6, msg="invstd")
     Yc, cc = run(True)
     assert torch.equal(Yb, Yc) and torch.equal(cb, cc)
+
+
+@pytest.mark.parametrize("E,half", [(1, False), (63, False), (1000, True), (300001, False), (300001, True)])
+def test_edge_attr_dw_streaming_reduction_matches_fp64(E, half):
+    """yolat_edge_attr_dw (edge.hip k_attr_dw): dWc4 = dH1^T . attr and db1 = column sums of dH1 — the part of the first edge
+    Linear's weight gradient that reads the edge attributes (torch_vertex.py:331) — against fp64, for fp32 and
+    bfloat16-stored gradients, ragged sizes, with and without the bias gradient; run-to-run bit identity."""
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    gen = torch.Generator().manual_seed(E + int(half))
+    dH = torch.randn(E, 64, generator=gen)
+    attr = (torch.randn(E, 4, generator=gen) * (torch.rand(E, 1, generator=gen) > 0.85)).contiguous()     # 85 % zero rows
+    dHd = dH.to(torch.bfloat16).cuda() if half else dH.cuda()
+    ref_w = dHd.double().cpu().t() @ attr.double()
+    ref_b = dHd.double().cpu().sum(0)
+    attr = attr.cuda()
+    work = torch.empty(lib.yolat_edge_attr_dw_work_elems(E), device="cuda")
+    st = torch.cuda.current_stream().cuda_stream
+    outs = []
+    for with_b in (True, False, True):
+        dw = torch.full((64, 4), float("nan"), device="cuda")
+        db = torch.full((64,), float("nan"), device="cuda")
+        check(lib.yolat_edge_attr_dw(dHd.data_ptr(), 64, int(half), attr.data_ptr(), E, 64, dw.data_ptr(),
+                                     db.data_ptr() if with_b else None, work.data_ptr(), st))
+        outs.append((dw, db))
+        assert float((dw.double().cpu() - ref_w).abs().max()) <= 2e-6 * max(float(ref_w.abs().max()), 1e-3) * max(1.0, E ** 0.5 / 30)
+        if with_b:
+            assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-6 * float(ref_b.abs().max() + E ** 0.5)
+        else:
+            assert torch.isnan(db).all()
+    assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])

@@ -1448,6 +1448,108 @@ extern "C" int yolat_edge_uv_sums_h(const uint16_t* dH1, int64_t ldh, const int3
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight gradient of the attr columns of the factorised first edge Linear + its bias gradient (training backward,
+// torch_vertex.py:331 nn.0 restricted to the 4 edge-attribute inputs):
+//   dWc4[c][j] = sum_e dH1[e][c] * attr[e][j]      (64 x 4)        db1[c] = sum_e dH1[e][c]
+// A pure streaming reduction over the [E, 64] gradient (307 MB fp32 / 154 MB bf16 at E = 1.2 M).  It used to run on the
+// general TN GEMM (k_gemm_tn split-row: 64 x 64 tiles for a [64 x 4] result): 279 us fp32 / 319 us bf16 per call = 0.15 /
+// 0.13 of HBM, 14 - 18 % of the cfg-5 train step.  Here: one pass, 16 bytes (fp32) / 8 bytes (bf16) per
+// lane, a 16-lane group per row (the row's attr quad is one broadcast 16-byte load), 64 rows per workgroup and step with
+// all loads of the step in flight, 16 + 4 register accumulators per lane; the 16 row groups of a workgroup are summed
+// through LDS in fixed order, the workgroups' partials by a second small launch in fixed order: deterministic.
+// ------------------------------------------------------------------------------------------------
+constexpr int ADW_WG_MAX = 2048;
+template <class T>
+__global__ void __launch_bounds__(256) k_attr_dw(const T* __restrict__ dH, long ldh, const float4* __restrict__ attr, int E,
+                                                 int rows_wg, float* __restrict__ part) {
+  __shared__ float red[16][16 * 20 + 4];
+  const int tid = threadIdx.x, sub = tid & 15, rg = tid >> 4;
+  const int b0 = blockIdx.x * rows_wg, b1 = yl_min(b0 + rows_wg, E);
+  float w[4][4], sb[4];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+    sb[c] = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) w[c][j] = 0.f;
+  }
+  const T* hp = dH + 4 * sub;
+  for (int r0 = b0; r0 < b1; r0 += 64) {
+    float4 h[4], a[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = yl_min(r0 + 16 * t + rg, E - 1);
+      h[t] = yl_ld4(hp + (long)r * ldh);
+      a[t] = attr[r];
+    }
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      if (r0 + 16 * t + rg < b1) {
+        const float hv[4] = {h[t].x, h[t].y, h[t].z, h[t].w}, av[4] = {a[t].x, a[t].y, a[t].z, a[t].w};
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          sb[c] += hv[c];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) w[c][j] = fmaf(hv[c], av[j], w[c][j]);
+        }
+      }
+    }
+  }
+  // this lane's 20 sums: columns 4 sub + c -> [c][j] at (4 sub + c) * 4 + j, bias at 256 + 4 sub + c
+  float* mine = red[rg];
+#pragma unroll
+  for (int c = 0; c < 4; ++c) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) mine[(4 * sub + c) * 4 + j] = w[c][j];
+    mine[256 + 4 * sub + c] = sb[c];
+  }
+  __syncthreads();
+  for (int i = tid; i < 320; i += 256) {
+    float s = red[0][i];
+#pragma unroll
+    for (int g2 = 1; g2 < 16; ++g2) s += red[g2][i];
+    part[(long)blockIdx.x * 320 + i] = s;
+  }
+}
+static __global__ void __launch_bounds__(320) k_attr_dw_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dWc4,
+                                                             float* __restrict__ db) {
+  const int i = threadIdx.x;
+  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                  // four interleaved chains, combined in fixed order
+  int g2 = 0;
+  for (; g2 + 4 <= nwg; g2 += 4) {
+    s0 += part[(long)g2 * 320 + i]; s1 += part[(long)(g2 + 1) * 320 + i];
+    s2 += part[(long)(g2 + 2) * 320 + i]; s3 += part[(long)(g2 + 3) * 320 + i];
+  }
+  for (; g2 < nwg; ++g2) s0 += part[(long)g2 * 320 + i];
+  const float s = (s0 + s1) + (s2 + s3);
+  if (i < 256) dWc4[i] = s;
+  else if (db != nullptr) db[i - 256] = s;
+}
+
+extern "C" size_t yolat_edge_attr_dw_work_elems(int64_t E) { (void)E; return (size_t)ADW_WG_MAX * 320; }
+
+extern "C" int yolat_edge_attr_dw(const void* dH1, int64_t ldh, int half, const float* attr_csr, int64_t E, int64_t C,
+                                  float* dWc4, float* db1, float* work, yolat_stream_t stream) {
+  if (E <= 0 || !dH1 || !attr_csr || !dWc4 || !work || ldh < C) return YOLAT_E_INVALID;
+  if (C != 64 || ldh % 4 != 0 || !yl_aligned16(attr_csr) || E >= (1LL << 31) - 64 ||
+      (((uintptr_t)dH1) & (half ? 7 : 15)) != 0)
+    return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  long rows_wg = (yl_cdiv(E, ADW_WG_MAX) + 63) / 64 * 64;
+  if (rows_wg < 256) rows_wg = 256;
+  const int nwg = yl_cdiv(E, rows_wg);
+  if (half)
+    hipLaunchKernelGGL(k_attr_dw<yl_bf16_t>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const yl_bf16_t*>(dH1), (long)ldh,
+                       reinterpret_cast<const float4*>(attr_csr), (int)E, (int)rows_wg, work);
+  else
+    hipLaunchKernelGGL(k_attr_dw<float>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const float*>(dH1), (long)ldh,
+                       reinterpret_cast<const float4*>(attr_csr), (int)E, (int)rows_wg, work);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(1), dim3(320), 0, st, work, nwg, dWc4, db1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
 // dW1 [C, 2Cin+4] from the gradients of the split weights (inverse of yolat_conv_split_w1):
 //   dW1[:, 0:Cin] = dWuv[0:C],  dW1[:, Cin:2Cin] = dWuv[C:2C] - dWuv[0:C],  dW1[:, 2Cin:] = dWc4
 static __global__ void k_conv_merge_dw1(const float* __restrict__ dWuv, const float* __restrict__ dWc4, int Cin, int C,

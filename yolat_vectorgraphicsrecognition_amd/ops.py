@@ -516,6 +516,19 @@ def split_w1(W1, Cin):
     return wuv, wc4
 
 
+def attr_dw(dH1, g, dwc4, db1=None):
+    """dWc4 [C, 4] = dH1^T . attr, db1 = column sums of dH1: the streaming reduction yolat_edge_attr_dw (C = 64, rows
+    16-byte aligned); other shapes fall back to the general weight-gradient GEMM."""
+    E, C = dH1.shape
+    half = _is_h(dH1)
+    if C == 64 and dH1.stride(1) == 1 and dH1.stride(0) % 4 == 0 and dH1.data_ptr() % 16 == 0 and E > 0:
+        work = torch.empty(int(lib.yolat_edge_attr_dw_work_elems(E)), dtype=torch.float32, device=dH1.device)
+        check(lib.yolat_edge_attr_dw(dH1.data_ptr(), dH1.stride(0), 1 if half else 0, g.attr.data_ptr(), E, C, _f(dwc4),
+                                     _f(db1, "db1", True), work.data_ptr(), _stream()), "yolat_edge_attr_dw")
+        return dwc4
+    return linear_bwd_w(dH1, g.attr, dwc4, db1)
+
+
 def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=False, wuv=None, side=None):
     """Backward of the first edge Linear through the per-node products (see yolat_edge_uv_sums): writes dW1, db1 and,
     when `dx` is given, (accumulates) the gradient w.r.t. the node features.  C = 64; pays when E >> N."""
@@ -536,7 +549,7 @@ def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=Fal
         dwuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
         linear_bwd_w(dUV, x, dwuv)
         dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
-        linear_bwd_w(dH1, g.attr, dwc4, db1)
+        attr_dw(dH1, g, dwc4, db1)
         check(lib.yolat_conv_merge_dw1(dwuv.data_ptr(), dwc4.data_ptr(), Cin, C, _f(dW1), _ld(dW1), 0, _stream()),
               "yolat_conv_merge_dw1")
     # `side` (engine._on_side): the three weight-gradient launches on a second stream, beside the dx GEMM below and
