@@ -21,7 +21,8 @@ STAGES = {
     "edge_uv_mlp2_mean[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "last_layer"),
     "edge_uv_mlp2_mean+node_uv_next[E x (U+V+attr) -> 64 -> 64 -> mean; N x 64 -> 128+64+64]": ("k_edge_uv_mlp2_mean", [CS + "common.hpp", CS + "edge.hip"], "with_next"),
     "node_uv[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_gemm_nt_node3", [CS + "common.hpp", CS + "dense.hip"], "all"),
-    "graph_prep[csr+attr+segments] + node_uv[layer 0]": ("k_prep_rows_node3", [CS + "common.hpp", CS + "graph.hip"], "all"),
+    # small graphs: the one-launch form (k_prep_small); larger ones: the last of the four launches
+    "graph_prep[csr+attr+segments] + node_uv[layer 0]": (("k_prep_small", "k_prep_rows_node3"), [CS + "common.hpp", CS + "graph.hip"], "all"),
 }
 
 
@@ -60,6 +61,12 @@ def parse(path):
 
 
 def select(table, kern, pick):
+    if isinstance(kern, tuple):          # candidates in order of preference: the first that was launched
+        for k in kern:
+            r = select(table, k, pick)
+            if r is not None:
+                return r
+        return None
     rows = [r for k in table if k.startswith(kern) for r in table[k]]
     if not rows:
         return None
@@ -87,7 +94,7 @@ def main():
         if fs is None or ws is None:
             ent.pop(stage, None)
             continue
-        ent[stage] = {"kernel": kern, "fetch_kib": round(fs[1], 1), "write_kib": round(ws[1], 1), "launches_sampled": fs[0],
+        ent[stage] = {"kernel": kern if isinstance(kern, str) else "|".join(kern), "fetch_kib": round(fs[1], 1), "write_kib": round(ws[1], 1), "launches_sampled": fs[0],
                       "launch_pick": pick,
                       "file": "profiles/%s_pmc_fetch.txt + profiles/%s_pmc_write.txt" % (prefix, prefix),
                       "sources": srcs, "source_digest": digest(srcs)}
