@@ -1511,19 +1511,28 @@ __global__ void __launch_bounds__(256) k_attr_dw(const T* __restrict__ dH, long 
     part[(long)blockIdx.x * 320 + i] = s;
   }
 }
-static __global__ void __launch_bounds__(320) k_attr_dw_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dWc4,
+// Sum of the workgroups' partials: 32 lanes per output (lane l takes partial rows l, l + 32, ...: eight loads in flight),
+// combined by a fixed shuffle tree -> deterministic.  8 outputs per 256-thread workgroup, 40 workgroups.  (One workgroup
+// walking all 2048 partials per output was 57 us per call — as long as the streaming pass it finishes.)
+static __global__ void __launch_bounds__(256) k_attr_dw_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dWc4,
                                                              float* __restrict__ db) {
-  const int i = threadIdx.x;
-  float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;                  // four interleaved chains, combined in fixed order
-  int g2 = 0;
-  for (; g2 + 4 <= nwg; g2 += 4) {
-    s0 += part[(long)g2 * 320 + i]; s1 += part[(long)(g2 + 1) * 320 + i];
-    s2 += part[(long)(g2 + 2) * 320 + i]; s3 += part[(long)(g2 + 3) * 320 + i];
+  const int l = threadIdx.x & 31, o = blockIdx.x * 8 + (threadIdx.x >> 5);      // o < 320 by the launch
+  float s = 0.f;
+  int g2 = l;
+  for (; g2 + 7 * 32 < nwg; g2 += 8 * 32) {
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = part[(long)(g2 + 32 * j) * 320 + o];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += v[j];
   }
-  for (; g2 < nwg; ++g2) s0 += part[(long)g2 * 320 + i];
-  const float s = (s0 + s1) + (s2 + s3);
-  if (i < 256) dWc4[i] = s;
-  else if (db != nullptr) db[i - 256] = s;
+  for (; g2 < nwg; g2 += 32) s += part[(long)g2 * 320 + o];
+#pragma unroll
+  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
+  if (l == 0) {
+    if (o < 256) dWc4[o] = s;
+    else if (db != nullptr) db[o - 256] = s;
+  }
 }
 
 extern "C" size_t yolat_edge_attr_dw_work_elems(int64_t E) { (void)E; return (size_t)ADW_WG_MAX * 320; }
@@ -1545,7 +1554,7 @@ extern "C" int yolat_edge_attr_dw(const void* dH1, int64_t ldh, int half, const 
     hipLaunchKernelGGL(k_attr_dw<float>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const float*>(dH1), (long)ldh,
                        reinterpret_cast<const float4*>(attr_csr), (int)E, (int)rows_wg, work);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(1), dim3(320), 0, st, work, nwg, dWc4, db1);
+  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(40), dim3(256), 0, st, work, nwg, dWc4, db1);
   YL_LAUNCH_CHECK();
   return 0;
 }
