@@ -234,9 +234,9 @@ def utilisation_view(r):
     t = r["avg_launch_us"] * 1e-6
     alg = r.pop("frac")
     r.pop("frac_algorithmic", None)
+    r["hbm_frac_counters"] = (r["traffic"] / t / (PEAK_HBM_GBS * 1e9)) if r.get("traffic") else None
     if r["bound"] == "hbm":
         r["credit_b_agg_of_hbm_peak"] = alg
-        r["hbm_frac_counters"] = (r["traffic"] / t / (PEAK_HBM_GBS * 1e9)) if r.get("traffic") else None
         must = r.get("executed_bytes", r.get("algorithmic_bytes", 0.0)) / t / (PEAK_HBM_GBS * 1e9)
         r["frac"] = r["hbm_frac_counters"] if r["hbm_frac_counters"] is not None else min(must, alg)
         r["frac_kind"] = ("HBM bytes by PMC counters / t / 8 TB/s" if r["hbm_frac_counters"] is not None else

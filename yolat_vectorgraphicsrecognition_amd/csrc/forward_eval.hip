@@ -83,8 +83,10 @@ hipEvent_t new_event() {
   if (!g_pool.empty()) { hipEvent_t e = g_pool.back(); g_pool.pop_back(); return e; }
   hipEvent_t e; (void)hipEventCreate(&e); return e;
 }
+// flops / bytes are SUMMED over the calls of a stage and reported per call (yolat_profile_get): the conv layers of a forward
+// share one stage name but not one size (the head layer's Cin is the raw feature width)
 StageRec& stage_rec(const char* name, double flops, double bytes) {
-  for (auto& s : g_stages) if (s.name == name) return s;
+  for (auto& s : g_stages) if (s.name == name) { s.flops += flops; s.bytes += bytes; return s; }
   g_stages.push_back(StageRec{name, flops, bytes, {}});
   return g_stages.back();
 }
@@ -137,8 +139,9 @@ extern "C" int yolat_profile_get(int index, char* name, int cap, float* total_ms
   for (auto& e : s.ev) { float ms = 0.f; if (hipEventElapsedTime(&ms, e.first, e.second) == hipSuccess) tot += ms; }
   if (total_ms) *total_ms = tot;
   if (calls) *calls = (int)s.ev.size();
-  if (flops) *flops = s.flops;
-  if (bytes) *bytes = s.bytes;
+  const double n = s.ev.empty() ? 1.0 : (double)s.ev.size();
+  if (flops) *flops = s.flops / n;
+  if (bytes) *bytes = s.bytes / n;
   return 0;
 }
 
