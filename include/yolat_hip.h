@@ -741,6 +741,23 @@ size_t yolat_edge_attr_dw_work_elems(int64_t E);
 int yolat_edge_attr_dw(const void* dH1, int64_t ldh, int half, const float* attr_csr, int64_t E, int64_t C, float* dWc4,
                        float* db1, float* work, yolat_stream_t stream);
 
+/* yolat_bn_apply_edge_sums (round 4): the apply pass of the BatchNorm + ReLU backward in front of the factorised first
+ * edge Linear (torch_vertex.py:331-332 nn.1 / nn.2; yolat_bn_relu_bwd_apply) fused with the consumers of its result that
+ * read it in CSR order — the dU half of yolat_edge_uv_sums and yolat_edge_attr_dw:
+ *   dH1[q] = scale (relu'(.) dA1[q] - c1 - xhat[q] c2)   stored (dH1 may alias dA1; the dV gather still reads it)
+ *   dUV[n, 0:64] = sum over CSR row n of dH1[q] (ascending q),  dWc4 [64, 4] = dH1^T . attr_csr,  db1 [64] = colsum (nullable)
+ * dA1 / H1 / dH1 [E, 64] fp32 (half = 0) or bfloat16 (half != 0: the sums take the rounded, stored values); coef [128] =
+ * (c1 | c2) as yolat_bn_csr_l2_bwd's next_coef.  Deterministic.  work: yolat_bn_apply_edge_sums_work_elems(N) floats.
+ * yolat_edge_uv_sums_v: the dV half alone, dUV[n, 64:128] = sum over the CSC column of n of dH1[slots[t]].         */
+size_t yolat_bn_apply_edge_sums_work_elems(int64_t N);
+int yolat_bn_apply_edge_sums(const void* dA1, int64_t ldda, const void* H1, int64_t ldh, void* dH1, int64_t lddh, int half,
+                             int64_t E, const float* save_mean, const float* save_invstd, const float* scale,
+                             const float* shift, int relu, const float* coef, const int32_t* row_ptr,
+                             const float* attr_csr, int64_t N, float* dUV, int64_t ld_uv, float* dWc4, float* db1,
+                             float* work, yolat_stream_t stream);
+int yolat_edge_uv_sums_v(const void* dH1, int64_t ldh, int half, const int32_t* col_ptr, const int32_t* slots, int64_t N,
+                         int64_t C, float* dUV, int64_t ld_uv, yolat_stream_t stream);
+
 /* LDS-tiled bf16x6-emulated fp32 GEMM (gemm_x6.hip): out [M, N] = act(A [M, K] . W'^T + shift), W' = row_scale (rows)
  * * W packed once per weight version by yolat_gemm_x6_pack (yolat_gemm_x6_packed_elems(N, K) bfloat16 values).
  * ~3e-7 relative to the fp32 product, deterministic (few rows: K is split over workgroups and the fp32 partials are

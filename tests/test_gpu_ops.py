@@ -95,6 +95,42 @@ def test_csr_large_random_matches_numpy_and_properties(N, E):
     np.testing.assert_array_equal(g.slots.cpu().numpy(), order2.astype(np.int32))
 
 
+@pytest.mark.parametrize("mix", ["grouped", "mixed", "window_edge"])
+def test_csr_large_grouped_edge_list_windowed_count(mix):
+    """The four-launch form on edge lists GROUPED by proposal, the order graph_dict3.py:582-600 + collate produce: the
+    counting launch (k_prep_count_win) ranks a workgroup's 2048 edges in an LDS window of destination rows and sends one
+    returning global atomic per touched row; a workgroup whose edges span more than 4096 rows takes the per-edge path.
+    'mixed': a third of the list shuffled, so both paths run in one launch and meet in the same counters;
+    'window_edge': spans of exactly 4096 and 4097 rows.  Bit-exact against numpy's stable argsort + the segment pointers."""
+    yv = _yv()
+    rng = np.random.default_rng(11)
+    P, n_p, e_p = 2400, 25, 110
+    N, E = P * n_p, P * e_p
+    owner = np.repeat(np.arange(P), e_p)
+    dst = owner * n_p + rng.integers(0, n_p, size=E)
+    src = owner * n_p + rng.integers(0, n_p, size=E)
+    if mix == "mixed":
+        k = E // 3
+        sel = rng.permutation(E)[:k]
+        dst[sel] = rng.integers(0, N, size=k)
+    if mix == "window_edge":
+        dst[0], dst[1] = 0, 4095                       # workgroup 0: span 4096 (window path)
+        dst[2048], dst[2049] = 100, 100 + 4096         # workgroup 1: span 4097 (per-edge path)
+    bbox = np.repeat(np.arange(P), n_p).astype(np.int64)
+    attr = torch.from_numpy(rng.standard_normal((E, 4)).astype(np.float32)).cuda()
+    g = yv.ops.build_graph(dev(np.stack([src, dst], 1).astype(np.int64)), attr, dev(bbox), N, P)
+    g.check_status()
+    order = np.argsort(dst, kind="stable")
+    np.testing.assert_array_equal(g.perm.cpu().numpy(), order.astype(np.int32))
+    np.testing.assert_array_equal(g.dst.cpu().numpy(), dst[order].astype(np.int32))
+    np.testing.assert_array_equal(g.src.cpu().numpy(), src[order].astype(np.int32))
+    np.testing.assert_array_equal(g.attr[:E].cpu().numpy(), attr.cpu().numpy()[order])
+    rp = np.concatenate([[0], np.cumsum(np.bincount(dst, minlength=N))]).astype(np.int32)
+    np.testing.assert_array_equal(g.row_ptr.cpu().numpy(), rp)
+    np.testing.assert_array_equal(g.seg_ptr.cpu().numpy(), (np.arange(P + 1) * n_p).astype(np.int32))
+    np.testing.assert_array_equal(g.node_seg.cpu().numpy(), bbox.astype(np.int32))
+
+
 def test_graph_prepare_four_launch_form_on_small_graphs():
     """YOLAT_PREP_SMALL=0 (graph.hip, read once per process): the four-launch form of yolat_graph_prepare at the sizes
     where the one-launch kernel is the default — the integer tests of this file again in a child process."""
@@ -1490,3 +1526,97 @@ def test_edge_attr_dw_streaming_reduction_matches_fp64(E, half):
         else:
             assert torch.isnan(db).all()
     assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+
+
+@pytest.mark.parametrize("N,E,half", [(1, 1, False), (40, 300, False), (5000, 42001, True), (50000, 300001, False),
+                                      (50000, 300001, True), (3000, 2500, False)])
+def test_bn_apply_edge_sums_equals_apply_then_sums(N, E, half):
+    """yolat_bn_apply_edge_sums + yolat_edge_uv_sums_v (edge.hip, round 4) against the three launches they replace —
+    yolat_bn_relu_bwd_apply, yolat_edge_uv_sums, yolat_edge_attr_dw (torch_vertex.py:331-332 backward): dH1 and dUV
+    BIT-identical (same arithmetic, same ascending row order per node; bf16 storage: sums of the stored values), dWc4 /
+    db1 against fp64 of the stored dH1 (their summation order differs from k_attr_dw's).  Skewed in-degrees incl. empty
+    rows ((3000, 2500): most nodes have no edge); run-to-run bit identity."""
+    yv = _yv()
+    ops = yv.ops
+    rng = np.random.default_rng(N + E)
+    src = rng.integers(0, N, size=E).astype(np.int64)
+    dst = (rng.integers(0, N, size=E) ** 2 // max(N, 1)).astype(np.int64)
+    gen = torch.Generator().manual_seed(E)
+    attr = (torch.randn(E, 4, generator=gen) * (torch.rand(E, 1, generator=gen) > 0.85)).contiguous().cuda()
+    g = ops.build_graph(dev(np.stack([src, dst], 1)), attr, None, N, 1)
+    g.ensure_csc()
+    dt = torch.bfloat16 if half else torch.float32
+    H1 = (torch.randn(E, 64, generator=gen) * 1.5 + 0.3).to(dt).cuda()
+    dA = torch.randn(E, 64, generator=gen).to(dt).cuda()
+    mean = torch.randn(64, generator=gen).cuda() * 0.2
+    invstd = (torch.rand(64, generator=gen) + 0.5).cuda()
+    gamma = (torch.rand(64, generator=gen) + 0.5).cuda()
+    scale = gamma * invstd
+    shift = torch.randn(64, generator=gen).cuda() * 0.1 - mean * scale
+    coef = (torch.randn(128, generator=gen) * 0.01).cuda()
+    # ---- the three launches
+    dH_ref = dA.clone()
+    ops.bn_relu_bwd_apply(dH_ref, H1, mean, invstd, scale, shift, True, coef, dH_ref)
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    st = torch.cuda.current_stream().cuda_stream
+    dUV_ref = torch.empty(N, 128, device="cuda")
+    if half:
+        check(lib.yolat_edge_uv_sums_h(dH_ref.data_ptr(), 64, g.row_ptr.data_ptr(), g.col_ptr.data_ptr(), g.slots.data_ptr(),
+                                       N, 64, dUV_ref.data_ptr(), 128, st))
+    else:
+        check(lib.yolat_edge_uv_sums(dH_ref.data_ptr(), 64, g.row_ptr.data_ptr(), g.col_ptr.data_ptr(), g.slots.data_ptr(),
+                                     N, 64, dUV_ref.data_ptr(), 128, st))
+    ref_w = dH_ref.double().cpu().t() @ g.attr[:E].double().cpu()
+    ref_b = dH_ref.double().cpu().sum(0)
+    # ---- fused
+    outs = []
+    for _ in range(2):
+        dH = dA.clone()
+        db = torch.full((64,), float("nan"), device="cuda")
+        dUV, dwc4 = ops.bn_apply_edge_sums(dH, H1, mean, invstd, scale, shift, True, coef, g, db)
+        dUV[:, 64:] = float("nan")
+        check(lib.yolat_edge_uv_sums_v(dH.data_ptr(), 64, int(half), g.col_ptr.data_ptr(), g.slots.data_ptr(), N, 64,
+                                       dUV.data_ptr(), 128, st))
+        outs.append((dH, dUV, dwc4, db))
+    dH, dUV, dwc4, db = outs[0]
+    assert torch.equal(dH, dH_ref)
+    assert torch.equal(dUV, dUV_ref)
+    assert float((dwc4.double().cpu() - ref_w).abs().max()) <= 2e-6 * max(float(ref_w.abs().max()), 1e-3) * max(1.0, E ** 0.5 / 30)
+    assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-6 * float(ref_b.abs().max() + E ** 0.5)
+    for a, b in zip(outs[0], outs[1]):
+        assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("M,pro", [(65536, True), (70001, True), (70001, False), (131072 + 33, True)])
+def test_linear64_row_stream_is_bit_identical_to_the_tile_kernel(M, pro):
+    """k_lin64_stream (dense.hip, round 4; taken by yolat_linear_fwd for K = Nout = 64, M >= 65536 with statistics: the
+    second edge Linear of a training conv layer, torch_vertex.py:331 nn.3) against the generic 64 x 64 tile kernel run on
+    row ranges below the threshold (48 000 rows: a multiple of 32, the statistics' group size): outputs and (sum, M2)
+    statistics BIT-identical, ragged last tile included; fp64 check of the product."""
+    yv = _yv()
+    ops = yv.ops
+    gen = torch.Generator().manual_seed(M)
+    A = torch.randn(M, 64, generator=gen).cuda()
+    W = (torch.randn(64, 64, generator=gen) / 8).cuda()
+    b = torch.randn(64, generator=gen).cuda()
+    sc = (torch.rand(64, generator=gen) + 0.5).cuda() if pro else None
+    sh = torch.randn(64, generator=gen).cuda() * 0.3 if pro else None
+    apro = (sc, sh) if pro else None
+    Y = torch.full((M, 64), float("nan"), device="cuda")
+    st = ops.stats_buffer(M, 64, A.device)
+    st.fill_(float("nan"))
+    ops.linear_fwd(A, W, b, Y, a_pro=apro, a_relu=pro, stats=st)
+    parts_y, parts_s = [], []
+    for lo in range(0, M, 48000):
+        hi = min(lo + 48000, M)
+        Yp = torch.empty(hi - lo, 64, device="cuda")
+        sp = ops.stats_buffer(hi - lo, 64, A.device)
+        ops.linear_fwd(A[lo:hi], W, b, Yp, a_pro=apro, a_relu=pro, stats=sp)
+        parts_y.append(Yp)
+        parts_s.append(sp.view(-1)[:2 * 64 * ((hi - lo + 31) // 32)])
+    assert torch.equal(Y, torch.cat(parts_y))
+    ngrp = (M + 31) // 32
+    assert torch.equal(st.view(-1)[:2 * 64 * ngrp], torch.cat(parts_s))
+    Ain = torch.relu(A.double() * sc.double() + sh.double()) if pro else A.double()
+    ref = Ain @ W.double().t() + b.double()
+    assert float((Y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())

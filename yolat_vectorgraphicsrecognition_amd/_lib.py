@@ -205,6 +205,10 @@ SIGNATURES = {
     "yolat_gemm_x6_pack_t": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p]),
     "yolat_edge_attr_dw_work_elems": (c_sz, [c_i64]),
     "yolat_edge_attr_dw": (c_int, [c_p, c_i64, c_int, c_p, c_i64, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_bn_apply_edge_sums_work_elems": (c_sz, [c_i64]),
+    "yolat_bn_apply_edge_sums": (c_int, [c_p, c_i64, c_p, c_i64, c_p, c_i64, c_int, c_i64, c_p, c_p, c_p, c_p, c_int, c_p,
+                                         c_p, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_edge_uv_sums_v": (c_int, [c_p, c_i64, c_int, c_p, c_p, c_i64, c_i64, c_p, c_i64, c_p]),
     "yolat_gemm_x6_work_elems": (c_sz, [c_i64, c_i64, c_i64]),
     "yolat_gemm_x6": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_int, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_gemm_x6_stats": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_i64, c_p, c_p]),

@@ -38,6 +38,7 @@ static inline bool yl_strict_fp32() {
 }
 
 __device__ __forceinline__ int yl_min(int a, int b) { return a < b ? a : b; }
+__device__ __forceinline__ int yl_max(int a, int b) { return a > b ? a : b; }
 // a*b rounded on its own: the empty asm keeps the compiler from contracting it with a following add into an
 // fma (-ffp-contract=fast does that even through __fmul_rn/__fadd_rn), so two kernels that must agree bit
 // for bit can pin the same two roundings

@@ -36,6 +36,115 @@ static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, 
   return 0;
 }
 
+// ------------------------------------------------------------------------------------------------
+// Many-row 64 -> 64 Linear as a row STREAM (round 4): the second edge Linear of a training conv layer (torch_vertex.py:331
+// nn.3 on the [E, 64] hidden activation, BatchNorm-1 + ReLU applied while loading, BatchNorm-2 statistics in the epilogue).
+// On the generic 64 x 64 tiles (k_gemm_nt) it was one workgroup per tile: 18 750 workgroups at E = 1.2 M that each fetch
+// the 16 KB weight from L2, stage, run 32 MFMAs per wave and drain — 178 us for 614 MB (0.43 of HBM, 0.35 of the fp32
+// MFMA rate).  Here the weight sits in LDS for the whole persistent workgroup, the next tile's rows are in flight under
+// the current tile's MFMAs, and the finished tile leaves through LDS with 16-byte stores.  Same products in the same
+// order as the tile kernel (k ascending in steps of two) and the same statistics arithmetic (wave_epilogue): bit-identical
+// outputs and statistics.
+// ------------------------------------------------------------------------------------------------
+#define L64_WGS 768
+__global__ void __launch_bounds__(256) k_lin64_stream(const float* __restrict__ A, long lda, int M,
+                                                      const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                      float a_floor, const float* __restrict__ W, long ldw,
+                                                      const float* __restrict__ bias, float* __restrict__ Y, long ldy,
+                                                      float2* __restrict__ stats, int tiles_per_wg) {
+  constexpr int LD = 65, LDO = 68;
+  __shared__ float As[64 * LD], Ws[64 * LD];
+  __shared__ __attribute__((aligned(16))) float Os[64 * LDO];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = tid & 15, rb = tid >> 4;                 // staging role: columns 4q.., rows rb + 16 t
+  const int ntiles = (M + 63) >> 6;
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = yl_min(ntiles, t0 + tiles_per_wg);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = rb + 16 * t;
+    const float4 w = *reinterpret_cast<const float4*>(W + (long)r * ldw + 4 * q);
+    float* d = Ws + r * LD + 4 * q;
+    d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+  }
+  float4 as = make_float4(1.f, 1.f, 1.f, 1.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a_scale) { as = *reinterpret_cast<const float4*>(a_scale + 4 * q); ah = *reinterpret_cast<const float4*>(a_shift + 4 * q); }
+  const float bv = bias ? bias[wn * 32 + l31] : 0.f;
+  float4 ra[4];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long e = yl_min(tile * 64 + rb + 16 * t, M - 1);
+      ra[t] = *reinterpret_cast<const float4*>(A + e * lda + 4 * q);
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      float* a = As + (rb + 16 * t) * LD + 4 * q;
+      if (a_scale) {
+        a[0] = fmaxf(fmaf(ra[t].x, as.x, ah.x), a_floor); a[1] = fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor);
+        a[2] = fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor); a[3] = fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor);
+      } else {
+        a[0] = ra[t].x; a[1] = ra[t].y; a[2] = ra[t].z; a[3] = ra[t].w;
+      }
+    }
+    __syncthreads();                                     // As complete (and the previous tile's Os reads are done)
+    if (tile + 1 < t1) fetch(tile + 1);                  // in flight under the MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll 8
+    for (int k = 0; k < 64; k += 2) {
+      const float av = As[(wm * 32 + l31) * LD + k + lhi];
+      const float wv = Ws[(wn * 32 + l31) * LD + k + lhi];
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += bv;
+    const int row_base = tile * 64 + wm * 32;
+    if (stats != nullptr) {                              // wave_epilogue's arithmetic (common.hpp), per 32-row group
+      int cnt = M - row_base;
+      cnt = cnt > 32 ? 32 : cnt;
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        sm += (row < M) ? acc[r] : 0.f;
+      }
+      sm += __shfl_xor(sm, 32);
+      const float mu = cnt > 0 ? sm / (float)cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float d = acc[r] - mu;
+        m2 += (row < M) ? d * d : 0.f;
+      }
+      m2 += __shfl_xor(m2, 32);
+      if (lhi == 0 && cnt > 0) stats[(long)(row_base >> 5) * 64 + wn * 32 + l31] = make_float2(sm, m2);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDO + wn * 32 + l31] = acc[r];
+    __syncthreads();                                     // Os complete; every read of As is done
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 16 * t;
+      const long row = (long)tile * 64 + r;
+      if (row < M) *reinterpret_cast<float4*>(Y + row * ldy + 4 * q) = *reinterpret_cast<const float4*>(Os + r * LDO + 4 * q);
+    }
+  }
+}
+
+static bool yl_lin64_stream_ok(const float* A, int64_t lda, int64_t M, int64_t K, const float* a_scale, const float* a_shift,
+                               const float* W, int64_t ldw, const float* bias, int64_t Nout, const float* o_scale, int o_relu,
+                               const float* Y, int64_t ldy, int accumulate, const float* stats) {
+  return K == 64 && Nout == 64 && M >= 65536 && stats != nullptr && bias != nullptr && o_scale == nullptr && !o_relu &&
+         !accumulate && lda % 4 == 0 && ldw % 4 == 0 && ldy % 4 == 0 && yl_aligned16(A) && yl_aligned16(W) && yl_aligned16(Y) &&
+         (((uintptr_t)stats) & 7) == 0 && (!a_scale || (yl_aligned16(a_scale) && yl_aligned16(a_shift)));
+}
+
 extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t K,
                                 const float* a_scale, const float* a_shift, int a_relu,
                                 const float* W, int64_t ldw, const float* bias, int64_t Nout,
@@ -46,6 +155,15 @@ extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t 
   if ((a_scale == nullptr) != (a_shift == nullptr)) return YOLAT_E_INVALID;
   if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
   if (a_relu && !a_scale) return YOLAT_E_INVALID;
+  if (yl_lin64_stream_ok(A, lda, M, K, a_scale, a_shift, W, ldw, bias, Nout, o_scale, o_relu, Y, ldy, accumulate, stats)) {
+    const int ntiles = (int)yl_cdiv(M, 64);
+    const int per = yl_cdiv(ntiles, L64_WGS);
+    hipLaunchKernelGGL(k_lin64_stream, dim3(yl_cdiv(ntiles, per)), dim3(256), 0, (hipStream_t)stream, A, (long)lda, (int)M,
+                       a_scale, a_shift, a_relu ? 0.f : -INFINITY, W, (long)ldw, bias, Y, (long)ldy,
+                       reinterpret_cast<float2*>(stats), per);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   DenseOp b = yl_dense(W, ldw, Nout, K);
   Epilogue ep;
   ep.bias = bias; ep.scale = o_scale; ep.shift = o_shift; ep.relu = o_relu;

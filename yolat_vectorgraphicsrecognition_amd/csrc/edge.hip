@@ -1381,14 +1381,15 @@ template <class T>
 __global__ void __launch_bounds__(256) k_edge_uv_sums(const T* __restrict__ dH, long ldh,
                                                       const int* __restrict__ row_ptr, const int* __restrict__ col_ptr,
                                                       const int* __restrict__ slots, int N, float* __restrict__ dUV,
-                                                      long ldo) {
+                                                      long ldo, int with_u) {
   const int sub = threadIdx.x & 15;
   const int n = blockIdx.x * 16 + (threadIdx.x >> 4);
   if (n >= N) return;
   const T* hp = dH + 4 * sub;
   auto acc = [](float4& s, const float4& v) { s.x += v.x; s.y += v.y; s.z += v.z; s.w += v.w; };
-  // ---- dU: the node's own CSR rows
-  const int q0 = row_ptr[n], q1 = row_ptr[n + 1];
+  // ---- dU: the node's own CSR rows (with_u == 0: written by yolat_bn_apply_edge_sums)
+  int q0 = 0, q1 = 0;
+  if (with_u) { q0 = row_ptr[n]; q1 = row_ptr[n + 1]; }
   float4 su = make_float4(0.f, 0.f, 0.f, 0.f);
   int q = q0;
   for (; q + 8 <= q1; q += 8) {
@@ -1421,7 +1422,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_sums(const T* __restrict__ dH, 
       if (t + j < t1) acc(sv, v[j]);
   }
   float* o = dUV + (long)n * ldo + 4 * sub;
-  *reinterpret_cast<float4*>(o) = su;
+  if (with_u) *reinterpret_cast<float4*>(o) = su;
   *reinterpret_cast<float4*>(o + 64) = sv;
 }
 
@@ -1431,7 +1432,24 @@ extern "C" int yolat_edge_uv_sums(const float* dH1, int64_t ldh, const int32_t* 
   if (N <= 0 || !dH1 || !row_ptr || !col_ptr || !slots || !dUV || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
   if (C != 64 || ldh % 4 != 0 || ld_uv % 4 != 0 || !yl_aligned16(dH1) || !yl_aligned16(dUV)) return YOLAT_E_UNSUPPORTED;
   hipLaunchKernelGGL(k_edge_uv_sums<float>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dH1, (long)ldh, row_ptr,
-                     col_ptr, slots, (int)N, dUV, (long)ld_uv);
+                     col_ptr, slots, (int)N, dUV, (long)ld_uv, 1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// The dV half alone (dUV columns [64, 128): sums over the CSC column of every node, gathered by slot), for callers that
+// got the dU half from yolat_bn_apply_edge_sums.  dH1 fp32 (half = 0) or bfloat16.
+extern "C" int yolat_edge_uv_sums_v(const void* dH1, int64_t ldh, int half, const int32_t* col_ptr, const int32_t* slots,
+                                    int64_t N, int64_t C, float* dUV, int64_t ld_uv, yolat_stream_t stream) {
+  if (N <= 0 || !dH1 || !col_ptr || !slots || !dUV || ldh < C || ld_uv < 2 * C) return YOLAT_E_INVALID;
+  if (C != 64 || ldh % 4 != 0 || ld_uv % 4 != 0 || (((uintptr_t)dH1) & (half ? 7 : 15)) != 0 || !yl_aligned16(dUV))
+    return YOLAT_E_UNSUPPORTED;
+  if (half)
+    hipLaunchKernelGGL(k_edge_uv_sums<yl_bf16_t>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const yl_bf16_t*>(dH1), (long)ldh, col_ptr, col_ptr, slots, (int)N, dUV, (long)ld_uv, 0);
+  else
+    hipLaunchKernelGGL(k_edge_uv_sums<float>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const float*>(dH1), (long)ldh, col_ptr, col_ptr, slots, (int)N, dUV, (long)ld_uv, 0);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -1443,7 +1461,7 @@ extern "C" int yolat_edge_uv_sums_h(const uint16_t* dH1, int64_t ldh, const int3
   if (C != 64 || ldh % 4 != 0 || ld_uv % 4 != 0 || (((uintptr_t)dH1) & 7) != 0 || !yl_aligned16(dUV))
     return YOLAT_E_UNSUPPORTED;
   hipLaunchKernelGGL(k_edge_uv_sums<yl_bf16_t>, dim3(yl_cdiv(N, 16)), dim3(256), 0, (hipStream_t)stream, dH1, (long)ldh,
-                     row_ptr, col_ptr, slots, (int)N, dUV, (long)ld_uv);
+                     row_ptr, col_ptr, slots, (int)N, dUV, (long)ld_uv, 1);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -1553,6 +1571,167 @@ extern "C" int yolat_edge_attr_dw(const void* dH1, int64_t ldh, int half, const 
   else
     hipLaunchKernelGGL(k_attr_dw<float>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const float*>(dH1), (long)ldh,
                        reinterpret_cast<const float4*>(attr_csr), (int)E, (int)rows_wg, work);
+  YL_LAUNCH_CHECK();
+  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(40), dim3(256), 0, st, work, nwg, dWc4, db1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// BatchNorm-1 backward apply + the CONTIGUOUS consumers of its result in one pass (round 4; training backward of the
+// factorised conv layer, torch_vertex.py:331-332 nn.1/nn.2 backward feeding nn.0's):
+//   dH1[q] = scale * (relu'(.) dA1[q] - c1 - xhat[q] c2)                        (k_bn_bwd_apply_v4's arithmetic, stored)
+//   dU[n]  = sum_{q in CSR row n} dH1[q]                                        (k_edge_uv_sums' first half, ascending q)
+//   dWc4   = dH1^T . attr,  db1 = column sums of dH1                            (k_attr_dw)
+// dH1 used to be written by the apply pass and read three times (dU rows, dV gather, attr gradient): 921 + 614 + 307 MB
+// per layer at E = 1.2 M.  Here the rows of a node are formed, stored (the dV gather of yolat_edge_uv_sums_v still
+// needs them) and summed while they are in registers: 921 MB + the gather.  One 16-lane group per node (a float4 of
+// columns per lane), 4 rows in flight, a workgroup owns a contiguous range of nodes = a contiguous range of rows;
+// 16 + 4 attr accumulators per lane over all the nodes of the group, reduced like k_attr_dw (LDS in fixed order, then
+// k_attr_dw_reduce over the workgroups): deterministic.  bf16 storage: the sums take the ROUNDED values, i.e. what the
+// gather reads back.
+// ------------------------------------------------------------------------------------------------
+constexpr int BA_NODES_MAX = 1024;
+__device__ __forceinline__ float ba_round(float v, float) { return v; }
+__device__ __forceinline__ float ba_round(float v, yl_bf16_t) { return __uint_as_float((yl_pack_bf16(v, 0.f) & 0xffffu) << 16); }
+__device__ __forceinline__ float ba_ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ba_ld1(const yl_bf16_t* p) { return __uint_as_float((unsigned)(*p) << 16); }
+__device__ __forceinline__ void ba_st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void ba_st1(yl_bf16_t* p, float v) { *p = (yl_bf16_t)(__float_as_uint(v) >> 16); }   // v is rounded already
+// Mapping: one WAVE per row, lane = column.  (The first version used a 16-lane group per node with a float4 of columns
+// per lane, like k_edge_uv_sums: 16 attr accumulators + 24 constants + the rows in flight = 124 VGPRs = 4 waves per SIMD,
+// and it ran at 184 us per call at E = 1.2 M against 144 for the apply pass alone.)  With the row wave-uniform the
+// attr quad is a scalar load, a lane holds 4 + 1 accumulators and 6 constants, eight rows are in flight with 16
+// registers, and the node boundaries are scalar branches.
+template <class T>
+__global__ void __launch_bounds__(256) k_bn_apply_edge_sums(const T* __restrict__ dZ, long lddz, const T* __restrict__ Y,
+                                                            long ldy, T* dY, long lddy,
+                                                            const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                            const float* __restrict__ scale, const float* __restrict__ shift,
+                                                            int relu, const float* __restrict__ coef,
+                                                            const int* __restrict__ row_ptr, const float4* __restrict__ attr,
+                                                            int N, int nodes_wg, float* __restrict__ dU, long ldo,
+                                                            float* __restrict__ part) {
+  __shared__ float red[4][320];
+  __shared__ int rp[BA_NODES_MAX + 1];
+  const int tid = threadIdx.x, c = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const float mu = mean[c], is = invstd[c], sc = scale[c], sh = shift[c], k1 = coef[c], k2 = coef[64 + c];
+  auto one = [&](float y, float g) {
+    if (relu && !(fmaf(y, sc, sh) > 0.f)) g = 0.f;
+    // the product is a stored value: the sums below must add exactly what the gather reads back — the empty asm keeps
+    // the compiler from contracting "sum + a * (...)" into an fma of its factors
+    float p = sc * (g - k1 - ((y - mu) * is) * k2);
+    asm volatile("" : "+v"(p));
+    return ba_round(p, T());
+  };
+  float w[4] = {0.f, 0.f, 0.f, 0.f}, sb = 0.f;
+  // The workgroup's nodes [n0, n1) are dealt to its 4 waves as 4 contiguous node ranges of (nearly) equal ROW counts:
+  // wave k owns the nodes whose first row lies in the k-th quarter of the workgroup's row range (the last wave also the
+  // trailing nodes without rows).  A function of the graph alone, so the order of every sum is fixed.
+  const int n0 = blockIdx.x * nodes_wg, n1 = yl_min(n0 + nodes_wg, N);
+  const int cnt = n1 - n0;                                  // <= BA_NODES_MAX by the launch
+  for (int i = tid; i <= cnt; i += 256) rp[i] = row_ptr[n0 + i];
+  __syncthreads();
+  const long Q0 = rp[0], QR = (long)rp[cnt] - Q0;
+  auto first_at_or_after = [&](long v) {                    // lowest i in [0, cnt] with rp[i] >= v
+    int lo = 0, hi = cnt;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (rp[mid] >= v) hi = mid; else lo = mid + 1;
+    }
+    return lo;
+  };
+  int i = __builtin_amdgcn_readfirstlane(first_at_or_after(Q0 + QR * wave / 4));
+  const int iend = wave == 3 ? cnt : __builtin_amdgcn_readfirstlane(first_at_or_after(Q0 + QR * (wave + 1) / 4));
+  // the wave's nodes [i, iend) own the contiguous rows [rp[i], rp[iend]): streamed eight at a time whatever the node
+  // boundaries are; a row that starts a new node first flushes the finished nodes' sums (nodes without rows: zeros)
+  if (i < iend) {
+    const int qa = __builtin_amdgcn_readfirstlane(rp[i]), qb = __builtin_amdgcn_readfirstlane(rp[iend]);
+    int qn = __builtin_amdgcn_readfirstlane(rp[i + 1]);     // first row that is NOT node i's
+    float su = 0.f;
+    for (int q = qa; q < qb; q += 8) {
+      float y[8], g[8];
+      float4 av[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        const long r = yl_min(q + k, qb - 1);               // wave-uniform
+        y[k] = ba_ld1(Y + r * ldy + c);
+        g[k] = ba_ld1(dZ + r * lddz + c);
+        av[k] = attr[r];                                    // scalar load
+      }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        if (q + k < qb) {
+          while (q + k >= qn) {
+            dU[(long)(n0 + i) * ldo + c] = su;
+            su = 0.f;
+            ++i;
+            qn = __builtin_amdgcn_readfirstlane(rp[i + 1]);
+          }
+          const float hv = one(y[k], g[k]);
+          ba_st1(dY + (long)(q + k) * lddy + c, hv);
+          su += hv;
+          sb += hv;
+          w[0] = fmaf(hv, av[k].x, w[0]); w[1] = fmaf(hv, av[k].y, w[1]);
+          w[2] = fmaf(hv, av[k].z, w[2]); w[3] = fmaf(hv, av[k].w, w[3]);
+        }
+      }
+    }
+    for (; i < iend; ++i) {                                 // the last node with rows + trailing nodes without
+      dU[(long)(n0 + i) * ldo + c] = su;
+      su = 0.f;
+    }
+  }
+  float* mine = red[wave];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) mine[c * 4 + j] = w[j];
+  mine[256 + c] = sb;
+  __syncthreads();
+  for (int e = tid; e < 320; e += 256) part[(long)blockIdx.x * 320 + e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+}
+
+static long ba_nodes_wg(int64_t N) {
+  // ~ADW_WG_MAX workgroups: 124 VGPRs = 4 workgroups per CU = 1024 resident on 256 CUs, so 2048 is two full rounds (the
+  // first version rounded the node count up to a multiple of 16: 1786 workgroups at cfg 5 = 1.74 rounds)
+  long nodes_wg = yl_cdiv(N, ADW_WG_MAX);
+  if (nodes_wg < 16) nodes_wg = 16;
+  if (nodes_wg > BA_NODES_MAX) nodes_wg = BA_NODES_MAX;      // N > 2 M nodes: more than ADW_WG_MAX workgroups
+  return nodes_wg;
+}
+extern "C" size_t yolat_bn_apply_edge_sums_work_elems(int64_t N) {
+  return (size_t)(N > 0 ? yl_cdiv(N, ba_nodes_wg(N)) : 1) * 320;
+}
+
+// dA1 / H1 / dH1 [E, 64] fp32 (half = 0) or bfloat16 (half != 0), rows in CSR order (dH1 may alias dA1); coef [128] =
+// (c1 | c2) of the BatchNorm backward (yolat_bn_csr_l2_bwd's next_coef); dUV [N, ld_uv]: columns [0, 64) are written
+// (the dV half: yolat_edge_uv_sums_v); dWc4 [64, 4], db1 [64] (nullable).  work: yolat_bn_apply_edge_sums_work_elems(N).
+extern "C" int yolat_bn_apply_edge_sums(const void* dA1, int64_t ldda, const void* H1, int64_t ldh, void* dH1, int64_t lddh,
+                                        int half, int64_t E, const float* save_mean, const float* save_invstd,
+                                        const float* scale, const float* shift, int relu, const float* coef,
+                                        const int32_t* row_ptr, const float* attr_csr, int64_t N, float* dUV, int64_t ld_uv,
+                                        float* dWc4, float* db1, float* work, yolat_stream_t stream) {
+  if (E <= 0 || N <= 0 || !dA1 || !H1 || !dH1 || !save_mean || !save_invstd || !scale || !shift || !coef || !row_ptr ||
+      !attr_csr || !dUV || !dWc4 || !work || ldda < 64 || ldh < 64 || lddh < 64 || ld_uv < 64)
+    return YOLAT_E_INVALID;
+  const uintptr_t al = half ? 7 : 15;
+  if (ldda % 4 != 0 || ldh % 4 != 0 || lddh % 4 != 0 || ld_uv % 4 != 0 || E >= (1LL << 31) - 64 || N >= (1LL << 31) - 64 ||
+      (((uintptr_t)dA1 | (uintptr_t)H1 | (uintptr_t)dH1) & al) || !yl_aligned16(save_mean) || !yl_aligned16(save_invstd) ||
+      !yl_aligned16(scale) || !yl_aligned16(shift) || !yl_aligned16(coef) || !yl_aligned16(attr_csr) || !yl_aligned16(dUV))
+    return YOLAT_E_UNSUPPORTED;
+  hipStream_t st = (hipStream_t)stream;
+  const long nodes_wg = ba_nodes_wg(N);
+  const int nwg = yl_cdiv(N, nodes_wg);
+  if (half)
+    hipLaunchKernelGGL(k_bn_apply_edge_sums<yl_bf16_t>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const yl_bf16_t*>(dA1),
+                       (long)ldda, reinterpret_cast<const yl_bf16_t*>(H1), (long)ldh, reinterpret_cast<yl_bf16_t*>(dH1),
+                       (long)lddh, save_mean, save_invstd, scale, shift, relu, coef, row_ptr,
+                       reinterpret_cast<const float4*>(attr_csr), (int)N, (int)nodes_wg, dUV, (long)ld_uv, work);
+  else
+    hipLaunchKernelGGL(k_bn_apply_edge_sums<float>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const float*>(dA1),
+                       (long)ldda, reinterpret_cast<const float*>(H1), (long)ldh, reinterpret_cast<float*>(dH1), (long)lddh,
+                       save_mean, save_invstd, scale, shift, relu, coef, row_ptr, reinterpret_cast<const float4*>(attr_csr),
+                       (int)N, (int)nodes_wg, dUV, (long)ld_uv, work);
   YL_LAUNCH_CHECK();
   hipLaunchKernelGGL(k_attr_dw_reduce, dim3(40), dim3(256), 0, st, work, nwg, dWc4, db1);
   YL_LAUNCH_CHECK();

@@ -206,8 +206,8 @@ extern "C" int yolat_segment_ptr(const int64_t* bbox_idx, int64_t N, int64_t P, 
 
 // ------------------------------------------------------------------------------------------------
 // yolat_graph_prepare: the whole per-batch structure in 4 launches + 1 memset.
-//   1. k_prep_count   edge e: int64 -> int32, range check, rank[e] = atomicAdd(cnt[dst]) (arrival order,
-//                     only used to place e somewhere inside its row); row r: segment pointers
+//   1. k_prep_count_win  edge e: int64 -> int32, range check, rank[e] = a unique position inside its row (arrival
+//                     order: only used to place e somewhere inside its row); row r: segment pointers
 //   2. k_prep_scan    per-4096-element-block exclusive scan of cnt (multi-workgroup) + block totals
 //   3. k_prep_fill    items[local[dst] + blockprefix + rank[e]] = e
 //   4. k_prep_rows    slot t: rank of items[t] among its row's items by edge id (restores the stable order),
@@ -220,32 +220,89 @@ __global__ void __launch_bounds__(256) k_zero_i32(int* p, int n) {      // n a m
   for (int j = 0; j < 4; ++j)
     if (i + j < n) p[i + j] = 0;
 }
-__global__ void k_prep_count(const int64_t* edge, long se, long sc, int E, int N, int* src32, int* dst32,
-                             int* rank, int* cnt, const int64_t* bbox, long P, int* seg_ptr, int* node_seg,
-                             int* status) {
-  const int t = blockIdx.x * blockDim.x + threadIdx.x;
-  if (t < E) {
-    int64_t s = edge[(long)t * se];
-    int64_t d = edge[(long)t * se + sc];
-    if (s < 0 || s >= N || d < 0 || d >= N) {
-      atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
-      s = s < 0 ? 0 : (s >= N ? N - 1 : s);
-      d = d < 0 ? 0 : (d >= N ? N - 1 : d);
+// Counting pre-aggregated per workgroup (round 4).  One RETURNING device-scope atomic per edge (rounds 1-3) executes
+// behind the XCDs' L2s, ~32 per ns for the whole device: 38 us at E = 1.2 M, a third of the large-graph preparation.  Edge lists of this domain are grouped by proposal (graph_dict3.py:582-600 builds them
+// proposal by proposal; collate concatenates graphs), so the PCW_E consecutive edges of a workgroup point into a narrow
+// window of destination rows.  When that window is at most PCW_WIN rows the workgroup ranks its edges with LDS atomics
+// and sends ONE returning global atomic per touched row (count added, base returned): rank = base + rank inside the
+// workgroup.  Any window wider than that (shuffled edge lists) takes the direct path — same result either way, because
+// the rank only places an edge somewhere inside its row (k_prep_rows restores the stable order).
+#define PCW_T 512
+#define PCW_PER 4
+#define PCW_E (PCW_T * PCW_PER)
+#define PCW_WIN 4096
+__global__ void __launch_bounds__(PCW_T) k_prep_count_win(const int64_t* edge, long se, long sc, int E, int N, int* src32,
+                                                          int* dst32, int* rank, int* cnt, const int64_t* bbox, long P,
+                                                          int* seg_ptr, int* node_seg, int* status) {
+  __shared__ int win[PCW_WIN];
+  __shared__ int wlo[PCW_T / 64], whi[PCW_T / 64];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int e0 = blockIdx.x * PCW_E;
+  int d[PCW_PER];
+  int lo = 0x7fffffff, hi = -1;
+#pragma unroll
+  for (int j = 0; j < PCW_PER; ++j) {
+    const int t = e0 + tid + PCW_T * j;
+    d[j] = -1;
+    if (t < E) {
+      int64_t s = edge[(long)t * se];
+      int64_t dd = edge[(long)t * se + sc];
+      if (s < 0 || s >= N || dd < 0 || dd >= N) {
+        atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
+        s = s < 0 ? 0 : (s >= N ? N - 1 : s);
+        dd = dd < 0 ? 0 : (dd >= N ? N - 1 : dd);
+      }
+      src32[t] = (int)s; dst32[t] = (int)dd;
+      d[j] = (int)dd;
+      lo = yl_min(lo, d[j]); hi = yl_max(hi, d[j]);
     }
-    src32[t] = (int)s; dst32[t] = (int)d;
-    rank[t] = atomicAdd(&cnt[d], 1);
   }
-  if (bbox != nullptr && t <= N) {
-    long prev = (t == 0) ? -1 : bbox[t - 1];
-    long cur = (t == N) ? P : bbox[t];
-    if (t < N) {
-      if (cur < 0 || cur >= P) { atomicOr(status, YOLAT_STATUS_SEG_RANGE); cur = cur < 0 ? 0 : P - 1; }
-      node_seg[t] = (int)cur;
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    lo = yl_min(lo, __shfl_xor(lo, off));
+    hi = yl_max(hi, __shfl_xor(hi, off));
+  }
+  if (lane == 0) { wlo[wave] = lo; whi[wave] = hi; }
+  __syncthreads();
+#pragma unroll
+  for (int w = 0; w < PCW_T / 64; ++w) { lo = yl_min(lo, wlo[w]); hi = yl_max(hi, whi[w]); }
+  const int span = hi - lo + 1;                           // <= 0: no edge in this workgroup
+  if (span > 0 && span <= PCW_WIN) {
+    for (int i = tid; i < span; i += PCW_T) win[i] = 0;
+    __syncthreads();
+    int lr[PCW_PER];
+#pragma unroll
+    for (int j = 0; j < PCW_PER; ++j) lr[j] = d[j] >= 0 ? atomicAdd(&win[d[j] - lo], 1) : 0;
+    __syncthreads();
+    for (int i = tid; i < span; i += PCW_T) {
+      const int c = win[i];
+      if (c > 0) win[i] = atomicAdd(&cnt[lo + i], c);
     }
-    if (prev >= P) prev = P - 1;
-    if (prev < -1) prev = -1;
-    if (cur < prev) atomicOr(status, YOLAT_STATUS_SEG_UNSORTED);
-    else for (long p = prev + 1; p <= cur; ++p) seg_ptr[p] = t;
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < PCW_PER; ++j)
+      if (d[j] >= 0) rank[e0 + tid + PCW_T * j] = win[d[j] - lo] + lr[j];
+  } else if (span > 0) {
+#pragma unroll
+    for (int j = 0; j < PCW_PER; ++j)
+      if (d[j] >= 0) rank[e0 + tid + PCW_T * j] = atomicAdd(&cnt[d[j]], 1);
+  }
+  if (bbox != nullptr) {
+#pragma unroll
+    for (int j = 0; j < PCW_PER; ++j) {
+      const int t = e0 + tid + PCW_T * j;
+      if (t > N) continue;
+      long prev = (t == 0) ? -1 : bbox[t - 1];
+      long cur = (t == N) ? P : bbox[t];
+      if (t < N) {
+        if (cur < 0 || cur >= P) { atomicOr(status, YOLAT_STATUS_SEG_RANGE); cur = cur < 0 ? 0 : P - 1; }
+        node_seg[t] = (int)cur;
+      }
+      if (prev >= P) prev = P - 1;
+      if (prev < -1) prev = -1;
+      if (cur < prev) atomicOr(status, YOLAT_STATUS_SEG_UNSORTED);
+      else for (long p = prev + 1; p <= cur; ++p) seg_ptr[p] = t;
+    }
   }
 }
 
@@ -694,7 +751,7 @@ int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_
     YL_LAUNCH_CHECK();
   }
   const long nthreads = (E > N + 1) ? E : N + 1;
-  hipLaunchKernelGGL(k_prep_count, dim3(yl_cdiv(nthreads, 256)), dim3(256), 0, st, edge, (long)stride_e,
+  hipLaunchKernelGGL(k_prep_count_win, dim3(yl_cdiv(nthreads, PCW_E)), dim3(PCW_T), 0, st, edge, (long)stride_e,
                      (long)stride_c, (int)E, (int)N, src32, dst32, rank, cnt, bbox_idx, (long)P, seg_ptr,
                      node_seg, status);
   YL_LAUNCH_CHECK();

@@ -268,6 +268,8 @@ def lbr_bwd(sv, dz, sink, dx_out=None, dx_accumulate=False, need_dx=True, dz_inp
 # ---------------------------------------------------------------------------------------------
 
 FUSED_BN_CSR_BWD = True
+# the BatchNorm-1 backward apply pass also takes dU, dWc4 and db1 of the factorised first edge Linear (round 4)
+FUSED_BN_APPLY_SUMS = True
 
 
 def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False, node_coef_out=None):
@@ -344,6 +346,9 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         H1, H2, c1, c2 = sv["H1"], sv["H2"], sv["c1"], sv["c2"]
         dA1 = torch.empty(E, C, dtype=H1.dtype, device=dev)
         bn1_done = False
+        partial, db1 = None, None
+        fact_bwd = H1.dtype == torch.bfloat16 or (FACTORISED_TRAIN and C == 64 and E >= FACT_BWD_RATIO * N
+                                                  and nn0.weight.is_contiguous() and nn0.bias is not None)
         one_kernel = C == 64 and nn3.in_features == 64 and nn3.weight.is_contiguous()
         # the fused kernels read the parameter / coefficient vectors with 16-byte loads: views of a flat parameter buffer
         # start wherever the preceding parameters end, so the alignment is part of the gate (else: the materialising path)
@@ -360,7 +365,13 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
                 coef1 = dh2.bwd_w_and_x(H1, nn3.weight, sink.get(nn3.weight), sink.get(nn3.bias), dA1,
                                         a_pro=(c1[0], c1[1]), a_relu=True,
                                         next_bn=(c1[2], c1[3], sink.get(bn1.weight), sink.get(bn1.bias)))
-                ops.bn_relu_bwd_apply(dA1, H1, c1[2], c1[3], c1[0], c1[1], True, coef1, dA1)
+                if fact_bwd and FUSED_BN_APPLY_SUMS and g.attr.data_ptr() % 16 == 0:
+                    # the apply pass forms dH1 row by row in CSR order: its per-node sums (dU), the attr weight gradient and
+                    # db1 are taken while the rows are in registers — dH1 is read again only by the gathered dV sums
+                    db1 = sink.get(nn0.bias)              # ONE get per parameter: the autograd sink hands out a fresh tensor each time
+                    partial = ops.bn_apply_edge_sums(dA1, H1, c1[2], c1[3], c1[0], c1[1], True, coef1, g, db1)
+                else:
+                    ops.bn_relu_bwd_apply(dA1, H1, c1[2], c1[3], c1[0], c1[1], True, coef1, dA1)
                 bn1_done = True
             else:
                 dh2.bwd_w(H1, sink.get(nn3.weight), sink.get(nn3.bias), a_pro=(c1[0], c1[1]), a_relu=True)
@@ -375,12 +386,10 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         if not bn1_done:
             ops.bn_relu_bwd(dA1, H1, bn1.weight, c1[2], c1[3], c1[0], c1[1], True,
                             sink.get(bn1.weight), sink.get(bn1.bias), dA1)           # dA1 -> dH1 in place
-        hdt = H1.dtype
-        if hdt == torch.bfloat16 or (FACTORISED_TRAIN and C == 64 and E >= FACT_BWD_RATIO * N and nn0.weight.is_contiguous()
-                                     and nn0.bias is not None):
+        if fact_bwd:
             # per-node sums of dH1 + N-row dense algebra instead of the gathered E-row GEMMs (pays when E >> N)
-            ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), sink.get(nn0.bias),
-                                         dx=dx if need_dx else None, dx_accumulate=True, side=_on_side)
+            ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), db1 if db1 is not None else sink.get(nn0.bias),
+                                         dx=dx if need_dx else None, dx_accumulate=True, side=_on_side, partial=partial)
         else:
             ops.edge_lin1_bwd_w(dA1, x, g, sink.get(nn0.weight), sink.get(nn0.bias))
             if need_dx:

@@ -529,33 +529,62 @@ def attr_dw(dH1, g, dwc4, db1=None):
     return linear_bwd_w(dH1, g.attr, dwc4, db1)
 
 
-def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=False, wuv=None, side=None):
+def bn_apply_edge_sums(dA1, H1, save_mean, save_invstd, scale, shift, relu, coef, g, db1):
+    """The BatchNorm + ReLU backward apply pass in front of the factorised first edge Linear, fused with the consumers
+    that read its result in CSR order (yolat_bn_apply_edge_sums): dA1 -> dH1 in place, returns (dUV [N, 128] with the dU
+    half written, dWc4 [64, 4]); db1 is written.  Hand both to edge_lin1_bwd_factorised(..., partial=(dUV, dWc4))."""
+    E, C = H1.shape
+    N = g.N
+    hp = _is_h(H1)
+    dUV = torch.empty(N, 2 * C, dtype=torch.float32, device=H1.device)
+    dwc4 = torch.empty(C, 4, dtype=torch.float32, device=H1.device)
+    work = torch.empty(int(lib.yolat_bn_apply_edge_sums_work_elems(N)), dtype=torch.float32, device=H1.device)
+    check(lib.yolat_bn_apply_edge_sums(_h(dA1, "dA1") if hp else _f(dA1, "dA1"), _ld(dA1), _h(H1, "H1") if hp else _f(H1, "H1"),
+                                       _ld(H1), dA1.data_ptr(), _ld(dA1), int(hp), E, _f(save_mean), _f(save_invstd),
+                                       _f(scale), _f(shift), int(relu), _f(coef), g.row_ptr.data_ptr(), g.attr.data_ptr(), N,
+                                       dUV.data_ptr(), 2 * C, dwc4.data_ptr(), _f(db1, "db1", True), work.data_ptr(),
+                                       _stream()), "yolat_bn_apply_edge_sums")
+    return dUV, dwc4
+
+
+def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=False, wuv=None, side=None, partial=None):
     """Backward of the first edge Linear through the per-node products (see yolat_edge_uv_sums): writes dW1, db1 and,
-    when `dx` is given, (accumulates) the gradient w.r.t. the node features.  C = 64; pays when E >> N."""
+    when `dx` is given, (accumulates) the gradient w.r.t. the node features.  C = 64; pays when E >> N.
+    partial = (dUV, dWc4) from bn_apply_edge_sums: the dU half, dWc4 and db1 exist already — only the gathered dV half
+    is left to sum."""
     N, Cin = x.shape
     C = W1.shape[0]
     g.ensure_csc()
     if wuv is None:
         wuv, _ = split_w1(W1, Cin)
-    dUV = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
-    if _is_h(dH1):
-        check(lib.yolat_edge_uv_sums_h(_h(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
-                                       g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()),
-              "yolat_edge_uv_sums_h")
+    dwc4_done = None
+    if partial is not None:
+        dUV, dwc4_done = partial
+        check(lib.yolat_edge_uv_sums_v(dH1.data_ptr(), _ld(dH1), int(_is_h(dH1)), g.col_ptr.data_ptr(), g.slots.data_ptr(),
+                                       N, C, dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums_v")
     else:
-        check(lib.yolat_edge_uv_sums(_f(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
-                                     g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums")
+        dUV = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
+        if _is_h(dH1):
+            check(lib.yolat_edge_uv_sums_h(_h(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
+                                           g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()),
+                  "yolat_edge_uv_sums_h")
+        else:
+            check(lib.yolat_edge_uv_sums(_f(dH1), _ld(dH1), g.row_ptr.data_ptr(), g.col_ptr.data_ptr(),
+                                         g.slots.data_ptr(), N, C, dUV.data_ptr(), 2 * C, _stream()), "yolat_edge_uv_sums")
     def weight_grads():
         dwuv = torch.empty(2 * C, Cin, dtype=torch.float32, device=x.device)
         linear_bwd_w(dUV, x, dwuv)
-        dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
-        attr_dw(dH1, g, dwc4, db1)
+        if dwc4_done is not None:
+            dwc4 = dwc4_done
+        else:
+            dwc4 = torch.empty(C, 4, dtype=torch.float32, device=x.device)
+            attr_dw(dH1, g, dwc4, db1)
         check(lib.yolat_conv_merge_dw1(dwuv.data_ptr(), dwc4.data_ptr(), Cin, C, _f(dW1), _ld(dW1), 0, _stream()),
               "yolat_conv_merge_dw1")
     # `side` (engine._on_side): the three weight-gradient launches on a second stream, beside the dx GEMM below and
     # whatever the caller issues next — nothing in the backward reads dW1 / db1
     if side is not None:
-        side(weight_grads, (dUV, x, dH1, g.attr))
+        side(weight_grads, (dUV, x, dH1, g.attr, dwc4_done))
     else:
         weight_grads()
     if dx is not None:
