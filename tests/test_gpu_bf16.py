@@ -454,9 +454,12 @@ def test_bf16_storage_ops_round_to_nearest_even_and_reject_fp32_mixups():
 @pytest.mark.gpu
 @pytest.mark.parametrize("N,E", [(300, 1000), (4000, 30000)])
 def test_fused_bn_csr_backward_bf16_storage_matches_fp32_on_the_same_values(N, E):
-    """ops.BnCsrGrad with bfloat16-STORED Y / A / dA (bn_csr.hip, one-kernel form): the fp32 instantiation run on the
-    same (bf16-representable) values is the reference — dgamma / dbeta / dW / db agree to fp32 summation noise, dA to one
-    bf16 rounding of the output."""
+    """ops.BnCsrGrad with bfloat16-STORED Y / A / dA (bn_csr.hip, one-kernel form k_bn_csr_l2_bwd_h): the fp32
+    instantiation run on the same (bf16-representable) values is the reference.  dgamma / dbeta / db are formed in fp32
+    from the same values: fp32 summation noise.  The two products run on the bf16 matrix cores (round 4) like the
+    forward Linear of this mode: dY, relu(bn(A)) and W are rounded to bfloat16 (2^-9 each) before dA = dY . W and
+    dW = dY^T . A1, accumulation fp32 — dW within 8e-3 of its largest element and 5e-3 in norm (a sum of E products with
+    independent 2^-8 errors; measured 4.3e-3 at E = 1000), dA within 2^-7 of its largest element (64 such products + the rounding of the stored output)."""
     import numpy as np
     yv = _yv()
     C = 64
@@ -486,8 +489,12 @@ def test_fused_bn_csr_backward_bf16_storage_matches_fp32_on_the_same_values(N, E
     got = run(H2, H1, torch.bfloat16)
     for name, a, b in zip(("dgamma", "dbeta", "dW", "db"), ref[:4], got[:4]):
         tol = 2e-5 * (float(ref[4].abs().sum(0).max()) if name == "db" else max(float(a.abs().max()), 1e-6))
+        if name == "dW":
+            tol = 8e-3 * float(a.abs().max())
         assert float((a - b).abs().max()) <= tol, name
-    assert float((ref[4] - got[4]).abs().max()) <= 2.0 ** -8 * float(ref[4].abs().max())
+    assert float((ref[4] - got[4]).abs().max()) <= 2.0 ** -7 * float(ref[4].abs().max())
+    rel = float((ref[2] - got[2]).norm() / ref[2].norm())
+    assert rel <= 5e-3, rel
     again = run(H2, H1, torch.bfloat16)
     for a, b in zip(got, again):
         assert torch.equal(a, b)

@@ -261,18 +261,30 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
   float4 p1 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p1;   // next BatchNorm's partial sums, columns 4q..4q+3
   float4 bm = p1, bi = p1;
   if (part1 != nullptr) { bm = *reinterpret_cast<const float4*>(bn_mean + 4 * q); bi = *reinterpret_cast<const float4*>(bn_invstd + 4 * q); }
+  // the destination ids run one tile AHEAD of the rows: dst[e] -> (inv_deg[n], d_out[n]) is a chain of two dependent
+  // global loads, and with two workgroups per CU the chain's second round trip was the tile time (the bf16 kernel: 10 k
+  // cycles per tile for 2 k cycles of work)
+  int nn[4];
+  auto fetch_idx = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) nn[t] = y.dst[yl_min(tile * 64 + rb + 16 * t, E - 1)];
+  };
   auto fetch = [&](int tile) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int e = yl_min(tile * 64 + rb + 16 * t, E - 1);
-      const int n = y.dst[e];
+      const int n = nn[t];
       rw[t] = y.inv_deg[n];
       ry[t] = yl_ld4(y.Y + (long)e * y.ldy + 4 * q);
       rg[t] = *reinterpret_cast<const float4*>(y.dout + (long)n * y.ldo + 4 * q);
       ra[t] = yl_ld4(A + (long)e * lda + 4 * q);
     }
   };
-  if (t0 < t1) fetch(t0);
+  if (t0 < t1) {
+    fetch_idx(t0);
+    fetch(t0);
+    if (t0 + 1 < t1) fetch_idx(t0 + 1);
+  }
   for (int tile = t0; tile < t1; ++tile) {
     // ---- the two tiles into LDS (rows beyond E: zero — they are in the reduction of dW / db)
 #pragma unroll
@@ -292,7 +304,10 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
       rh[t] = ra[t];                                     // raw A of this tile (ra is refilled by the prefetch)
     }
     __syncthreads();
-    if (tile + 1 < t1) fetch(tile + 1);                  // in flight under the MFMAs
+    if (tile + 1 < t1) {                                 // in flight under the MFMAs
+      fetch(tile + 1);
+      if (tile + 2 < t1) fetch_idx(tile + 2);
+    }
     // ---- dA tile = dY . W   (rows wm*32.., columns wn*32..)
     f32x16 acca;
 #pragma unroll
@@ -385,6 +400,197 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
   if (tid < 64) P[64 * 64 + tid] = dbacc;
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// The same kernel for bfloat16 STORAGE on the bf16 matrix cores (round 4).  The fp32-MFMA instantiation above spends
+// 64 x 64 cycles of v_mfma_f32_32x32x2f32 per tile and wave — 125 us of matrix-core time at E = 1.2 M before any
+// staging, which made the bf16-storage step's kernel SLOWER than the fp32 one (288 vs 276 us) although it moves half the
+// bytes.  In this mode the operands are bfloat16-stored values anyway and the two [E,64] x [64,64] Linears of the
+// forward / dX path already run on v_mfma_f32_32x32x16_bf16 (dense.hip hgemm_tile), so here too: the dY tile (formed in
+// fp32 from Y, the gathered d_out rows and the coefficients) and the prologue'd input tile A1 are rounded to bfloat16
+// (nearest even) on their way into LDS, W is rounded once per workgroup; accumulation stays fp32.
+//   dA[tile] = dY . W        A operand: dY rows (two 8-byte LDS reads), B operand: W^T rows (one 16-byte read)   4 MFMAs
+//   dW      += dY^T . A1     both operands are COLUMNS of the row-major tiles: eight 2-byte LDS reads each       4 MFMAs
+// (column reads: 64 per tile and wave instead of the 128 4-byte reads of the fp32 kernel; row stride 68 bf16 = 34 banks,
+// so the two lane halves, 8 rows apart, land 16 banks apart).  db: per-thread sums of the fp32 dY values over the
+// thread's rows, combined over the 16 row groups in fixed order at the end.  Two barriers per tile instead of four.
+// ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bcl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned bcl_u32x4 __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd_h(BnCsrOpT<yl_bf16_t> y, const yl_bf16_t* __restrict__ A, long lda,
+                                                         const float* __restrict__ a_scale, const float* __restrict__ a_shift,
+                                                         float a_floor, const float* __restrict__ W, long ldw,
+                                                         yl_bf16_t* __restrict__ dA, long ldda, int E, int tiles_per_wg,
+                                                         float* __restrict__ partial, const float* __restrict__ bn_mean,
+                                                         const float* __restrict__ bn_invstd, float2* __restrict__ part1) {
+  constexpr int LDH = 68, LDW = 72, LDO = 68;
+  __shared__ __attribute__((aligned(16))) unsigned short Dh[64 * LDH], Ah[64 * LDH], Wt[64 * LDW];
+  __shared__ __attribute__((aligned(16))) float Os[64 * LDO];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = tid & 15, rb = tid >> 4;                 // staging role: columns 4q.., rows rb + 16 t
+  const int ntiles = (E + 63) >> 6;
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = yl_min(ntiles, t0 + tiles_per_wg);
+  // W [64 c][64 k] -> Wt[k][c] (bf16): the B operand of dA = dY . W wants eight consecutive c per lane
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = rb + 16 * t;
+    const float4 w = *reinterpret_cast<const float4*>(W + (long)r * ldw + 4 * q);
+    Wt[(4 * q + 0) * LDW + r] = (unsigned short)(yl_pack_bf16(w.x, 0.f) & 0xffffu);
+    Wt[(4 * q + 1) * LDW + r] = (unsigned short)(yl_pack_bf16(w.y, 0.f) & 0xffffu);
+    Wt[(4 * q + 2) * LDW + r] = (unsigned short)(yl_pack_bf16(w.z, 0.f) & 0xffffu);
+    Wt[(4 * q + 3) * LDW + r] = (unsigned short)(yl_pack_bf16(w.w, 0.f) & 0xffffu);
+  }
+  const float4 mu = *reinterpret_cast<const float4*>(y.mean + 4 * q), is = *reinterpret_cast<const float4*>(y.invstd + 4 * q);
+  const float4 sc = *reinterpret_cast<const float4*>(y.scale + 4 * q), sh = *reinterpret_cast<const float4*>(y.shift + 4 * q);
+  const float4 k1 = *reinterpret_cast<const float4*>(y.coef + 4 * q), k2 = *reinterpret_cast<const float4*>(y.coef + 64 + 4 * q);
+  float4 as = make_float4(1.f, 1.f, 1.f, 1.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a_scale) { as = *reinterpret_cast<const float4*>(a_scale + 4 * q); ah = *reinterpret_cast<const float4*>(a_shift + 4 * q); }
+  f32x16 accw;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) accw[r] = 0.f;
+  float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);          // column sums of dY over this thread's rows, columns 4q..4q+3
+  float4 ry[4], rg[4], ra[4], rh[4];
+  float rw[4];
+  float4 p1 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p1;   // next BatchNorm's partial sums, columns 4q..4q+3
+  float4 bm = p1, bi = p1;
+  if (part1 != nullptr) { bm = *reinterpret_cast<const float4*>(bn_mean + 4 * q); bi = *reinterpret_cast<const float4*>(bn_invstd + 4 * q); }
+  // the destination ids run one tile AHEAD of the rows: dst[e] -> (inv_deg[n], d_out[n]) is a chain of two dependent
+  // global loads, and with two workgroups per CU the chain's second round trip was the tile time (the bf16 kernel: 10 k
+  // cycles per tile for 2 k cycles of work)
+  int nn[4];
+  auto fetch_idx = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) nn[t] = y.dst[yl_min(tile * 64 + rb + 16 * t, E - 1)];
+  };
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int e = yl_min(tile * 64 + rb + 16 * t, E - 1);
+      const int n = nn[t];
+      rw[t] = y.inv_deg[n];
+      ry[t] = yl_ld4(y.Y + (long)e * y.ldy + 4 * q);
+      rg[t] = *reinterpret_cast<const float4*>(y.dout + (long)n * y.ldo + 4 * q);
+      ra[t] = yl_ld4(A + (long)e * lda + 4 * q);
+    }
+  };
+  auto col8 = [&](const unsigned short* base) {           // eight consecutive rows of one column -> an MFMA operand
+    bcl_u32x4 v;
+    v[0] = (unsigned)base[0 * LDH] | ((unsigned)base[1 * LDH] << 16);
+    v[1] = (unsigned)base[2 * LDH] | ((unsigned)base[3 * LDH] << 16);
+    v[2] = (unsigned)base[4 * LDH] | ((unsigned)base[5 * LDH] << 16);
+    v[3] = (unsigned)base[6 * LDH] | ((unsigned)base[7 * LDH] << 16);
+    return __builtin_bit_cast(bcl_bf16x8, v);
+  };
+  if (t0 < t1) {
+    fetch_idx(t0);
+    fetch(t0);
+    if (t0 + 1 < t1) fetch_idx(t0 + 1);
+  }
+  for (int tile = t0; tile < t1; ++tile) {
+    // ---- the two tiles into LDS as bfloat16 (rows beyond E: zero — they are in the reduction of dW / db)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 16 * t;
+      const bool ok = tile * 64 + r < E;
+      const float d0 = ok ? y.one(rg[t].x, rw[t], ry[t].x, mu.x, is.x, sc.x, sh.x, k1.x, k2.x) : 0.f;
+      const float d1 = ok ? y.one(rg[t].y, rw[t], ry[t].y, mu.y, is.y, sc.y, sh.y, k1.y, k2.y) : 0.f;
+      const float d2 = ok ? y.one(rg[t].z, rw[t], ry[t].z, mu.z, is.z, sc.z, sh.z, k1.z, k2.z) : 0.f;
+      const float d3 = ok ? y.one(rg[t].w, rw[t], ry[t].w, mu.w, is.w, sc.w, sh.w, k1.w, k2.w) : 0.f;
+      dbp.x += d0; dbp.y += d1; dbp.z += d2; dbp.w += d3;
+      const float a0 = ok ? fmaxf(fmaf(ra[t].x, as.x, ah.x), a_floor) : 0.f;
+      const float a1 = ok ? fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor) : 0.f;
+      const float a2 = ok ? fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor) : 0.f;
+      const float a3 = ok ? fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor) : 0.f;
+      *reinterpret_cast<uint2*>(&Dh[r * LDH + 4 * q]) = make_uint2(yl_pack_bf16(d0, d1), yl_pack_bf16(d2, d3));
+      *reinterpret_cast<uint2*>(&Ah[r * LDH + 4 * q]) = make_uint2(yl_pack_bf16(a0, a1), yl_pack_bf16(a2, a3));
+      rh[t] = ra[t];                                     // raw A of this tile (ra is refilled by the prefetch)
+    }
+    __syncthreads();                                     // tiles complete; the previous tile's Os reads are done
+    if (tile + 1 < t1) {                                 // in flight under the MFMAs
+      fetch(tile + 1);
+      if (tile + 2 < t1) fetch_idx(tile + 2);
+    }
+    f32x16 acca;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acca[r] = 0.f;
+    // ---- dA tile = dY . W   (rows wm*32.., columns wn*32..)
+    {
+      const unsigned short* dr = &Dh[(wm * 32 + l31) * LDH + 8 * lhi];
+      const unsigned short* wr = &Wt[(wn * 32 + l31) * LDW + 8 * lhi];
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(dr + 16 * ks), hi = *reinterpret_cast<const uint2*>(dr + 16 * ks + 4);
+        const bcl_u32x4 av = {lo.x, lo.y, hi.x, hi.y};
+        const bcl_bf16x8 bv = *reinterpret_cast<const bcl_bf16x8*>(wr + 16 * ks);
+        acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bcl_bf16x8, av), bv, acca, 0, 0, 0);
+      }
+    }
+    // ---- dW += dY^T . A1   (rows = dY columns wm*32.., columns = A1 columns wn*32..; k = the tile's 64 rows)
+    // (not unrolled: with all 64 column reads of the four steps hoisted the kernel needed 293 registers)
+#pragma unroll 1
+    for (int ks = 0; ks < 4; ++ks) {
+      const bcl_bf16x8 av = col8(&Dh[(16 * ks + 8 * lhi) * LDH + wm * 32 + l31]);
+      const bcl_bf16x8 bv = col8(&Ah[(16 * ks + 8 * lhi) * LDH + wn * 32 + l31]);
+      accw = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bv, accw, 0, 0, 0);
+    }
+    // ---- dA tile -> LDS in the staging layout
+    {
+      const int col = wn * 32 + l31;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDO + col] = acca[r];
+    }
+    __syncthreads();                                     // Os complete; every read of Dh / Ah is done
+    auto acc1 = [&](float h, float g, float m, float i, float a, float b, float& t1s, float& t2s) {
+      if (a_floor == 0.f && !(fmaf(h, a, b) > 0.f)) g = 0.f;
+      t1s += g;
+      t2s += g * ((h - m) * i);
+    };
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 16 * t;
+      const long row = (long)tile * 64 + r;
+      if (row < E) {
+        float4 v = *reinterpret_cast<const float4*>(Os + r * LDO + 4 * q);
+        yl_st4(dA + row * ldda + 4 * q, v);
+        if (part1 != nullptr) {
+          // the statistics take the STORED (rounded) values, as the apply pass will read them
+          v = make_float4(bcl_round(v.x), bcl_round(v.y), bcl_round(v.z), bcl_round(v.w));
+          acc1(rh[t].x, v.x, bm.x, bi.x, as.x, ah.x, p1.x, p2.x);
+          acc1(rh[t].y, v.y, bm.y, bi.y, as.y, ah.y, p1.y, p2.y);
+          acc1(rh[t].z, v.z, bm.z, bi.z, as.z, ah.z, p1.z, p2.z);
+          acc1(rh[t].w, v.w, bm.w, bi.w, as.w, ah.w, p1.w, p2.w);
+        }
+      }
+    }
+  }
+  // ---- the 16 row groups of a column quad, summed in order by row group 0: next BatchNorm's partials, then db
+  float4* red1 = reinterpret_cast<float4*>(Os);          // 64 * 68 floats hold 3 x 16 x 16 float4
+  float4* red2 = red1 + 256;
+  float4* red3 = red2 + 256;
+  __syncthreads();
+  red1[rb * 16 + q] = p1; red2[rb * 16 + q] = p2; red3[rb * 16 + q] = dbp;
+  __syncthreads();
+  float* P = partial + (long)blockIdx.x * (64 * 64 + 64);
+  if (rb == 0) {
+    float4 a = red1[q], b = red2[q], d = red3[q];
+    for (int t = 1; t < 16; ++t) {
+      a.x += red1[t * 16 + q].x; a.y += red1[t * 16 + q].y; a.z += red1[t * 16 + q].z; a.w += red1[t * 16 + q].w;
+      b.x += red2[t * 16 + q].x; b.y += red2[t * 16 + q].y; b.z += red2[t * 16 + q].z; b.w += red2[t * 16 + q].w;
+      d.x += red3[t * 16 + q].x; d.y += red3[t * 16 + q].y; d.z += red3[t * 16 + q].z; d.w += red3[t * 16 + q].w;
+    }
+    if (part1 != nullptr) {
+      float2* o = part1 + (long)blockIdx.x * 64 + 4 * q;
+      o[0] = make_float2(a.x, b.x); o[1] = make_float2(a.y, b.y); o[2] = make_float2(a.z, b.z); o[3] = make_float2(a.w, b.w);
+    }
+    *reinterpret_cast<float4*>(P + 64 * 64 + 4 * q) = d;
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+    P[c * 64 + wn * 32 + l31] = accw[r];
+  }
+}
+
 extern "C" size_t yolat_bn_csr_l2_bwd_work_elems(void) { return (size_t)BCL_WGS * (64 * 64 + 64 + 128) + 8; }
 
 // C = K = Nout = 64 only.  dW [64, 64] (+= when accumulate) = dY^T . pro(A), db [64] (+=) = column sums of dY (nullable),
@@ -419,7 +625,7 @@ extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const 
   if (g->half) {
     BnCsrOpT<yl_bf16_t> y = make_op_t<yl_bf16_t>(g, E, 64);
     if (!y.vec) return YOLAT_E_UNSUPPORTED;
-    hipLaunchKernelGGL(k_bn_csr_l2_bwd<yl_bf16_t>, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const yl_bf16_t*>(A),
+    hipLaunchKernelGGL(k_bn_csr_l2_bwd_h, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const yl_bf16_t*>(A),
                        (long)lda, a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<yl_bf16_t*>(dA), (long)ldda, (int)E,
                        per, work, next_mean, next_invstd, part1);
   } else {
