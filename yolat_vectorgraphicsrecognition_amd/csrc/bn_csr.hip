@@ -262,8 +262,9 @@ __global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* _
   float4 bm = p1, bi = p1;
   if (part1 != nullptr) { bm = *reinterpret_cast<const float4*>(bn_mean + 4 * q); bi = *reinterpret_cast<const float4*>(bn_invstd + 4 * q); }
   // the destination ids run one tile AHEAD of the rows: dst[e] -> (inv_deg[n], d_out[n]) is a chain of two dependent
-  // global loads, and with two workgroups per CU the chain's second round trip was the tile time (the bf16 kernel: 10 k
-  // cycles per tile for 2 k cycles of work)
+  // global loads (measured neutral here, 276 -> 280 us: this kernel is bound by its 921 MB of mixed read / write traffic
+  // at ~3.3 TB/s beside 125 us of fp32 matrix-core time, not by the chain; two tiles of rows in flight with the constants
+  // moved to LDS, 252 registers, was 285 us — DESIGN.md Appendix R)
   int nn[4];
   auto fetch_idx = [&](int tile) {
 #pragma unroll
@@ -440,37 +441,38 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd_h(BnCsrOpT<yl_bf16_t> 
     Wt[(4 * q + 2) * LDW + r] = (unsigned short)(yl_pack_bf16(w.z, 0.f) & 0xffffu);
     Wt[(4 * q + 3) * LDW + r] = (unsigned short)(yl_pack_bf16(w.w, 0.f) & 0xffffu);
   }
-  const float4 mu = *reinterpret_cast<const float4*>(y.mean + 4 * q), is = *reinterpret_cast<const float4*>(y.invstd + 4 * q);
-  const float4 sc = *reinterpret_cast<const float4*>(y.scale + 4 * q), sh = *reinterpret_cast<const float4*>(y.shift + 4 * q);
-  const float4 k1 = *reinterpret_cast<const float4*>(y.coef + 4 * q), k2 = *reinterpret_cast<const float4*>(y.coef + 64 + 4 * q);
-  float4 as = make_float4(1.f, 1.f, 1.f, 1.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
-  if (a_scale) { as = *reinterpret_cast<const float4*>(a_scale + 4 * q); ah = *reinterpret_cast<const float4*>(a_shift + 4 * q); }
+  __shared__ __attribute__((aligned(16))) float cst[10][64];   // per-column constants, as in k_bn_csr_l2_bwd
+  if (tid < 64) {
+    cst[0][tid] = y.mean[tid]; cst[1][tid] = y.invstd[tid]; cst[2][tid] = y.scale[tid]; cst[3][tid] = y.shift[tid];
+    cst[4][tid] = y.coef[tid]; cst[5][tid] = y.coef[64 + tid];
+    cst[6][tid] = a_scale ? a_scale[tid] : 1.f; cst[7][tid] = a_scale ? a_shift[tid] : 0.f;
+    cst[8][tid] = part1 ? bn_mean[tid] : 0.f; cst[9][tid] = part1 ? bn_invstd[tid] : 0.f;
+  }
+  auto cq = [&](int i) { return *reinterpret_cast<const float4*>(&cst[i][4 * q]); };
+  auto widen = [](const uint2& u) { return make_float4(yl_bf16_lo(u.x), yl_bf16_hi(u.x), yl_bf16_lo(u.y), yl_bf16_hi(u.y)); };
   f32x16 accw;
 #pragma unroll
   for (int r = 0; r < 16; ++r) accw[r] = 0.f;
   float4 dbp = make_float4(0.f, 0.f, 0.f, 0.f);          // column sums of dY over this thread's rows, columns 4q..4q+3
-  float4 ry[4], rg[4], ra[4], rh[4];
-  float rw[4];
+  // two tiles of rows in flight, the bfloat16 ones kept packed (36 registers per set); destination ids a tile further
+  struct Rows { uint2 ry[4], ra[4]; float4 rg[4]; float rw[4]; };
+  Rows R0, R1;
+  uint2 rh[4];
   float4 p1 = make_float4(0.f, 0.f, 0.f, 0.f), p2 = p1;   // next BatchNorm's partial sums, columns 4q..4q+3
-  float4 bm = p1, bi = p1;
-  if (part1 != nullptr) { bm = *reinterpret_cast<const float4*>(bn_mean + 4 * q); bi = *reinterpret_cast<const float4*>(bn_invstd + 4 * q); }
-  // the destination ids run one tile AHEAD of the rows: dst[e] -> (inv_deg[n], d_out[n]) is a chain of two dependent
-  // global loads, and with two workgroups per CU the chain's second round trip was the tile time (the bf16 kernel: 10 k
-  // cycles per tile for 2 k cycles of work)
   int nn[4];
   auto fetch_idx = [&](int tile) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) nn[t] = y.dst[yl_min(tile * 64 + rb + 16 * t, E - 1)];
   };
-  auto fetch = [&](int tile) {
+  auto fetch = [&](int tile, Rows& R) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const int e = yl_min(tile * 64 + rb + 16 * t, E - 1);
       const int n = nn[t];
-      rw[t] = y.inv_deg[n];
-      ry[t] = yl_ld4(y.Y + (long)e * y.ldy + 4 * q);
-      rg[t] = *reinterpret_cast<const float4*>(y.dout + (long)n * y.ldo + 4 * q);
-      ra[t] = yl_ld4(A + (long)e * lda + 4 * q);
+      R.rw[t] = y.inv_deg[n];
+      R.ry[t] = *reinterpret_cast<const uint2*>(y.Y + (long)e * y.ldy + 4 * q);
+      R.rg[t] = *reinterpret_cast<const float4*>(y.dout + (long)n * y.ldo + 4 * q);
+      R.ra[t] = *reinterpret_cast<const uint2*>(A + (long)e * lda + 4 * q);
     }
   };
   auto col8 = [&](const unsigned short* base) {           // eight consecutive rows of one column -> an MFMA operand
@@ -483,32 +485,41 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd_h(BnCsrOpT<yl_bf16_t> 
   };
   if (t0 < t1) {
     fetch_idx(t0);
-    fetch(t0);
-    if (t0 + 1 < t1) fetch_idx(t0 + 1);
+    fetch(t0, R0);
+    if (t0 + 1 < t1) {
+      fetch_idx(t0 + 1);
+      fetch(t0 + 1, R1);
+      if (t0 + 2 < t1) fetch_idx(t0 + 2);
+    }
   }
-  for (int tile = t0; tile < t1; ++tile) {
+  __syncthreads();                                       // cst, Wt
+  auto step = [&](int tile, Rows& R) {                   // R: this tile's rows; refilled with tile + 2's
     // ---- the two tiles into LDS as bfloat16 (rows beyond E: zero — they are in the reduction of dW / db)
+    {
+      const float4 mu = cq(0), is = cq(1), sc = cq(2), sh = cq(3), k1 = cq(4), k2 = cq(5), as = cq(6), ah = cq(7);
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      const int r = rb + 16 * t;
-      const bool ok = tile * 64 + r < E;
-      const float d0 = ok ? y.one(rg[t].x, rw[t], ry[t].x, mu.x, is.x, sc.x, sh.x, k1.x, k2.x) : 0.f;
-      const float d1 = ok ? y.one(rg[t].y, rw[t], ry[t].y, mu.y, is.y, sc.y, sh.y, k1.y, k2.y) : 0.f;
-      const float d2 = ok ? y.one(rg[t].z, rw[t], ry[t].z, mu.z, is.z, sc.z, sh.z, k1.z, k2.z) : 0.f;
-      const float d3 = ok ? y.one(rg[t].w, rw[t], ry[t].w, mu.w, is.w, sc.w, sh.w, k1.w, k2.w) : 0.f;
-      dbp.x += d0; dbp.y += d1; dbp.z += d2; dbp.w += d3;
-      const float a0 = ok ? fmaxf(fmaf(ra[t].x, as.x, ah.x), a_floor) : 0.f;
-      const float a1 = ok ? fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor) : 0.f;
-      const float a2 = ok ? fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor) : 0.f;
-      const float a3 = ok ? fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor) : 0.f;
-      *reinterpret_cast<uint2*>(&Dh[r * LDH + 4 * q]) = make_uint2(yl_pack_bf16(d0, d1), yl_pack_bf16(d2, d3));
-      *reinterpret_cast<uint2*>(&Ah[r * LDH + 4 * q]) = make_uint2(yl_pack_bf16(a0, a1), yl_pack_bf16(a2, a3));
-      rh[t] = ra[t];                                     // raw A of this tile (ra is refilled by the prefetch)
+      for (int t = 0; t < 4; ++t) {
+        const int r = rb + 16 * t;
+        const bool ok = tile * 64 + r < E;
+        const float4 yv = widen(R.ry[t]), av = widen(R.ra[t]);
+        const float d0 = ok ? y.one(R.rg[t].x, R.rw[t], yv.x, mu.x, is.x, sc.x, sh.x, k1.x, k2.x) : 0.f;
+        const float d1 = ok ? y.one(R.rg[t].y, R.rw[t], yv.y, mu.y, is.y, sc.y, sh.y, k1.y, k2.y) : 0.f;
+        const float d2 = ok ? y.one(R.rg[t].z, R.rw[t], yv.z, mu.z, is.z, sc.z, sh.z, k1.z, k2.z) : 0.f;
+        const float d3 = ok ? y.one(R.rg[t].w, R.rw[t], yv.w, mu.w, is.w, sc.w, sh.w, k1.w, k2.w) : 0.f;
+        dbp.x += d0; dbp.y += d1; dbp.z += d2; dbp.w += d3;
+        const float a0 = ok ? fmaxf(fmaf(av.x, as.x, ah.x), a_floor) : 0.f;
+        const float a1 = ok ? fmaxf(fmaf(av.y, as.y, ah.y), a_floor) : 0.f;
+        const float a2 = ok ? fmaxf(fmaf(av.z, as.z, ah.z), a_floor) : 0.f;
+        const float a3 = ok ? fmaxf(fmaf(av.w, as.w, ah.w), a_floor) : 0.f;
+        *reinterpret_cast<uint2*>(&Dh[r * LDH + 4 * q]) = make_uint2(yl_pack_bf16(d0, d1), yl_pack_bf16(d2, d3));
+        *reinterpret_cast<uint2*>(&Ah[r * LDH + 4 * q]) = make_uint2(yl_pack_bf16(a0, a1), yl_pack_bf16(a2, a3));
+        rh[t] = R.ra[t];                                 // raw A of this tile (R is refilled by the prefetch)
+      }
     }
     __syncthreads();                                     // tiles complete; the previous tile's Os reads are done
-    if (tile + 1 < t1) {                                 // in flight under the MFMAs
-      fetch(tile + 1);
-      if (tile + 2 < t1) fetch_idx(tile + 2);
+    if (tile + 2 < t1) {                                 // two tiles ahead, in flight under the MFMAs
+      fetch(tile + 2, R);
+      if (tile + 3 < t1) fetch_idx(tile + 3);
     }
     f32x16 acca;
 #pragma unroll
@@ -540,6 +551,7 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd_h(BnCsrOpT<yl_bf16_t> 
       for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDO + col] = acca[r];
     }
     __syncthreads();                                     // Os complete; every read of Dh / Ah is done
+    const float4 as = cq(6), ah = cq(7), bm = cq(8), bi = cq(9);
     auto acc1 = [&](float h, float g, float m, float i, float a, float b, float& t1s, float& t2s) {
       if (a_floor == 0.f && !(fmaf(h, a, b) > 0.f)) g = 0.f;
       t1s += g;
@@ -555,13 +567,18 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd_h(BnCsrOpT<yl_bf16_t> 
         if (part1 != nullptr) {
           // the statistics take the STORED (rounded) values, as the apply pass will read them
           v = make_float4(bcl_round(v.x), bcl_round(v.y), bcl_round(v.z), bcl_round(v.w));
-          acc1(rh[t].x, v.x, bm.x, bi.x, as.x, ah.x, p1.x, p2.x);
-          acc1(rh[t].y, v.y, bm.y, bi.y, as.y, ah.y, p1.y, p2.y);
-          acc1(rh[t].z, v.z, bm.z, bi.z, as.z, ah.z, p1.z, p2.z);
-          acc1(rh[t].w, v.w, bm.w, bi.w, as.w, ah.w, p1.w, p2.w);
+          const float4 hv = widen(rh[t]);
+          acc1(hv.x, v.x, bm.x, bi.x, as.x, ah.x, p1.x, p2.x);
+          acc1(hv.y, v.y, bm.y, bi.y, as.y, ah.y, p1.y, p2.y);
+          acc1(hv.z, v.z, bm.z, bi.z, as.z, ah.z, p1.z, p2.z);
+          acc1(hv.w, v.w, bm.w, bi.w, as.w, ah.w, p1.w, p2.w);
         }
       }
     }
+  };
+  for (int tile = t0; tile < t1; tile += 2) {
+    step(tile, R0);
+    if (tile + 1 < t1) step(tile + 1, R1);
   }
   // ---- the 16 row groups of a column quad, summed in order by row group 0: next BatchNorm's partials, then db
   float4* red1 = reinterpret_cast<float4*>(Os);          // 64 * 68 floats hold 3 x 16 x 16 float4

@@ -42,7 +42,9 @@ static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, 
 // On the generic 64 x 64 tiles (k_gemm_nt) it was one workgroup per tile: 18 750 workgroups at E = 1.2 M that each fetch
 // the 16 KB weight from L2, stage, run 32 MFMAs per wave and drain — 178 us for 614 MB (0.43 of HBM, 0.35 of the fp32
 // MFMA rate).  Here the weight sits in LDS for the whole persistent workgroup, the next tile's rows are in flight under
-// the current tile's MFMAs, and the finished tile leaves through LDS with 16-byte stores.  Same products in the same
+// the current tile's MFMAs, and the finished tile leaves through LDS with 16-byte stores: 131 us = 4.7 TB/s, the rate of a
+// plain device copy on this part (profiles/r03_stream_bw.txt: 4.85 TB/s read + write; two tiles of rows in flight
+// instead of one: 142 us).  Same products in the same
 // order as the tile kernel (k ascending in steps of two) and the same statistics arithmetic (wave_epilogue): bit-identical
 // outputs and statistics.
 // ------------------------------------------------------------------------------------------------
