@@ -122,12 +122,18 @@ class OpTimer(object):
             # two sparse P*F-term passes (dW, dA) of K each + the K x K / F x K dense algebra + the N-row dA GEMM
             return 4.0 * g.P * F * K + 2.0 * g.N * K * K, 4.0 * (3.0 * g.P * F + 2.0 * g.N * K + 2.0 * K * F), \
                 "fusion_pool_train_bwd[P=%d x %d, N=%d]" % (g.P, F, g.N)
+        if name == "bn_apply_edge_sums":
+            dA1, g = args[0], args[8]
+            E, C = dA1.shape
+            es = dA1.element_size()
+            # reads dA1 and H1, writes dH1 (3 passes over [E, C]) + the attr quads + the [N, C] per-node sums
+            return 22.0 * E * C, 3.0 * E * C * es + 16.0 * E + 4.0 * g.N * C, "bn_apply_edge_sums[E=%d,%dB]" % (E, es)
         return 0.0, 0.0, name
 
     def __enter__(self):
         for name in ("linear_fwd", "edge_lin1_fwd", "csr_mean_fwd", "segment_max_fwd", "segment_mean_fwd",
                      "build_graph", "scale_shift_relu", "bn_eval_coeffs", "linear_bwd_w", "linear_fwd_wt",
-                     "fusion_pool_train_fwd", "fusion_pool_train_bwd"):
+                     "fusion_pool_train_fwd", "fusion_pool_train_bwd", "bn_apply_edge_sums"):
             if not hasattr(self.ops, name):
                 continue
             fn = getattr(self.ops, name)

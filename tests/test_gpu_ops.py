@@ -1162,7 +1162,10 @@ def test_fused_bn_csr_backward_matches_materialised_path(N, E):
         return dg, db, dW, dbias, dA
     got = fused()
     for name, a, b in zip(("dgamma", "dbeta", "dW", "db", "dA"), (dg_a, db_a, dW_a, dbias_a, dA_a), got):
-        assert float((a - b).abs().max()) <= 2e-5 * max(float(a.abs().max()), 1e-6), name
+        # db = column sums of dY is exactly 0 in exact arithmetic (BatchNorm's backward): both paths return rounding noise
+        # of the sum, which moves with the block size of the statistics pass — measured against the column sums of |dY|
+        ref_scale = float(dM.abs().sum(0).max()) if name == "db" else max(float(a.abs().max()), 1e-6)
+        assert float((a - b).abs().max()) <= 2e-5 * ref_scale, name
 
     def fused_one_kernel():
         dg, db = torch.empty(C).cuda(), torch.empty(C).cuda()

@@ -58,7 +58,9 @@ struct BnCsrOpT {
 typedef BnCsrOpT<float> BnCsrOp;
 
 namespace {
-#define BCS_ROWS 512
+// 640 rows per workgroup: E = 1.2 M is 1875 workgroups = one round of the 2048 that fit (512 rows: 2344 = a full round and
+// a seventh of a second one)
+#define BCS_ROWS 640
 // per 512-row block and column: (sum g, sum g*xhat), g = relu'(.) * d_out[dst] / deg — k_bn_bwd_partial_v4 with the
 // gradient gathered instead of read
 template <class T>

@@ -1015,7 +1015,21 @@ __global__ void __launch_bounds__(256) k_edge_uv_lin1(const float* __restrict__ 
     const int base = row0 + 32 * grp;
     int cnt = E - base;
     cnt = cnt > 32 ? 32 : cnt;
-    if (cnt > 0) {
+    if (cnt == 32) {
+      // full group: the 32 values in registers (reads in flight together; the rolled loops below were 2 x 32 dependent
+      // LDS round trips per workgroup), same order of additions
+      float v[32];
+#pragma unroll
+      for (int r = 0; r < 32; ++r) v[r] = T[(32 * grp + r) * LDT + c];
+      float sum = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) sum += v[r];
+      const float mu = sum / 32.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 32; ++r) { const float d = v[r] - mu; m2 += d * d; }
+      stats[(long)(base >> 5) * 64 + c] = make_float2(sum, m2);
+    } else if (cnt > 0) {
       float sum = 0.f;
       for (int r = 0; r < cnt; ++r) sum += T[(32 * grp + r) * LDT + c];
       const float mu = sum / (float)cnt;
