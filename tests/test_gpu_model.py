@@ -634,6 +634,46 @@ def test_weight_gradients_on_the_side_stream_are_bit_identical():
     assert torch.equal(pa, pb)
 
 
+@pytest.mark.parametrize("flag,precision", [("FUSED_BN_APPLY_SUMS", "fp32"), ("FUSED_BN_APPLY_SUMS", "bf16"),
+                                            ("FUSED_BN_CSR_BWD", "fp32"), ("FACTORISED_TRAIN", "fp32")])
+def test_training_schedule_flags_give_the_same_step(flag, precision):
+    """The module flags of engine.py that choose between kernel sequences of the conv-layer training step:
+    FUSED_BN_APPLY_SUMS (round 4: BatchNorm-1 backward apply + per-node dU sums + attr weight gradient in one pass,
+    yolat_bn_apply_edge_sums, vs three launches), FUSED_BN_CSR_BWD (the gradient of the aggregation formed inside its
+    consumers vs materialised), FACTORISED_TRAIN (per-node products + gather-add vs the gathered K = 2 Cin + 4 GEMM).
+    Each flag off against the default on a dense-enough batch (E >= 2 N, so that every default path is taken): same loss
+    bits (the forward of the first two is untouched; 1e-5 for the third), every gradient tensor within 2e-4 of its own
+    largest element + 2e-5 of the step's largest gradient (different summation orders; the floor covers the
+    mathematically-zero bias gradients in front of a BatchNorm).  bf16 storage: 2e-2 (one more rounding of dH1 sums)."""
+    import yolat_vectorgraphicsrecognition_amd as yv
+    from yolat_vectorgraphicsrecognition_amd import engine
+    data, slices = yv.synth_batch(2, 91, num_proposals=40, nodes_lo=10, nodes_hi=20, edges_per_proposal=70)
+    assert data.edge.shape[0] >= 2 * data.x.shape[0]
+
+    def run(value):
+        old = getattr(engine, flag)
+        setattr(engine, flag, value)
+        try:
+            model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 17).cuda()
+            tr = yv.Trainer(model, yv.Opt(), lr=1e-3, weight_decay=1e-5, precision=precision)
+            data._yolat_stage = None
+            loss = float(tr.step(data, slices))
+            names = [(n, p.numel()) for n, p in model.named_parameters()]      # the flat buffer's layout (trainer.FlatParams)
+            return loss, tr.flat.grad.clone(), names
+        finally:
+            setattr(engine, flag, old)
+    (la, ga, names), (lb, gb, _) = run(True), run(False)
+    assert abs(la - lb) <= (1e-5 if flag == "FACTORISED_TRAIN" else 0.0) * abs(la)
+    gmax = float(ga.abs().max())
+    assert gmax > 0 and sum(k for _, k in names) == ga.numel()
+    rel, floor = (2e-2, 2e-3) if precision == "bf16" else (2e-4, 2e-5)
+    off = 0
+    for n, k in names:
+        a, b = ga[off:off + k], gb[off:off + k]
+        off += k
+        assert float((a - b).abs().max()) <= rel * float(a.abs().max()) + floor * gmax, n
+
+
 @pytest.mark.parametrize("precision", ["fp32", "bf16"])
 def test_primed_workspace_forwards_equal_self_contained_forwards(precision):
     """plan.EvalPlan skips the memset of the CSR-build counters when its workspace was last used by a forward of the same
