@@ -148,11 +148,33 @@ class OpTimer(object):
                 self.records.append((label, s, e, fl, by))
                 return r
             setattr(self.ops, name, wrapped)
+        # the one-kernel backward of the second edge Linear is a method (ops.BnCsrGrad.bwd_w_and_x -> yolat_bn_csr_l2_bwd):
+        # dA = dY.W and dW += dY^T.A1 (2 x 2 E C^2 flops); reads Y and A, writes dA (3 passes over [E, C]) + the d_out rows
+        cls = getattr(self.ops, "BnCsrGrad", None)
+        if cls is not None and hasattr(cls, "bwd_w_and_x"):
+            fn = cls.bwd_w_and_x
+            self.orig_method = (cls, fn)
+
+            def wrapped_m(obj, A, *a, _fn=fn, **k):
+                s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                s.record()
+                r = _fn(obj, A, *a, **k)
+                e.record()
+                E, C = A.shape
+                es = A.element_size()
+                self.records.append(("bn_csr_l2_bwd%s[E=%d,%dB]" % ("_bf16" if es == 2 else "", E, es), s, e, 4.0 * E * C * C,
+                                     3.0 * E * C * es + 4.0 * obj._keep[1].N * C))
+                return r
+            cls.bwd_w_and_x = wrapped_m
         return self
 
     def __exit__(self, *exc):
         for name, fn in self.orig.items():
             setattr(self.ops, name, fn)
+        if getattr(self, "orig_method", None):
+            cls, fn = self.orig_method
+            cls.bwd_w_and_x = fn
+            self.orig_method = None
 
     def summary(self):
         torch.cuda.synchronize()
@@ -635,7 +657,7 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
         for _ in range(10):
             step()
         table = timer.summary()
-    roof = roofline_entry(table)
+    roof = roofline_entry(table, None, precision)
     roof["note"] = "dominant op of the step by HIP-event time (ops.* entry points; each is one or a few launches)"
     nb, C, D, F = optkw["n_blocks"], 64, 128, 1024
     K = optkw["n_classes"]
