@@ -165,3 +165,29 @@ def test_dp_exchange_over_rccl_in_a_one_rank_group_equals_the_local_step(tmp_pat
     # ... and the check can FAIL: with the head bucket's exchange issued at the start of the backward
     # (engine._FAULT_EARLY_HEAD_EXCHANGE) its gradients land after the doubling and the parameters differ
     assert not np.array_equal(r["p_pf"], r["p_lb"]), "the exchange-ordering check did not see an exchange issued too early"
+
+
+def test_bench_line_with_two_ranks_launched_the_way_the_driver_launches_them():
+    """bench.py under `python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 ... bench.py --gpus 2` — the driver's
+    N > 1 form — with both ranks on the one GPU of this box over gloo (YOLAT_BENCH_DEVICE / YOLAT_BENCH_BACKEND exist for
+    exactly this): rank 0 prints ONE JSON line, `value` is the aggregate over the ranks (graph-id sharding, weak scaling:
+    every rank steps through its own graph), the timed region is bracketed by the group barrier.  The RCCL run with one
+    GPU per rank is the driver's; this pins the control flow (rendezvous on 127.0.0.1, per-rank seeds, MAX over ranks)."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, YOLAT_BENCH_DEVICE="0", YOLAT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-extras", "--no-cpu-baseline"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 20 and d["warmup"] == 5 and d["scaling"] == "weak"
+    assert d["metric"] == "graphs_per_sec" and d["value"] > 0 and d["higher_is_better"] is True
+    # aggregate = graphs of both ranks per step / the slowest rank's time
+    assert abs(d["value"] - 2.0 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
