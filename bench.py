@@ -653,12 +653,23 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
         return trainer.step(data, slices)
 
     t, n = _timed_loop(step, budget_s, lo=5, hi=100, warm=4)
-    with OpTimer(yv.ops) as timer:
-        for _ in range(10):
+    # per-op times with every launch on ONE stream: with the weight gradients and node branches on the second stream
+    # (the default, which `ms_per_step` above is measured with) the HIP events around an op also cover whatever the other
+    # stream runs beside it, and per-op times stop meaning anything (profiles/r04_train_cfg3_kernel_stats.txt)
+    side = yv.engine.SIDE_STREAM
+    yv.engine.SIDE_STREAM = False
+    try:
+        for _ in range(2):
             step()
-        table = timer.summary()
+        with OpTimer(yv.ops) as timer:
+            for _ in range(10):
+                step()
+            table = timer.summary()
+    finally:
+        yv.engine.SIDE_STREAM = side
     roof = roofline_entry(table, None, precision)
-    roof["note"] = "dominant op of the step by HIP-event time (ops.* entry points; each is one or a few launches)"
+    roof["note"] = ("dominant op of the step by HIP-event time, all launches on one stream (ops.* entry points; each is one "
+                    "or a few launches)")
     nb, C, D, F = optkw["n_blocks"], 64, 128, 1024
     K = optkw["n_classes"]
     fwd = (2.0 * E * (14 * C + C * C) + 2.0 * E * ((2 * C + 4) * C + C * C) * (nb - 1) + 4.0 * N * 5 * C
@@ -672,7 +683,9 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
                           "frac_of_fp32_mfma_peak": 3.0 * fwd / t / 1e12 / PEAK_MFMA_F32_TFLOPS,
                           "note": "3 x the unfactorised forward flops of SURVEY 8(d) over the step time"},
            "roofline": roof,
-           "op_breakdown_us": {k: round(v["ms_total"] / 10.0 * 1e3, 1) for k, v in top}}
+           "op_breakdown_us": {k: round(v["ms_total"] / 10.0 * 1e3, 1) for k, v in top},
+           "op_breakdown_us_per_call": {k: round(v["ms_avg"] * 1e3, 1) for k, v in top},
+           "op_breakdown_note": "per step / per call, one-stream schedule (engine.SIDE_STREAM off for this table only)"}
     del trainer, model
     if cpu:
         c = cpu_baseline(cfg, optkw, "train", budget_s=10, thread_counts=(32,))

@@ -1623,3 +1623,29 @@ def test_linear64_row_stream_is_bit_identical_to_the_tile_kernel(M, pro):
     Ain = torch.relu(A.double() * sc.double() + sh.double()) if pro else A.double()
     ref = Ain @ W.double().t() + b.double()
     assert float((Y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+
+
+@pytest.mark.parametrize("M,K,acc", [(70001, 64, False), (70001, 64, True), (131072 + 33, 128, True), (65536, 128, False)])
+def test_linear_fwd_wt_row_stream_is_bit_identical_to_the_tile_kernel(M, K, acc):
+    """yolat_linear_fwd_wt for Nout = 64, K in {64, 128}, M >= 65536 on the row-stream kernel (dense.hip k_lin64_stream<KH,
+    WT, ACC>: the input-gradient Linears of the training backward over the N nodes — lin_r / mlp_node backward,
+    torch_vertex.py:325-327, and dx += dUV . Wuv of the factorised edge Linear) against the generic tile kernel run on row
+    ranges below the threshold: BIT-identical with and without accumulation (same products in the same order, the
+    epilogue's (acc) + old); fp64 check of the product."""
+    yv = _yv()
+    ops = yv.ops
+    gen = torch.Generator().manual_seed(M + K)
+    A = torch.randn(M, K, generator=gen).cuda()
+    Wt = (torch.randn(K, 64, generator=gen) / 8).cuda()
+    Y0 = torch.randn(M, 64, generator=gen).cuda()
+    Y = Y0.clone()
+    ops.linear_fwd_wt(A, Wt, Y, accumulate=acc)
+    parts = []
+    for lo in range(0, M, 48000):
+        hi = min(lo + 48000, M)
+        Yp = Y0[lo:hi].clone()
+        ops.linear_fwd_wt(A[lo:hi], Wt, Yp, accumulate=acc)
+        parts.append(Yp)
+    assert torch.equal(Y, torch.cat(parts))
+    ref = A.double() @ Wt.double() + (Y0.double() if acc else 0)
+    assert float((Y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())

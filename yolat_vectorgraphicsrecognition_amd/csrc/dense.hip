@@ -49,59 +49,86 @@ static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, 
 // outputs and statistics.
 // ------------------------------------------------------------------------------------------------
 #define L64_WGS 768
+// KH: K = 64 KH (the rows' K halves pass through one 64 x 64 LDS tile one after the other); WT: the weight is given
+// transposed ([K, 64] row-major: yolat_linear_fwd_wt, the input-gradient Linears of the training backward); ACC: Y += .
+// (the generic epilogue's order: (acc + bias) + old).  The a_scale prologue and the statistics are for KH == 1 only.
+template <int KH, bool WT, bool ACC>
 __global__ void __launch_bounds__(256) k_lin64_stream(const float* __restrict__ A, long lda, int M,
                                                       const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                       float a_floor, const float* __restrict__ W, long ldw,
-                                                      const float* __restrict__ bias, float* __restrict__ Y, long ldy,
+                                                      const float* __restrict__ bias, float* Y, long ldy,
                                                       float2* __restrict__ stats, int tiles_per_wg) {
-  constexpr int LD = 65, LDO = 68;
-  __shared__ float As[64 * LD], Ws[64 * LD];
+  constexpr int LD = 65, LDW = 64 * KH + 1, LDO = 68;
+  __shared__ float As[64 * LD], Ws[64 * LDW];
   __shared__ __attribute__((aligned(16))) float Os[64 * LDO];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
   const int q = tid & 15, rb = tid >> 4;                 // staging role: columns 4q.., rows rb + 16 t
   const int ntiles = (M + 63) >> 6;
   const int t0 = blockIdx.x * tiles_per_wg, t1 = yl_min(ntiles, t0 + tiles_per_wg);
+  // Ws[n][k] = the weight of output column n
 #pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int r = rb + 16 * t;
-    const float4 w = *reinterpret_cast<const float4*>(W + (long)r * ldw + 4 * q);
-    float* d = Ws + r * LD + 4 * q;
-    d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-  }
+  for (int h = 0; h < KH; ++h)
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 16 * t;
+      if (WT) {                                          // row r + 64 h of Wt = input channel k, columns n = 4q..
+        const float4 w = *reinterpret_cast<const float4*>(W + (long)(r + 64 * h) * ldw + 4 * q);
+        Ws[(4 * q + 0) * LDW + 64 * h + r] = w.x; Ws[(4 * q + 1) * LDW + 64 * h + r] = w.y;
+        Ws[(4 * q + 2) * LDW + 64 * h + r] = w.z; Ws[(4 * q + 3) * LDW + 64 * h + r] = w.w;
+      } else {
+        const float4 w = *reinterpret_cast<const float4*>(W + (long)r * ldw + 64 * h + 4 * q);
+        float* d = Ws + r * LDW + 64 * h + 4 * q;
+        d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
+      }
+    }
   float4 as = make_float4(1.f, 1.f, 1.f, 1.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
   if (a_scale) { as = *reinterpret_cast<const float4*>(a_scale + 4 * q); ah = *reinterpret_cast<const float4*>(a_shift + 4 * q); }
   const float bv = bias ? bias[wn * 32 + l31] : 0.f;
-  float4 ra[4];
-  auto fetch = [&](int tile) {
+  float4 ra[KH][4], ro[4];
+  auto fetch = [&](int tile, int h) {
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
       const long e = yl_min(tile * 64 + rb + 16 * t, M - 1);
-      ra[t] = *reinterpret_cast<const float4*>(A + e * lda + 4 * q);
+      ra[h][t] = *reinterpret_cast<const float4*>(A + e * lda + 64 * h + 4 * q);
     }
   };
-  if (t0 < t1) fetch(t0);
-  for (int tile = t0; tile < t1; ++tile) {
+  if (t0 < t1) {
 #pragma unroll
-    for (int t = 0; t < 4; ++t) {
-      float* a = As + (rb + 16 * t) * LD + 4 * q;
-      if (a_scale) {
-        a[0] = fmaxf(fmaf(ra[t].x, as.x, ah.x), a_floor); a[1] = fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor);
-        a[2] = fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor); a[3] = fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor);
-      } else {
-        a[0] = ra[t].x; a[1] = ra[t].y; a[2] = ra[t].z; a[3] = ra[t].w;
-      }
-    }
-    __syncthreads();                                     // As complete (and the previous tile's Os reads are done)
-    if (tile + 1 < t1) fetch(tile + 1);                  // in flight under the MFMAs
+    for (int h = 0; h < KH; ++h) fetch(t0, h);
+  }
+  for (int tile = t0; tile < t1; ++tile) {
     f32x16 acc;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int h = 0; h < KH; ++h) {
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        float* a = As + (rb + 16 * t) * LD + 4 * q;
+        if (a_scale) {
+          a[0] = fmaxf(fmaf(ra[h][t].x, as.x, ah.x), a_floor); a[1] = fmaxf(fmaf(ra[h][t].y, as.y, ah.y), a_floor);
+          a[2] = fmaxf(fmaf(ra[h][t].z, as.z, ah.z), a_floor); a[3] = fmaxf(fmaf(ra[h][t].w, as.w, ah.w), a_floor);
+        } else {
+          a[0] = ra[h][t].x; a[1] = ra[h][t].y; a[2] = ra[h][t].z; a[3] = ra[h][t].w;
+        }
+      }
+      __syncthreads();                                   // As complete (and the previous tile's Os reads are done)
+      if (tile + 1 < t1) fetch(tile + 1, h);             // in flight under the MFMAs
+      if (ACC && h == 0) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+          const long e = yl_min(tile * 64 + rb + 16 * t, M - 1);
+          ro[t] = *reinterpret_cast<const float4*>(Y + e * ldy + 4 * q);
+        }
+      }
 #pragma unroll 8
-    for (int k = 0; k < 64; k += 2) {
-      const float av = As[(wm * 32 + l31) * LD + k + lhi];
-      const float wv = Ws[(wn * 32 + l31) * LD + k + lhi];
-      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
+      for (int k = 0; k < 64; k += 2) {
+        const float av = As[(wm * 32 + l31) * LD + k + lhi];
+        const float wv = Ws[(wn * 32 + l31) * LDW + 64 * h + k + lhi];
+        acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, wv, acc, 0, 0, 0);
+      }
+      if (h + 1 < KH) __syncthreads();                   // every read of this half's As is done
     }
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc[r] += bv;
@@ -134,9 +161,25 @@ __global__ void __launch_bounds__(256) k_lin64_stream(const float* __restrict__ 
     for (int t = 0; t < 4; ++t) {
       const int r = rb + 16 * t;
       const long row = (long)tile * 64 + r;
-      if (row < M) *reinterpret_cast<float4*>(Y + row * ldy + 4 * q) = *reinterpret_cast<const float4*>(Os + r * LDO + 4 * q);
+      float4 o = *reinterpret_cast<const float4*>(Os + r * LDO + 4 * q);
+      if (ACC) { o.x += ro[t].x; o.y += ro[t].y; o.z += ro[t].z; o.w += ro[t].w; }
+      if (row < M) *reinterpret_cast<float4*>(Y + row * ldy + 4 * q) = o;
     }
   }
+}
+
+// launcher shared by yolat_linear_fwd (W [64, K]) and yolat_linear_fwd_wt (Wt [K, 64])
+template <int KH, bool WT, bool ACC>
+static int yl_launch_lin64_stream(const float* A, long lda, long M, const float* a_scale, const float* a_shift, int a_relu,
+                                  const float* W, long ldw, const float* bias, float* Y, long ldy, float* stats,
+                                  hipStream_t st) {
+  const int ntiles = (int)yl_cdiv(M, 64);
+  const int wgs = KH == 1 ? L64_WGS : 512;               // 51 KB of LDS: three per CU; K = 128: 67 KB, two per CU
+  const int per = yl_cdiv(ntiles, wgs);
+  hipLaunchKernelGGL((k_lin64_stream<KH, WT, ACC>), dim3(yl_cdiv(ntiles, per)), dim3(256), 0, st, A, lda, (int)M, a_scale,
+                     a_shift, a_relu ? 0.f : -INFINITY, W, ldw, bias, Y, ldy, reinterpret_cast<float2*>(stats), per);
+  YL_LAUNCH_CHECK();
+  return 0;
 }
 
 static bool yl_lin64_stream_ok(const float* A, int64_t lda, int64_t M, int64_t K, const float* a_scale, const float* a_shift,
@@ -158,13 +201,8 @@ extern "C" int yolat_linear_fwd(const float* A, int64_t lda, int64_t M, int64_t 
   if ((o_scale == nullptr) != (o_shift == nullptr)) return YOLAT_E_INVALID;
   if (a_relu && !a_scale) return YOLAT_E_INVALID;
   if (yl_lin64_stream_ok(A, lda, M, K, a_scale, a_shift, W, ldw, bias, Nout, o_scale, o_relu, Y, ldy, accumulate, stats)) {
-    const int ntiles = (int)yl_cdiv(M, 64);
-    const int per = yl_cdiv(ntiles, L64_WGS);
-    hipLaunchKernelGGL(k_lin64_stream, dim3(yl_cdiv(ntiles, per)), dim3(256), 0, (hipStream_t)stream, A, (long)lda, (int)M,
-                       a_scale, a_shift, a_relu ? 0.f : -INFINITY, W, (long)ldw, bias, Y, (long)ldy,
-                       reinterpret_cast<float2*>(stats), per);
-    YL_LAUNCH_CHECK();
-    return 0;
+    return yl_launch_lin64_stream<1, false, false>(A, (long)lda, (long)M, a_scale, a_shift, a_relu, W, (long)ldw, bias, Y,
+                                                   (long)ldy, stats, (hipStream_t)stream);
   }
   DenseOp b = yl_dense(W, ldw, Nout, K);
   Epilogue ep;
@@ -352,6 +390,17 @@ extern "C" int yolat_linear_fwd_wt(const float* A, int64_t lda, int64_t M, int64
                                    int64_t ldy, int accumulate, yolat_stream_t stream) {
   if (M < 0 || K <= 0 || Nout <= 0 || (M > 0 && (!A || !Y)) || !Wt) return YOLAT_E_INVALID;
   if (M >= (1LL << 31) || lda < K || ldw < Nout || ldy < Nout) return YOLAT_E_INVALID;
+  if (Nout == 64 && (K == 64 || K == 128) && M >= 65536 && lda % 4 == 0 && ldw % 4 == 0 && ldy % 4 == 0 && yl_aligned16(A) &&
+      yl_aligned16(Wt) && yl_aligned16(Y)) {
+    // the input-gradient Linears of the training backward over the N nodes ([N, 64 | 128] . [64 | 128, 64], some of them
+    // accumulating): row streams like the forward's (k_lin64_stream), same products in the same order as the tiles
+    hipStream_t st = (hipStream_t)stream;
+    if (K == 64)
+      return accumulate ? yl_launch_lin64_stream<1, true, true>(A, (long)lda, (long)M, nullptr, nullptr, 0, Wt, (long)ldw, nullptr, Y, (long)ldy, nullptr, st)
+                        : yl_launch_lin64_stream<1, true, false>(A, (long)lda, (long)M, nullptr, nullptr, 0, Wt, (long)ldw, nullptr, Y, (long)ldy, nullptr, st);
+    return accumulate ? yl_launch_lin64_stream<2, true, true>(A, (long)lda, (long)M, nullptr, nullptr, 0, Wt, (long)ldw, nullptr, Y, (long)ldy, nullptr, st)
+                      : yl_launch_lin64_stream<2, true, false>(A, (long)lda, (long)M, nullptr, nullptr, 0, Wt, (long)ldw, nullptr, Y, (long)ldy, nullptr, st);
+  }
   DenseOp a = yl_dense(A, lda, M, K);
   TransOp b;
   b.p = Wt; b.ld = ldw; b.rows = (int)Nout; b.cols = (int)K; b.vec = 1;
