@@ -19,6 +19,8 @@
 // fusion_block_super (P rows, its own weights, plain relu store) is a second problem of the same launch.
 #include "x6.hpp"
 #include "segmax.hpp"
+#include <algorithm>
+#include <vector>
 
 namespace {
 // training-mode epilogue: the extreme of s*z per run with its (lowest) row, as the key of wave_epilogue's key64 branch
@@ -62,6 +64,7 @@ struct FxProb {
   float* out2; long ldo2; int ct2;
   int F, relu;
   int tm, groups, ng;
+  int full = 0;          // the first `full` row tiles (a multiple of 8) are walked WHOLE by one workgroup each (fx_plan)
   // training-mode pooling (fusion_train.hip): key64 != NULL (with seg) -> for every (proposal, column) the row with the
   // largest s*z (s = sign of sgn[column], z = the accumulator) is recorded by a 64-bit atomicMax on
   // orderable(s*z) << 32 | ~row (ties -> lowest row); nothing else is written
@@ -102,20 +105,26 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   const int id = blockIdx.x;
   // workgroups past both problems: pooling-prologue rider (common.hpp; reads A like the GEMM, writes columns of the
   // pooled rows that nothing in this launch reads)
+  // the big problem: p0.full whole-row-tile workgroups first, then the remaining row tiles split into column groups
+  const int n0t = (p0.tm - p0.full) * p0.groups, n0 = p0.full + n0t;
   if constexpr (RIDER) {
-    if (id >= n1p + p0.tm * p0.groups) {
-      yl_pool_rider(rider, id - (n1p + p0.tm * p0.groups), rider.blocks, tid, T);
+    if (id >= n1p + n0) {
+      yl_pool_rider(rider, id - (n1p + n0), rider.blocks, tid, T);
       return;
     }
   }
   int logical;
+  bool whole = false;
   if (id < n1p) {
     if (id >= n1) return;
     logical = id;
+  } else if (id - n1p < p0.full) {
+    logical = id - n1p;
+    whole = true;
   } else {
     // (row tile, column group) pairs, column group fastest, dealt to the XCDs in contiguous ranges
-    const int n0 = p0.tm * p0.groups, j0 = id - n1p;
-    const int chunk = n0 >> 3, rem = n0 & 7;
+    const int j0 = id - n1p - p0.full;
+    const int chunk = n0t >> 3, rem = n0t & 7;
     const int xcd = j0 & 7, slot = j0 >> 3;
     logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
   }
@@ -147,10 +156,11 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   P.ng = small ? p1.ng : p0.ng;
   const float* __restrict__ A = P.A;
   const int N = P.N;
-  const int rt = logical / P.groups, cg = logical % P.groups;
   const int tn = (F + 63) >> 6;
+  const int rt = whole ? logical : (small ? 0 : p0.full) + logical / P.groups;
+  const int cg = whole ? 0 : logical % P.groups;
   const int ct0 = cg * P.ng;
-  const int ngl = yl_min(P.ng, tn - ct0);
+  const int ngl = whole ? tn : yl_min(P.ng, tn - ct0);
   if (ngl <= 0) return;
 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
@@ -376,6 +386,57 @@ extern "C" int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int
   return 0;
 }
 
+// Work split of the big problem (round 4).  One launch runs in rounds of `slots` resident workgroups; a workgroup costs one
+// prologue (load + three-way split of its rows of A, measured ~ one column tile's time) plus its column tiles.  Rounds 2-3
+// picked ONE power-of-two column split for all row tiles, i.e. paid either the round quantisation of whole-row workgroups
+// (782 row tiles on 256 slots: 4 rounds of 17 units for 3.05 rounds of work) or a prologue per few column tiles (4 column
+// tiles per workgroup at cfg 5: 5 units for 4 of work).  Now the first `full` row tiles — whole rounds — go to one workgroup
+// each, and only the remainder is split into column groups: the plan with the smallest makespan of a list schedule in
+// dispatch order (small problem's workgroups, cost 2; whole-row workgroups, cost 1 + tn; tail workgroups, cost 1 + ng).
+namespace {
+struct FxPlan { int full, groups, ng; };
+double fx_makespan(int slots, long n_small, long n_full, int c_full, long n_tail, int c_tail) {
+  // identical slots, three homogeneous batches in order: per batch the slots' finish times stay within one job of each
+  // other, so a sorted multiset of at most `slots` times with run-length counts is enough
+  std::vector<double> t((size_t)slots, 0.0);            // kept sorted ascending: next job goes to t[0]
+  auto run = [&](long n, double c) {
+    for (long i = 0; i < n; ++i) {
+      // t is sorted; assigning to the earliest slot and re-inserting: since all jobs of a batch have equal cost the
+      // new time is >= every time assigned in this batch, so rotating is enough when the batch started sorted
+      const double v = t[0] + c;
+      size_t pos = (size_t)(std::upper_bound(t.begin() + 1, t.end(), v) - t.begin());
+      std::move(t.begin() + 1, t.begin() + (long)pos, t.begin());
+      t[pos - 1] = v;
+    }
+  };
+  run(n_small, 2.0);
+  run(n_full, (double)c_full);
+  run(n_tail, (double)c_tail);
+  return t.back();
+}
+FxPlan fx_plan(int tm, int tn, long n_small, int slots) {
+  struct Key { int tm, tn, slots; long n_small; FxPlan plan; };
+  static thread_local Key cache[8];
+  static thread_local int used = 0, next = 0;
+  for (int i = 0; i < used; ++i)
+    if (cache[i].tm == tm && cache[i].tn == tn && cache[i].slots == slots && cache[i].n_small == n_small) return cache[i].plan;
+  FxPlan best{0, 1, tn};
+  double best_t = 1e300;
+  for (int full = 0; full <= tm; full += slots) {        // whole rounds only (slots is a multiple of 8)
+    for (int g = 1; g <= tn; g *= 2) {
+      const int ng = yl_cdiv(tn, g), groups = yl_cdiv(tn, ng);
+      if (full == tm && g > 1) break;
+      const double t = fx_makespan(slots, n_small, full, 1 + tn, (long)(tm - full) * groups, 1 + ng);
+      if (t < best_t - 1e-9) { best_t = t; best = FxPlan{full, groups, ng}; }
+    }
+  }
+  cache[next] = Key{tm, tn, slots, n_small, best};
+  next = (next + 1) & 7;
+  if (used < 8) ++used;
+  return best;
+}
+}  // namespace
+
 // pool[p, 0:F] = max over the rows of proposal p of relu(A . (sf (.) Wf)^T + tfold),  Ys = relu(S . (sfs (.) Wfs)^T
 // + tsfold): both fusion blocks with pre-split weights (yolat_split_bf16x3 of the scaled rows) and folded shifts
 // (s*b + t).  `pool` must be zero-filled first (yolat_pool_prepare).  D in {64, 128}, F % 64 == 0.
@@ -407,19 +468,11 @@ int yl_fusion_pair_eval_x6_impl(const float* A, int64_t lda, int64_t N, int64_t 
   p1.tm = yl_cdiv(P, rows_wg);
   p1.groups = tn; p1.ng = 1;
   const long n1 = (((long)p1.tm * tn + 7) & ~7L);
-  int best_g = 1;
-  double best = 1e300;
-  for (int g = 1; g <= tn; g *= 2) {
-    const int ng = yl_cdiv(tn, g);
-    const long wgs = (long)p0.tm * yl_cdiv(tn, ng) + n1;
-    const double cost = (double)((wgs + wg_round - 1) / wg_round) * (1.0 + ng);
-    if (cost < best) { best = cost; best_g = g; }
-  }
-  p0.ng = yl_cdiv(tn, best_g);
-  p0.groups = yl_cdiv(tn, p0.ng);
+  const FxPlan plan = fx_plan(p0.tm, tn, n1, wg_round);
+  p0.full = plan.full; p0.groups = plan.groups; p0.ng = plan.ng;
   PoolRider pr{};
   if (rider && rider->blocks > 0) pr = *rider;
-  const long total = (long)p0.tm * p0.groups + (((long)p1.tm * p1.groups + 7) & ~7L) + pr.blocks;
+  const long total = (long)p0.full + (long)(p0.tm - p0.full) * p0.groups + n1 + pr.blocks;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (pr.blocks > 0) {
@@ -463,19 +516,11 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
   p0.a_scale = nullptr; p0.a_shift = nullptr; p0.a_floor = 0.f; p0.stats = nullptr;
   const int rows_wg = K == 64 ? FxShape<64>::ROWS : FxShape<128>::ROWS, wg_round = K == 64 ? 512 : 256;
   p0.tm = yl_cdiv(N, rows_wg);
-  int best_g = 1;
-  double best = 1e300;
-  for (int g = 1; g <= tn; g *= 2) {
-    const int ng = yl_cdiv(tn, g);
-    const long wgs = (long)p0.tm * yl_cdiv(tn, ng);
-    const double cost = (double)((wgs + wg_round - 1) / wg_round) * (1.0 + ng);
-    if (cost < best) { best = cost; best_g = g; }
-  }
-  p0.ng = yl_cdiv(tn, best_g);
-  p0.groups = yl_cdiv(tn, p0.ng);
+  const FxPlan plan = fx_plan(p0.tm, tn, 0, wg_round);
+  p0.full = plan.full; p0.groups = plan.groups; p0.ng = plan.ng;
   p1 = p0;
-  p1.tm = 0; p1.groups = 1; p1.ng = 1;
-  const long total = (long)p0.tm * p0.groups;
+  p1.tm = 0; p1.groups = 1; p1.ng = 1; p1.full = 0;
+  const long total = (long)p0.full + (long)(p0.tm - p0.full) * p0.groups;
   if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
   if (K == 128) hipLaunchKernelGGL(k_fusion_rows_x6<128>, dim3((unsigned)total), dim3(FxShape<128>::T), 0, st, p0, p1, PoolRider{});
