@@ -20,6 +20,7 @@
 #include "x6.hpp"
 #include "segmax.hpp"
 #include <algorithm>
+#include <queue>
 #include <vector>
 
 namespace {
@@ -396,23 +397,22 @@ extern "C" int yolat_split_bf16x3(const float* W, int64_t ldw, int64_t rows, int
 namespace {
 struct FxPlan { int full, groups, ng; };
 double fx_makespan(int slots, long n_small, long n_full, int c_full, long n_tail, int c_tail) {
-  // identical slots, three homogeneous batches in order: per batch the slots' finish times stay within one job of each
-  // other, so a sorted multiset of at most `slots` times with run-length counts is enough
-  std::vector<double> t((size_t)slots, 0.0);            // kept sorted ascending: next job goes to t[0]
+  // list schedule in dispatch order on identical slots (the next job goes to the slot that frees first)
+  std::priority_queue<double, std::vector<double>, std::greater<double>> t;
+  for (int i = 0; i < slots; ++i) t.push(0.0);
+  double last = 0.0;
   auto run = [&](long n, double c) {
     for (long i = 0; i < n; ++i) {
-      // t is sorted; assigning to the earliest slot and re-inserting: since all jobs of a batch have equal cost the
-      // new time is >= every time assigned in this batch, so rotating is enough when the batch started sorted
-      const double v = t[0] + c;
-      size_t pos = (size_t)(std::upper_bound(t.begin() + 1, t.end(), v) - t.begin());
-      std::move(t.begin() + 1, t.begin() + (long)pos, t.begin());
-      t[pos - 1] = v;
+      const double v = t.top() + c;
+      t.pop();
+      t.push(v);
+      last = v > last ? v : last;
     }
   };
   run(n_small, 2.0);
   run(n_full, (double)c_full);
   run(n_tail, (double)c_tail);
-  return t.back();
+  return last;
 }
 FxPlan fx_plan(int tm, int tn, long n_small, int slots) {
   struct Key { int tm, tn, slots; long n_small; FxPlan plan; };
@@ -422,7 +422,13 @@ FxPlan fx_plan(int tm, int tn, long n_small, int slots) {
     if (cache[i].tm == tm && cache[i].tn == tn && cache[i].slots == slots && cache[i].n_small == n_small) return cache[i].plan;
   FxPlan best{0, 1, tn};
   double best_t = 1e300;
-  for (int full = 0; full <= tm; full += slots) {        // whole rounds only (slots is a multiple of 8)
+  // whole rounds only (slots is a multiple of 8); candidates: none, all whole rounds, one round fewer — the schedule is
+  // simulated job by job, and very large inputs would otherwise try hundreds of values
+  const int f1 = (tm / slots) * slots;
+  const int cand[3] = {0, f1, f1 >= slots ? f1 - slots : 0};
+  for (int ci = 0; ci < 3; ++ci) {
+    const int full = cand[ci];
+    if (ci > 0 && full == cand[ci - 1]) continue;
     for (int g = 1; g <= tn; g *= 2) {
       const int ng = yl_cdiv(tn, g), groups = yl_cdiv(tn, ng);
       if (full == tm && g > 1) break;
