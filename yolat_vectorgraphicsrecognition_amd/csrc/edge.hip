@@ -1543,25 +1543,29 @@ __global__ void __launch_bounds__(256) k_attr_dw(const T* __restrict__ dH, long 
     part[(long)blockIdx.x * 320 + i] = s;
   }
 }
-// Sum of the workgroups' partials: 32 lanes per output (lane l takes partial rows l, l + 32, ...: eight loads in flight),
-// combined by a fixed shuffle tree -> deterministic.  8 outputs per 256-thread workgroup, 40 workgroups.  (One workgroup
-// walking all 2048 partials per output was 57 us per call — as long as the streaming pass it finishes.)
+// Sum of the workgroups' partials: ONE 256-thread workgroup per output (320 of them), thread t takes partial rows t, t + 256,
+// ... (eight loads in flight), the 256 thread sums meet in a fixed tree (shuffles inside a wave, then the four wave sums
+// in order) -> deterministic.  (32 lanes per output in 40 workgroups walked 64 partials per lane: 15 us per call for 2.6 MB,
+// four calls per cfg-5 step; one workgroup walking all 2048 partials per output was 57 us.)
 static __global__ void __launch_bounds__(256) k_attr_dw_reduce(const float* __restrict__ part, int nwg, float* __restrict__ dWc4,
                                                              float* __restrict__ db) {
-  const int l = threadIdx.x & 31, o = blockIdx.x * 8 + (threadIdx.x >> 5);      // o < 320 by the launch
+  __shared__ float ws[4];
+  const int o = blockIdx.x, t = threadIdx.x;                     // o < 320 by the launch
   float s = 0.f;
-  int g2 = l;
-  for (; g2 + 7 * 32 < nwg; g2 += 8 * 32) {
+  for (int g0 = t; g0 < nwg; g0 += 8 * 256) {
     float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = part[(long)(g2 + 32 * j) * 320 + o];
+    for (int j = 0; j < 8; ++j) v[j] = part[(long)yl_min(g0 + 256 * j, nwg - 1) * 320 + o];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) s += v[j];
+    for (int j = 0; j < 8; ++j)
+      if (g0 + 256 * j < nwg) s += v[j];
   }
-  for (; g2 < nwg; g2 += 32) s += part[(long)g2 * 320 + o];
 #pragma unroll
-  for (int off = 16; off > 0; off >>= 1) s += __shfl_down(s, off, 32);
-  if (l == 0) {
+  for (int off = 32; off > 0; off >>= 1) s += __shfl_down(s, off);
+  if ((t & 63) == 0) ws[t >> 6] = s;
+  __syncthreads();
+  if (t == 0) {
+    s = ((ws[0] + ws[1]) + ws[2]) + ws[3];
     if (o < 256) dWc4[o] = s;
     else if (db != nullptr) db[o - 256] = s;
   }
@@ -1586,7 +1590,7 @@ extern "C" int yolat_edge_attr_dw(const void* dH1, int64_t ldh, int half, const 
     hipLaunchKernelGGL(k_attr_dw<float>, dim3(nwg), dim3(256), 0, st, reinterpret_cast<const float*>(dH1), (long)ldh,
                        reinterpret_cast<const float4*>(attr_csr), (int)E, (int)rows_wg, work);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(40), dim3(256), 0, st, work, nwg, dWc4, db1);
+  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(320), dim3(256), 0, st, work, nwg, dWc4, db1);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -1747,7 +1751,7 @@ extern "C" int yolat_bn_apply_edge_sums(const void* dA1, int64_t ldda, const voi
                        save_mean, save_invstd, scale, shift, relu, coef, row_ptr, reinterpret_cast<const float4*>(attr_csr),
                        (int)N, (int)nodes_wg, dUV, (long)ld_uv, work);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(40), dim3(256), 0, st, work, nwg, dWc4, db1);
+  hipLaunchKernelGGL(k_attr_dw_reduce, dim3(320), dim3(256), 0, st, work, nwg, dWc4, db1);
   YL_LAUNCH_CHECK();
   return 0;
 }
