@@ -120,29 +120,30 @@ __global__ void __launch_bounds__(256) k_bn_csr_partial(const float* __restrict_
   }
 }
 
-// fp64 ordered sum over the blocks (16 partitions, 8 loads in flight) -> dgamma, dbeta, coef = (s1/M, s2/M)
-__global__ void __launch_bounds__(1024) k_bn_csr_finalize(const float2* part, long nb, long M, int C, float* dgamma,
-                                                          float* dbeta, int accumulate, float* coef) {
-  __shared__ double s1s[16][64], s2s[16][64];
-  const int cl = threadIdx.x & 63, p = threadIdx.x >> 6;
-  const int c = blockIdx.x * 64 + cl;
-  const long per = (nb + 15) / 16;
-  long b0 = p * per, b1 = b0 + per;
-  if (b1 > nb) b1 = nb;
+// fp64 sum over the blocks in a fixed order -> dgamma, dbeta, coef = (s1/M, s2/M).  ONE 256-thread workgroup per column:
+// thread t takes blocks t, t + 256, ... (eight loads in flight; E = 1.2 M: 1875 blocks = one round), the 256 thread sums
+// meet in a fixed tree (shuffles inside a wave, the four wave sums in order).  (One 1024-thread workgroup for 64 columns
+// walked 117 blocks per thread in 16 partitions: 16 - 27 us per call, eight calls per cfg-5 step.)
+__global__ void __launch_bounds__(256) k_bn_csr_finalize(const float2* part, long nb, long M, int C, float* dgamma,
+                                                         float* dbeta, int accumulate, float* coef) {
+  __shared__ double wa[4], wb[4];
+  const int c = blockIdx.x, t = threadIdx.x;
   double a = 0.0, b = 0.0;
-  if (c < C)
-    for (long i = b0; i < b1; i += 16) {                    // 16 loads in flight (E = 1.2 M: 147 partials per partition)
-      float2 t[16];
+  for (long i = t; i < nb; i += 8 * 256) {
+    float2 v[8];
 #pragma unroll
-      for (int k = 0; k < 16; ++k) t[k] = part[(i + k < b1 ? i + k : b1 - 1) * C + c];
+    for (int k = 0; k < 8; ++k) v[k] = part[(i + 256 * k < nb ? i + 256 * k : nb - 1) * C + c];
 #pragma unroll
-      for (int k = 0; k < 16; ++k)
-        if (i + k < b1) { a += (double)t[k].x; b += (double)t[k].y; }
-    }
-  s1s[p][cl] = a; s2s[p][cl] = b;
+    for (int k = 0; k < 8; ++k)
+      if (i + 256 * k < nb) { a += (double)v[k].x; b += (double)v[k].y; }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { a += __shfl_down(a, off); b += __shfl_down(b, off); }
+  if ((t & 63) == 0) { wa[t >> 6] = a; wb[t >> 6] = b; }
   __syncthreads();
-  if (p == 0 && c < C) {
-    for (int t = 1; t < 16; ++t) { a += s1s[t][cl]; b += s2s[t][cl]; }
+  if (t == 0) {
+    a = ((wa[0] + wa[1]) + wa[2]) + wa[3];
+    b = ((wb[0] + wb[1]) + wb[2]) + wb[3];
     float dg = (float)b, dbt = (float)a;
     if (accumulate) { dg += dgamma[c]; dbt += dbeta[c]; }
     dgamma[c] = dg; dbeta[c] = dbt;
@@ -660,7 +661,7 @@ extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const 
                      (long)lddw, db, accumulate);
   YL_LAUNCH_CHECK();
   if (next) {
-    hipLaunchKernelGGL(k_bn_csr_finalize, dim3(1), dim3(1024), 0, st, part1, (long)wgs, (long)E, 64, next_dgamma, next_dbeta,
+    hipLaunchKernelGGL(k_bn_csr_finalize, dim3(64), dim3(256), 0, st, part1, (long)wgs, (long)E, 64, next_dgamma, next_dbeta,
                        0, next_coef);
     YL_LAUNCH_CHECK();
   }
@@ -710,7 +711,7 @@ extern "C" int yolat_bn_csr_bwd_stats(const yolat_bn_csr_grad* g, int64_t E, int
                      g->dst, g->inv_deg, reinterpret_cast<const float*>(g->Y), (long)g->ldy, (long)E, (int)C, g->mean, g->invstd,
                      g->scale, g->shift, g->relu, part);
   YL_LAUNCH_CHECK();
-  hipLaunchKernelGGL(k_bn_csr_finalize, dim3(yl_cdiv(C, 64)), dim3(1024), 0, st, part, nb, (long)E, (int)C, dgamma, dbeta,
+  hipLaunchKernelGGL(k_bn_csr_finalize, dim3((unsigned)C), dim3(256), 0, st, part, nb, (long)E, (int)C, dgamma, dbeta,
                      accumulate, coef_out);
   YL_LAUNCH_CHECK();
   return 0;
