@@ -295,7 +295,7 @@ def conv_fwd(conv, g, x, xn, out_f, out_s, training, half=False, node_coef_out=N
             st1 = ops.stats_buffer(E, C, dev)
             if factorised:
                 # per-node products + gather-add instead of the gathered K = 132 GEMM (pays when E >> N)
-                ops.edge_lin1_fwd_factorised(x, g, nn0.weight, nn0.bias, H1, stats=st1)
+                ops.edge_lin1_fwd_factorised(x, g, nn0.weight, nn0.bias, H1, stats=st1, keep=sv)
             else:
                 ops.edge_lin1_fwd(x, g, nn0.weight, nn0.bias, H1, stats=st1)
             c1 = _bn_train(st1, E, bn1, dev)
@@ -389,7 +389,8 @@ def conv_bwd(sv, g, d_f, d_s, sink, dx=None, dx_acc=False, dxn=None, dxn_acc=Fal
         if fact_bwd:
             # per-node sums of dH1 + N-row dense algebra instead of the gathered E-row GEMMs (pays when E >> N)
             ops.edge_lin1_bwd_factorised(dA1, x, g, nn0.weight, sink.get(nn0.weight), db1 if db1 is not None else sink.get(nn0.bias),
-                                         dx=dx if need_dx else None, dx_accumulate=True, side=_on_side, partial=partial)
+                                         dx=dx if need_dx else None, dx_accumulate=True, side=_on_side, partial=partial,
+                                         wuv=sv.get("wuv"))
         else:
             ops.edge_lin1_bwd_w(dA1, x, g, sink.get(nn0.weight), sink.get(nn0.bias))
             if need_dx:

@@ -592,13 +592,15 @@ def edge_lin1_bwd_factorised(dH1, x, g, W1, dW1, db1, dx=None, dx_accumulate=Fal
     return dW1
 
 
-def edge_lin1_fwd_factorised(x, g, W1, b1, H1, stats=None):
+def edge_lin1_fwd_factorised(x, g, W1, b1, H1, stats=None, keep=None):
     """Same result as edge_lin1_fwd (to fp32 rounding) through the per-node products: UV = x.[W1a-W1b | W1b]^T by a
     dense GEMM over the N nodes, then a gather-add over the E edges (csrc/edge.hip, yolat_edge_uv_lin1_fwd).  Pays
     when E >> N; Cin == C == 64 only."""
     N, Cin = x.shape
     C = W1.shape[0]
     wuv, wc4 = split_w1(W1, Cin)
+    if keep is not None:
+        keep["wuv"] = wuv               # the backward of the same step needs the same split (edge_lin1_bwd_factorised)
     uv = torch.empty(N, 2 * C, dtype=torch.float32, device=x.device)
     linear_fwd(x, wuv, None, uv)
     if _is_h(H1):
