@@ -613,3 +613,40 @@ def test_edge_chain_kernel_soak_50_runs_bit_identical_and_exact(shape):
     tol = want.abs() * 2.0 ** -8 + 2e-5 * mscale
     assert torch.isfinite(first.float()).all()
     assert float((d > tol).float().mean()) < 2e-5 and not bool((d > tol + flip).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("M,pro", [(70001, True), (65536, False), (131072 + 33, True)])
+def test_linear64_bf16_row_stream_is_bit_identical_to_the_tile_kernel(M, pro):
+    """k_hlin64_stream (bf16_eval.hip, round 4; taken by yolat_linear_fwd_h for K = Nout = 64, M >= 65536: the second edge
+    Linear of a bf16-storage training conv layer, torch_vertex.py:331 nn.3) against the hgemm tile kernel run on row ranges
+    below the threshold (48 000 rows: a multiple of 32, the statistics' group size): bf16 outputs and fp32 (sum, M2)
+    statistics BIT-identical, ragged last tile included; fp64 check of the product on the widened values."""
+    yv = _yv()
+    ops = yv.ops
+    gen = torch.Generator().manual_seed(M)
+    A = torch.randn(M, 64, generator=gen).cuda().bfloat16()
+    W = (torch.randn(64, 64, generator=gen) / 8).cuda()
+    b = torch.randn(64, generator=gen).cuda()
+    sc = (torch.rand(64, generator=gen) + 0.5).cuda() if pro else None
+    sh = torch.randn(64, generator=gen).cuda() * 0.3 if pro else None
+    apro = (sc, sh) if pro else None
+    Y = torch.zeros(M, 64, device="cuda", dtype=torch.bfloat16)
+    st = ops.stats_buffer(M, 64, A.device)
+    st.fill_(float("nan"))
+    ops.linear_fwd(A, W, b, Y, a_pro=apro, a_relu=pro, stats=st)
+    parts_y, parts_s = [], []
+    for lo in range(0, M, 48000):
+        hi = min(lo + 48000, M)
+        Yp = torch.zeros(hi - lo, 64, device="cuda", dtype=torch.bfloat16)
+        sp = ops.stats_buffer(hi - lo, 64, A.device)
+        ops.linear_fwd(A[lo:hi], W, b, Yp, a_pro=apro, a_relu=pro, stats=sp)
+        parts_y.append(Yp)
+        parts_s.append(sp.view(-1)[:2 * 64 * ((hi - lo + 31) // 32)])
+    assert torch.equal(Y, torch.cat(parts_y))
+    assert torch.equal(st.view(-1)[:2 * 64 * ((M + 31) // 32)], torch.cat(parts_s))
+    Ain = A.double()
+    if pro:
+        Ain = torch.relu(A.float() * sc + sh).bfloat16().double()
+    ref = Ain @ W.bfloat16().double().t() + b.double()
+    assert float((Y.double() - ref).abs().max()) <= 2.0 ** -7 * float(ref.abs().max())

@@ -914,6 +914,105 @@ static __global__ void k_f32_to_bf16_rows(const float* __restrict__ W, long ldw,
   dst[i] = (u16)(yl_pack_bf16(W[(long)(i / K) * ldw + (i % K)], 0.f) & 0xFFFFu);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Many-row 64 -> 64 Linear on bf16-stored rows as a row STREAM (round 4; the bf16 twin of dense.hip's k_lin64_stream):
+// the second edge Linear of a bf16-storage training conv layer was one 64 x 64 hgemm tile per workgroup (18 750 at
+// E = 1.2 M: 86 us, 3.8 TB/s by counters against the 4.7 TB/s of the fp32 stream).  Persistent workgroups, the bf16 weight
+// in LDS once, the next tile's rows in flight under the current tile's work, BatchNorm + ReLU prologue while staging
+// (HProOp's arithmetic), statistics from the fp32 accumulators (wave_epilogue's arithmetic), output through LDS with
+// 8-byte bf16 stores.  Same MFMAs on the same operands in the same order as hgemm_tile: bit-identical.
+// ------------------------------------------------------------------------------------------------
+static __global__ void __launch_bounds__(256) k_hlin64_stream(const u16* __restrict__ A, long lda, int M,
+                                                              const float* __restrict__ a_scale,
+                                                              const float* __restrict__ a_shift, float a_floor,
+                                                              const u16* __restrict__ Wb, const float* __restrict__ bias,
+                                                              u16* __restrict__ Y, long ldy, float2* __restrict__ stats,
+                                                              int tiles_per_wg) {
+  constexpr int LDH = YL_HRS, LDO = 68;                    // 72 bf16 = 144 B rows (16-byte fragment reads)
+  __shared__ __attribute__((aligned(16))) u16 Ah[64 * LDH], Wh[64 * LDH];
+  __shared__ __attribute__((aligned(16))) float Os[64 * LDO];
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int q = tid & 15, rb = tid >> 4;                   // staging role: columns 4q.., rows rb + 16 t
+  const int ntiles = (M + 63) >> 6;
+  const int t0 = blockIdx.x * tiles_per_wg, t1 = yl_min(ntiles, t0 + tiles_per_wg);
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = rb + 16 * t;
+    *reinterpret_cast<uint2*>(&Wh[r * LDH + 4 * q]) = *reinterpret_cast<const uint2*>(Wb + r * 64 + 4 * q);
+  }
+  float4 as = make_float4(1.f, 1.f, 1.f, 1.f), ah = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (a_scale) { as = *reinterpret_cast<const float4*>(a_scale + 4 * q); ah = *reinterpret_cast<const float4*>(a_shift + 4 * q); }
+  const float bv = bias ? bias[wn * 32 + l31] : 0.f;
+  uint2 ra[4];
+  auto fetch = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const long e = yl_min(tile * 64 + rb + 16 * t, M - 1);
+      ra[t] = *reinterpret_cast<const uint2*>(A + e * lda + 4 * q);
+    }
+  };
+  if (t0 < t1) fetch(t0);
+  for (int tile = t0; tile < t1; ++tile) {
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      uint2 o = ra[t];
+      if (a_scale) {                                       // HProOp::load's arithmetic
+        o.x = yl_pack_bf16(fmaxf(fmaf(yl_bf16_lo(ra[t].x), as.x, ah.x), a_floor), fmaxf(fmaf(yl_bf16_hi(ra[t].x), as.y, ah.y), a_floor));
+        o.y = yl_pack_bf16(fmaxf(fmaf(yl_bf16_lo(ra[t].y), as.z, ah.z), a_floor), fmaxf(fmaf(yl_bf16_hi(ra[t].y), as.w, ah.w), a_floor));
+      }
+      *reinterpret_cast<uint2*>(&Ah[(rb + 16 * t) * LDH + 4 * q]) = o;
+    }
+    __syncthreads();                                       // Ah complete (and the previous tile's Os reads are done)
+    if (tile + 1 < t1) fetch(tile + 1);                    // in flight under the MFMAs
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      const bf16x8 a = *reinterpret_cast<const bf16x8*>(Ah + (wm * 32 + l31) * LDH + ks * 16 + lhi * 8);
+      const bf16x8 b = *reinterpret_cast<const bf16x8*>(Wh + (wn * 32 + l31) * LDH + ks * 16 + lhi * 8);
+      acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] += bv;
+    const int row_base = tile * 64 + wm * 32;
+    if (stats != nullptr) {                                // wave_epilogue's arithmetic (common.hpp), per 32-row group
+      int cnt = M - row_base;
+      cnt = cnt > 32 ? 32 : cnt;
+      float sm = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        sm += (row < M) ? acc[r] : 0.f;
+      }
+      sm += __shfl_xor(sm, 32);
+      const float mu = cnt > 0 ? sm / (float)cnt : 0.f;
+      float m2 = 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = row_base + (r & 3) + 8 * (r >> 2) + 4 * lhi;
+        const float d = acc[r] - mu;
+        m2 += (row < M) ? d * d : 0.f;
+      }
+      m2 += __shfl_xor(m2, 32);
+      if (lhi == 0 && cnt > 0) stats[(long)(row_base >> 5) * 64 + wn * 32 + l31] = make_float2(sm, m2);
+    }
+#pragma unroll
+    for (int r = 0; r < 16; ++r) Os[(wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * lhi) * LDO + wn * 32 + l31] = acc[r];
+    __syncthreads();                                       // Os complete; every read of Ah is done
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int r = rb + 16 * t;
+      const long row = (long)tile * 64 + r;
+      if (row < M) {
+        const float4 v = *reinterpret_cast<const float4*>(Os + r * LDO + 4 * q);
+        *reinterpret_cast<uint2*>(Y + row * ldy + 4 * q) = make_uint2(yl_pack_bf16(v.x, v.y), yl_pack_bf16(v.z, v.w));
+      }
+    }
+  }
+}
+
 extern "C" int yolat_linear_fwd_h(const uint16_t* A, int64_t lda, int64_t M, int64_t K, const float* a_scale,
                                   const float* a_shift, int a_relu, const float* W, int64_t ldw, const float* bias,
                                   int64_t Nout, uint16_t* Y, int64_t ldy, float* stats, uint16_t* w_work,
@@ -928,6 +1027,15 @@ extern "C" int yolat_linear_fwd_h(const uint16_t* A, int64_t lda, int64_t M, int
   hipLaunchKernelGGL(k_f32_to_bf16_rows, dim3(yl_cdiv(K * Nout, 256)), dim3(256), 0, st, W, (long)ldw, (int)K, (int)Nout,
                      w_work);
   YL_LAUNCH_CHECK();
+  if (K == 64 && Nout == 64 && M >= 65536 && ldy % 4 == 0 && (((uintptr_t)Y) & 7) == 0 && lda % 4 == 0 &&
+      (!stats || (((uintptr_t)stats) & 7) == 0)) {
+    const int ntiles = (int)yl_cdiv(M, 64);
+    const int per = yl_cdiv(ntiles, 1024);                  // 36 KB of LDS: four workgroups per CU
+    hipLaunchKernelGGL(k_hlin64_stream, dim3(yl_cdiv(ntiles, per)), dim3(256), 0, st, A, (long)lda, (int)M, a_scale, a_shift,
+                       a_relu ? 0.f : -INFINITY, w_work, bias, Y, (long)ldy, reinterpret_cast<float2*>(stats), per);
+    YL_LAUNCH_CHECK();
+    return 0;
+  }
   Epilogue ep = plain_epilogue();
   ep.bias = bias; ep.Yh = Y; ep.ldy = ldy; ep.stats = stats;
   HOp b{w_work, K, (int)Nout};
