@@ -221,13 +221,8 @@ BnCsrOp make_op(const yolat_bn_csr_grad* g, int64_t E, int64_t C) { return make_
 __device__ __forceinline__ void bcl_store(float* p, float v) { *p = v; }
 __device__ __forceinline__ void bcl_store(yl_bf16_t* p, float v) { *p = (yl_bf16_t)(yl_pack_bf16(v, 0.f) & 0xffffu); }
 __device__ __forceinline__ float bcl_round(float v) { return __uint_as_float((yl_pack_bf16(v, 0.f) & 0xffffu) << 16); }
-typedef __bf16 bcl_bf16x8 __attribute__((ext_vector_type(8)));
-typedef unsigned bcl_u32x4 __attribute__((ext_vector_type(4)));
-// SPLIT (round 4, not under YOLAT_STRICT_FP32): dA = dY . W on the bf16 matrix cores with dY and W each split into TWO
-// bf16 terms (nearest-even; three products hh + hm + mh reproduce the fp32 product to ~2^-17, fp32 accumulation — the
-// scheme of k_fus_da_mfma with rounded instead of truncated terms): 12 MFMAs of 32 cycles per tile and wave instead of 32 of 64.  dW stays on fp32 MFMAs.
-template <class T, bool SPLIT = false>
-__global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* __restrict__ A, long lda,
+template <class T>
+__global__ void __launch_bounds__(256) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T* __restrict__ A, long lda,
                                                        const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                        float a_floor, const float* __restrict__ W, long ldw,
                                                        T* __restrict__ dA, long ldda, int E, int tiles_per_wg,
@@ -238,15 +233,8 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T
   // (A - bn_mean) bn_invstd — the dA tile is passed through LDS into the staging layout, where the raw A values still
   // sit in registers, and leaves for global memory from there with 16-byte stores
   constexpr int LD = 65;
-  __shared__ __attribute__((aligned(16))) float Ds[64 * LD], As[64 * LD];
-  __shared__ __attribute__((aligned(16))) float Ws[SPLIT ? 4 : 64 * LD];
-  constexpr int LDH = 68, LDWT = 72;
-  __shared__ __attribute__((aligned(16))) unsigned short Dhh[SPLIT ? 64 * LDH : 8], Dhm[SPLIT ? 64 * LDH : 8];
-  __shared__ __attribute__((aligned(16))) unsigned short Wth[SPLIT ? 64 * LDWT : 8], Wtm[SPLIT ? 64 * LDWT : 8];
-  auto split2 = [](float x, unsigned& h, unsigned& m) {   // x = h + m + O(2^-18 x), both bf16 (round to nearest even)
-    h = yl_pack_bf16(x, 0.f) & 0xFFFFu;
-    m = yl_pack_bf16(x - __uint_as_float(h << 16), 0.f) & 0xFFFFu;
-  };
+  __shared__ float Ds[64 * LD], As[64 * LD];
+  __shared__ __attribute__((aligned(16))) float Ws[64 * LD];
   __shared__ float dbs[4][64];
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int wm = wave >> 1, wn = wave & 1;
@@ -258,19 +246,8 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T
   for (int t = 0; t < 4; ++t) {
     const int r = rb + 16 * t;
     const float4 w = *reinterpret_cast<const float4*>(W + (long)r * ldw + 4 * q);
-    if (SPLIT) {                                           // W^T [k][c] in two bf16 planes: the B operand of dA = dY . W
-      const float wv[4] = {w.x, w.y, w.z, w.w};
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        unsigned h, m;
-        split2(wv[j], h, m);
-        Wth[(4 * q + j) * LDWT + r] = (unsigned short)h;
-        Wtm[(4 * q + j) * LDWT + r] = (unsigned short)m;
-      }
-    } else {
-      float* d = Ws + r * LD + 4 * q;
-      d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
-    }
+    float* d = Ws + r * LD + 4 * q;
+    d[0] = w.x; d[1] = w.y; d[2] = w.z; d[3] = w.w;
   }
   const float4 mu = *reinterpret_cast<const float4*>(y.mean + 4 * q), is = *reinterpret_cast<const float4*>(y.invstd + 4 * q);
   const float4 sc = *reinterpret_cast<const float4*>(y.scale + 4 * q), sh = *reinterpret_cast<const float4*>(y.shift + 4 * q);
@@ -328,13 +305,6 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T
       a[1] = ok ? fmaxf(fmaf(ra[t].y, as.y, ah.y), a_floor) : 0.f;
       a[2] = ok ? fmaxf(fmaf(ra[t].z, as.z, ah.z), a_floor) : 0.f;
       a[3] = ok ? fmaxf(fmaf(ra[t].w, as.w, ah.w), a_floor) : 0.f;
-      if (SPLIT) {
-        unsigned h[4], m[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) split2(d[j], h[j], m[j]);
-        *reinterpret_cast<uint2*>(&Dhh[r * LDH + 4 * q]) = make_uint2(h[0] | (h[1] << 16), h[2] | (h[3] << 16));
-        *reinterpret_cast<uint2*>(&Dhm[r * LDH + 4 * q]) = make_uint2(m[0] | (m[1] << 16), m[2] | (m[3] << 16));
-      }
       rh[t] = ra[t];                                     // raw A of this tile (ra is refilled by the prefetch)
     }
     __syncthreads();
@@ -346,30 +316,11 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T
     f32x16 acca;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acca[r] = 0.f;
-    if (SPLIT) {
-      const unsigned short* dh = &Dhh[(wm * 32 + l31) * LDH + 8 * lhi];
-      const unsigned short* dm = &Dhm[(wm * 32 + l31) * LDH + 8 * lhi];
-      const unsigned short* wh = &Wth[(wn * 32 + l31) * LDWT + 8 * lhi];
-      const unsigned short* wl = &Wtm[(wn * 32 + l31) * LDWT + 8 * lhi];
-#pragma unroll
-      for (int ks = 0; ks < 4; ++ks) {
-        const uint2 h0 = *reinterpret_cast<const uint2*>(dh + 16 * ks), h1 = *reinterpret_cast<const uint2*>(dh + 16 * ks + 4);
-        const uint2 m0 = *reinterpret_cast<const uint2*>(dm + 16 * ks), m1 = *reinterpret_cast<const uint2*>(dm + 16 * ks + 4);
-        const bcl_u32x4 ahv = {h0.x, h0.y, h1.x, h1.y}, amv = {m0.x, m0.y, m1.x, m1.y};
-        const bcl_bf16x8 ah8 = __builtin_bit_cast(bcl_bf16x8, ahv), am8 = __builtin_bit_cast(bcl_bf16x8, amv);
-        const bcl_bf16x8 bh8 = *reinterpret_cast<const bcl_bf16x8*>(wh + 16 * ks);
-        const bcl_bf16x8 bm8 = *reinterpret_cast<const bcl_bf16x8*>(wl + 16 * ks);
-        acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(am8, bh8, acca, 0, 0, 0);   // small terms first
-        acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah8, bm8, acca, 0, 0, 0);
-        acca = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah8, bh8, acca, 0, 0, 0);
-      }
-    } else {
 #pragma unroll 8
-      for (int c = 0; c < 64; c += 2) {
-        const float av = Ds[(wm * 32 + l31) * LD + c + lhi];
-        const float bv = Ws[(c + lhi) * LD + wn * 32 + l31];
-        acca = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acca, 0, 0, 0);
-      }
+    for (int c = 0; c < 64; c += 2) {
+      const float av = Ds[(wm * 32 + l31) * LD + c + lhi];
+      const float bv = Ws[(c + lhi) * LD + wn * 32 + l31];
+      acca = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acca, 0, 0, 0);
     }
     // ---- dW += dY^T . A1   (rows = dY columns wm*32.., columns = A1 columns wn*32..)
 #pragma unroll 8
@@ -429,7 +380,7 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T
   }
   if (part1 != nullptr) {
     // the 16 row groups of a column quad, summed in order by row group 0
-    float4* red1 = reinterpret_cast<float4*>(SPLIT ? As : Ws);   // 64 * 65 floats hold 2 x 16 x 16 float4
+    float4* red1 = reinterpret_cast<float4*>(Ws);        // Ws (64 * 65 floats) holds 2 x 16 x 16 float4
     float4* red2 = red1 + 256;
     __syncthreads();
     red1[rb * 16 + q] = p1; red2[rb * 16 + q] = p2;
@@ -467,6 +418,8 @@ __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd(BnCsrOpT<T> y, const T
 // so the two lane halves, 8 rows apart, land 16 banks apart).  db: per-thread sums of the fp32 dY values over the
 // thread's rows, combined over the 16 row groups in fixed order at the end.  Two barriers per tile instead of four.
 // ------------------------------------------------------------------------------------------------------------------
+typedef __bf16 bcl_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned bcl_u32x4 __attribute__((ext_vector_type(4)));
 __global__ void __launch_bounds__(256, 2) k_bn_csr_l2_bwd_h(BnCsrOpT<yl_bf16_t> y, const yl_bf16_t* __restrict__ A, long lda,
                                                          const float* __restrict__ a_scale, const float* __restrict__ a_shift,
                                                          float a_floor, const float* __restrict__ W, long ldw,
@@ -698,14 +651,9 @@ extern "C" int yolat_bn_csr_l2_bwd(const yolat_bn_csr_grad* g, int64_t E, const 
   } else {
     BnCsrOp y = make_op(g, E, 64);
     if (!y.vec) return YOLAT_E_UNSUPPORTED;
-    if (yl_strict_fp32())
-      hipLaunchKernelGGL((k_bn_csr_l2_bwd<float, false>), dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const float*>(A),
-                         (long)lda, a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<float*>(dA), (long)ldda, (int)E, per,
-                         work, next_mean, next_invstd, part1);
-    else
-      hipLaunchKernelGGL((k_bn_csr_l2_bwd<float, true>), dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const float*>(A),
-                         (long)lda, a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<float*>(dA), (long)ldda, (int)E, per,
-                         work, next_mean, next_invstd, part1);
+    hipLaunchKernelGGL(k_bn_csr_l2_bwd<float>, dim3(wgs), dim3(256), 0, st, y, reinterpret_cast<const float*>(A), (long)lda,
+                       a_scale, a_shift, floor, W, (long)ldw, reinterpret_cast<float*>(dA), (long)ldda, (int)E, per, work,
+                       next_mean, next_invstd, part1);
   }
   YL_LAUNCH_CHECK();
   // partial layout [wg][64*64 | 64]: reduce the two pieces with the element stride of the slab
