@@ -48,7 +48,6 @@ static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, 
 // order as the tile kernel (k ascending in steps of two) and the same statistics arithmetic (wave_epilogue): bit-identical
 // outputs and statistics.
 // ------------------------------------------------------------------------------------------------
-#define L64_WGS 768
 // KH: K = 64 KH (the rows' K halves pass through one 64 x 64 LDS tile one after the other); WT: the weight is given
 // transposed ([K, 64] row-major: yolat_linear_fwd_wt, the input-gradient Linears of the training backward); ACC: Y += .
 // (the generic epilogue's order: (acc + bias) + old).  The a_scale prologue and the statistics are for KH == 1 only.
@@ -174,7 +173,9 @@ static int yl_launch_lin64_stream(const float* A, long lda, long M, const float*
                                   const float* W, long ldw, const float* bias, float* Y, long ldy, float* stats,
                                   hipStream_t st) {
   const int ntiles = (int)yl_cdiv(M, 64);
-  const int wgs = KH == 1 ? L64_WGS : 512;               // 51 KB of LDS: three per CU; K = 128: 67 KB, two per CU
+  // two workgroups per CU: three fit (51 KB of LDS each) and the kernel alone is as fast with 768, but they fill a CU's
+  // LDS and keep the side stream's kernels of the training step off it: cfg-5 step 7.21 (768) / 7.18 (512) / 7.45 ms (256)
+  const int wgs = 512;
   const int per = yl_cdiv(ntiles, wgs);
   hipLaunchKernelGGL((k_lin64_stream<KH, WT, ACC>), dim3(yl_cdiv(ntiles, per)), dim3(256), 0, st, A, lda, (int)M, a_scale,
                      a_shift, a_relu ? 0.f : -INFINITY, W, ldw, bias, Y, ldy, reinterpret_cast<float2*>(stats), per);
