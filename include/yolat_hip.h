@@ -618,7 +618,29 @@ typedef struct {
    * Wf_fold = bf16(diag(sf) Wf) [F, D], tf_fold = sf*bf + tf [F] fp32; same for the super block */
   const uint16_t *Wf_fold, *Wfs_fold;
   const float *tf_fold, *tfs_fold;
+  /* ABI 5, optional (NULL keeps the per-layer launches): the conv stack's weights in the register-fragment order of the
+   * one-launch proposal-local kernel (conv_local.hip), yolat_conv_local_pack_bytes(n_blocks) bytes filled by
+   * yolat_conv_local_pack from the members above */
+  const void* conv_local;
 } yolat_model_eval_bf16;
+
+/* All conv layers + the pooling prologue of the bf16-storage forward in ONE launch (conv_local.hip): Backbone.forward,
+ * architecture3cc_rpn_gp_iter2.py:44-69 + the segment max / mean of :67,122 over the concat columns, for batches whose
+ * edges stay inside their proposal (Datasets/graph_dict3.py:582-600,733) and whose proposals fit a 64-node / 640-edge tile.
+ *   yolat_conv_local_pack_bytes / yolat_conv_local_pack: the packed weight image (once per weight version; `m` must carry
+ *     every member the bf16 forward needs; C = 64, Cin0 <= 8, else YOLAT_E_UNSUPPORTED).
+ *   yolat_conv_stack_local_bf16: on a prepared graph g (yolat_graph_prepare outputs) writes
+ *     feats [N, ld_feats] bf16 = the concat of the last n_blocks_out layer outputs, and per proposal p of Z [P, ldz] fp32:
+ *     Z[p, 0:F] = 0, Z[p, F:F+D] = max over the proposal's rows of feats, Z[p, 2F+D:2F+2D] = mean of the node branch
+ *     (D = C * n_blocks_out) — what the per-layer launches + k_pool_prepare leave behind.
+ *     *flag (device int32, zero on entry) is raised to 1 when the batch does not have the property (an edge leaving its
+ *     tile, a proposal that does not fit): the outputs are then incomplete and the caller must run the per-layer path;
+ *     yolat_forward_eval_bf16 does that by itself (its per-layer launches stay enqueued, gated on the flag).            */
+size_t yolat_conv_local_pack_bytes(int64_t n_layers);
+int yolat_conv_local_pack(const yolat_model_eval_bf16* m, void* dst, size_t dst_bytes, yolat_stream_t stream);
+int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* m, const void* pack, const float* x, int64_t ldx,
+                                const yolat_graph_csr* g, int64_t N, int64_t E, int64_t P, uint16_t* feats,
+                                int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag, yolat_stream_t stream);
 
 /* The edge stage of the bf16-storage forward on its own (op tests, benchmarks): factorised edge MLP + mean
  * aggregation of one conv layer, gcn_lib/sparse/torch_vertex.py:319-337 in eval mode.

@@ -1,0 +1,253 @@
+"""GPU tests (-m gpu) of the one-launch proposal-local conv stack of the bf16-storage eval forward
+(csrc/conv_local.hip: yolat_conv_local_pack, yolat_conv_stack_local_bf16, and its use inside yolat_forward_eval_bf16).
+
+Reference path: Backbone.forward, cad_recognition/architecture3cc_rpn_gp_iter2.py:44-69 (conv layers, concat, segment
+mean of the node branch) + the segment max of :122 over the concat columns; AttrRelativeEdgeConvGlobalPool2,
+gcn_lib/sparse/torch_vertex.py:319-337.  Oracle: oracle/oracle_torch.py (fp32 / fp64 on the CPU).  Tolerances are the
+bf16-storage ones of tests/test_gpu_bf16.py (<= 1e-2 of the scale, rms)."""
+import ctypes
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+from oracle import oracle_torch as orc
+
+pytestmark = pytest.mark.gpu
+
+RTOL_BF16 = 2e-2
+RMS_BF16 = 1e-2
+
+
+def _yv():
+    import yolat_vectorgraphicsrecognition_amd as yv
+    return yv
+
+
+def _model(yv, optkw, seed):
+    return gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), seed).cuda().eval().set_eval_precision("bf16")
+
+
+class _mode(object):
+    """YOLAT_CONV_LOCAL for the duration of a block (read per call by yolat_forward_eval_bf16)."""
+
+    def __init__(self, v):
+        self.v = str(v)
+
+    def __enter__(self):
+        self.old = os.environ.get("YOLAT_CONV_LOCAL")
+        os.environ["YOLAT_CONV_LOCAL"] = self.v
+
+    def __exit__(self, *a):
+        if self.old is None:
+            os.environ.pop("YOLAT_CONV_LOCAL", None)
+        else:
+            os.environ["YOLAT_CONV_LOCAL"] = self.old
+
+
+def _rel(got, want):
+    got, want = got.double().cpu(), want.double().cpu()
+    scale = float(want.abs().max())
+    return (float((got - want).abs().max()) / scale,
+            float((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt().clamp(min=1e-30)))
+
+
+def _ragged(yv, P, seed, lo=2, hi=40, edge_factor=2.1, classes=17, edges_per_proposal=None):
+    d = yv.synth_graph(num_proposals=P, nodes_lo=lo, nodes_hi=hi, edge_factor=edge_factor, n_classes=classes, seed=seed,
+                       edges_per_proposal=edges_per_proposal)
+    return d
+
+
+def _run_stack(yv, model, d):
+    """yolat_conv_stack_local_bf16 on the model's packed weights: (feats [N,D] bf16, Z [P, 2(F+D)] fp32, flag)."""
+    from yolat_vectorgraphicsrecognition_amd import ops
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check, GraphCsr
+    with torch.no_grad():
+        model(d, None)                      # builds the plan (weights folded / packed)
+    plan = model._yolat_plan
+    h = plan._desc_h
+    assert h is not None and h.conv_local, "the plan did not pack the conv stack"
+    base = plan._desc
+    N, P = d.x.shape[0], d.bbox.shape[0]
+    dev = torch.device("cuda")
+    g = ops.build_graph(d.edge.to(dev), d.e_attr.to(dev), d.bbox_idx.to(dev), N, P)
+    g.check_status()
+    D, F = base.C * base.n_blocks_out, base.F
+    feats = torch.full((N, D), float("nan"), dtype=torch.bfloat16, device=dev)
+    Z = torch.full((P, 2 * (F + D)), float("nan"), dtype=torch.float32, device=dev)
+    flag = torch.zeros(1, dtype=torch.int32, device=dev)
+    x = d.x.to(dev).contiguous()
+    gc = GraphCsr(*g.device_pointers())
+    check(lib.yolat_conv_stack_local_bf16(ctypes.byref(h), h.conv_local, x.data_ptr(), x.stride(0), ctypes.byref(gc), N, g.E,
+                                          P, feats.data_ptr(), D, Z.data_ptr(), Z.stride(0), flag.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream), "yolat_conv_stack_local_bf16")
+    torch.cuda.synchronize()
+    return feats, Z, int(flag.item()), (F, D)
+
+
+def _oracle_backbone(optkw, seed, d):
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), seed).eval()
+    with torch.no_grad():
+        x = d.x
+        edge_index = d.edge.t()
+        out_feat, out_sup = ref.cls_net(x, [edge_index], [None], [d.e_attr], d.bbox_idx)
+    return ref, out_feat, out_sup
+
+
+@pytest.mark.parametrize("blocks,blocks_out,cin,P,seed,shape", [
+    (2, 2, 5, 300, 1, dict(lo=2, hi=40, edge_factor=2.1)),                 # ragged, nodes without in-edges
+    (4, 2, 5, 1500, 2, dict(lo=25, hi=25, edges_per_proposal=150)),       # cfg-5-like: 6 in-edges per node
+    (4, 4, 5, 257, 3, dict(lo=3, hi=24, edge_factor=1.2)),                 # ~1.2 edges per node (Diagrams-like)
+    (3, 1, 3, 64, 4, dict(lo=30, hi=60, edges_per_proposal=500)),         # one proposal per tile, in-degree ~11
+    (2, 2, 8, 5, 5, dict(lo=5, hi=9, edge_factor=2.0)),                    # a handful of proposals, in_channels 8
+])
+def test_conv_stack_local_matches_cpu_oracle(blocks, blocks_out, cin, P, seed, shape):
+    """feats (the concat of the last n_blocks_out layer outputs), their per-proposal max, the per-proposal mean of the node
+    branch and the zeroed fusion columns against the fp32 CPU oracle's Backbone; flag stays 0; bit-identical run to run."""
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=blocks, n_blocks_out=blocks_out, in_channels=cin)
+    d = _ragged(yv, P, 100 + seed, **shape)
+    if cin != 5:
+        d.x = torch.randn(d.x.shape[0], cin, generator=torch.Generator().manual_seed(cin)) * 0.7
+    model = _model(yv, optkw, 40 + seed)
+    feats, Z, flag, (F, D) = _run_stack(yv, model, d)
+    feats2, Z2, flag2, _ = _run_stack(yv, model, d)
+    assert flag == 0 and flag2 == 0
+    assert torch.equal(feats.view(torch.int16), feats2.view(torch.int16))
+    written = torch.cat([Z[:, :F + D], Z[:, 2 * F + D:]], 1)
+    assert torch.isfinite(written).all() and torch.equal(written, torch.cat([Z2[:, :F + D], Z2[:, 2 * F + D:]], 1))
+    _, out_feat, out_sup = _oracle_backbone(optkw, 40 + seed, d)
+    want_feats = out_feat[:, F:]
+    depth = max(1.0, blocks / 4.0)
+    for name, got, want in (("feats", feats.float(), want_feats),
+                            ("mean(node branch)", Z[:, 2 * F + D:], out_sup[:, F:])):
+        assert torch.isfinite(got).all(), name
+        mx, rms = _rel(got, want)
+        assert mx <= RTOL_BF16 * depth and rms <= RMS_BF16 * depth, "%s: max %.2e rms %.2e" % (name, mx, rms)
+    # the pooled maximum is exactly the maximum of the feats rows the kernel stored
+    bb = d.bbox_idx.cuda()
+    want_max = torch.full((P, D), -float("inf"), device="cuda").scatter_reduce(
+        0, bb[:, None].expand(-1, D), feats.float(), "amax", include_self=True)
+    assert torch.equal(Z[:, F:F + D], want_max)
+    assert bool((Z[:, :F] == 0).all())
+
+
+def _with_big_proposal(d, p_mid, n_nodes):
+    """merge the proposals around p_mid into ONE proposal of n_nodes nodes (ids renumbered: consecutive and sorted)"""
+    bb = d.bbox_idx.clone()
+    n_lo = int((bb < p_mid).sum())
+    bb[n_lo:n_lo + n_nodes] = p_mid
+    _, inv = torch.unique_consecutive(bb, return_inverse=True)
+    d.bbox_idx = inv
+    P2 = int(inv.max()) + 1
+    d.bbox = d.bbox[:P2].clone()
+    d.stat_feats = d.stat_feats[:P2].clone()
+    d.labels = d.labels[:P2].clone()
+    return d
+
+
+def test_conv_stack_local_raises_the_flag_for_batches_without_the_property():
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2)
+    model = _model(yv, optkw, 3)
+    # (a) a proposal of 100 nodes does not fit a 64-node tile
+    assert _run_stack(yv, model, _with_big_proposal(_ragged(yv, 60, 7, lo=3, hi=20), 20, 100))[2] == 1
+    # (b) an edge that leaves its proposal (and its tile)
+    d3 = _ragged(yv, 40, 9, lo=3, hi=20)
+    d3.edge = d3.edge.clone()
+    d3.edge[5, 0] = d3.x.shape[0] - 1
+    assert _run_stack(yv, model, d3)[2] == 1
+    # (c) more edges than a tile holds
+    assert _run_stack(yv, model, _ragged(yv, 3, 10, lo=40, hi=40, edges_per_proposal=900))[2] == 1
+    # (d) and the ordinary batch keeps it down
+    assert _run_stack(yv, model, _ragged(yv, 40, 11, lo=3, hi=20))[2] == 0
+
+
+@pytest.mark.parametrize("blocks,blocks_out,P,seed,shape", [
+    (2, 2, 211, 1, dict(lo=2, hi=40, edge_factor=2.1)),
+    (4, 2, 1200, 2, dict(lo=25, hi=25, edges_per_proposal=150)),
+    (4, 2, 1100, 3, dict(lo=4, hi=40, edge_factor=1.2)),
+])
+def test_forward_with_the_local_conv_stack_matches_oracle_and_per_layer_path(blocks, blocks_out, P, seed, shape):
+    """the whole bf16 forward with the one-launch conv stack forced on (YOLAT_CONV_LOCAL=2) against the CPU oracle (same
+    bounds as the per-layer path) and against the per-layer path (YOLAT_CONV_LOCAL=0): two bf16 evaluations of the same
+    function, a fraction of the bf16 error budget apart; deterministic."""
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=blocks, n_blocks_out=blocks_out)
+    d = _ragged(yv, P, 200 + seed, **shape)
+    d.edge = torch.cat([d.edge, d.edge[:17]], 0)            # duplicate edges are defined by the PyG semantics
+    d.e_attr = torch.cat([d.e_attr, d.e_attr[:17]], 0)
+    model = _model(yv, optkw, 60 + seed)
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 60 + seed).eval()
+    with torch.no_grad():
+        want = ref(d, None)[0]
+        with _mode(2):
+            got = model(d, None)[0].clone()
+            again = model(d, None)[0].clone()
+        with _mode(0):
+            layers = model(d, None)[0].clone()
+    model._yolat_plan.check_status()
+    assert torch.equal(got, again)
+    depth = max(1.0, blocks / 4.0)
+    for name, t in (("local", got), ("per-layer", layers)):
+        mx, rms = _rel(t, want)
+        assert mx <= RTOL_BF16 * depth and rms <= RMS_BF16 * depth, "%s: max %.2e rms %.2e" % (name, mx, rms)
+    mx, rms = _rel(got, layers)
+    assert mx <= RTOL_BF16 * depth and rms <= RMS_BF16 * depth, "local vs per-layer: max %.2e rms %.2e" % (mx, rms)
+
+
+def test_forward_falls_back_to_the_per_layer_launches_bit_exactly():
+    """a batch without the property (a 100-node proposal; an edge between two proposals): the gated per-layer launches run
+    and the logits are bit-identical to the per-layer path's."""
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=3, n_blocks_out=2)
+    model = _model(yv, optkw, 5)
+    base = _ragged(yv, 1500, 21, lo=3, hi=30)
+    cases = []
+    d = _ragged(yv, 1500, 21, lo=3, hi=30)
+    d.edge = d.edge.clone()
+    d.edge[7, 0] = d.x.shape[0] - 2                          # an edge from the last proposal into the first
+    cases.append(("crossing edge", d))
+    d = _with_big_proposal(_ragged(yv, 1500, 22, lo=3, hi=30), 700, 100)
+    cases.append(("100-node proposal", d))
+    for name, d in cases:
+        with torch.no_grad():
+            with _mode(2):
+                got = model(d, None)[0].clone()
+            with _mode(0):
+                want = model(d, None)[0].clone()
+        assert torch.equal(got, want), name
+    # and on an ordinary batch the two paths are NOT the same arithmetic (the test above would be vacuous otherwise)
+    with torch.no_grad():
+        with _mode(2):
+            got = model(base, None)[0].clone()
+        with _mode(0):
+            want = model(base, None)[0].clone()
+    assert not torch.equal(got, want)
+    mx, rms = _rel(got, want)
+    assert mx <= RTOL_BF16 and rms <= RMS_BF16
+
+
+def test_cfg5_full_size_local_conv_stack_vs_fp32_path():
+    """configs[4] (N = 200 k / E = 1.2 M / P = 8000, n_blocks 4): the default bf16 forward takes the one-launch conv stack;
+    against the fp32 HIP forward (itself pinned to 1e-4 by the other tests), deterministic, and block-diagonal: the two
+    proposal halves run separately give the whole graph's logits up to the bf16 noise of a different tiling."""
+    yv = _yv()
+    data, slices, optkw, _ = yv.config("5")
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 9).cuda().eval()
+    with torch.no_grad():
+        want = model(data, slices)[0].clone()
+        model.set_eval_precision("bf16")
+        with _mode(1):
+            got = model(data, slices)[0].clone()
+            again = model(data, slices)[0].clone()
+        with _mode(0):
+            layers = model(data, slices)[0].clone()
+    assert torch.equal(got, again)
+    assert not torch.equal(got, layers)                      # the local path ran (different arithmetic)
+    mx, rms = _rel(got, want)
+    assert mx <= RTOL_BF16 and rms <= RMS_BF16, (mx, rms)
+    mx, rms = _rel(got, layers)
+    assert mx <= RTOL_BF16 and rms <= RMS_BF16, (mx, rms)

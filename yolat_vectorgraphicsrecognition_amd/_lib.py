@@ -51,7 +51,7 @@ class ModelEvalBf16(ctypes.Structure):
                 [(n, c_p * YOLAT_MAX_LAYERS) for n in ("Wuv", "Wr", "Wn", "W2", "uv_scale", "uv_shift")] +
                 [(n, c_p) for n in ("Wf", "Wfs", "Wc1", "Wc2", "Wc3")] +
                 [("t2f", c_p * YOLAT_MAX_LAYERS)] +
-                [(n, c_p) for n in ("Wf_fold", "Wfs_fold", "tf_fold", "tfs_fold")])
+                [(n, c_p) for n in ("Wf_fold", "Wfs_fold", "tf_fold", "tfs_fold", "conv_local")])
 
 
 class Span(ctypes.Structure):
@@ -238,6 +238,10 @@ SIGNATURES = {
     "yolat_forward_eval_bf16_workspace_bytes": (c_sz, [ctypes.POINTER(ModelEvalBf16), c_i64, c_i64, c_i64]),
     "yolat_forward_eval_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_conv_local_pack_bytes": (c_sz, [c_i64]),
+    "yolat_conv_local_pack": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_sz, c_p]),
+    "yolat_conv_stack_local_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_p, c_i64, ctypes.POINTER(GraphCsr), c_i64,
+                                             c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_forward_eval_bf16_primed": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
 }

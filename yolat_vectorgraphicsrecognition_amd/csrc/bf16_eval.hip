@@ -13,6 +13,7 @@
 // scale against the fp32 oracle (SURVEY.md §8c "bf16 variant"); the fp32 path keeps the 1e-4 bar.
 #include "common.hpp"
 #include <stdlib.h>
+#include <atomic>
 
 typedef unsigned short u16;
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -354,8 +355,9 @@ struct NodeUvH {
   Epilogue euv, er, en;
   int N, C, Cin;
 };
-static __global__ void __launch_bounds__(256) k_hgemm_node3(NodeUvH a) {
+static __global__ void __launch_bounds__(256) k_hgemm_node3(NodeUvH a, YlGate gate) {
   __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<1, 1>::elems];
+  if (yl_gate_dead(gate)) return;      // fall-back of the one-launch conv stack (conv_local.hip): dead launch
   const int x = blockIdx.x, y = blockIdx.y;
   if (y < 2) hgemm_tile<1, 1, HOp>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y, smem);
   else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
@@ -394,7 +396,8 @@ static __global__ void __launch_bounds__(256, (NG == 1 ? 4 : 3)) k_edge_uv_mlp2_
     const float* __restrict__ attr, const int* __restrict__ row_ptr, int N, int npt, const float* __restrict__ Wc4,
     const float* __restrict__ s1, const u16* __restrict__ W2h, const float* __restrict__ b2,
     const float* __restrict__ s2, const float* __restrict__ t2, const float* __restrict__ root, unsigned ld_r,
-    u16* __restrict__ f_out, unsigned ld_fo, int E) {
+    u16* __restrict__ f_out, unsigned ld_fo, int E, YlGate gate) {
+  if (yl_gate_dead(gate)) return;      // fall-back of the one-launch conv stack (conv_local.hip): dead launch
   constexpr int LDM = 68;
   __shared__ __attribute__((aligned(16))) u16 Hs[64 * YL_HRS];   // layer-1 activations of the pass (bf16)
   __shared__ __attribute__((aligned(16))) float Ms[64 * LDM];   // layer-2 messages of the pass (fp32)
@@ -521,7 +524,9 @@ static __global__ void __launch_bounds__(256, (NG == 1 ? 4 : 3)) k_edge_uv_mlp2_
 //   Z[p, 0:F] = 0;  Z[p, F:F+D] = max over rows of feats;  Z[p, 2F+D:2F+2D] = mean over rows of fsup   (fp32)
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) k_pool_prepare_h(const u16* feats, const u16* fsup, long ld, int D, int F,
-                                                               const int* seg_ptr, float* Z, long ldz) {
+                                                               const int* seg_ptr, float* Z, long ldz,
+                                                               YlGate gate) {
+  if (yl_gate_dead(gate)) return;      // fall-back of the one-launch conv stack (conv_local.hip): dead launch
   const int c = blockIdx.x * 256 + threadIdx.x;
   const int p = blockIdx.y;
   float* z = Z + (long)p * ldz;
@@ -564,7 +569,19 @@ static __global__ void __launch_bounds__(256) k_pool_prepare_h(const u16* feats,
 int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                        const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
                        const float* s1, const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
-                       uint16_t* f_out, int64_t ld_fo, hipStream_t st);
+                       uint16_t* f_out, int64_t ld_fo, hipStream_t st, YlGate gate);
+
+bool yl_conv_local_model_ok(const yolat_model_eval_bf16* mh);
+int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const float* x, int64_t ldx, const int32_t* row_ptr,
+                       const int32_t* src, const int32_t* dst, const float* attr, const int32_t* seg_ptr, int64_t N,
+                       int64_t E, int64_t P, uint16_t* feats, int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag,
+                       int32_t flag_val, hipStream_t st);
+// YOLAT_CONV_LOCAL: 0 = never, 1 = batches with >= 1024 proposals (default), 2 = every batch
+// (read per call: tests flip it in-process)
+static int yl_conv_local_mode() {
+  const char* e = getenv("YOLAT_CONV_LOCAL");
+  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+}
 
 int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wf, const float* tf,
                      const int32_t* seg, float* pool, int64_t ld_pool, int64_t F, const float* As, int64_t lda_s, int64_t P,
@@ -573,12 +590,12 @@ int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const
 static int yl_edge_uv_mlp2_mean_bf16_impl(const u16* UV, long ld_uv, const int* src, const int* dst, const float* attr,
                                           const int* row_ptr, long N, long E, const float* Wc4, const float* s1,
                                           const u16* W2f, const float* t2f, const float* root, long ld_r, u16* f_out,
-                                          long ld_fo, int variant, hipStream_t st) {
+                                          long ld_fo, int variant, hipStream_t st, YlGate gate = YlGate{nullptr, 0}) {
   // the chained kernel walks the EDGE list: it needs enough edges to fill 2048 waves and pays per finished node
   if (variant == 0) variant = (E >= 131072 && E >= 2 * N) ? 2 : 1;
   if (variant == 2) {
     if (E < 16) return YOLAT_E_UNSUPPORTED;
-    return yl_edge_chain_bf16(UV, ld_uv, src, dst, attr, row_ptr, N, E, Wc4, s1, W2f, t2f, root, ld_r, f_out, ld_fo, st);
+    return yl_edge_chain_bf16(UV, ld_uv, src, dst, attr, row_ptr, N, E, Wc4, s1, W2f, t2f, root, ld_r, f_out, ld_fo, st, gate);
   }
   long npt = E > 0 ? (56 * N) / E : 64;
   {
@@ -589,7 +606,7 @@ static int yl_edge_uv_mlp2_mean_bf16_impl(const u16* UV, long ld_uv, const int* 
   }
   hipLaunchKernelGGL((npt <= 16 ? k_edge_uv_mlp2_mean_h<1> : k_edge_uv_mlp2_mean_h<4>), dim3(yl_cdiv(N, npt)), dim3(256), 0,
                      st, UV, (unsigned)ld_uv, src, dst, attr, row_ptr, (int)N, (int)npt, Wc4, s1, W2f, (const float*)nullptr,
-                     (const float*)nullptr, t2f, root, (unsigned)ld_r, f_out, (unsigned)ld_fo, (int)(E > 0 ? E : 1));
+                     (const float*)nullptr, t2f, root, (unsigned)ld_r, f_out, (unsigned)ld_fo, (int)(E > 0 ? E : 1), gate);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -628,6 +645,7 @@ struct PlanH {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
   u16* UV; float* root; u16* f_tmp[YOLAT_MAX_LAYERS]; u16* s_tmp[YOLAT_MAX_LAYERS];
   u16* feats; u16* fsup; float* Z; float* c1; float* c2;
+  int* local_flag;
   size_t bytes;
 };
 PlanH carve_h(const yolat_model_eval* m, long N, long E, long P, void* ws) {
@@ -645,6 +663,7 @@ PlanH carve_h(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   }
   p.feats = c.take<u16>(N * D); p.fsup = c.take<u16>(N * D);
   p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
+  p.local_flag = c.take<int>(64);
   p.bytes = c.off + 256;
   return p;
 }
@@ -765,19 +784,38 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   auto s_slot = [&](int l) { return l - lo >= 0 ? p.fsup + (l - lo) * C : p.s_tmp[l]; };
   auto ld_slot = [&](int l) { return l - lo >= 0 ? D : C; };
 
+  // ---- the one-launch conv stack (conv_local.hip) applies to models of its shapes on batches large enough to fill the
+  // chip; whether THIS batch has the property (edges inside their proposal, proposals that fit a tile) is found out on the
+  // device: the per-layer launches below stay enqueued, gated on the word the conv kernel raises
+  const yolat_conv_eval& cv0 = m->conv[0];
+  NodeUv a0;
+  // the fp32 destinations are placeholders for the builder's checks; UV and the node branch go to bf16
+  YL_TRY(yl_build_node_uv(&a0, x, ldx, x, ldx, N, cv0.Cin, cv0.Wuv, nullptr, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C,
+                          p.root, 2 * C, p.root, C, p.root, C));
+  a0.euv.Y = nullptr; a0.euv.Yh = p.UV; a0.euv.ldy = 2 * C;
+  a0.euv.scale = mh->uv_scale[0]; a0.euv.shift = mh->uv_shift[0];
+  a0.en.Y = nullptr; a0.en.Yh = s_slot(0); a0.en.ldy = ld_slot(0);
+  const int local_mode = yl_conv_local_mode();
+  const bool local = local_mode != 0 && mh->conv_local != nullptr && yl_conv_local_model_ok(mh) &&
+                     yl_node3_smallk_shape_ok(a0) && D % 8 == 0 && ZW % 4 == 0 && (local_mode == 2 || P >= 1024);
+  YlGate gate{nullptr, 0};
+  if (local) {
+    static std::atomic<int> epoch_counter{0x10000};
+    int epoch = ++epoch_counter;
+    if (epoch == 0) epoch = ++epoch_counter;
+    gate.p = p.local_flag; gate.val = epoch;
+  }
+
   // ---- graph structure + node side of layer 0 (fp32 MFMA on the raw K = Cin0 features, bf16 / fp32 outputs)
   char nm[112];
   YL_HSTAGE("graph_prep[csr+attr+segments] + node_uv[layer 0, bf16 out]", 8.0 * N * m->conv[0].Cin * C,
             16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N + 4.0 * N * m->conv[0].Cin + 2.0 * N * 3 * C + 4.0 * N * C, {
-    const yolat_conv_eval& cv0 = m->conv[0];
-    NodeUv a;
-    // the fp32 destinations are placeholders for the builder's checks; UV and the node branch go to bf16
-    YL_TRY(yl_build_node_uv(&a, x, ldx, x, ldx, N, cv0.Cin, cv0.Wuv, nullptr, cv0.Wr, cv0.br, cv0.Wn, cv0.bn, cv0.sn, cv0.tn, C,
-                            p.root, 2 * C, p.root, C, p.root, C));
-    a.euv.Y = nullptr; a.euv.Yh = p.UV; a.euv.ldy = 2 * C;
-    a.euv.scale = mh->uv_scale[0]; a.euv.shift = mh->uv_shift[0];
-    a.en.Y = nullptr; a.en.Yh = s_slot(0); a.en.ldy = ld_slot(0);
-    if (g != nullptr && yl_node3_smallk_ok(a)) {
+    const NodeUv& a = a0;
+    if (local) {
+      if (g == nullptr)
+        YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
+                                     p.attr, p.seg_ptr, p.node_seg, p.work, status, nullptr, primed, stream));
+    } else if (g != nullptr && yl_node3_smallk_ok(a)) {
       YL_TRY(yl_node3_smallk(a, st));
     } else if (g != nullptr) {
       const dim3 grid(yl_cdiv(N, 64), 4);
@@ -789,10 +827,23 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
                                  p.attr, p.seg_ptr, p.node_seg, p.work, status, &a, primed, stream));
     }
   });
+  if (local) {
+    double fl = 0.0;
+    for (int l = 0; l < m->n_blocks; ++l) fl += 2.0 * E * (4.0 * C + C * C) + 8.0 * N * m->conv[l].Cin * C;
+    // bytes: what the stack has to move — x, ids, e_attr in; feats + the pooled rows out
+    YL_HSTAGE("conv_local_bf16[all conv layers + pooling prologue, one launch]", fl,
+              4.0 * N * cv0.Cin + 8.0 * E + 16.0 * E + 4.0 * N + 2.0 * N * D + 4.0 * P * (F + 2 * D), {
+      YL_TRY(yl_conv_local_bf16(mh, mh->conv_local, x, ldx, p.row_ptr, p.src, p.dst, p.attr, p.seg_ptr, N, E, P, p.feats, D,
+                                p.Z, ZW, p.local_flag, gate.val, st));
+    });
+    // the fall-back's layer-0 node side (dead unless the flag was raised)
+    YL_TRY(yl_node3_smallk(a0, st, gate));
+  }
   for (int l = 0; l < m->n_blocks; ++l) {
     const yolat_conv_eval& cv = m->conv[l];
     if (l > 0) {
-      snprintf(nm, sizeof nm, "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> %ld+%ld+%ld]", 2 * C, C, C);
+      snprintf(nm, sizeof nm, "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> %ld+%ld+%ld]%s", 2 * C, C, C,
+               local ? " (gated fall-back)" : "");
       YL_HSTAGE(nm, 8.0 * N * 64 * C, 2.0 * (2.0 * N * 64 + 3.0 * N * C) + 4.0 * N * C, {
       NodeUvH a;
       a.af = HOp{f_slot(l - 1), ld_slot(l - 1), (int)N};
@@ -804,25 +855,27 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
       a.en = plain_epilogue(); a.en.bias = cv.bn; a.en.scale = cv.sn; a.en.shift = cv.tn; a.en.relu = 1;
       a.en.Yh = s_slot(l); a.en.ldy = ld_slot(l);
       a.N = (int)N; a.C = (int)C; a.Cin = 64;
-      hipLaunchKernelGGL(k_hgemm_node3, dim3(yl_cdiv(N, 64), 4), dim3(256), 0, st, a);
+      hipLaunchKernelGGL(k_hgemm_node3, dim3(yl_cdiv(N, 64), 4), dim3(256), 0, st, a, gate);
       YL_LAUNCH_CHECK();
       });
     }
-    snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]", C, C);
+    snprintf(nm, sizeof nm, "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> %ld -> %ld -> mean]%s", C, C,
+             local ? " (gated fall-back)" : "");
     // bytes: SURVEY.md 8(d) B_agg(l) of the UNFACTORISED layer at 2 bytes per feature element,
     // E ((2 Cin + 4) s + 2 * 4) + N C s — the credit figure; what the kernel has to move is priced in bench.py
     YL_HSTAGE(nm, 2.0 * E * (4.0 * C + C * C), E * ((2.0 * cv.Cin + 4.0) * 2.0 + 8.0) + 2.0 * N * C, {
       YL_TRY(yl_edge_uv_mlp2_mean_bf16_impl(p.UV, 2 * C, p.src, p.dst, p.attr, p.row_ptr, N, E, cv.Wc4, cv.s1, mh->W2[l],
-                                            mh->t2f[l], p.root, C, f_slot(l), ld_slot(l), 0, st));
+                                            mh->t2f[l], p.root, C, f_slot(l), ld_slot(l), 0, st, gate));
     });
   }
 
   // ---- pooling prologue, fusion block (+ per-proposal max) | fusion_block_super, classifier
-  YL_HSTAGE("pool_prepare_bf16[max(feats), mean(fsup), zero]", 2.0 * N * D, 4.0 * N * D + 4.0 * P * (F + 2 * D), {
+  YL_HSTAGE(local ? "pool_prepare_bf16[max(feats), mean(fsup), zero] (gated fall-back)"
+                  : "pool_prepare_bf16[max(feats), mean(fsup), zero]", 2.0 * N * D, 4.0 * N * D + 4.0 * P * (F + 2 * D), {
   for (int64_t p0 = 0; p0 < P; p0 += 65535) {
     const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
     hipLaunchKernelGGL(k_pool_prepare_h, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)np), dim3(256), 0, st, p.feats, p.fsup, D,
-                       (int)D, (int)F, p.seg_ptr + p0, p.Z + p0 * ZW, ZW);
+                       (int)D, (int)F, p.seg_ptr + p0, p.Z + p0 * ZW, ZW, gate);
     YL_LAUNCH_CHECK();
   }
   });

@@ -37,6 +37,11 @@ static inline bool yl_strict_fp32() {
   return v != 0;
 }
 
+// A launch that is the fall-back of another one (conv_local.hip's one-launch conv stack): it runs only when the word at p
+// holds val — the epoch the forward raised the flag with — and is a dead launch otherwise.  p == nullptr: always runs.
+struct YlGate { const int* p; int val; };
+__device__ __forceinline__ bool yl_gate_dead(const YlGate& g) { return g.p != nullptr && *g.p != g.val; }
+
 __device__ __forceinline__ int yl_min(int a, int b) { return a < b ? a : b; }
 __device__ __forceinline__ int yl_max(int a, int b) { return a > b ? a : b; }
 // a*b rounded on its own: the empty asm keeps the compiler from contracting it with a following add into an
@@ -833,7 +838,7 @@ __device__ __forceinline__ void node3_smallk_body(const NodeUv& a, int vb) {
 // the node side of the first conv layer (K = in_channels <= 8) of a large graph as an output stream (dense.hip)
 bool yl_node3_smallk_ok(const NodeUv& a);
 bool yl_node3_smallk_shape_ok(const NodeUv& a);
-int yl_node3_smallk(const NodeUv& a, hipStream_t st);
+int yl_node3_smallk(const NodeUv& a, hipStream_t st, YlGate gate = YlGate{nullptr, 0});
 // training-mode fusion GEMM with the key64 pooling epilogue on the bf16x6 rows kernel (fusion_x6.hip)
 int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const float* W, const float* bias, long F,
                             const float* sgn, const int* node_seg, unsigned long long* keys, uint16_t* wsplit,

@@ -319,6 +319,11 @@ namespace {
 __global__ void __launch_bounds__(256) k_node3_smallk(NodeUv a) {
   node3_smallk_body(a, blockIdx.x);
 }
+// the same launch as the fall-back of the one-launch conv stack (conv_local.hip): dead unless *gate != 0
+__global__ void __launch_bounds__(256) k_node3_smallk_gated(NodeUv a, YlGate gate) {
+  if (yl_gate_dead(gate)) return;
+  node3_smallk_body(a, blockIdx.x);
+}
 bool n3_epi_ok(const Epilogue& e) {
   if (e.accumulate || e.stats || e.seg || e.pool || e.key64 || e.agg) return false;
   if ((e.scale == nullptr) != (e.shift == nullptr)) return false;
@@ -335,8 +340,9 @@ bool yl_node3_smallk_shape_ok(const NodeUv& a) {       // what node3_smallk_body
 bool yl_node3_smallk_ok(const NodeUv& a) {             // ... and where it beats the 64 x 64 MFMA tiles as a launch of its own
   return a.N >= 32768 && yl_node3_smallk_shape_ok(a);
 }
-int yl_node3_smallk(const NodeUv& a, hipStream_t st) {
-  hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);
+int yl_node3_smallk(const NodeUv& a, hipStream_t st, YlGate gate) {
+  if (gate.p) hipLaunchKernelGGL(k_node3_smallk_gated, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a, gate);
+  else hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);
   YL_LAUNCH_CHECK();
   return 0;
 }

@@ -102,7 +102,8 @@ __global__ void __launch_bounds__(256, 3) k_edge_chain_h(
     const float* __restrict__ attr, const int* __restrict__ row_ptr, int N, int E, int chunk,
     const float* __restrict__ Wc4, const float* __restrict__ s1, const u16* __restrict__ W2f,
     const float* __restrict__ t2f, const float* __restrict__ root, unsigned ld_r, u16* __restrict__ f_out,
-    unsigned ld_fo) {
+    unsigned ld_fo, YlGate gate) {
+  if (yl_gate_dead(gate)) return;      // fall-back of the one-launch conv stack (conv_local.hip): dead launch
   __shared__ __attribute__((aligned(16))) float stage_s[4][32 * 64];
   __shared__ __attribute__((aligned(8))) int2 slot_s[4][32];          // (node, bits of 1/deg) of the step's finished nodes
   __shared__ __attribute__((aligned(16))) ec_u32x4 w2_s[8][64];       // W2's 8 B fragments (nb, k-step) x lane
@@ -400,7 +401,7 @@ __global__ void __launch_bounds__(256, 3) k_edge_chain_h(
 int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr, const int32_t* dst_csr,
                        const float* attr_csr, const int32_t* row_ptr, int64_t N, int64_t E, const float* Wc4,
                        const float* s1, const uint16_t* W2f, const float* t2f, const float* root, int64_t ld_r,
-                       uint16_t* f_out, int64_t ld_fo, hipStream_t st) {
+                       uint16_t* f_out, int64_t ld_fo, hipStream_t st, YlGate gate) {
   const long wgs = 768;        // measured: 256 / 512 / 768 / 1024 workgroups 63 / 52 / 49 / 62 us at cfg 5
   const long streams = 8 * wgs;
   long chunk = ((E + streams - 1) / streams + 15) / 16 * 16;
@@ -411,7 +412,7 @@ int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr
 #define EC_LAUNCH(A)                                                                                                    \
   hipLaunchKernelGGL(k_edge_chain_h<A>, dim3((unsigned)grid), dim3(256), 0, st, UV, (unsigned)ld_uv, src_csr, dst_csr,    \
                      attr_csr, row_ptr, (int)N, (int)E, (int)chunk, Wc4, s1, W2f, t2f, root, (unsigned)ld_r, f_out,       \
-                     (unsigned)ld_fo)
+                     (unsigned)ld_fo, gate)
   EC_LAUNCH(0);       // (template argument: the phase-ablation variants behind profiles/r03_edge_chain_bf16_ablation.txt)
 #undef EC_LAUNCH
   YL_LAUNCH_CHECK();

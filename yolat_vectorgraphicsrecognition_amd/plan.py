@@ -17,6 +17,10 @@ from ._lib import lib, check, ModelEval, ModelEvalBf16, YOLAT_MAX_LAYERS
 # (tests/test_gpu_model.py runs both)
 PRIMED_WS = True
 
+# bf16 plan: all conv layers + the pooling prologue in ONE launch for proposal-local batches (csrc/conv_local.hip; the
+# per-layer launches stay enqueued as its gated fall-back).  False: the per-layer launches only.
+CONV_LOCAL = True
+
 
 def _x6_on(default=True):
     """A bf16x6-emulated stage of the fp32 plan: off as a whole under YOLAT_STRICT_FP32=1 (csrc/x6.hpp: strict IEEE
@@ -252,6 +256,17 @@ class EvalPlan(object):
                 setattr(h, wname, half((lin.weight.detach() * sc[:, None]).contiguous()))
                 setattr(h, tname, tfold.data_ptr())
             h.Wc1, h.Wc2, h.Wc3 = half(m1[0].weight), half(m2[0].weight), half(m3[0].weight)
+            # the conv stack's weights in the fragment order of the one-launch proposal-local kernel (csrc/conv_local.hip);
+            # models outside its shapes (C != 64, in_channels > 8) keep the per-layer launches
+            if CONV_LOCAL:
+                nbytes = int(lib.yolat_conv_local_pack_bytes(d.n_blocks))
+                pack = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+                rc = lib.yolat_conv_local_pack(ctypes.byref(h), pack.data_ptr(), nbytes, ops._stream())
+                if rc == 0:
+                    keep.append(pack)
+                    h.conv_local = pack.data_ptr()
+                elif rc != -2:        # YOLAT_E_UNSUPPORTED: shapes the kernel is not written for
+                    check(rc, "yolat_conv_local_pack")
             self._desc_h = h
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
