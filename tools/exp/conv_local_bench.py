@@ -87,3 +87,37 @@ for g0, abl in [(g, ab) for g in ([os.environ.get("YOLAT_CONV_LOCAL_G0", "")] if
     print("conv_local standalone N=%d E=%d P=%d L=%d G0=%s abl=%s: %.1f us  flag %d  compulsory %.0f MB -> %.2f TB/s  finite %s"
           % (N, g.E, P, base.n_blocks, g0 or "auto", abl, t, int(flag.item()), by / 1e6, by / t / 1e6,
              bool(torch.isfinite(feats.float()).all())))
+
+# ---- in-kernel phase stamps (s_memtime, shader cycles) of the first tiles of every workgroup
+if os.environ.get("CL_STAMPS", "1") == "1":
+    import numpy as np
+    os.environ["YOLAT_CONV_LOCAL_ABL"] = "0"
+    os.environ.pop("YOLAT_CONV_LOCAL_G0", None)
+    nwg = 4096
+    stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
+    hook = lib.yolat_conv_local_debug_stamps
+    hook.restype = None
+    hook.argtypes = [ctypes.c_void_p]
+    hook(stamps.data_ptr())
+    run()
+    torch.cuda.synchronize()
+    hook(None)
+    st_ = stamps.cpu().numpy().reshape(nwg, 64)
+    used = st_[:, 0] != 0
+    st_ = st_[used]
+    L = base.n_blocks
+    per_tile = 3 + 5 * L
+    names = ["tile load", "stream set-up"]
+    for l in range(L):
+        names += ["L%d node phase" % l, "L%d node barrier" % l, "L%d mean-pool + steps" % l, "L%d finalize+barrier" % l, "L%d outputs" % l]
+    for tile in range(2):
+        seg = st_[:, tile * per_tile:(tile + 1) * per_tile + 1].astype(np.float64)
+        ok = (seg != 0).all(1)
+        seg = seg[ok]
+        d = np.diff(seg, axis=1)
+        print("tile %d: %d workgroups, total %.0f cycles (to next tile start)" % (tile, len(seg), (seg[:, -1] - seg[:, 0]).mean()))
+        for i, nme in enumerate(names + ["zero Z + barrier"]):
+            if i < d.shape[1]:
+                print("   %-24s mean %7.0f  p10 %7.0f  p90 %7.0f" % (nme, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+    print("workgroup start spread: %.0f cycles; end-to-end (first start .. last stamp) %.0f cycles" %
+          (st_[:, 0].max() - st_[:, 0].min(), st_.max() - st_[:, 0].min()))

@@ -44,15 +44,14 @@ typedef __bf16 cl_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short cl_s16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
+long long* g_cl_stamps = nullptr;
 
-constexpr int CL_T = 64;                 // nodes per tile
-constexpr int CL_ET = 640;               // edges per tile
 constexpr int CL_UVB = 272;              // UV tile row stride, bytes (128 bf16 + 16 B pad)
 constexpr int CL_RB = 272;               // R tile row stride, bytes (64 fp32 + 16 B pad)
 constexpr int CL_FB = 144;               // f / s tile row stride, bytes (64 bf16 + 16 B pad)
 constexpr int CL_GMAX = 64;              // proposals per workgroup (group arrays in LDS)
 constexpr int CL_EDGE_BYTES = 12 * 1024; // packed image, per layer: W2F[8] WCA[2] TB[2] fragments
-constexpr int CL_NODE_BYTES = 32 * 1024; //   node weights: 4 groups x (2 x 4) fragments (layer 0: W0 [256][8] fp32)
+constexpr int CL_NODE_BYTES = 32 * 1024; //   node weights: 4 groups x (2 x 4) fragments (layer 0: (W_hi | W_hi), (W_lo | 0), 0, 0)
 constexpr int CL_SHIFT_BYTES = 1024;     //   shift [256] fp32
 constexpr int CL_LAYER_BYTES = CL_EDGE_BYTES + CL_NODE_BYTES + CL_SHIFT_BYTES;
 
@@ -71,6 +70,10 @@ __device__ __forceinline__ unsigned cl_relu_pk(unsigned p) {
 __device__ __forceinline__ f32x16 cl_mfma(const cl_bf16x8& a, const cl_bf16x8& b, const f32x16& c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
+// workgroup barrier that waits for this wave's LDS traffic only: global loads (the weight-fragment prefetches) and stores
+// (feats, Z) stay in flight across it — nothing inside the kernel consumes another wave's global stores
+__device__ __forceinline__ void cl_lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__device__ __forceinline__ int cl_opaque(int v) { asm volatile("" : "+v"(v)); return v; }
 // bits pos, pos + 1 of mask -> packed bf16 pair of 1.0 / 0.0
 __device__ __forceinline__ unsigned cl_sel2(unsigned mask, int pos) {
   const unsigned t = (mask >> pos) & 3u;
@@ -87,111 +90,190 @@ struct ClArgs {
   float* Z; int ldz; int F, D;
   int* flag; int flag_val;
   int abl;
+  long long* stamps;     // debug: per-workgroup phase time stamps (tools/exp/conv_local_bench.py)
 };
 
-__global__ void __launch_bounds__(256, 2) k_conv_local_h(const ClArgs a) {
-  __shared__ __attribute__((aligned(16))) unsigned char uv_s[CL_T * CL_UVB];
-  __shared__ __attribute__((aligned(16))) unsigned char r_s[CL_T * CL_RB];
-  __shared__ __attribute__((aligned(16))) unsigned char f_s[CL_T * CL_FB];      // also: the x tile [64][8] fp32
-  __shared__ __attribute__((aligned(16))) unsigned char s_s[CL_T * CL_FB];
-  __shared__ __attribute__((aligned(16))) cl_u32x4 ab_s[CL_ET];
-  __shared__ unsigned idx_s[CL_ET];
-  __shared__ int rp_s[CL_T + 4];
-  __shared__ int gseg_s[CL_GMAX + 1], grow_s[CL_GMAX + 1];
+// quad reductions through DPP (lanes 4q .. 4q + 3 hold the four row parts of one item)
+__device__ __forceinline__ float cl_quad_xor1(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0xB1, 0xF, 0xF, true));
+}
+__device__ __forceinline__ float cl_quad_xor2(float v) {
+  return __int_as_float(__builtin_amdgcn_mov_dpp(__float_as_int(v), 0x4E, 0xF, 0xF, true));
+}
 
-  const int tid = threadIdx.x, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+// NW waves per workgroup: tiles of T = 16 NW nodes / ET = 128 NW edges.  NW = 4: 256 threads, 77 KB of LDS, two workgroups
+// per CU; NW = 8: 512 threads, 141 KB, one per CU (two waves per SIMD either way).
+template <int NW>
+__global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
+  constexpr int T = 16 * NW, ET = 128 * NW, NT = 64 * NW, NS = 2 * NW;
+  constexpr int NE = (768 + NT - 1) / NT;          // 16-byte pieces of the edge fragments per thread
+  __shared__ __attribute__((aligned(16))) unsigned char uv_s[T * CL_UVB];
+  __shared__ __attribute__((aligned(16))) unsigned char r_s[T * CL_RB];
+  __shared__ __attribute__((aligned(16))) unsigned char f_s[T * CL_FB];      // also: the x tile [T][8] fp32
+  __shared__ __attribute__((aligned(16))) unsigned char s_s[T * CL_FB];
+  __shared__ __attribute__((aligned(16))) cl_u32x4 ab_s[ET];
+  __shared__ unsigned idx_s[ET];
+  __shared__ int rp_s[T + 4];
+  __shared__ int gseg_s[CL_GMAX + 1], grow_s[CL_GMAX + 1];
+  __shared__ __attribute__((aligned(16))) float shift_s[256];                  // the coming node phase's shifts
+  __shared__ __attribute__((aligned(16))) cl_u32x4 ef_s[12 * 64];              // the layer's edge-phase fragments
+
+  const int tid0 = threadIdx.x;
+  const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
+  const int grp = wv & 3, rbp = wv >> 2;           // node phase: output group, 64-row half of the tile
   const int p_lo = blockIdx.x * a.G0;
   const int np = yl_min(a.G0, a.P - p_lo);
   if (np <= 0) return;
-  for (int i = tid; i <= np; i += 256) {
+  for (int i = tid0; i <= np; i += NT) {
     const int s = a.seg_ptr[p_lo + i];
     gseg_s[i] = s;
     grow_s[i] = a.row_ptr[yl_min(yl_max(s, 0), a.N)];
   }
+  if (tid0 < 256) shift_s[tid0] = reinterpret_cast<const float*>(a.pack + CL_EDGE_BYTES + CL_NODE_BYTES)[tid0];
+  // node-phase weight fragments of this wave's output group, one phase ahead.  Layer 0 uses [.][0..1] only: while no
+  // fragments are in flight (last layer -> next tile) the other four hold the NEXT tile's raw loads (pre0..3 below)
+  cl_u32x4 af[2][4];
+  cl_u32x4 est[NE];         // this thread's 16-byte pieces of the coming layer's edge-phase fragments
+#pragma unroll
+  for (int i = 0; i < NE; ++i) est[i] = reinterpret_cast<const cl_u32x4*>(a.pack)[yl_min(tid0 + NT * i, 767)];
   __syncthreads();
 
   // identity fragments of the transposed first layer: A[m][k] = 1 iff k == m - 16 j  (edge_chain.hip)
   cl_bf16x8 Id[2];
+  {
+    const int lane = tid0 & 63, l31 = lane & 31, lhi = lane >> 5;
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const bool mine = ((l31 >> 4) == j) && (((l31 >> 3) & 1) == lhi);
-    const int i = l31 & 7;
-    unsigned d[4];
+    for (int j = 0; j < 2; ++j) {
+      const bool mine = ((l31 >> 4) == j) && (((l31 >> 3) & 1) == lhi);
+      const int i = l31 & 7;
+      unsigned d[4];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) d[k] = (mine && (i >> 1) == k) ? (0x3F80u << (16 * (i & 1))) : 0u;
-    Id[j] = cl_frag(d[0], d[1], d[2], d[3]);
-  }
-  const cl_bf16x8 OnesA = lhi ? cl_frag(0u, 0u, 0u, 0u) : cl_frag(0x3F803F80u, 0x00003F80u, 0u, 0u);
-
-  int p0 = 0;
-  while (p0 < np) {
-    // ---- greedy tile: proposals [p0, p1) with <= CL_T nodes and <= CL_ET edges
-    int p1 = p0;
-    const int sg0 = gseg_s[p0], rg0 = grow_s[p0];
-    while (p1 < np && gseg_s[p1 + 1] - sg0 <= CL_T && grow_s[p1 + 1] - rg0 <= CL_ET && gseg_s[p1 + 1] >= gseg_s[p1]) ++p1;
-    if (p1 == p0) {                    // a proposal that does not fit (or an unsorted segment table): the gated path runs
-      if (tid == 0) *a.flag = a.flag_val;
-      ++p0;
-      continue;
+      for (int k = 0; k < 4; ++k) d[k] = (mine && (i >> 1) == k) ? (0x3F80u << (16 * (i & 1))) : 0u;
+      Id[j] = cl_frag(d[0], d[1], d[2], d[3]);
     }
-    const int n0 = sg0, nt = gseg_s[p1] - sg0, e0 = rg0, et = grow_s[p1] - rg0;
+  }
+  const cl_bf16x8 OnesA = (tid0 & 32) ? cl_frag(0u, 0u, 0u, 0u) : cl_frag(0x3F803F80u, 0x00003F80u, 0u, 0u);
+
+  int stamp_k = 0;
+#define CL_STAMP() do { if (a.stamps != nullptr && tid0 == 0 && stamp_k < 64) a.stamps[blockIdx.x * 64 + stamp_k++] = clock64(); } while (0)
+
+  // greedy tile: the first proposals [q0, q1) from `from` on with <= T nodes and <= ET edges; a proposal that does not
+  // fit (or an unsorted segment table) raises the flag (the gated per-layer path then runs) and is skipped
+  auto next_tile = [&](int from, int& q0, int& q1) {
+    q0 = from;
+    q1 = from;
+    while (q0 < np) {
+      const int sg = gseg_s[q0], rg = grow_s[q0];
+      q1 = q0;
+      while (q1 < np && gseg_s[q1 + 1] - sg <= T && grow_s[q1 + 1] - rg <= ET && gseg_s[q1 + 1] >= gseg_s[q1]) ++q1;
+      if (q1 > q0) return;
+      if (tid0 == 0) *a.flag = a.flag_val;
+      ++q0;
+    }
+  };
+  // the raw loads of a tile: row_ptr | x (2 floats) | dst (2) | src (2) | e_attr (2 x 4)  — 15 registers
+  auto issue_tile_loads = [&](int q0, int q1, cl_u32x4& r0, cl_u32x4& r1, cl_u32x4& r2, cl_u32x4& r3) {
+    const int tid = cl_opaque(tid0);
+    const int n0 = gseg_s[q0], nt = gseg_s[q1] - n0, e0 = grow_s[q0], et = grow_s[q1] - e0;
+    r0.x = (unsigned)a.row_ptr[n0 + yl_min(tid, nt)];
+    unsigned xv[2], dv[2], sv[2];
+    cl_u32x4 av[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      const int i = tid + NT * t, n = i >> 3, k = i & 7;
+      xv[t] = __float_as_uint(a.x[(long)yl_min(n0 + n, a.N - 1) * a.ldx + yl_min(k, a.cin0 - 1)]);
+      const int ec = yl_min(e0 + yl_min(i, et > 0 ? et - 1 : 0), a.E > 0 ? a.E - 1 : 0);
+      dv[t] = (unsigned)a.dst[ec];
+      sv[t] = (unsigned)a.src[ec];
+      av[t] = *reinterpret_cast<const cl_u32x4*>(a.attr + 4l * ec);
+    }
+    r0.y = xv[0]; r0.z = xv[1]; r0.w = dv[0];
+    r1.x = dv[1]; r1.y = sv[0]; r1.z = sv[1]; r1.w = 0u;
+    r2 = av[0]; r3 = av[1];
+  };
+
+  int p0, p1;
+  next_tile(0, p0, p1);
+  cl_u32x4& pre0 = af[0][2];
+  cl_u32x4& pre1 = af[0][3];
+  cl_u32x4& pre2 = af[1][2];
+  cl_u32x4& pre3 = af[1][3];
+  if (p0 < np && a.E > 0) issue_tile_loads(p0, p1, pre0, pre1, pre2, pre3);
+  while (p0 < np) {
+    CL_STAMP();      // 0: tile start
+    // (lane ids re-derived from an opaque copy per section: keeps the compiler from hoisting every lane-derived address
+    // out of the tile loop and spilling it — a scratch reload waits on vmcnt, i.e. on every global load / store in flight)
+    const int tid = cl_opaque(tid0), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+    const int n0 = gseg_s[p0], nt = gseg_s[p1] - n0, e0 = grow_s[p0], et = grow_s[p1] - e0;
     const int npr = p1 - p0;
+    int pn0, pn1;                      // the next tile (its loads are issued during this tile's last layer)
+    next_tile(p1, pn0, pn1);
 
     // ---- tile -> LDS: row_ptr (tile-local), x rows, packed edge ids, e_attr fragments
-    if (tid <= nt) rp_s[tid] = a.row_ptr[n0 + tid] - e0;
-    {
+    if (a.E == 0) {                    // (no edge arrays to read from)
+      if (tid <= nt) rp_s[tid] = 0;
       float* xs = reinterpret_cast<float*>(f_s);
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const int i = tid + 256 * t, n = i >> 3, k = i & 7;
+        const int i = tid + NT * t, n = i >> 3, k = i & 7;
         const float v = a.x[(long)yl_min(n0 + n, a.N - 1) * a.ldx + yl_min(k, a.cin0 - 1)];
         xs[i] = (n < nt && k < a.cin0) ? v : 0.f;
       }
-    }
-    {
+    } else {
+      if (tid <= nt) rp_s[tid] = (int)pre0.x - e0;
+      float* xs = reinterpret_cast<float*>(f_s);
+      const unsigned xv[2] = {pre0.y, pre0.z}, dv[2] = {pre0.w, pre1.x}, sv[2] = {pre1.y, pre1.z};
       bool bad = false;
 #pragma unroll
-      for (int t = 0; t < (CL_ET + 255) / 256; ++t) {
-        const int e = tid + 256 * t;
-        const int ec = yl_min(e0 + yl_min(e, et > 0 ? et - 1 : 0), a.E > 0 ? a.E - 1 : 0);
-        const int d = a.dst[ec] - n0, s = a.src[ec] - n0;
-        const float4 q = *reinterpret_cast<const float4*>(a.attr + 4l * ec);
-        if (e < et) {
-          const bool ok = (unsigned)s < (unsigned)nt && (unsigned)d < (unsigned)nt;
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + NT * t, n = i >> 3, k = i & 7;
+        xs[i] = (n < nt && k < a.cin0) ? __uint_as_float(xv[t]) : 0.f;
+        const int d = (int)dv[t] - n0, sr = (int)sv[t] - n0;
+        const cl_u32x4 qa = t ? pre3 : pre2;
+        const float4 q = __builtin_bit_cast(float4, qa);
+        if (i < et) {
+          const bool ok = (unsigned)sr < (unsigned)nt && (unsigned)d < (unsigned)nt;
           bad |= !ok;
-          idx_s[e] = ok ? ((unsigned)d | ((unsigned)s << 8)) : 0u;
+          idx_s[i] = ok ? ((unsigned)d | ((unsigned)sr << 8)) : 0u;
           const unsigned h01 = yl_pack_bf16(q.x, q.y), h23 = yl_pack_bf16(q.z, q.w);
           const unsigned l01 = yl_pack_bf16(q.x - yl_bf16_lo(h01), q.y - yl_bf16_hi(h01));
           const unsigned l23 = yl_pack_bf16(q.z - yl_bf16_lo(h23), q.w - yl_bf16_hi(h23));
           const cl_u32x4 fr = {h01, h23, l01, l23};
-          ab_s[e] = fr;
+          ab_s[i] = fr;
         }
       }
       if (bad) *a.flag = a.flag_val;
     }
-    __syncthreads();
+    {   // layer 0's node-phase fragments (two k-steps): in flight under the barrier and the stream set-up
+      const cl_u32x4* ap = reinterpret_cast<const cl_u32x4*>(a.pack + CL_EDGE_BYTES) + (grp * 8) * 64 + lane;
+#pragma unroll
+      for (int nt_ = 0; nt_ < 2; ++nt_)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) af[nt_][ks] = ap[(nt_ * 4 + ks) * 64];
+    }
+    CL_STAMP();      // 1: tile loads landed + LDS written
+    cl_lds_barrier();
 
-    // ---- the wave's two edge streams: node boundaries nb[0..8] (edge-balanced, node-aligned, <= 16 nodes each)
+    // ---- the wave's two edge streams: node boundaries nb[0..NS] (edge-balanced, node-aligned, <= 16 nodes each)
     int ns[3], sb[3];
     {
       int cand = 0;
       {
-        const int k = lane < 8 ? lane : 8;
+        const int k = lane < NS ? lane : NS;
         if (et > 0) {
-          const int tgt = (et * k) >> 3;
+          const int tgt = (et * k) / NS;
           const int d = (int)(idx_s[yl_min(tgt, et - 1)] & 0xFFu);
-          cand = (k >= 8) ? nt : ((rp_s[d] == tgt) ? d : d + 1);
+          cand = (k >= NS) ? nt : ((rp_s[d] == tgt) ? d : d + 1);
         } else {
-          cand = (nt * k) >> 3;
+          cand = (nt * k) / NS;
         }
       }
       int nb = 0;
       ns[0] = ns[1] = ns[2] = 0;
 #pragma unroll
-      for (int k = 1; k <= 8; ++k) {
+      for (int k = 1; k <= NS; ++k) {
         const int c = __builtin_amdgcn_readlane(cand, k);
-        const int lob = yl_max(nb, nt - 16 * (8 - k)), hib = yl_min(nb + 16, nt);
+        const int lob = yl_max(nb, nt - 16 * (NS - k)), hib = yl_min(nb + 16, nt);
         nb = yl_min(yl_max(c, lob), hib);
         if (k == 2 * wv) ns[0] = nb;
         if (k == 2 * wv + 1) ns[1] = nb;
@@ -212,75 +294,79 @@ __global__ void __launch_bounds__(256, 2) k_conv_local_h(const ClArgs a) {
     const int g_base = sb[gs] + gr, g_last = yl_max(sb[gs + 1] - 1, 0);
     const int k_base = sb[lhi], k_len = lhi ? len1 : len0;     // the stream my aggregation k-slots belong to
 
+    CL_STAMP();      // 2: stream set-up done
     for (int l = 0; l < a.L; ++l) {
-      const unsigned char* pk = a.pack + (long)l * CL_LAYER_BYTES;
-      const float* shift = reinterpret_cast<const float*>(pk + CL_EDGE_BYTES + CL_NODE_BYTES);
+      const int tid = cl_opaque(tid0), lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+      const float* shift = shift_s;
+      // the edge phase's weight fragments (12 KB, one copy per workgroup in LDS; loaded a phase ahead) and the next node
+      // phase's shifts
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        if (NT * (i + 1) <= 768 || tid + NT * i < 768) ef_s[tid + NT * i] = est[i];   // (the previous layer's reads are behind a barrier)
+      const int l_nx = (l + 1 < a.L) ? l + 1 : 0;
+      const float sh_nx = reinterpret_cast<const float*>(a.pack + (long)l_nx * CL_LAYER_BYTES + CL_EDGE_BYTES + CL_NODE_BYTES)[tid & 255];
       // =========================== node phase ===========================
-      if (l == 0 && (a.abl & 4)) {
-      } else if (l > 0 && (a.abl & 2)) {
-      } else if (l == 0) {
-        // K = in_channels raw features: thread = column pair (2 cp, 2 cp + 1) of [U | V | R | S], half of the rows
-        const int cp = tid & 127, rh = tid >> 7;
-        const float* w = reinterpret_cast<const float*>(pk + CL_EDGE_BYTES) + 16 * cp;
-        const float4 w00 = *reinterpret_cast<const float4*>(w), w01 = *reinterpret_cast<const float4*>(w + 4);
-        const float4 w10 = *reinterpret_cast<const float4*>(w + 8), w11 = *reinterpret_cast<const float4*>(w + 12);
-        const float2 sh = *reinterpret_cast<const float2*>(shift + 2 * cp);
-        const float* xs = reinterpret_cast<const float*>(f_s);
-#pragma unroll 4
-        for (int i = 0; i < 32; ++i) {
-          const int n = 32 * rh + i;
-          const float4 x0 = *reinterpret_cast<const float4*>(xs + 8 * n), x1 = *reinterpret_cast<const float4*>(xs + 8 * n + 4);
-          float v0 = sh.x, v1 = sh.y;
-          v0 = fmaf(w00.x, x0.x, v0); v0 = fmaf(w00.y, x0.y, v0); v0 = fmaf(w00.z, x0.z, v0); v0 = fmaf(w00.w, x0.w, v0);
-          v0 = fmaf(w01.x, x1.x, v0); v0 = fmaf(w01.y, x1.y, v0); v0 = fmaf(w01.z, x1.z, v0); v0 = fmaf(w01.w, x1.w, v0);
-          v1 = fmaf(w10.x, x0.x, v1); v1 = fmaf(w10.y, x0.y, v1); v1 = fmaf(w10.z, x0.z, v1); v1 = fmaf(w10.w, x0.w, v1);
-          v1 = fmaf(w11.x, x1.x, v1); v1 = fmaf(w11.y, x1.y, v1); v1 = fmaf(w11.z, x1.z, v1); v1 = fmaf(w11.w, x1.w, v1);
-          if (cp < 64) {
-            *reinterpret_cast<unsigned*>(uv_s + n * CL_UVB + 4 * cp) = yl_pack_bf16(v0, v1);
-          } else if (cp < 96) {
-            *reinterpret_cast<float2*>(r_s + n * CL_RB + 8 * (cp - 64)) = make_float2(v0, v1);
-          } else {
-            *reinterpret_cast<unsigned*>(s_s + n * CL_FB + 4 * (cp - 96)) = yl_pack_bf16(fmaxf(v0, 0.f), fmaxf(v1, 0.f));
-          }
-        }
-      } else {
-        // outputs of layer l - 1 that leave the chip: waves 0-2 copy f rows / take the per-proposal max, wave 3 the mean of s
-        // (done below, after this layer's operands are in registers)
-        const unsigned char* bsrc = (wv == 3) ? s_s : f_s;
+      // wave (grp, rbp) computes OUT^T[64 grp .. + 63][64 rbp .. + 63] = W'_grp . in^T (+ shift): U | V | root | node branch.
+      // Layer 0: the raw features as bf16 (hi | lo) halves of ONE k-step against (W_hi | W_hi) and (W_lo | 0): three of the
+      // four cross terms, 2^-16 relative.  Other layers: four k-steps on the f (node branch: s) tile.
+      if (!((l == 0 && (a.abl & 4)) || (l > 0 && (a.abl & 2)))) {
         cl_u32x4 bf[2][4];
+        if (l == 0) {
+          const float* xs = reinterpret_cast<const float*>(f_s);
 #pragma unroll
-        for (int rb = 0; rb < 2; ++rb)
+          for (int rb = 0; rb < 2; ++rb) {
+            const int n = 64 * rbp + 32 * rb + l31;
+            const float4 x0 = *reinterpret_cast<const float4*>(xs + 8 * n);
+            const float4 x1 = *reinterpret_cast<const float4*>(xs + 8 * n + 4);
+            const unsigned h0 = yl_pack_bf16(x0.x, x0.y), h1 = yl_pack_bf16(x0.z, x0.w), h2 = yl_pack_bf16(x1.x, x1.y),
+                           h3 = yl_pack_bf16(x1.z, x1.w);
+            const unsigned l0 = yl_pack_bf16(x0.x - yl_bf16_lo(h0), x0.y - yl_bf16_hi(h0)),
+                           l1 = yl_pack_bf16(x0.z - yl_bf16_lo(h1), x0.w - yl_bf16_hi(h1)),
+                           l2 = yl_pack_bf16(x1.x - yl_bf16_lo(h2), x1.y - yl_bf16_hi(h2)),
+                           l3 = yl_pack_bf16(x1.z - yl_bf16_lo(h3), x1.w - yl_bf16_hi(h3));
+            const cl_u32x4 fr = {lhi ? l0 : h0, lhi ? l1 : h1, lhi ? l2 : h2, lhi ? l3 : h3};
+            bf[rb][0] = fr; bf[rb][1] = fr;
+          }
+        } else {
+          const unsigned char* bsrc = (grp == 3) ? s_s : f_s;
 #pragma unroll
-          for (int ks = 0; ks < 4; ++ks)
-            bf[rb][ks] = *reinterpret_cast<const cl_u32x4*>(bsrc + (32 * rb + l31) * CL_FB + 32 * ks + 16 * lhi);
-        const cl_u32x4* ap = reinterpret_cast<const cl_u32x4*>(pk + CL_EDGE_BYTES) + (wv * 8) * 64 + lane;
-        cl_u32x4 af[2][4];
+          for (int rb = 0; rb < 2; ++rb)
 #pragma unroll
-        for (int nt_ = 0; nt_ < 2; ++nt_)
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) af[nt_][ks] = ap[(nt_ * 4 + ks) * 64];
+            for (int ks = 0; ks < 4; ++ks)
+              bf[rb][ks] = *reinterpret_cast<const cl_u32x4*>(bsrc + (64 * rbp + 32 * rb + l31) * CL_FB + 32 * ks + 16 * lhi);
+        }
         f32x16 acc[2][2];
 #pragma unroll
         for (int nt_ = 0; nt_ < 2; ++nt_)
 #pragma unroll
           for (int q = 0; q < 4; ++q) {
-            const float4 s4 = *reinterpret_cast<const float4*>(shift + 64 * wv + 32 * nt_ + 8 * q + 4 * lhi);
+            const float4 s4 = *reinterpret_cast<const float4*>(shift + 64 * grp + 32 * nt_ + 8 * q + 4 * lhi);
 #pragma unroll
             for (int rb = 0; rb < 2; ++rb) {
               acc[rb][nt_][4 * q] = s4.x; acc[rb][nt_][4 * q + 1] = s4.y;
               acc[rb][nt_][4 * q + 2] = s4.z; acc[rb][nt_][4 * q + 3] = s4.w;
             }
           }
+        if (l == 0) {
 #pragma unroll
-        for (int ks = 0; ks < 4; ++ks)
+          for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-          for (int nt_ = 0; nt_ < 2; ++nt_)
+            for (int nt_ = 0; nt_ < 2; ++nt_)
 #pragma unroll
-            for (int rb = 0; rb < 2; ++rb)
-              acc[rb][nt_] = cl_mfma(cl_frag(af[nt_][ks]), cl_frag(bf[rb][ks]), acc[rb][nt_]);
+              for (int rb = 0; rb < 2; ++rb)
+                acc[rb][nt_] = cl_mfma(cl_frag(af[nt_][ks]), cl_frag(bf[rb][ks]), acc[rb][nt_]);
+        } else {
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+            for (int nt_ = 0; nt_ < 2; ++nt_)
+#pragma unroll
+              for (int rb = 0; rb < 2; ++rb)
+                acc[rb][nt_] = cl_mfma(cl_frag(af[nt_][ks]), cl_frag(bf[rb][ks]), acc[rb][nt_]);
+        }
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
-          const int n = 32 * rb + l31;
+          const int n = 64 * rbp + 32 * rb + l31;
 #pragma unroll
           for (int nt_ = 0; nt_ < 2; ++nt_)
 #pragma unroll
@@ -288,10 +374,10 @@ __global__ void __launch_bounds__(256, 2) k_conv_local_h(const ClArgs a) {
               const int ch = 32 * nt_ + 8 * q + 4 * lhi;
               const float v0 = acc[rb][nt_][4 * q], v1 = acc[rb][nt_][4 * q + 1], v2 = acc[rb][nt_][4 * q + 2],
                           v3 = acc[rb][nt_][4 * q + 3];
-              if (wv < 2) {
+              if (grp < 2) {
                 cl_u32x2 o = {yl_pack_bf16(v0, v1), yl_pack_bf16(v2, v3)};
-                *reinterpret_cast<cl_u32x2*>(uv_s + n * CL_UVB + 128 * wv + 2 * ch) = o;
-              } else if (wv == 2) {
+                *reinterpret_cast<cl_u32x2*>(uv_s + n * CL_UVB + 128 * grp + 2 * ch) = o;
+              } else if (grp == 2) {
                 *reinterpret_cast<float4*>(r_s + n * CL_RB + 4 * ch) = make_float4(v0, v1, v2, v3);
               } else {
                 cl_u32x2 o = {cl_relu_pk(yl_pack_bf16(v0, v1)), cl_relu_pk(yl_pack_bf16(v2, v3))};
@@ -300,65 +386,95 @@ __global__ void __launch_bounds__(256, 2) k_conv_local_h(const ClArgs a) {
             }
         }
       }
-      __syncthreads();      // UV, R (and s) of this layer are complete; every read of f is done
+      CL_STAMP();    // 3 + 5 l: node phase done (before barrier)
+      cl_lds_barrier();     // UV, R, s of this layer and its edge fragments are complete; every read of f is done
+      CL_STAMP();    // 4 + 5 l: node barrier passed
+      if (tid < 256) shift_s[tid] = sh_nx;  // read after the edge phase's closing barrier
+      // the next node phase's copy of the edge fragments (next layer, or layer 0 of the next tile): a phase ahead
+#pragma unroll
+      for (int i = 0; i < NE; ++i)
+        est[i] = reinterpret_cast<const cl_u32x4*>(a.pack + (long)l_nx * CL_LAYER_BYTES)[yl_min(tid + NT * i, 767)];
+      // the NEXT layer's node-phase weight fragments — or, in the last layer, the next tile's raw loads (in front of this
+      // tile's output stores: vmcnt retires in order)
+      if (l + 1 < a.L) {
+        const cl_u32x4* ap = reinterpret_cast<const cl_u32x4*>(a.pack + (long)(l + 1) * CL_LAYER_BYTES + CL_EDGE_BYTES) + (grp * 8) * 64 + lane;
+#pragma unroll
+        for (int nt_ = 0; nt_ < 2; ++nt_)
+#pragma unroll
+          for (int ks = 0; ks < 4; ++ks) af[nt_][ks] = ap[(nt_ * 4 + ks) * 64];
+      } else if (pn0 < np && a.E > 0) {
+        issue_tile_loads(pn0, pn1, pre0, pre1, pre2, pre3);
+      }
+      // per-proposal mean of the node branch of an output layer: s is complete and nobody writes it before the next
+      // node phase.  item = (proposal, 8-channel group, row part): the four lanes of a quad take every fourth row with
+      // 16-byte reads and meet through DPP
+      if (l >= a.lo && !(a.abl & 8)) {
+        const int j = l - a.lo;
+        for (int i = tid; i < npr * 32; i += NT) {
+          const int part = i & 3, cg = (i >> 2) & 7, pp = i >> 5;
+          const int r0 = gseg_s[p0 + pp] - n0, r1 = gseg_s[p0 + pp + 1] - n0;
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = 0.f;
+#pragma unroll 2
+          for (int r = r0 + part; r < r1; r += 4) {
+            const cl_u32x4 q = *reinterpret_cast<const cl_u32x4*>(s_s + r * CL_FB + 16 * cg);
+            v[0] += yl_bf16_lo(q.x); v[1] += yl_bf16_hi(q.x); v[2] += yl_bf16_lo(q.y); v[3] += yl_bf16_hi(q.y);
+            v[4] += yl_bf16_lo(q.z); v[5] += yl_bf16_hi(q.z); v[6] += yl_bf16_lo(q.w); v[7] += yl_bf16_hi(q.w);
+          }
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { v[k] += cl_quad_xor1(v[k]); v[k] += cl_quad_xor2(v[k]); }
+          if (part == 0) {
+            const int cnt = r1 - r0;
+            const float sc = 1.f / (float)(cnt > 1 ? cnt : 1);
+            float* z = a.Z + (long)(p_lo + p0 + pp) * a.ldz + 2 * a.F + a.D + 64 * j + 8 * cg;
+            *reinterpret_cast<float4*>(z) = make_float4(v[0] * sc, v[1] * sc, v[2] * sc, v[3] * sc);
+            *reinterpret_cast<float4*>(z + 4) = make_float4(v[4] * sc, v[5] * sc, v[6] * sc, v[7] * sc);
+          }
+        }
+      }
 
       // =========================== edge phase ===========================
       {
-        const cl_u32x4* ep = reinterpret_cast<const cl_u32x4*>(pk) + lane;
-        cl_bf16x8 w2f[8], WcA[2], TB[2];
-        if (a.abl & 16) {
-#pragma unroll
-          for (int i = 0; i < 8; ++i) w2f[i] = Id[i & 1];
-          WcA[0] = WcA[1] = TB[0] = TB[1] = Id[0];
-        } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) w2f[i] = cl_frag(ep[i * 64]);
-#pragma unroll
-        for (int i = 0; i < 2; ++i) { WcA[i] = cl_frag(ep[(8 + i) * 64]); TB[i] = cl_frag(ep[(10 + i) * 64]); }
-        }
         f32x16 agg0, agg1;
 #pragma unroll
         for (int i = 0; i < 16; ++i) { agg0[i] = 0.f; agg1[i] = 0.f; }
-        for (int t = 0; t < nsteps; ++t) {
+        // One step = 16 edges of each of the wave's two streams, in two stages that are software-pipelined across steps
+        // (stage B of step t - 1 and stage A of step t are independent: one stage's ReLU / convert / mask work runs under
+        // the other's MFMAs — a single step is a chain MFMA -> VALU -> MFMA -> VALU -> MFMA):
+        //   A(t): gather U'[dst] | V'[src] chunks + e_attr fragment, layer 1 transposed (10 MFMAs), ReLU + bf16 -> hp[16]
+        //   B(t): layer 2 on hp (10 MFMAs), ReLU + bf16, incidence fragments, aggregation (4 MFMAs)
+        auto stage_a = [&](int t, unsigned (&hp)[16]) {
           const int e = yl_min(yl_min(g_base + 16 * t, g_last), et - 1);
           const unsigned iw = idx_s[e];
+          // (a step-dependent zero keeps the fragment reads inside the loop — hoisted, the layer's 12 fragments are 48
+          // registers — without an asm statement, which would split the scheduling region)
+          const cl_u32x4* efl = ef_s + lane + (t >> 24);
           const unsigned uo = (iw & 0xFFu) * CL_UVB + 16u * lhi, vo = ((iw >> 8) & 0xFFu) * CL_UVB + 128u + 16u * lhi;
-          cl_u32x4 ru[4], rv[4];
-#pragma unroll
-          for (int ks = 0; ks < 4; ++ks) {
-            ru[ks] = *reinterpret_cast<const cl_u32x4*>(uv_s + uo + 32 * ks);
-            rv[ks] = *reinterpret_cast<const cl_u32x4*>(uv_s + vo + 32 * ks);
-          }
           const cl_u32x4 aq = ab_s[e];
           const cl_bf16x8 ab = cl_frag(aq.x, aq.y, lhi ? 0u : aq.z, lhi ? 0u : aq.w);
-          // ---- layer 1, transposed: z[r] = pre-activation of channel 32 b + (r & 3) + 8 (r >> 2) + 4 lhi of MY edge
-          unsigned hp[16];
+          // layer 1, transposed: z[r] = pre-activation of channel 32 b + (r & 3) + 8 (r >> 2) + 4 lhi of MY edge
 #pragma unroll
           for (int b = 0; b < 2; ++b) {
+            const cl_u32x4 u0 = *reinterpret_cast<const cl_u32x4*>(uv_s + uo + 64 * b);
+            const cl_u32x4 u1 = *reinterpret_cast<const cl_u32x4*>(uv_s + uo + 64 * b + 32);
+            const cl_u32x4 v0 = *reinterpret_cast<const cl_u32x4*>(uv_s + vo + 64 * b);
+            const cl_u32x4 v1 = *reinterpret_cast<const cl_u32x4*>(uv_s + vo + 64 * b + 32);
             f32x16 z;
 #pragma unroll
             for (int i = 0; i < 16; ++i) z[i] = 0.f;
-            z = cl_mfma(Id[0], cl_frag(ru[2 * b]), z);
-            z = cl_mfma(Id[1], cl_frag(ru[2 * b + 1]), z);
-            z = cl_mfma(Id[0], cl_frag(rv[2 * b]), z);
-            z = cl_mfma(Id[1], cl_frag(rv[2 * b + 1]), z);
-            z = cl_mfma(WcA[b], ab, z);
+            z = cl_mfma(Id[0], cl_frag(u0), z);
+            z = cl_mfma(Id[1], cl_frag(u1), z);
+            z = cl_mfma(Id[0], cl_frag(v0), z);
+            z = cl_mfma(Id[1], cl_frag(v1), z);
+            z = cl_mfma(cl_frag(efl[(8 + b) * 64]), ab, z);
 #pragma unroll
             for (int i = 0; i < 8; ++i) hp[8 * b + i] = cl_relu_pk(yl_pack_bf16(z[2 * i], z[2 * i + 1]));
           }
-          // ---- layer 2: m_nb[r] = pre-ReLU message of edge (stream lhi, row r), channel 32 nb + l31
-          f32x16 m0, m1;
-#pragma unroll
-          for (int i = 0; i < 16; ++i) { m0[i] = 0.f; m1[i] = 0.f; }
-          m0 = cl_mfma(OnesA, TB[0], m0);
-          m1 = cl_mfma(OnesA, TB[1], m1);
-#pragma unroll
-          for (int sk = 0; sk < 4; ++sk) {
-            const cl_bf16x8 hA = cl_frag(hp[4 * sk], hp[4 * sk + 1], hp[4 * sk + 2], hp[4 * sk + 3]);
-            m0 = cl_mfma(hA, w2f[sk], m0);
-            m1 = cl_mfma(hA, w2f[4 + sk], m1);
-          }
-          // ---- mean aggregation as an MFMA: incidence of the step's edges (k-slots: stream lhi, rows 8 j ..) on MY node slot
+        };
+        auto stage_b = [&](int t, const unsigned (&hp)[16]) {
+          const cl_u32x4* efl = ef_s + lane + (t >> 24);
+          // mean aggregation as an MFMA: incidence of the step's edges (k-slots: stream lhi, rows 8 j ..) on MY node slot
           unsigned mask;
           {
             const int base = k_base + 16 * t;
@@ -366,22 +482,133 @@ __global__ void __launch_bounds__(256, 2) k_conv_local_h(const ClArgs a) {
             const int lo = yl_max(my_rp0 - base, 0), hi = yl_min(my_rp1 - base, lim);
             mask = (hi > lo) ? ((0xFFFFu >> (16 - hi)) & (0xFFFFu << lo)) : 0u;
           }
+          const cl_bf16x8 S0 = cl_frag(cl_sel2(mask, 0), cl_sel2(mask, 2), cl_sel2(mask, 4), cl_sel2(mask, 6));
+          const cl_bf16x8 S1 = cl_frag(cl_sel2(mask, 8), cl_sel2(mask, 10), cl_sel2(mask, 12), cl_sel2(mask, 14));
+          // layer 2, one 32-channel block at a time: m[r] = pre-ReLU message of edge (stream lhi, row r), channel
+          // 32 nb + l31; ReLU + bf16 -> the A operand of the aggregation
 #pragma unroll
-          for (int j = 0; j < 2; ++j) {
-            const cl_bf16x8 S = cl_frag(cl_sel2(mask, 8 * j), cl_sel2(mask, 8 * j + 2), cl_sel2(mask, 8 * j + 4),
-                                        cl_sel2(mask, 8 * j + 6));
-            const cl_bf16x8 a0 = cl_frag(cl_relu_pk(yl_pack_bf16(m0[8 * j], m0[8 * j + 1])),
-                                         cl_relu_pk(yl_pack_bf16(m0[8 * j + 2], m0[8 * j + 3])),
-                                         cl_relu_pk(yl_pack_bf16(m0[8 * j + 4], m0[8 * j + 5])),
-                                         cl_relu_pk(yl_pack_bf16(m0[8 * j + 6], m0[8 * j + 7])));
-            const cl_bf16x8 a1 = cl_frag(cl_relu_pk(yl_pack_bf16(m1[8 * j], m1[8 * j + 1])),
-                                         cl_relu_pk(yl_pack_bf16(m1[8 * j + 2], m1[8 * j + 3])),
-                                         cl_relu_pk(yl_pack_bf16(m1[8 * j + 4], m1[8 * j + 5])),
-                                         cl_relu_pk(yl_pack_bf16(m1[8 * j + 6], m1[8 * j + 7])));
-            agg0 = cl_mfma(a0, S, agg0);
-            agg1 = cl_mfma(a1, S, agg1);
+          for (int nb = 0; nb < 2; ++nb) {
+            f32x16 m;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) m[i] = 0.f;
+            m = cl_mfma(OnesA, cl_frag(efl[(10 + nb) * 64]), m);
+#pragma unroll
+            for (int sk = 0; sk < 4; ++sk)
+              m = cl_mfma(cl_frag(hp[4 * sk], hp[4 * sk + 1], hp[4 * sk + 2], hp[4 * sk + 3]), cl_frag(efl[(4 * nb + sk) * 64]), m);
+            const cl_bf16x8 a0 = cl_frag(cl_relu_pk(yl_pack_bf16(m[0], m[1])), cl_relu_pk(yl_pack_bf16(m[2], m[3])),
+                                         cl_relu_pk(yl_pack_bf16(m[4], m[5])), cl_relu_pk(yl_pack_bf16(m[6], m[7])));
+            const cl_bf16x8 a1 = cl_frag(cl_relu_pk(yl_pack_bf16(m[8], m[9])), cl_relu_pk(yl_pack_bf16(m[10], m[11])),
+                                         cl_relu_pk(yl_pack_bf16(m[12], m[13])), cl_relu_pk(yl_pack_bf16(m[14], m[15])));
+            if (nb == 0) { agg0 = cl_mfma(a0, S0, agg0); agg0 = cl_mfma(a1, S1, agg0); }
+            else { agg1 = cl_mfma(a0, S0, agg1); agg1 = cl_mfma(a1, S1, agg1); }
+          }
+        };
+        // A(t) and B(t - 1) as ONE hand-ordered instruction stream.  A wave issues in order and the compiler emits every
+        // MFMA chain back to back with the ReLU / convert / mask blocks in between (the matrix pipe idles through each ALU
+        // block, the ALU through each chain: ~1500 cycles per step for 768 cycles of MFMA).  Here every MFMA is followed by
+        // <= 8 ALU instructions of the OTHER stage; CL_FENCE pins MFMA and ALU order (LDS reads and scalar code may move).
+#define CL_FENCE() __builtin_amdgcn_sched_barrier(0x0014)
+#define CL_PK(v, i) cl_relu_pk(yl_pack_bf16((v)[2 * (i)], (v)[2 * (i) + 1]))
+        auto pipe = [&](int t, const unsigned (&hb)[16], unsigned (&ha)[16]) {
+          const cl_u32x4* efl = ef_s + lane + (t >> 24);
+          // ---- A(t): ids; B(t - 1): the first half's weight fragments (TB0, W2F 0..3) and A's attr weights
+          const int e = yl_min(yl_min(g_base + 16 * t, g_last), et - 1);
+          const unsigned iw = idx_s[e];
+          cl_u32x4 fr0 = efl[10 * 64], fr1 = efl[0 * 64], fr2 = efl[1 * 64], fr3 = efl[2 * 64], fr4 = efl[3 * 64];
+          const cl_u32x4 aq = ab_s[e];
+          cl_u32x4 wca = efl[8 * 64];
+          const unsigned uo = (iw & 0xFFu) * CL_UVB + 16u * lhi, vo = ((iw >> 8) & 0xFFu) * CL_UVB + 128u + 16u * lhi;
+          cl_u32x4 gu0 = *reinterpret_cast<const cl_u32x4*>(uv_s + uo), gu1 = *reinterpret_cast<const cl_u32x4*>(uv_s + uo + 32);
+          cl_u32x4 gv0 = *reinterpret_cast<const cl_u32x4*>(uv_s + vo), gv1 = *reinterpret_cast<const cl_u32x4*>(uv_s + vo + 32);
+          const cl_bf16x8 ab = cl_frag(aq.x, aq.y, lhi ? 0u : aq.z, lhi ? 0u : aq.w);
+          // ---- B(t - 1): incidence mask of step t - 1
+          unsigned mask;
+          {
+            const int base = k_base + 16 * (t - 1);
+            const int lim = yl_min(16, k_len - 16 * (t - 1));
+            const int lo = yl_max(my_rp0 - base, 0), hi = yl_min(my_rp1 - base, lim);
+            mask = (hi > lo) ? ((0xFFFFu >> (16 - hi)) & (0xFFFFu << lo)) : 0u;
+          }
+          unsigned sd[8], pa[8];
+          f32x16 m, z;
+#pragma unroll
+          for (int i = 0; i < 16; ++i) { m[i] = 0.f; z[i] = 0.f; }
+          CL_FENCE();
+          // B: layer 2, channels 0..31  |  ALU: incidence fragments
+          m = cl_mfma(OnesA, cl_frag(fr0), m);                                            CL_FENCE();
+          sd[0] = cl_sel2(mask, 0); sd[1] = cl_sel2(mask, 2);                             CL_FENCE();
+          m = cl_mfma(cl_frag(hb[0], hb[1], hb[2], hb[3]), cl_frag(fr1), m);              CL_FENCE();
+          sd[2] = cl_sel2(mask, 4); sd[3] = cl_sel2(mask, 6);                             CL_FENCE();
+          m = cl_mfma(cl_frag(hb[4], hb[5], hb[6], hb[7]), cl_frag(fr2), m);              CL_FENCE();
+          sd[4] = cl_sel2(mask, 8); sd[5] = cl_sel2(mask, 10);                            CL_FENCE();
+          m = cl_mfma(cl_frag(hb[8], hb[9], hb[10], hb[11]), cl_frag(fr3), m);            CL_FENCE();
+          sd[6] = cl_sel2(mask, 12); sd[7] = cl_sel2(mask, 14);                           CL_FENCE();
+          m = cl_mfma(cl_frag(hb[12], hb[13], hb[14], hb[15]), cl_frag(fr4), m);          CL_FENCE();
+          // the second half's fragments (TB1, W2F 4..7) into the same registers: in flight under A's first chain
+          fr0 = efl[11 * 64]; fr1 = efl[4 * 64]; fr2 = efl[5 * 64]; fr3 = efl[6 * 64]; fr4 = efl[7 * 64];   CL_FENCE();
+          // A: layer 1, channels 0..31  |  ALU: ReLU + bf16 of B's messages
+          z = cl_mfma(Id[0], cl_frag(gu0), z);                                            CL_FENCE();
+          pa[0] = CL_PK(m, 0); pa[1] = CL_PK(m, 1);                                       CL_FENCE();
+          z = cl_mfma(Id[1], cl_frag(gu1), z);                                            CL_FENCE();
+          pa[2] = CL_PK(m, 2); pa[3] = CL_PK(m, 3);                                       CL_FENCE();
+          z = cl_mfma(Id[0], cl_frag(gv0), z);                                            CL_FENCE();
+          pa[4] = CL_PK(m, 4); pa[5] = CL_PK(m, 5);                                       CL_FENCE();
+          z = cl_mfma(Id[1], cl_frag(gv1), z);                                            CL_FENCE();
+          pa[6] = CL_PK(m, 6); pa[7] = CL_PK(m, 7);                                       CL_FENCE();
+          z = cl_mfma(cl_frag(wca), ab, z);                                               CL_FENCE();
+          // second half of A's gathers and attr weights (the first half's registers are free)
+          gu0 = *reinterpret_cast<const cl_u32x4*>(uv_s + uo + 64); gu1 = *reinterpret_cast<const cl_u32x4*>(uv_s + uo + 96);
+          gv0 = *reinterpret_cast<const cl_u32x4*>(uv_s + vo + 64); gv1 = *reinterpret_cast<const cl_u32x4*>(uv_s + vo + 96);
+          wca = efl[9 * 64];                                                              CL_FENCE();
+          // B: aggregation of channels 0..31, layer 2 of channels 32..63  |  ALU: ReLU + bf16 of A's hidden activations
+          agg0 = cl_mfma(cl_frag(pa[0], pa[1], pa[2], pa[3]), cl_frag(sd[0], sd[1], sd[2], sd[3]), agg0);   CL_FENCE();
+          ha[0] = CL_PK(z, 0); ha[1] = CL_PK(z, 1);                                       CL_FENCE();
+          agg0 = cl_mfma(cl_frag(pa[4], pa[5], pa[6], pa[7]), cl_frag(sd[4], sd[5], sd[6], sd[7]), agg0);   CL_FENCE();
+          ha[2] = CL_PK(z, 2); ha[3] = CL_PK(z, 3);                                       CL_FENCE();
+#pragma unroll
+          for (int i = 0; i < 16; ++i) m[i] = 0.f;
+          m = cl_mfma(OnesA, cl_frag(fr0), m);                                            CL_FENCE();
+          ha[4] = CL_PK(z, 4); ha[5] = CL_PK(z, 5);                                       CL_FENCE();
+          m = cl_mfma(cl_frag(hb[0], hb[1], hb[2], hb[3]), cl_frag(fr1), m);              CL_FENCE();
+          ha[6] = CL_PK(z, 6); ha[7] = CL_PK(z, 7);                                       CL_FENCE();
+          m = cl_mfma(cl_frag(hb[4], hb[5], hb[6], hb[7]), cl_frag(fr2), m);              CL_FENCE();
+          m = cl_mfma(cl_frag(hb[8], hb[9], hb[10], hb[11]), cl_frag(fr3), m);            CL_FENCE();
+          m = cl_mfma(cl_frag(hb[12], hb[13], hb[14], hb[15]), cl_frag(fr4), m);          CL_FENCE();
+          // A: layer 1, channels 32..63  |  ALU: ReLU + bf16 of B's messages
+#pragma unroll
+          for (int i = 0; i < 16; ++i) z[i] = 0.f;
+          z = cl_mfma(Id[0], cl_frag(gu0), z);                                            CL_FENCE();
+          pa[0] = CL_PK(m, 0); pa[1] = CL_PK(m, 1);                                       CL_FENCE();
+          z = cl_mfma(Id[1], cl_frag(gu1), z);                                            CL_FENCE();
+          pa[2] = CL_PK(m, 2); pa[3] = CL_PK(m, 3);                                       CL_FENCE();
+          z = cl_mfma(Id[0], cl_frag(gv0), z);                                            CL_FENCE();
+          pa[4] = CL_PK(m, 4); pa[5] = CL_PK(m, 5);                                       CL_FENCE();
+          z = cl_mfma(Id[1], cl_frag(gv1), z);                                            CL_FENCE();
+          pa[6] = CL_PK(m, 6); pa[7] = CL_PK(m, 7);                                       CL_FENCE();
+          z = cl_mfma(cl_frag(wca), ab, z);                                               CL_FENCE();
+          // B: aggregation of channels 32..63  |  ALU: ReLU + bf16 of A's hidden activations
+          agg1 = cl_mfma(cl_frag(pa[0], pa[1], pa[2], pa[3]), cl_frag(sd[0], sd[1], sd[2], sd[3]), agg1);   CL_FENCE();
+          ha[8] = CL_PK(z, 0); ha[9] = CL_PK(z, 1); ha[10] = CL_PK(z, 2); ha[11] = CL_PK(z, 3);             CL_FENCE();
+          agg1 = cl_mfma(cl_frag(pa[4], pa[5], pa[6], pa[7]), cl_frag(sd[4], sd[5], sd[6], sd[7]), agg1);   CL_FENCE();
+          ha[12] = CL_PK(z, 4); ha[13] = CL_PK(z, 5); ha[14] = CL_PK(z, 6); ha[15] = CL_PK(z, 7);           CL_FENCE();
+        };
+#undef CL_PK
+        if (nsteps > 0) {
+          unsigned h0[16], h1[16];
+          stage_a(0, h0);
+          int t = 1;
+          for (; t + 1 < nsteps; t += 2) {
+            pipe(t, h0, h1);
+            pipe(t + 1, h1, h0);
+          }
+          if (t < nsteps) {
+            pipe(t, h0, h1);
+            stage_b(t, h1);
+          } else {
+            stage_b(t - 1, h0);
           }
         }
+        CL_STAMP();  // 5 + 5 l: steps done
         // ---- finalize: f[node] = bf16(root + sum / deg); a lane holds channels 32 nb + 8 q + 4 lhi .. + 3 of its node
         if (my_valid) {
           const int deg = my_rp1 - my_rp0;
@@ -399,52 +626,60 @@ __global__ void __launch_bounds__(256, 2) k_conv_local_h(const ClArgs a) {
             }
         }
       }
-      __syncthreads();      // f of this layer is complete; every gather of UV / R is done
+      cl_lds_barrier();     // f of this layer is complete; every gather of UV / R is done
+      CL_STAMP();    // 6 + 5 l: edge barrier passed
 
       // =========================== outputs of this layer ===========================
+      // f rows -> feats, per-proposal max of f -> Z (nobody writes f before the next edge phase's finalize)
       if (l >= a.lo && !(a.abl & 8)) {
+        const int tid = cl_opaque(tid0);
         const int j = l - a.lo;
-        if (wv < 3) {
-          for (int i = tid; i < nt * 8; i += 192) {
-            const int n = i >> 3, c = i & 7;
-            const cl_u32x4 v = *reinterpret_cast<const cl_u32x4*>(f_s + n * CL_FB + 16 * c);
-            *reinterpret_cast<cl_u32x4*>(a.feats + (long)(n0 + n) * a.ld_feats + 64 * j + 8 * c) = v;
+        for (int i = tid; i < nt * 8; i += NT) {
+          const int n = i >> 3, c = i & 7;
+          const cl_u32x4 v = *reinterpret_cast<const cl_u32x4*>(f_s + n * CL_FB + 16 * c);
+          *reinterpret_cast<cl_u32x4*>(a.feats + (long)(n0 + n) * a.ld_feats + 64 * j + 8 * c) = v;
+        }
+        for (int i = tid; i < npr * 32; i += NT) {
+          const int part = i & 3, cg = (i >> 2) & 7, pp = i >> 5;
+          const int r0 = gseg_s[p0 + pp] - n0, r1 = gseg_s[p0 + pp + 1] - n0;
+          float v[8];
+#pragma unroll
+          for (int k = 0; k < 8; ++k) v[k] = -INFINITY;
+#pragma unroll 2
+          for (int r = r0 + part; r < r1; r += 4) {
+            const cl_u32x4 q = *reinterpret_cast<const cl_u32x4*>(f_s + r * CL_FB + 16 * cg);
+            v[0] = fmaxf(v[0], yl_bf16_lo(q.x)); v[1] = fmaxf(v[1], yl_bf16_hi(q.x));
+            v[2] = fmaxf(v[2], yl_bf16_lo(q.y)); v[3] = fmaxf(v[3], yl_bf16_hi(q.y));
+            v[4] = fmaxf(v[4], yl_bf16_lo(q.z)); v[5] = fmaxf(v[5], yl_bf16_hi(q.z));
+            v[6] = fmaxf(v[6], yl_bf16_lo(q.w)); v[7] = fmaxf(v[7], yl_bf16_hi(q.w));
           }
-          for (int i = tid; i < npr * 64; i += 192) {
-            const int pp = i >> 6, c = i & 63;
-            const int r0 = gseg_s[p0 + pp] - n0, r1 = gseg_s[p0 + pp + 1] - n0;
-            float best = 0.f;
-            bool any = false;
-            for (int r = r0; r < r1; ++r) {
-              const float v = __uint_as_float((unsigned)*reinterpret_cast<const u16*>(f_s + r * CL_FB + 2 * c) << 16);
-              if (!any || v > best) { best = v; any = true; }
-            }
-            a.Z[(long)(p_lo + p0 + pp) * a.ldz + a.F + 64 * j + c] = best;
-          }
-        } else {
-          for (int pp = 0; pp < npr; ++pp) {
-            const int r0 = gseg_s[p0 + pp] - n0, r1 = gseg_s[p0 + pp + 1] - n0;
-            float sm = 0.f;
-            for (int r = r0; r < r1; ++r)
-              sm += __uint_as_float((unsigned)*reinterpret_cast<const u16*>(s_s + r * CL_FB + 2 * lane) << 16);
-            const int cnt = r1 - r0;
-            a.Z[(long)(p_lo + p0 + pp) * a.ldz + 2 * a.F + a.D + 64 * j + lane] = sm / (float)(cnt > 1 ? cnt : 1);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { v[k] = fmaxf(v[k], cl_quad_xor1(v[k])); v[k] = fmaxf(v[k], cl_quad_xor2(v[k])); }
+          if (part == 0) {
+            const bool any = r1 > r0;
+            float* z = a.Z + (long)(p_lo + p0 + pp) * a.ldz + a.F + 64 * j + 8 * cg;
+            *reinterpret_cast<float4*>(z) = make_float4(any ? v[0] : 0.f, any ? v[1] : 0.f, any ? v[2] : 0.f, any ? v[3] : 0.f);
+            *reinterpret_cast<float4*>(z + 4) = make_float4(any ? v[4] : 0.f, any ? v[5] : 0.f, any ? v[6] : 0.f, any ? v[7] : 0.f);
           }
         }
       }
+      CL_STAMP();    // 7 + 5 l: outputs of the layer done
     }
     // Z[p, 0:F] = 0 for the tile's proposals (the fusion launch max-accumulates into it)
     if (!(a.abl & 8)) {
       const int f4 = a.F >> 2;
-      const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-      for (int i = tid; i < npr * f4; i += 256) {
+      const float zf = __int_as_float(cl_opaque(0));        // (a hoisted zero vector was the kernel's last spill)
+      const float4 z4 = make_float4(zf, zf, zf, zf);
+      for (int i = tid; i < npr * f4; i += NT) {
         const int pp = i / f4, c = i - pp * f4;
         *reinterpret_cast<float4*>(a.Z + (long)(p_lo + p0 + pp) * a.ldz + 4 * c) = z4;
       }
     }
-    __syncthreads();        // the tiles are dead: the next tile may be loaded
-    p0 = p1;
+    cl_lds_barrier();       // the tiles are dead: the next tile may be written
+    p0 = pn0;
+    p1 = pn1;
   }
+#undef CL_STAMP
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -499,13 +734,18 @@ __global__ void k_conv_local_pack(ClPackLayer p, int layer, unsigned char* dst) 
   };
   if (j < 32 * 64) {
     cl_u32x4 o = {0u, 0u, 0u, 0u};
-    if (layer == 0) {                 // W0 [256][8] fp32, columns >= Cin zero
-      if (j < 512) {
-        const int c = j >> 1, k0 = 4 * (j & 1);
-        float v[4];
+    if (layer == 0) {                 // fragments (g, nt, ks): ks 0 = W_hi[ch][0..7] in both lane halves, ks 1 = W_lo | 0
+      const int fi = j >> 6, g = fi >> 3, nt_ = (fi >> 2) & 1, ks = fi & 3;
+      const int c = 64 * g + 32 * nt_ + l31;
+      if (ks < 2 && !(ks == 1 && lhi)) {
+        unsigned v[8];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] = (k0 + k < p.Cin) ? wrow(c, k0 + k) : 0.f;
-        o.x = __float_as_uint(v[0]); o.y = __float_as_uint(v[1]); o.z = __float_as_uint(v[2]); o.w = __float_as_uint(v[3]);
+        for (int k = 0; k < 8; ++k) {
+          const float w = k < p.Cin ? wrow(c, k) : 0.f;
+          const unsigned h = bf(w);
+          v[k] = ks == 0 ? h : bf(w - __uint_as_float(h << 16));
+        }
+        o.x = v[0] | (v[1] << 16); o.y = v[2] | (v[3] << 16); o.z = v[4] | (v[5] << 16); o.w = v[6] | (v[7] << 16);
       }
     } else {                          // A fragments (g, nt, ks): elements e -> W'[64 g + 32 nt + l31][16 ks + 8 lhi + e]
       const int fi = j >> 6, g = fi >> 3, nt_ = (fi >> 2) & 1, ks = fi & 3;
@@ -577,7 +817,10 @@ int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const 
   a.x = x; a.ldx = (int)ldx; a.cin0 = (int)m->conv[0].Cin;
   a.row_ptr = row_ptr; a.src = src; a.dst = dst; a.attr = attr; a.seg_ptr = seg_ptr;
   a.N = (int)N; a.E = (int)E; a.P = (int)P;
-  long g0 = (P + 511) / 512;          // one round of two workgroups per CU
+  int nw = 4;
+  { const char* e = getenv("YOLAT_CONV_LOCAL_NW"); if (e && atoi(e) == 8) nw = 8; }
+  const long slots = nw == 8 ? 256 : 512;          // one round: one 8-wave / two 4-wave workgroups per CU
+  long g0 = (P + slots - 1) / slots;
   if (g0 < 4) g0 = 4;
   if (g0 > CL_GMAX) g0 = CL_GMAX;
   {
@@ -591,7 +834,9 @@ int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const 
   a.Z = Z; a.ldz = (int)ldz; a.F = (int)m->F; a.D = (int)(m->C * m->n_blocks_out);
   a.flag = flag; a.flag_val = flag_val;
   { const char* e = getenv("YOLAT_CONV_LOCAL_ABL"); a.abl = e ? atoi(e) : 0; }
-  hipLaunchKernelGGL(k_conv_local_h, dim3((unsigned)((P + g0 - 1) / g0)), dim3(256), 0, st, a);
+  a.stamps = g_cl_stamps;
+  if (nw == 8) hipLaunchKernelGGL(k_conv_local_h<8>, dim3((unsigned)((P + g0 - 1) / g0)), dim3(512), 0, st, a);
+  else hipLaunchKernelGGL(k_conv_local_h<4>, dim3((unsigned)((P + g0 - 1) / g0)), dim3(256), 0, st, a);
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -610,3 +855,6 @@ extern "C" int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* mh, cons
   return yl_conv_local_bf16(mh, pack, x, ldx, g->row_ptr, g->src, g->dst, g->attr, g->seg_ptr, N, E, P, feats, ld_feats, Z,
                             ldz, flag, 1, (hipStream_t)stream);
 }
+
+// debug hook of tools/exp/conv_local_bench.py: device buffer of 64 int64 per workgroup, or NULL
+extern "C" void yolat_conv_local_debug_stamps(long long* p) { g_cl_stamps = p; }
