@@ -638,6 +638,10 @@ typedef struct {
  *     yolat_forward_eval_bf16 does that by itself (its per-layer launches stay enqueued, gated on the flag).            */
 size_t yolat_conv_local_pack_bytes(int64_t n_layers);
 int yolat_conv_local_pack(const yolat_model_eval_bf16* m, void* dst, size_t dst_bytes, yolat_stream_t stream);
+/* tuning / debug hook of the kernel above (process-wide; tests and tools/exp/conv_local_bench.py): nw = waves per workgroup
+ * (4: 64-node tiles, 8: 128-node tiles; 0 = automatic), g0 = proposals per workgroup (0 = automatic), abl = phase-ablation
+ * bits (non-zero: results are wrong on purpose), stamps = device buffer of 64 int64 s_memtime stamps per workgroup or NULL */
+void yolat_conv_local_tune(int nw, int g0, int abl, long long* stamps);
 int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* m, const void* pack, const float* x, int64_t ldx,
                                 const yolat_graph_csr* g, int64_t N, int64_t E, int64_t P, uint16_t* feats,
                                 int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag, yolat_stream_t stream);

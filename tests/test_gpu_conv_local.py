@@ -54,6 +54,15 @@ def _rel(got, want):
             float((got - want).pow(2).mean().sqrt() / want.pow(2).mean().sqrt().clamp(min=1e-30)))
 
 
+@pytest.fixture(params=[4, 8], autouse=True)
+def _waves(request):
+    """every test on both tile shapes of the kernel: 4-wave workgroups / 64-node tiles and 8-wave / 128-node tiles"""
+    from yolat_vectorgraphicsrecognition_amd._lib import lib
+    lib.yolat_conv_local_tune(request.param, 0, 0, None)
+    yield request.param
+    lib.yolat_conv_local_tune(0, 0, 0, None)
+
+
 def _ragged(yv, P, seed, lo=2, hi=40, edge_factor=2.1, classes=17, edges_per_proposal=None):
     d = yv.synth_graph(num_proposals=P, nodes_lo=lo, nodes_hi=hi, edge_factor=edge_factor, n_classes=classes, seed=seed,
                        edges_per_proposal=edges_per_proposal)
@@ -148,19 +157,22 @@ def _with_big_proposal(d, p_mid, n_nodes):
     return d
 
 
-def test_conv_stack_local_raises_the_flag_for_batches_without_the_property():
+def test_conv_stack_local_raises_the_flag_for_batches_without_the_property(_waves):
     yv = _yv()
     optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2)
     model = _model(yv, optkw, 3)
-    # (a) a proposal of 100 nodes does not fit a 64-node tile
-    assert _run_stack(yv, model, _with_big_proposal(_ragged(yv, 60, 7, lo=3, hi=20), 20, 100))[2] == 1
+    T = 16 * _waves
+    # (a) a proposal of T + 36 nodes does not fit a T-node tile (and one of exactly T nodes does)
+    assert _run_stack(yv, model, _with_big_proposal(_ragged(yv, 60, 7, lo=3, hi=20), 20, T + 36))[2] == 1
+    assert _run_stack(yv, model, _ragged(yv, 5, 8, lo=T + 1, hi=T + 1, edges_per_proposal=300))[2] == 1
+    assert _run_stack(yv, model, _ragged(yv, 5, 8, lo=T, hi=T, edges_per_proposal=300))[2] == 0
     # (b) an edge that leaves its proposal (and its tile)
     d3 = _ragged(yv, 40, 9, lo=3, hi=20)
     d3.edge = d3.edge.clone()
     d3.edge[5, 0] = d3.x.shape[0] - 1
     assert _run_stack(yv, model, d3)[2] == 1
-    # (c) more edges than a tile holds
-    assert _run_stack(yv, model, _ragged(yv, 3, 10, lo=40, hi=40, edges_per_proposal=900))[2] == 1
+    # (c) more edges than a tile holds (8 T)
+    assert _run_stack(yv, model, _ragged(yv, 3, 10, lo=40, hi=40, edges_per_proposal=8 * T + 100))[2] == 1
     # (d) and the ordinary batch keeps it down
     assert _run_stack(yv, model, _ragged(yv, 40, 11, lo=3, hi=20))[2] == 0
 
@@ -198,7 +210,7 @@ def test_forward_with_the_local_conv_stack_matches_oracle_and_per_layer_path(blo
     assert mx <= RTOL_BF16 * depth and rms <= RMS_BF16 * depth, "local vs per-layer: max %.2e rms %.2e" % (mx, rms)
 
 
-def test_forward_falls_back_to_the_per_layer_launches_bit_exactly():
+def test_forward_falls_back_to_the_per_layer_launches_bit_exactly(_waves):
     """a batch without the property (a 100-node proposal; an edge between two proposals): the gated per-layer launches run
     and the logits are bit-identical to the per-layer path's."""
     yv = _yv()
@@ -210,8 +222,8 @@ def test_forward_falls_back_to_the_per_layer_launches_bit_exactly():
     d.edge = d.edge.clone()
     d.edge[7, 0] = d.x.shape[0] - 2                          # an edge from the last proposal into the first
     cases.append(("crossing edge", d))
-    d = _with_big_proposal(_ragged(yv, 1500, 22, lo=3, hi=30), 700, 100)
-    cases.append(("100-node proposal", d))
+    d = _with_big_proposal(_ragged(yv, 1500, 22, lo=3, hi=30), 700, 16 * _waves + 36)
+    cases.append(("oversize proposal", d))
     for name, d in cases:
         with torch.no_grad():
             with _mode(2):

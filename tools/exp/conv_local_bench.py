@@ -22,6 +22,7 @@ dev = torch.device("cuda")
 
 def fwd_ms(mode):
     os.environ["YOLAT_CONV_LOCAL"] = str(mode)
+    lib.yolat_conv_local_tune(int(os.environ.get("CL_NW", "0")), 0, 0, None)
     with torch.no_grad():
         for _ in range(5):
             model(data, slices)
@@ -45,6 +46,8 @@ def fwd_ms(mode):
 t0, out0 = fwd_ms(0)
 t1, out1 = fwd_ms(1)
 t2, out2 = fwd_ms(2)
+t3, out3 = fwd_ms(3)
+print('forward without the gated fall-back launches (measurement only): %.4f ms' % t3)
 d = (out1.double() - out0.double())
 print("cfg %s forward bf16: per-layer %.4f ms | local (auto) %.4f ms | local (forced) %.4f ms | max diff %.3e of scale %.3e, same as forced %s"
       % (cfg, t0, t1, t2, float(d.abs().max()), float(out0.abs().max()), bool(torch.equal(out1, out2))))
@@ -68,12 +71,11 @@ def run():
                                           feats.data_ptr(), D, Z.data_ptr(), Z.stride(0), flag.data_ptr(), st))
 
 
+NW = int(os.environ.get("CL_NW", "0"))
 abls = ["0"] if len(sys.argv) <= 4 else sys.argv[4].split(",")
-for g0, abl in [(g, ab) for g in ([os.environ.get("YOLAT_CONV_LOCAL_G0", "")] if len(sys.argv) <= 3 else sys.argv[3].split(","))
+for g0, abl in [(g, ab) for g in (["auto"] if len(sys.argv) <= 3 else sys.argv[3].split(","))
                 for ab in abls]:
-    if g0 and g0 != "auto":
-        os.environ["YOLAT_CONV_LOCAL_G0"] = g0
-    os.environ["YOLAT_CONV_LOCAL_ABL"] = abl
+    lib.yolat_conv_local_tune(NW, 0 if g0 == "auto" else int(g0), int(abl), None)
     for _ in range(5):
         run()
     s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -91,17 +93,12 @@ for g0, abl in [(g, ab) for g in ([os.environ.get("YOLAT_CONV_LOCAL_G0", "")] if
 # ---- in-kernel phase stamps (s_memtime, shader cycles) of the first tiles of every workgroup
 if os.environ.get("CL_STAMPS", "1") == "1":
     import numpy as np
-    os.environ["YOLAT_CONV_LOCAL_ABL"] = "0"
-    os.environ.pop("YOLAT_CONV_LOCAL_G0", None)
     nwg = 4096
     stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
-    hook = lib.yolat_conv_local_debug_stamps
-    hook.restype = None
-    hook.argtypes = [ctypes.c_void_p]
-    hook(stamps.data_ptr())
+    lib.yolat_conv_local_tune(NW, 0, 0, stamps.data_ptr())
     run()
     torch.cuda.synchronize()
-    hook(None)
+    lib.yolat_conv_local_tune(0, 0, 0, None)
     st_ = stamps.cpu().numpy().reshape(nwg, 64)
     used = st_[:, 0] != 0
     st_ = st_[used]

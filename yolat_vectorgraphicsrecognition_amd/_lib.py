@@ -240,6 +240,7 @@ SIGNATURES = {
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
     "yolat_conv_local_pack_bytes": (c_sz, [c_i64]),
     "yolat_conv_local_pack": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_sz, c_p]),
+    "yolat_conv_local_tune": (None, [c_int, c_int, c_int, c_p]),
     "yolat_conv_stack_local_bf16": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_p, c_i64, ctypes.POINTER(GraphCsr), c_i64,
                                              c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_forward_eval_bf16_primed": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,

@@ -355,13 +355,25 @@ struct NodeUvH {
   Epilogue euv, er, en;
   int N, C, Cin;
 };
-static __global__ void __launch_bounds__(256) k_hgemm_node3(NodeUvH a, YlGate gate) {
+static __global__ void __launch_bounds__(256) k_hgemm_node3(NodeUvH a) {
   __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<1, 1>::elems];
-  if (yl_gate_dead(gate)) return;      // fall-back of the one-launch conv stack (conv_local.hip): dead launch
   const int x = blockIdx.x, y = blockIdx.y;
   if (y < 2) hgemm_tile<1, 1, HOp>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y, smem);
   else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
   else hgemm_tile<1, 1, HOp>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0, smem);
+}
+// the same as the fall-back of the one-launch conv stack (conv_local.hip): dead unless the gate word holds its value; a few
+// hundred persistent workgroups walk the row tiles, so that the dead launch is a boundary, not a dispatch of 12 500 workgroups
+static __global__ void __launch_bounds__(256) k_hgemm_node3_gated(NodeUvH a, YlGate gate) {
+  __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<1, 1>::elems];
+  if (yl_gate_dead(gate)) return;
+  const int y = blockIdx.y, ntile = (a.N + 63) >> 6;
+  for (int x = blockIdx.x; x < ntile; x += gridDim.x) {
+    if (y < 2) hgemm_tile<1, 1, HOp>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y, smem);
+    else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
+    else hgemm_tile<1, 1, HOp>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0, smem);
+    if (x + (int)gridDim.x < ntile) __syncthreads();
+  }
 }
 
 static Epilogue plain_epilogue() {
@@ -525,40 +537,42 @@ static __global__ void __launch_bounds__(256, (NG == 1 ? 4 : 3)) k_edge_uv_mlp2_
 // ------------------------------------------------------------------------------------------------
 static __global__ void __launch_bounds__(256) k_pool_prepare_h(const u16* feats, const u16* fsup, long ld, int D, int F,
                                                                const int* seg_ptr, float* Z, long ldz,
-                                                               YlGate gate) {
+                                                               YlGate gate, int np) {
   if (yl_gate_dead(gate)) return;      // fall-back of the one-launch conv stack (conv_local.hip): dead launch
   const int c = blockIdx.x * 256 + threadIdx.x;
-  const int p = blockIdx.y;
-  float* z = Z + (long)p * ldz;
-  if (c < F) { z[c] = 0.f; return; }
-  if (c >= F + 2 * D) return;
-  const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
-  const bool is_max = c < F + D;
-  const int k = is_max ? c - F : c - F - D;
-  const u16* srcp = (is_max ? feats : fsup) + k;
-  float best = 0.f, s = 0.f;
-  bool any = false;
-  int r = r0;
-  for (; r + 8 <= r1; r += 8) {
-    float v[8];
+  // (the gated launch covers its np proposals with a few hundred rows of workgroups: gridDim.y < np)
+  for (int p = blockIdx.y; p < np; p += gridDim.y) {
+    float* z = Z + (long)p * ldz;
+    if (c < F) { z[c] = 0.f; continue; }
+    if (c >= F + 2 * D) continue;
+    const int r0 = seg_ptr[p], r1 = seg_ptr[p + 1];
+    const bool is_max = c < F + D;
+    const int k = is_max ? c - F : c - F - D;
+    const u16* srcp = (is_max ? feats : fsup) + k;
+    float best = 0.f, s = 0.f;
+    bool any = false;
+    int r = r0;
+    for (; r + 8 <= r1; r += 8) {
+      float v[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) v[j] = __uint_as_float((unsigned)srcp[(long)(r + j) * ld] << 16);
+      for (int j = 0; j < 8; ++j) v[j] = __uint_as_float((unsigned)srcp[(long)(r + j) * ld] << 16);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (!any || v[j] > best) { best = v[j]; any = true; }
-      s += v[j];
+      for (int j = 0; j < 8; ++j) {
+        if (!any || v[j] > best) { best = v[j]; any = true; }
+        s += v[j];
+      }
     }
-  }
-  for (; r < r1; ++r) {
-    const float v = __uint_as_float((unsigned)srcp[(long)r * ld] << 16);
-    if (!any || v > best) { best = v; any = true; }
-    s += v;
-  }
-  if (is_max) {
-    z[F + k] = best;
-  } else {
-    const int cnt = r1 - r0;
-    z[2 * F + D + k] = s / (float)(cnt > 1 ? cnt : 1);
+    for (; r < r1; ++r) {
+      const float v = __uint_as_float((unsigned)srcp[(long)r * ld] << 16);
+      if (!any || v > best) { best = v; any = true; }
+      s += v;
+    }
+    if (is_max) {
+      z[F + k] = best;
+    } else {
+      const int cnt = r1 - r0;
+      z[2 * F + D + k] = s / (float)(cnt > 1 ? cnt : 1);
+    }
   }
 }
 
@@ -580,7 +594,7 @@ int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const 
 // (read per call: tests flip it in-process)
 static int yl_conv_local_mode() {
   const char* e = getenv("YOLAT_CONV_LOCAL");
-  return (e && e[0] >= '0' && e[0] <= '2') ? e[0] - '0' : 1;
+  return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;      // (3: measurement only — forced, WITHOUT the gated fall-back)
 }
 
 int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wf, const float* tf,
@@ -797,7 +811,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   a0.en.Y = nullptr; a0.en.Yh = s_slot(0); a0.en.ldy = ld_slot(0);
   const int local_mode = yl_conv_local_mode();
   const bool local = local_mode != 0 && mh->conv_local != nullptr && yl_conv_local_model_ok(mh) &&
-                     yl_node3_smallk_shape_ok(a0) && D % 8 == 0 && ZW % 4 == 0 && (local_mode == 2 || P >= 1024);
+                     yl_node3_smallk_shape_ok(a0) && D % 8 == 0 && ZW % 4 == 0 && (local_mode >= 2 || P >= 1024);
   YlGate gate{nullptr, 0};
   if (local) {
     static std::atomic<int> epoch_counter{0x10000};
@@ -837,9 +851,9 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
                                 p.Z, ZW, p.local_flag, gate.val, st));
     });
     // the fall-back's layer-0 node side (dead unless the flag was raised)
-    YL_TRY(yl_node3_smallk(a0, st, gate));
+    if (local_mode != 3) YL_TRY(yl_node3_smallk(a0, st, gate));
   }
-  for (int l = 0; l < m->n_blocks; ++l) {
+  for (int l = 0; l < m->n_blocks && !(local && local_mode == 3); ++l) {
     const yolat_conv_eval& cv = m->conv[l];
     if (l > 0) {
       snprintf(nm, sizeof nm, "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> %ld+%ld+%ld]%s", 2 * C, C, C,
@@ -855,7 +869,9 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
       a.en = plain_epilogue(); a.en.bias = cv.bn; a.en.scale = cv.sn; a.en.shift = cv.tn; a.en.relu = 1;
       a.en.Yh = s_slot(l); a.en.ldy = ld_slot(l);
       a.N = (int)N; a.C = (int)C; a.Cin = 64;
-      hipLaunchKernelGGL(k_hgemm_node3, dim3(yl_cdiv(N, 64), 4), dim3(256), 0, st, a, gate);
+      const int ntile = yl_cdiv(N, 64);
+      if (gate.p) hipLaunchKernelGGL(k_hgemm_node3_gated, dim3(ntile > 128 ? 128 : ntile, 4), dim3(256), 0, st, a, gate);
+      else hipLaunchKernelGGL(k_hgemm_node3, dim3(ntile, 4), dim3(256), 0, st, a);
       YL_LAUNCH_CHECK();
       });
     }
@@ -870,12 +886,13 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   }
 
   // ---- pooling prologue, fusion block (+ per-proposal max) | fusion_block_super, classifier
+  if (!(local && local_mode == 3))
   YL_HSTAGE(local ? "pool_prepare_bf16[max(feats), mean(fsup), zero] (gated fall-back)"
                   : "pool_prepare_bf16[max(feats), mean(fsup), zero]", 2.0 * N * D, 4.0 * N * D + 4.0 * P * (F + 2 * D), {
   for (int64_t p0 = 0; p0 < P; p0 += 65535) {
     const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
-    hipLaunchKernelGGL(k_pool_prepare_h, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)np), dim3(256), 0, st, p.feats, p.fsup, D,
-                       (int)D, (int)F, p.seg_ptr + p0, p.Z + p0 * ZW, ZW, gate);
+    hipLaunchKernelGGL(k_pool_prepare_h, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)(gate.p && np > 128 ? 128 : np)), dim3(256), 0,
+                       st, p.feats, p.fsup, D, (int)D, (int)F, p.seg_ptr + p0, p.Z + p0 * ZW, ZW, gate, (int)np);
     YL_LAUNCH_CHECK();
   }
   });

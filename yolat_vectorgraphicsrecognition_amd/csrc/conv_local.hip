@@ -44,6 +44,8 @@ typedef __bf16 cl_bf16x8 __attribute__((ext_vector_type(8)));
 typedef short cl_s16x2 __attribute__((ext_vector_type(2)));
 
 namespace {
+// tuning / debug state of yolat_conv_local_tune (0 = automatic)
+int g_cl_nw = 0, g_cl_g0 = 0, g_cl_abl = 0;
 long long* g_cl_stamps = nullptr;
 
 constexpr int CL_UVB = 272;              // UV tile row stride, bytes (128 bf16 + 16 B pad)
@@ -817,23 +819,21 @@ int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const 
   a.x = x; a.ldx = (int)ldx; a.cin0 = (int)m->conv[0].Cin;
   a.row_ptr = row_ptr; a.src = src; a.dst = dst; a.attr = attr; a.seg_ptr = seg_ptr;
   a.N = (int)N; a.E = (int)E; a.P = (int)P;
-  int nw = 4;
-  { const char* e = getenv("YOLAT_CONV_LOCAL_NW"); if (e && atoi(e) == 8) nw = 8; }
+  // 8-wave workgroups (128-node tiles, one per CU) once there are enough proposals to give each of 256 workgroups a few
+  // tiles; 4-wave workgroups (64-node tiles, two per CU) below that
+  int nw = g_cl_nw == 4 || g_cl_nw == 8 ? g_cl_nw : (P >= 2048 ? 8 : 4);
   const long slots = nw == 8 ? 256 : 512;          // one round: one 8-wave / two 4-wave workgroups per CU
   long g0 = (P + slots - 1) / slots;
   if (g0 < 4) g0 = 4;
   if (g0 > CL_GMAX) g0 = CL_GMAX;
-  {
-    const char* e = getenv("YOLAT_CONV_LOCAL_G0");
-    if (e && atoi(e) > 0 && atoi(e) <= CL_GMAX) g0 = atoi(e);
-  }
+  if (g_cl_g0 > 0 && g_cl_g0 <= CL_GMAX) g0 = g_cl_g0;
   a.G0 = (int)g0;
   a.L = m->n_blocks; a.lo = m->n_blocks - m->n_blocks_out;
   a.pack = reinterpret_cast<const unsigned char*>(pack);
   a.feats = feats; a.ld_feats = (int)ld_feats;
   a.Z = Z; a.ldz = (int)ldz; a.F = (int)m->F; a.D = (int)(m->C * m->n_blocks_out);
   a.flag = flag; a.flag_val = flag_val;
-  { const char* e = getenv("YOLAT_CONV_LOCAL_ABL"); a.abl = e ? atoi(e) : 0; }
+  a.abl = g_cl_abl;
   a.stamps = g_cl_stamps;
   if (nw == 8) hipLaunchKernelGGL(k_conv_local_h<8>, dim3((unsigned)((P + g0 - 1) / g0)), dim3(512), 0, st, a);
   else hipLaunchKernelGGL(k_conv_local_h<4>, dim3((unsigned)((P + g0 - 1) / g0)), dim3(256), 0, st, a);
@@ -856,5 +856,9 @@ extern "C" int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* mh, cons
                             ldz, flag, 1, (hipStream_t)stream);
 }
 
-// debug hook of tools/exp/conv_local_bench.py: device buffer of 64 int64 per workgroup, or NULL
-extern "C" void yolat_conv_local_debug_stamps(long long* p) { g_cl_stamps = p; }
+// tuning / debug hook (tests, tools/exp/conv_local_bench.py): waves per workgroup (4 | 8, 0 = automatic), proposals per
+// workgroup (0 = automatic), phase-ablation bits (results are then WRONG on purpose: 1 no edge steps, 2 no node phase of
+// layers >= 1, 4 no node phase of layer 0, 8 no outputs), device buffer of 64 int64 phase stamps per workgroup or NULL
+extern "C" void yolat_conv_local_tune(int nw, int g0, int abl, long long* stamps) {
+  g_cl_nw = nw; g_cl_g0 = g0; g_cl_abl = abl; g_cl_stamps = stamps;
+}

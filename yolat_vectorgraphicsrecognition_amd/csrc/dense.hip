@@ -319,10 +319,15 @@ namespace {
 __global__ void __launch_bounds__(256) k_node3_smallk(NodeUv a) {
   node3_smallk_body(a, blockIdx.x);
 }
-// the same launch as the fall-back of the one-launch conv stack (conv_local.hip): dead unless *gate != 0
-__global__ void __launch_bounds__(256) k_node3_smallk_gated(NodeUv a, YlGate gate) {
+// the same launch as the fall-back of the one-launch conv stack (conv_local.hip): dead unless the gate word holds its value
+// (a few hundred persistent workgroups walking the row blocks: as a dead launch it costs a boundary, not a dispatch of
+// thousands of workgroups)
+__global__ void __launch_bounds__(256) k_node3_smallk_gated(NodeUv a, YlGate gate, int nblocks) {
   if (yl_gate_dead(gate)) return;
-  node3_smallk_body(a, blockIdx.x);
+  for (int b = blockIdx.x; b < nblocks; b += gridDim.x) {
+    node3_smallk_body(a, b);
+    __syncthreads();
+  }
 }
 bool n3_epi_ok(const Epilogue& e) {
   if (e.accumulate || e.stats || e.seg || e.pool || e.key64 || e.agg) return false;
@@ -341,7 +346,8 @@ bool yl_node3_smallk_ok(const NodeUv& a) {             // ... and where it beats
   return a.N >= 32768 && yl_node3_smallk_shape_ok(a);
 }
 int yl_node3_smallk(const NodeUv& a, hipStream_t st, YlGate gate) {
-  if (gate.p) hipLaunchKernelGGL(k_node3_smallk_gated, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a, gate);
+  const int nb = yl_cdiv(a.N, N3_ROWS * N3_ITERS);
+  if (gate.p) hipLaunchKernelGGL(k_node3_smallk_gated, dim3(nb < 512 ? nb : 512), dim3(256), 0, st, a, gate, nb);
   else hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);
   YL_LAUNCH_CHECK();
   return 0;
