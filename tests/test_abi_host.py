@@ -223,6 +223,32 @@ def test_reference_checkpoint_with_numpy_best_value_and_optimizer_state_loads_fr
         assert torch.equal(model.state_dict()[k], v), k
 
 
+def test_reference_checkpoint_saved_under_numpy_1_loads_with_the_safe_unpickler(tmp_path):
+    """The reference's own checkpoints were written under numpy 1.x: their pickle names `numpy.core.multiarray.scalar`
+    (numpy 2.x writes `numpy._core.multiarray.scalar`).  The safe loader must accept both spellings without
+    trust_pickle."""
+    import sys
+    import yolat_vectorgraphicsrecognition_amd as yv
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    import golden_util as gu
+    from oracle import oracle_torch as orc
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt()), 8)
+    path = str(tmp_path / "ckpt_np1.pth")
+    torch.save({"epoch": 3, "state_dict": ref.state_dict(), "best_value": np.float64(0.625)}, path,
+               _use_new_zipfile_serialization=False)
+    raw = open(path, "rb").read()
+    new_name, old_name = b"numpy._core.multiarray\nscalar", b"numpy.core.multiarray\nscalar"
+    if new_name in raw:                      # running numpy 2.x: rewrite the GLOBAL to the numpy 1.x module path
+        raw = raw.replace(new_name, old_name)
+    assert old_name in raw
+    open(path, "wb").write(raw)
+    model = yv.SparseCADGCN(yv.Opt())
+    epoch, best = yv.load_reference_checkpoint(model, path)
+    assert epoch == 3 and float(best) == 0.625
+    for k, v in ref.state_dict().items():
+        assert torch.equal(model.state_dict()[k], v), k
+
+
 class _Evil(object):
     def __reduce__(self):
         return (os.system, ("echo pwned > /dev/null",))
@@ -250,6 +276,9 @@ def test_item_csr_cache_is_rebuilt_when_the_item_changes():
     item, _ = yv.synth_batch(1, 5, num_proposals=6, nodes_lo=4, nodes_hi=9)
     c0 = ydata.item_csr(item)
     assert ydata.item_csr(item) is c0                          # unchanged item: the cached entry
+    item.x.mul_(0.5)                                           # node features / boxes do not enter the CSR: a normalisation
+    item.bbox.add_(0.25)                                       # or augmentation of them keeps the sorted graph
+    assert ydata.item_csr(item) is c0
     attr0 = c0["attr"].copy()
     item.e_attr.mul_(2.0)                                      # in place (an augmentation)
     c1 = ydata.item_csr(item)

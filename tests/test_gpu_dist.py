@@ -109,30 +109,31 @@ def _nccl_worker(rank, world, port, outdir):
         model = gu.fill_state_(yv.SparseCADGCN(opt), 61).cuda()
         # premul: the buckets are doubled before their all-reduce, Adam halves them (exact) — the exchange is no longer
         # an identity; premul_fault: the same with the head bucket's exchange issued before its gradients exist
-        engine._FAULT_EARLY_HEAD_EXCHANGE = (mode == "premul_fault")
-        tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5, force_exchange=(not mode.startswith("local")),
-                        exchange_premul=(2.0 if mode.startswith("premul") else None))
-        assert tr.flat.conv_end > 0                       # the two-bucket branch is the one that runs
-        fired = []
-        if mode == "exchange":
-            real = dist.all_reduce
+        import contextlib
+        fault = engine.fault_early_head_exchange() if mode == "premul_fault" else contextlib.nullcontext()
+        with fault:
+            tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5, force_exchange=(not mode.startswith("local")),
+                            exchange_premul=(2.0 if mode.startswith("premul") else None))
+            assert tr.flat.conv_end > 0                       # the two-bucket branch is the one that runs
+            fired = []
+            if mode == "exchange":
+                real = dist.all_reduce
 
-            def spy(t, *a, **k):
-                fired.append((int(t.numel()), bool(k.get("async_op", False))))
-                return real(t, *a, **k)
-            dist.all_reduce = spy
-        data, slices = batches["big" if mode.startswith("premul") or mode == "local_big" else "small"]
-        losses = []
-        for _ in range(3):
-            data._yolat_stage = None
-            losses.append(float(tr.step(data, slices)))
-        torch.cuda.synchronize()
-        if mode == "exchange":
-            dist.all_reduce = real
-            # per step: bucket 1 (fusion + classifier) from inside the backward, bucket 2 (conv layers) after it
-            assert len(fired) == 6 and all(a for _, a in fired), fired
-            assert fired[0][0] == tr.flat.numel - tr.flat.conv_end and fired[1][0] == tr.flat.conv_end, fired
-        engine._FAULT_EARLY_HEAD_EXCHANGE = False
+                def spy(t, *a, **k):
+                    fired.append((int(t.numel()), bool(k.get("async_op", False))))
+                    return real(t, *a, **k)
+                dist.all_reduce = spy
+            data, slices = batches["big" if mode.startswith("premul") or mode == "local_big" else "small"]
+            losses = []
+            for _ in range(3):
+                data._yolat_stage = None
+                losses.append(float(tr.step(data, slices)))
+            torch.cuda.synchronize()
+            if mode == "exchange":
+                dist.all_reduce = real
+                # per step: bucket 1 (fusion + classifier) from inside the backward, bucket 2 (conv layers) after it
+                assert len(fired) == 6 and all(a for _, a in fired), fired
+                assert fired[0][0] == tr.flat.numel - tr.flat.conv_end and fired[1][0] == tr.flat.conv_end, fired
         res[mode] = (tr.flat.param.cpu().numpy().copy(), np.array(losses))
     np.savez(os.path.join(outdir, "nccl.npz"), p_ex=res["exchange"][0], p_lo=res["local"][0],
              l_ex=res["exchange"][1], l_lo=res["local"][1], p_pm=res["premul"][0], l_pm=res["premul"][1],

@@ -126,9 +126,10 @@ def _source_key(item, names):
     """(data_ptr, version counter, shape) of the tensors a cache entry was computed from: an in-place edit (augmentation,
     normalisation) or a re-assignment of any of them invalidates the entry — the same rule `_stage` applies to the
     non-csr path."""
+    d = item.__dict__          # (the attribute bag itself: `item.keys` builds a list per look-up)
     out = []
     for k in names:
-        t = item[k] if k in item.keys else None
+        t = d.get(k)
         out.append(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)))
     return tuple(out)
 
@@ -139,7 +140,9 @@ def item_csr(item):
     item's graph never changes (the reference caches its proposals the same way, Datasets/graph_dict3.py:924-929).
     Raises like ``Graph.check_status`` on ids outside [0, N) / an unsorted ``bbox_idx``."""
     c = item.__dict__.get("_yolat_csr")
-    key = _source_key(item, ("edge", "e_attr", "bbox_idx", "x", "bbox"))
+    # the CSR is a function of edge, e_attr, bbox_idx and the two row COUNTS only: an in-place normalisation / augmentation of
+    # x (or of the boxes) must not throw the sorted graph away
+    key = _source_key(item, ("edge", "e_attr", "bbox_idx")) + (int(item.x.shape[0]), int(item.bbox.shape[0]))
     if c is not None and c.get("key") == key:
         return c
     from ._lib import lib, check

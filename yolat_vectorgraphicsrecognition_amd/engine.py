@@ -229,6 +229,21 @@ def _adopt(*tensors):
 _FAULT_EARLY_HEAD_EXCHANGE = False
 
 
+class fault_early_head_exchange(object):
+    """`with engine.fault_early_head_exchange():` — the only way the fault is switched on (tests/test_gpu_dist.py): it is off
+    again however the block ends, and Trainer.step refuses to run with it outside a doubled-bucket (exchange_premul) test."""
+
+    def __enter__(self):
+        global _FAULT_EARLY_HEAD_EXCHANGE
+        _FAULT_EARLY_HEAD_EXCHANGE = True
+        return self
+
+    def __exit__(self, *exc):
+        global _FAULT_EARLY_HEAD_EXCHANGE
+        _FAULT_EARLY_HEAD_EXCHANGE = False
+        return False
+
+
 def _join_side():
     """The current stream waits for the side-stream work issued so far."""
     cur = ops.current_stream_object()

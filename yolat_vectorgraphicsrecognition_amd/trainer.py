@@ -160,11 +160,17 @@ def _load_checkpoint_file(path, trust_pickle):
     unpickler."""
     import numpy as np
     allow = [np.dtype, np.float64, np.float32, np.int64, np.ndarray]
+    core = getattr(np, "_core", None) if hasattr(np, "_core") else getattr(np, "core", None)
     for name in ("scalar", "_reconstruct"):
-        for mod in ((getattr(np, "_core", None),) if hasattr(np, "_core") else (getattr(np, "core", None),)):
-            fn = getattr(getattr(mod, "multiarray", None), name, None) if mod is not None else None
-            if fn is not None and fn not in allow:
-                allow.append(fn)
+        fn = getattr(getattr(core, "multiarray", None), name, None) if core is not None else None
+        if fn is None:
+            continue
+        allow.append(fn)
+        # the pickle names the module path of the numpy that SAVED the file: numpy 1.x (the reference's vintage,
+        # deepgcn_env_install.sh) writes numpy.core.multiarray.*, numpy 2.x numpy._core.multiarray.* — allow both spellings
+        # for the one function object (the (callable, "qualified name") form of safe_globals)
+        for legacy in ("numpy.core.multiarray.", "numpy._core.multiarray."):
+            allow.append((fn, legacy + name))
     for tname in ("Float64DType", "Float32DType", "Int64DType"):
         t = getattr(getattr(np, "dtypes", None), tname, None)
         if t is not None:
@@ -268,6 +274,10 @@ class Trainer(object):
 
     def step(self, data, slices=None):
         """One training step on this rank's batch.  Returns the (device) loss tensor."""
+        from . import engine
+        if engine._FAULT_EARLY_HEAD_EXCHANGE and self.exchange_premul is None:
+            raise RuntimeError("engine._FAULT_EARLY_HEAD_EXCHANGE is set outside its test (a leaked fault-injection flag): "
+                               "the head bucket would be exchanged before its gradients exist")
         self.model.train()
         self.optimizer.zero_grad()
         out = self.model(data, slices)
