@@ -451,20 +451,26 @@ def edge_layer_roofline(cfg_name="5", reps=10):
     out = {"kernel": "edge_uv_mlp2_mean[E=%d, N=%d, C=%d] (factorised edge MLP + mean aggregation, one kernel)" % (E, N, C),
            "traffic": None, "avg_launch_us": t * 1e6, "algorithmic_bytes": b_agg, "algorithmic_flops": f_edge,
            "hbm_equivalent_GBs": b_agg / t / 1e9, "frac": max(t_bytes, t_flops) / t,
-           "note": "frac / achieved: SURVEY 8(d) pricing of a fused kernel, max(bytes/BW, flops/peak)/t with the bytes / "
-                   "flops of the UNFACTORISED layer (B_agg, F_edge) — credit for the algebra, not pipe utilisation; "
-                   "`executed` prices the work the kernel really does",
+           "note": "credit_algorithmic_frac / achieved: SURVEY 8(d) pricing of a fused kernel, max(bytes/BW, flops/peak)/t with "
+                   "the bytes / flops of the UNFACTORISED layer (B_agg, F_edge) — credit for the algebra, not pipe "
+                   "utilisation; `executed` prices the work the kernel really does",
            "executed": {"compulsory_bytes": x_bytes, "hbm_GBs": x_bytes / t / 1e9,
                         "hbm_frac": x_bytes / t / 1e9 / PEAK_HBM_GBS,
                         "fp32_equivalent_flops": x_flops_f32, "fp32_equivalent_TFLOPs": x_flops_f32 / t / 1e12,
                         "bf16_mfma_flops": x_flops_bf16, "bf16_mfma_frac": x_flops_bf16 / t / 1e12 / PEAK_MFMA_BF16_TFLOPS,
                         "frac_of_executed_bound": x_bound / t,
-                        "limiter": "VALU issue (PMC: profiles/r02_edge_x6_pmc_sq.txt, VALU busy ~60 % of the kernel; "
-                                   "operand splits + gather-add + epilogue), not HBM or the matrix cores"}}
+                        "limiter": "VALU issue (PMC: profiles/r04_fwd_cfg5_pmc_sq_a.txt, _b.txt: SQ_ACTIVE_INST_VALU 56 % of "
+                                   "SQ_BUSY_CYCLES x 8; operand splits + gather-add + epilogue), not HBM or the matrix cores"}}
     if t_flops > t_bytes:
         out.update(bound="mfma", achieved=f_edge / t / 1e12, peak=PEAK_MFMA_F32_TFLOPS, unit="TFLOP/s")
     else:
         out.update(bound="hbm", achieved=b_agg / t / 1e9, peak=PEAK_HBM_GBS, unit="GB/s")
+    # like the sub-records (utilisation_view): `frac` is a utilisation figure (<= 1), what is priced on the unfactorised
+    # layer's algorithmic work is credit
+    out["credit_algorithmic_frac"] = out.pop("frac")
+    out["frac"] = out["executed"]["frac_of_executed_bound"]
+    out["frac_kind"] = "max(compulsory bytes / 8 TB/s, bf16 MFMA flops issued / 2.5 PF) / t: the executed work against its bound"
+    out["achieved_note"] = "`achieved` is algorithmic work / t (credit); `frac` is the utilisation figure"
     return out
 
 
@@ -785,6 +791,31 @@ def single_rank_nccl_dp_record(yv, gu, steps=10):
             dist.destroy_process_group()
 
 
+def participation_record(ms_local, world):
+    """What makes an N > 1 line self-verifying: `ranks_seen` = a SUM all-reduce of ones over the collective backend (= N only
+    if N ranks took part in the same group), every rank's OWN ms/step (all-gather), its device and host, the backend and
+    the RCCL version."""
+    import socket
+    import torch.distributed as dist
+    dev = "cuda" if dist.get_backend() == "nccl" else "cpu"
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    mine = torch.tensor([ms_local], dtype=torch.float64, device=dev)
+    gathered = [torch.zeros_like(mine) for _ in range(world)]
+    dist.all_gather(gathered, mine)
+    ids = [None] * world
+    me = {"rank": dist.get_rank(), "host": socket.gethostname(),
+          "device": (torch.cuda.current_device() if torch.cuda.is_available() else None),
+          "device_name": (torch.cuda.get_device_name() if torch.cuda.is_available() else None)}
+    dist.all_gather_object(ids, me)
+    try:
+        ver = ".".join(str(v) for v in torch.cuda.nccl.version()) if dist.get_backend() == "nccl" else None
+    except Exception:
+        ver = None
+    return {"ranks_seen": int(round(float(ones.item()))), "world_size": world, "backend": dist.get_backend(),
+            "rccl_version": ver, "per_rank_ms_per_step": [round(float(t.item()), 5) for t in gathered], "ranks": ids}
+
+
 def train_dp_record(yv, gu, rank, world, steps, warmup):
     """BASELINE.json configs[3]: Diagrams-style batches of 32 graphs per rank (K = 22), one training step = forward +
     CE + backward + RCCL all-reduce of the flat gradient (two async buckets overlapping the conv backward) + Adam.
@@ -797,16 +828,21 @@ def train_dp_record(yv, gu, rank, world, steps, warmup):
     to_device(data)
     trainer = yv.Trainer(model, opt, lr=2.5e-4, weight_decay=1e-5)
 
-    def timed(fn, n):
+    own = {}
+
+    def timed(fn, n, name=None):
         dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         for _ in range(n):
             fn()
         torch.cuda.synchronize()
+        t_own = time.perf_counter() - t0              # this rank's own time, before it waits for the others
         dist.barrier()
         t = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        if name:
+            own[name] = t_own / n * 1e3
         return float(t.item()) / n
 
     def step():
@@ -815,7 +851,7 @@ def train_dp_record(yv, gu, rank, world, steps, warmup):
 
     for _ in range(max(warmup, 3)):
         step()
-    t_step = timed(step, steps)
+    t_step = timed(step, steps, "step")
     trainer.exchange_gradients = False
     for _ in range(2):
         step()
@@ -836,7 +872,8 @@ def train_dp_record(yv, gu, rank, world, steps, warmup):
             "exchange_cost_ms_after_overlap": (t_step - t_local) * 1e3, "allreduce_bytes": nbytes,
             "allreduce_alone_ms": t_ar * 1e3, "allreduce_alone_GBs": nbytes / t_ar / 1e9, "steps": steps,
             "collective": "2 async SUM all-reduces per step (fusion+classifier bucket during the conv backward, conv "
-                          "bucket after it) over %s" % dist.get_backend()}
+                          "bucket after it) over %s" % dist.get_backend(),
+            "participation": participation_record(own["step"], world)}
 
 
 def main():
@@ -928,7 +965,9 @@ def main():
         step()
     barrier()
     elapsed = time.perf_counter() - t0
+    dist_proof = None
     if world > 1:
+        dist_proof = participation_record(elapsed / args.steps * 1e3, world)      # every rank's own time, before the MAX
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -1069,6 +1108,7 @@ def main():
             "value": n_graphs * world * args.steps / elapsed,
             "unit": "graphs/s",
             "n_gpus": world,
+            "participation": dist_proof,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms,

@@ -72,3 +72,29 @@ def test_single_process_allreduce_is_identity():
     assert trainer.allreduce_mean_(g) == 1.0
     assert torch.equal(g, torch.arange(5.0))
     assert trainer.shard_graph_ids(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def _proof_worker(rank, world, port, out):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(os.path.dirname(os.path.dirname(
+        os.path.abspath(__file__))), "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+    out[rank] = bench.participation_record(1.5 + rank, world)
+    dist.destroy_process_group()
+
+
+def test_bench_participation_record_world2():
+    """bench.py's N > 1 proof (ranks_seen, per-rank ms / step, rank identities) over a two-rank gloo group"""
+    world, port = 2, _free_port()
+    mgr = mp.Manager()
+    out = mgr.dict()
+    mp.spawn(_proof_worker, args=(world, port, out), nprocs=world, join=True)
+    for rank in range(world):
+        pr = out[rank]
+        assert pr["ranks_seen"] == 2 and pr["world_size"] == 2 and pr["backend"] == "gloo" and pr["rccl_version"] is None
+        assert pr["per_rank_ms_per_step"] == [1.5, 2.5]
+        assert [r["rank"] for r in pr["ranks"]] == [0, 1]

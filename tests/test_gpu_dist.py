@@ -192,3 +192,9 @@ def test_bench_line_with_two_ranks_launched_the_way_the_driver_launches_them():
     assert d["metric"] == "graphs_per_sec" and d["value"] > 0 and d["higher_is_better"] is True
     # aggregate = graphs of both ranks per step / the slowest rank's time
     assert abs(d["value"] - 2.0 / (d["ms_per_step"] * 1e-3)) <= 1e-6 * d["value"]
+    # the N > 1 line proves that N ranks took part: a SUM all-reduce of ones, every rank's own ms / step, who they were
+    pr = d["participation"]
+    assert pr["ranks_seen"] == 2 and pr["world_size"] == 2 and pr["backend"] == "gloo"
+    assert len(pr["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in pr["per_rank_ms_per_step"])
+    assert max(pr["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-6) + 1e-9
+    assert sorted(r_["rank"] for r_ in pr["ranks"]) == [0, 1]
