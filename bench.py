@@ -1019,6 +1019,25 @@ def main():
         # item by the library's host code) and merged into the batch's by offset-add at collate time (csr=True): the
         # forward skips the COO -> CSR conversion, the staging buffer carries int32 CSR arrays instead of int64 COO
         h2d_csr = handover_rate(True)
+
+        # the same hand-over OFF this thread: data.DeviceLoader (csrc/loader.hip: native worker thread, ring of pinned /
+        # device slots, copy stream + events) collates and copies batch i + 1 while batch i's forward is enqueued and runs
+        def loader_rate():
+            def run(n):
+                loader = yv.DeviceLoader(([cpu_item] for _ in range(n)), slots=3)
+                with torch.no_grad():
+                    for b, sl in loader:
+                        model(b, sl)
+                torch.cuda.synchronize()
+                loader.close()
+            run(40)
+            rates = []
+            for _ in range(5):
+                t2 = time.perf_counter()
+                run(200)
+                rates.append(n_graphs * 200 / (time.perf_counter() - t2))
+            return sorted(rates)[2]
+        h2d_loader = loader_rate()
         # merged mode with the batch resident: one forward at a time on the prepared graph
         b, sl = yv.collate_to_device([cpu_item], csr=True)
         for _ in range(5):
@@ -1031,7 +1050,8 @@ def main():
                 model(b, sl)
         torch.cuda.synchronize()
         merged_ms = (time.perf_counter() - t2) / nh * 1e3
-        csr_mode = {"h2d_inclusive_graphs_per_sec": h2d_csr, "ms_per_forward_resident": merged_ms,
+        csr_mode = {"h2d_inclusive_graphs_per_sec": h2d_csr, "h2d_inclusive_graphs_per_sec_device_loader": h2d_loader,
+                    "ms_per_forward_resident": merged_ms,
                     "note": "per-item CSR cached on the dataset item (host, once), merged by offset-add at collate "
                             "(yolat_collate_csr_pack), forward on the prepared graph (yolat_forward_eval_csr); the "
                             "headline keeps csr_rebuilt_each_step = true"}
@@ -1159,6 +1179,7 @@ def main():
             "train_cfg5_bf16_ms": pick(line, "train_cfg5_bf16", "ms_per_step"),
             "csr_merged_ms": pick(line, "csr_merged_mode", "ms_per_forward_resident"),
             "csr_merged_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec"),
+            "loader_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec_device_loader"),
             "h2d_inclusive_gps": pick(line, "h2d_inclusive_graphs_per_sec"), "multi_stream_gps": pick(line, "multi_stream", "value"),
             "floorplans_ms": pick(line, "floorplans_sized", "ms_per_forward"),
             "floorplans_x_cpu": pick(line, "floorplans_sized", "speedup_vs_cpu_one_at_a_time"),

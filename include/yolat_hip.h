@@ -576,6 +576,34 @@ typedef struct {
 int yolat_collate_batch(const yolat_item_desc* const* items, int64_t B, void* dst, int64_t cap, int64_t* off,
                         int64_t* total, int64_t* slices, int64_t* totals);
 
+/* The same hand-over OFF the consumer's thread (loader.hip; the reference hides collate behind DataLoader(num_workers=8)
+ * worker processes, cad_recognition/train.py:178-189, and copies six tensors synchronously inside forward(),
+ * architecture3cc_rpn_gp_iter2.py:107-115).  One native worker thread per loader runs yolat_collate_batch into a ring of
+ * `slots` (2..16) pinned staging buffers and enqueues ONE asynchronous H2D copy per batch on the loader's own stream while the
+ * consumer still works on the previous batch.
+ *   submit   queue a batch (the pointer list is copied; the descriptors and the arrays they point to must stay alive
+ *            until yolat_loader_next has returned this batch).  Batches come out in submission order.
+ *   next     blocks (host) until the oldest submitted batch's copy has been ENQUEUED, makes `consumer_stream` wait for
+ *            that copy (stream-side) and describes the batch: `device` holds, at byte offsets off[0 .. n_keys + 5], key
+ *            0 .. n_keys - 1, then row_ptr, src, dst, attr, seg_ptr, node_seg (yolat_collate_batch's layout); slices as
+ *            yolat_collate_batch writes them (valid until the slot is released).  Returns the batch's error code.
+ *   release  the consumer has enqueued everything that reads the slot's device buffer on `consumer_stream`: the slot is
+ *            rewritten once that work has completed.  Every batch obtained from next must be released.
+ * create uses the calling thread's current HIP device.  submit / next / release are meant for ONE consumer thread.   */
+typedef struct yolat_loader yolat_loader;
+typedef struct {
+  void* device;
+  int64_t total, n_keys, B, N, E, P;
+  int64_t off[YOLAT_MAX_KEYS + 6];
+  const int64_t* slices;
+  int32_t slot, rc;
+} yolat_loader_batch;
+yolat_loader* yolat_loader_create(int slots);
+int yolat_loader_submit(yolat_loader* loader, const yolat_item_desc* const* items, int64_t B);
+int yolat_loader_next(yolat_loader* loader, yolat_stream_t consumer_stream, yolat_loader_batch* out);
+int yolat_loader_release(yolat_loader* loader, int slot, yolat_stream_t consumer_stream);
+void yolat_loader_destroy(yolat_loader* loader);
+
 /* A prepared graph on the DEVICE (the outputs of yolat_graph_prepare, or the device copy of yolat_collate_csr_pack's
  * staging) for the forwards below: the forward then skips the COO -> CSR conversion (4 launches) and runs the first
  * layer's node side as a launch of its own.  The caller has validated the ids (host status word).                      */

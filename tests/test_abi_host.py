@@ -21,7 +21,7 @@ def _header_decls():
     src = open(os.path.join(REPO, "include", "yolat_hip.h")).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|size_t|int64_t|void|const char\*)\s+(yolat_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|size_t|int64_t|void|const char\*|yolat_loader\*)\s+(yolat_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         args = m.group(2).strip()
         n = 0 if args in ("", "void") else len([a for a in args.split(",") if a.strip()])
         decls[m.group(1)] = n

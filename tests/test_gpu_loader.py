@@ -1,0 +1,105 @@
+"""GPU tests (-m gpu) of the native batch loader (csrc/loader.hip, data.DeviceLoader): collate + offset fix-up + merged CSR +
+the one host -> device copy of a batch on a native worker thread, a ring of pinned / device slots, events instead of host
+synchronisation.  Reference behaviour: cad_recognition/train.py:123-171,238-258 (collate + fix-up; the bytes are those of
+yolat_collate_batch, pinned by tests/test_abi_host.py against the reference's own collate) behind
+DataLoader(num_workers=8), train.py:178-189."""
+import numpy as np
+import pytest
+import torch
+
+import golden_util as gu
+
+pytestmark = pytest.mark.gpu
+
+
+def _yv():
+    import yolat_vectorgraphicsrecognition_amd as yv
+    return yv
+
+
+def _lists(yv, n_lists, seed0=0, with_roots=False):
+    out = []
+    for i in range(n_lists):
+        items = [yv.synth_graph(num_proposals=5 + 7 * ((i + j) % 4), nodes_lo=3, nodes_hi=9 + 3 * j, edge_factor=1.3,
+                                seed=seed0 + 10 * i + j, with_roots=with_roots) for j in range(1 + i % 3)]
+        out.append(items)
+    return out
+
+
+def _same_batch(yv, got, want):
+    (gb, gs), (wb, ws) = got, want
+    assert sorted(gs.keys()) == sorted(ws.keys())
+    for k in ws:
+        assert torch.equal(torch.as_tensor(gs[k]), torch.as_tensor(ws[k])), k
+    for k in wb.keys:
+        a, b = gb[k], wb[k]
+        if isinstance(b, torch.Tensor):
+            assert a.dtype == b.dtype and a.shape == b.shape and a.device.type == b.device.type, k
+            assert torch.equal(a, b), k
+    gg, wg = gb._yolat_graph, wb._yolat_graph
+    assert (gg.N, gg.E, gg.P) == (wg.N, wg.E, wg.P)
+    for name in ("row_ptr", "src", "dst", "attr", "seg_ptr", "node_seg"):
+        assert torch.equal(getattr(gg, name), getattr(wg, name)), name
+
+
+def test_device_loader_batches_are_bit_identical_to_collate_to_device():
+    """ragged batches of 1..3 items of different sizes (so that the ring's buffers grow), in order; tensors, slices and the
+    merged destination-sorted graph equal what collate_to_device(items, csr=True) ships"""
+    yv = _yv()
+    lists = _lists(yv, 9)
+    # a late, much larger batch: the slot it lands in must be re-allocated
+    lists.append([yv.synth_graph(num_proposals=300, nodes_lo=4, nodes_hi=30, seed=991)])
+    lists += _lists(yv, 3, seed0=500)
+    loader = yv.DeviceLoader(lists, slots=3)
+    n = 0
+    for (batch, slices), items in zip(loader, lists):
+        want = yv.collate_to_device(items, csr=True)
+        _same_batch(yv, (batch, slices), want)
+        n += 1
+    assert n == len(lists)
+    with pytest.raises(StopIteration):
+        next(loader)
+    loader.close()
+
+
+def test_device_loader_forward_soak_1000_batches_no_stale_or_overwritten_buffers():
+    """1000 batches cycling over 7 different item lists through a 3-slot ring with a forward on each: every batch's logits
+    equal the logits of the same items handed over synchronously — a slot rewritten while its forward is still in flight,
+    or read before its copy has landed, shows up as a mismatch"""
+    yv = _yv()
+    lists = _lists(yv, 7, seed0=40)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 5).cuda().eval()
+    want = []
+    with torch.no_grad():
+        for items in lists:
+            b, sl = yv.collate_to_device(items, csr=True)
+            want.append(model(b, sl)[0].clone())
+    torch.cuda.synchronize()
+    seq = [i % len(lists) for i in range(1000)]
+    loader = yv.DeviceLoader((lists[i] for i in seq), slots=3)
+    outs = []
+    with torch.no_grad():
+        for k, (batch, slices) in enumerate(loader):
+            outs.append((seq[k], model(batch, slices)[0]))      # no synchronisation between batches
+    torch.cuda.synchronize()
+    assert len(outs) == 1000
+    bad = [k for k, (i, o) in enumerate(outs) if not torch.equal(o, want[i])]
+    assert not bad, "batches %s differ from the synchronous hand-over" % bad[:10]
+    loader.close()
+
+
+def test_device_loader_close_with_batches_in_flight_and_host_keys():
+    """the loader can be dropped with submitted batches not drawn (worker joined, slots handed back); non-tensor keys
+    (`roots`) are assembled on the host like collate does"""
+    yv = _yv()
+    lists = _lists(yv, 6, seed0=77, with_roots=True)
+    loader = yv.DeviceLoader(lists, slots=4)
+    batch, slices = next(loader)
+    wb, ws = yv.collate_to_device(lists[0], csr=True)
+    assert len(batch.roots) == len(wb.roots) and torch.equal(torch.as_tensor(slices["roots"]), torch.as_tensor(ws["roots"]))
+    loader.close()
+    loader.close()                 # idempotent
+    # a second loader right after: fresh worker, fresh ring
+    l2 = yv.DeviceLoader(lists[:2], slots=2)
+    assert sum(1 for _ in l2) == 2
+    l2.close()

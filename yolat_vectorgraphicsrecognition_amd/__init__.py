@@ -17,7 +17,7 @@ from . import _lib  # noqa: F401  (raises if libyolat_hip.so is missing)
 from . import ops, engine  # noqa: F401
 from .nn_modules import MultiSeq, MLP, GraphConv, ResBlock, scatter  # noqa: F401
 from .architecture import Backbone, SparseCADGCN, DetectionLoss, Opt  # noqa: F401
-from .data import (Data, collate, collate_to_device, item_csr, fixup_offsets, synth_graph, synth_batch, synth_roots, idxTree, config,  # noqa: F401
+from .data import (Data, DeviceLoader, collate, collate_to_device, item_csr, fixup_offsets, synth_graph, synth_batch, synth_roots, idxTree, config,  # noqa: F401
                    select_tree_nodes, build_subset)
 from .postprocess import non_max_suppression, get_batch_statistics, ap_per_class, compute_ap, bbox_iou  # noqa: F401
 from .evaluation import evaluate_batch, test as evaluate  # noqa: F401

@@ -73,6 +73,13 @@ class ItemDesc(ctypes.Structure):
     _fields_ = [("n_keys", c_i64), ("key", Span * YOLAT_MAX_KEYS), ("rows", c_i64 * YOLAT_MAX_KEYS), ("csr", ItemCsr)]
 
 
+class LoaderBatch(ctypes.Structure):
+    """yolat_loader_batch"""
+    _fields_ = [("device", c_p), ("total", c_i64), ("n_keys", c_i64), ("B", c_i64), ("N", c_i64), ("E", c_i64), ("P", c_i64),
+                ("off", c_i64 * (YOLAT_MAX_KEYS + 6)), ("slices", ctypes.POINTER(c_i64)), ("slot", ctypes.c_int32),
+                ("rc", ctypes.c_int32)]
+
+
 class GraphCsr(ctypes.Structure):
     """yolat_graph_csr"""
     _fields_ = [("row_ptr", c_p), ("src", c_p), ("dst", c_p), ("attr", c_p), ("seg_ptr", c_p), ("node_seg", c_p)]
@@ -229,6 +236,11 @@ SIGNATURES = {
                                      c_p]),
     "yolat_collate_csr_pack": (c_int, [ctypes.POINTER(ItemCsr), c_i64, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_collate_batch": (c_int, [c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_p]),
+    "yolat_loader_create": (c_p, [c_int]),
+    "yolat_loader_submit": (c_int, [c_p, c_p, c_i64]),
+    "yolat_loader_next": (c_int, [c_p, c_p, ctypes.POINTER(LoaderBatch)]),
+    "yolat_loader_release": (c_int, [c_p, c_int, c_p]),
+    "yolat_loader_destroy": (None, [c_p]),
     "yolat_forward_eval_csr": (c_int, [ctypes.POINTER(ModelEval), c_p, c_i64, ctypes.POINTER(GraphCsr), c_i64, c_i64,
                                         c_i64, c_p, c_i64, c_p, c_sz, c_p]),
     "yolat_forward_eval_bf16_csr": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, ctypes.POINTER(GraphCsr), c_i64,

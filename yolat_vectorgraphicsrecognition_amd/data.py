@@ -321,16 +321,7 @@ def collate_to_device(data_list, device="cuda", csr=False):
             slices[k] = torch.from_numpy(ends)
     # host-side assembly of everything that is not a device tensor
     if rest:
-        host_items = [first.__class__(**{k: it[k] for k in rest}) for it in data_list]
-        hb, hs = collate(host_items)
-        for k in rest:
-            batch[k] = hb[k]
-            slices[k] = hs[k]
-        node_slices = slices["pos"] if "pos" in slices else slices["x"]
-        for k in rest:                 # host-resident index tensors get the reference's fix-up too (train.py:244)
-            if "edge" in k and isinstance(batch[k], torch.Tensor) and batch[k].dtype == torch.long:
-                for i in range(B):
-                    batch[k][int(slices[k][i]):int(slices[k][i + 1])] += node_slices[i]
+        _collate_host_keys(data_list, rest, batch, slices)
     if csr:
         return batch, slices
     node_ptr = slices["pos"] if "pos" in slices else slices["x"]
@@ -394,6 +385,255 @@ def collate_to_device(data_list, device="cuda", csr=False):
                                   ops._stream()), "yolat_fixup_offsets")
     batch._device_buffer = dbuf
     return batch, slices
+
+
+class _Thunk(object):
+    __slots__ = ("fn",)
+
+    def __init__(self, fn):
+        self.fn = fn
+
+
+class _LazySlices(dict):
+    """`slices` of a DeviceLoader batch: a dict whose values are produced on first access (the forward never reads them)."""
+
+    def __getitem__(self, k):
+        v = dict.__getitem__(self, k)
+        if isinstance(v, _Thunk):
+            v = v.fn()
+            dict.__setitem__(self, k, v)
+        return v
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def _all(self):
+        for k in list(dict.keys(self)):
+            self[k]
+
+    def items(self):
+        self._all()
+        return dict.items(self)
+
+    def values(self):
+        self._all()
+        return dict.values(self)
+
+    def copy(self):
+        self._all()
+        return dict(dict.items(self))
+
+
+class _LazyBatch(Data):
+    """The batch of a DeviceLoader: attributes listed in `_lazy` (views of the device buffer other than x, host-side keys)
+    are produced on first access."""
+
+    def __init__(self):
+        pass
+
+    def __getattr__(self, name):               # only reached when the normal look-up fails
+        lz = self.__dict__.get("_lazy")
+        if lz is not None and name in lz:
+            v = lz.pop(name)()
+            self.__dict__[name] = v
+            return v
+        raise AttributeError(name)
+
+    @property
+    def keys(self):
+        lz = self.__dict__.get("_lazy")
+        for name in list(lz or ()):
+            getattr(self, name)
+        return Data.keys.fget(self)
+
+
+class _DeviceMemory(object):
+    """A device allocation owned by the native loader as a zero-copy torch tensor (CUDA array interface)."""
+
+    def __init__(self, ptr, nbytes):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False), "version": 2}
+
+
+class DeviceLoader(object):
+    """Iterator over device batches whose collate + host -> device copy run on a NATIVE worker thread
+    (csrc/loader.hip) while the consumer still works on the previous batch — what the reference gets from
+    DataLoader(num_workers=8) (train.py:178-189) plus the six .cuda() copies of forward() (arch:107-115), without a Python
+    thread in the way.
+
+        for batch, slices in DeviceLoader(lists_of_items):      # lists_of_items: iterable of lists of CPU `Data`
+            logits, boxes = model(batch, slices)
+
+    Every batch is what ``collate_to_device(items, csr=True)`` returns (bit-identical: same native call), i.e. it carries
+    the merged destination-sorted graph (``item_csr`` of each item, cached on the item) instead of edge / e_attr /
+    bbox_idx.  A batch's tensors live in the loader's ring of ``slots`` device buffers: they are valid until ``slots - 1``
+    further batches have been drawn, and everything that reads them must have been ENQUEUED on the current stream by the
+    time the next batch is drawn (the loader then hands the slot back behind an event on that stream)."""
+
+    def __init__(self, batches, device="cuda", slots=3):
+        from ._lib import lib
+        if slots < 2:
+            raise ValueError("DeviceLoader needs at least two slots")
+        self._it = iter(batches)
+        self._device = torch.device(device)
+        self._slots = int(slots)
+        with torch.cuda.device(self._device):
+            self._h = lib.yolat_loader_create(self._slots)
+        if not self._h:
+            raise RuntimeError("yolat_loader_create failed")
+        self._pending = []          # submitted, not yet drawn: (items, ship, tkeys, rest, pointer array)
+        self._held = None           # slot of the batch the consumer holds
+        self._mem = {}              # slot -> (ptr, capacity, tensor)
+        self._done = False
+
+    def __iter__(self):
+        return self
+
+    def _submit_one(self):
+        from ._lib import lib, check
+        if self._done:
+            return False
+        try:
+            items = next(self._it)
+        except StopIteration:
+            self._done = True
+            return False
+        items = list(items)
+        first = items[0]
+        keys = first.keys
+        tkeys = [k for k in keys if isinstance(first[k], torch.Tensor) and first[k].dim() > 0 and k in _DEVICE_KEYS]
+        rest = [k for k in keys if k not in tkeys]
+        ship = tuple(k for k in tkeys if k not in _CSR_SKIP)
+        ptrs = (ctypes.c_void_p * len(items))(*[ctypes.addressof(_item_desc(it, ship)) for it in items])
+        check(lib.yolat_loader_submit(self._h, ptrs, len(items)), "yolat_loader_submit")
+        self._pending.append((items, ship, tkeys, rest, ptrs))
+        return True
+
+    def __next__(self):
+        from . import ops
+        from ._lib import lib, check, LoaderBatch
+        stream = ops._stream()
+        if self._held is not None:       # the consumer is done ENQUEUEING on the previous batch
+            check(lib.yolat_loader_release(self._h, self._held, stream), "yolat_loader_release")
+            self._held = None
+        while len(self._pending) < self._slots - 1 and self._submit_one():
+            pass
+        if not self._pending:
+            raise StopIteration
+        items, ship, tkeys, rest, _ptrs = self._pending.pop(0)
+        out = LoaderBatch()
+        check(lib.yolat_loader_next(self._h, stream, ctypes.byref(out)), "yolat_loader_next")
+        self._held = int(out.slot)
+        while len(self._pending) < self._slots - 1 and self._submit_one():      # keep the worker busy under the forward
+            pass
+        B, nk = len(items), len(ship)
+        mem = self._mem.get(self._held)
+        if mem is None or mem[0] != out.device or mem[1] < out.total:
+            t = torch.as_tensor(_DeviceMemory(out.device, out.total), device=self._device)
+            mem = self._mem[self._held] = (out.device, int(out.total), t)
+        dbuf = mem[2][:int(out.total)]
+        sl = np.ctypeslib.as_array(out.slices, shape=(nk * (B + 1) + 1,))[:nk * (B + 1)].reshape(nk, B + 1).copy()
+        offs = [int(out.off[i]) for i in range(nk + 6)]
+        first = items[0]
+        # Only what every forward reads is made eagerly (x, the prepared graph); the other batched tensors, the slices and
+        # the host-side keys are produced on first access — a hand-over is bound by this thread's Python, ~10 us per
+        # tensor view / small tensor
+        batch = _LazyBatch()
+        slices = _LazySlices()
+        typed = {}
+
+        def view(o, dtype, shape):
+            b = typed.get(dtype)
+            if b is None:
+                b = typed[dtype] = dbuf.view(dtype)
+            es = b.element_size()
+            n = 1
+            for d_ in shape:
+                n *= d_
+            return b[o // es:o // es + n].view(shape)
+
+        lazy = batch.__dict__["_lazy"] = {}
+        for f, k in enumerate(ship):
+            t = first[k]
+            make = (lambda o=offs[f], dt=t.dtype, shp=(int(sl[f, B]),) + tuple(t.shape[1:]): view(o, dt, shp))
+            if k == "x":
+                batch.x = make()
+            else:
+                lazy[k] = make
+            dict.__setitem__(slices, k, _Thunk(lambda f=f: torch.from_numpy(sl[f])))
+        for k in tkeys:
+            if k not in slices:
+                def ends_of(k=k):
+                    ends = np.zeros(B + 1, dtype=np.int64)
+                    np.cumsum([it[k].shape[0] for it in items], out=ends[1:])
+                    return torch.from_numpy(ends)
+                dict.__setitem__(slices, k, _Thunk(ends_of))
+        if rest:
+            host = {}
+
+            def host_keys():
+                if not host:
+                    hb, hs = first.__class__(), {}
+                    for k in tkeys:                     # the fix-up of host-resident edge tensors needs the node slices
+                        hs[k] = slices[k]
+                    _collate_host_keys(items, rest, hb, hs)
+                    host["b"], host["s"] = hb, hs
+                return host
+            for k in rest:
+                lazy[k] = (lambda k=k: host_keys()["b"][k])
+                dict.__setitem__(slices, k, _Thunk(lambda k=k: host_keys()["s"][k]))
+        g = ops.PackedGraph.from_buffer(dbuf, offs[nk:nk + 6], int(out.N), int(out.E), int(out.P))
+        batch.__dict__["_yolat_graph"] = g
+        batch.__dict__["_device_buffer"] = dbuf
+        return batch, slices
+
+    def close(self):
+        from ._lib import lib
+        if getattr(self, "_h", None):
+            if self._held is not None:
+                lib.yolat_loader_release(self._h, self._held, ops_stream_or_zero())
+                self._held = None
+            # draw (and hand back) what the worker has already been given: it may hold pointers into the items
+            from ._lib import LoaderBatch
+            while self._pending:
+                self._pending.pop(0)
+                out = LoaderBatch()
+                if lib.yolat_loader_next(self._h, ops_stream_or_zero(), ctypes.byref(out)) == 0:
+                    lib.yolat_loader_release(self._h, int(out.slot), ops_stream_or_zero())
+            torch.cuda.synchronize(self._device)
+            lib.yolat_loader_destroy(self._h)
+            self._h = None
+            self._mem.clear()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def ops_stream_or_zero():
+    from . import ops
+    try:
+        return ops._stream()
+    except Exception:
+        return 0
+
+
+def _collate_host_keys(data_list, rest, batch, slices):
+    """host-side assembly of everything that is not a device tensor (roots ...), with the reference's index fix-up of
+    host-resident edge tensors (train.py:244)"""
+    first = data_list[0]
+    B = len(data_list)
+    host_items = [first.__class__(**{k: it[k] for k in rest}) for it in data_list]
+    hb, hs = collate(host_items)
+    for k in rest:
+        batch[k] = hb[k]
+        slices[k] = hs[k]
+    node_slices = slices["pos"] if "pos" in slices else slices["x"]
+    for k in rest:
+        if "edge" in k and isinstance(batch[k], torch.Tensor) and batch[k].dtype == torch.long:
+            for i in range(B):
+                batch[k][int(slices[k][i]):int(slices[k][i + 1])] += node_slices[i]
 
 
 # --------------------------------------------------------------------------------------

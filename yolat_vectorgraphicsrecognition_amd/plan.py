@@ -54,12 +54,13 @@ class EvalPlan(object):
         self._ws = None
         self._status = None
         self._graphs = {}
+        self._need = {}           # (N, E, P, descriptor build) -> workspace bytes of the prepared-graph forward
         self._primed = None        # (workspace, descriptor build, N, E, P, stream) of the last completed direct launch
         self._desc_key = 0
         self.use_graph = False      # model.use_hip_graphs(True) turns the captured-graph replay on
 
     def _version_key(self):
-        return tuple(t._version for t in self._tensors) + (self._tensors[0].data_ptr(), ops.weight_epoch())
+        return tuple([t._version for t in self._tensors]) + (self._tensors[0].data_ptr(), ops.weight_epoch())
 
     def _build(self):
         self._desc_key += 1
@@ -299,18 +300,25 @@ class EvalPlan(object):
 
     def run_prepared(self, x, g):
         """The forward on a prepared device graph (ops.Graph; yolat_forward_eval_csr / _bf16_csr): no COO -> CSR
-        conversion inside the call.  (hipGraph replay of this path was measured and dropped: batches arrive in fresh
-        allocations, so captured graphs rarely match — 4.3 k vs 6.2 k graphs/s H2D-inclusive at cfg 2.)"""
+        conversion inside the call.  (hipGraph replay of this path was measured and dropped twice: batches arrive in fresh
+        allocations, so captured graphs rarely match — 4.3 k vs 6.2 k graphs/s H2D-inclusive at cfg 2, round 3; keyed by the
+        fixed slot addresses of a data.DeviceLoader ring they do match, and replay + the copy out of the static output
+        still lose to seven direct launches — 7.3 k vs 7.9 k graphs/s, round 5.)"""
         key = self._version_key()
         if key != self._key:
             self._build()
             self._key = key
             self._graphs.clear()
         N, E, P = g.N, g.E, g.P
-        if self._desc_h is not None:
-            need = int(lib.yolat_forward_eval_bf16_workspace_bytes(ctypes.byref(self._desc_h), N, E, P))
-        else:
-            need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
+        need = self._need.get((N, E, P, self._desc_key))
+        if need is None:
+            if self._desc_h is not None:
+                need = int(lib.yolat_forward_eval_bf16_workspace_bytes(ctypes.byref(self._desc_h), N, E, P))
+            else:
+                need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
+            if len(self._need) > 64:
+                self._need.clear()
+            self._need[(N, E, P, self._desc_key)] = need
         if self._ws is None or self._ws.numel() < need:
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=x.device)
             self._graphs.clear()
