@@ -1077,6 +1077,113 @@ __global__ void __launch_bounds__(256) k_gemm_nt_sk(AL A, BL B, Epilogue ep, int
 }
 
 // ------------------------------------------------------------------------------------------------
+// EXPERIMENT (round 5): k_gemm_nt_sk with its operand tiles brought in by LDS-DMA
+// (global_load_lds_dwordx4: global -> LDS without passing through registers) instead of global -> VGPR -> ds_write.
+// The DMA writes a wave's 64 x 16 bytes to CONSECUTIVE LDS addresses, so the tile rows cannot be padded; the bank
+// conflicts of the fragment reads are avoided by swizzling the 16-byte granules through the per-lane SOURCE address:
+//   LDS[row r][granule g'] = X[r][k0 + 4 (g' ^ (r & 15))]          (32 granules of 4 floats per 128-deep row)
+// and the MFMA operands are read with ds_read_b128 (16 lanes = 16 rows at one logical granule hit 16 different bank
+// groups) instead of 4 x ds_read_b32 on a 129-float padded row.  Two LDS stages; a stage's 8 DMA pieces per wave are
+// waited for with a counted vmcnt, the barrier is the raw one (no vmcnt drain), so the next stage's pieces stay in flight
+// under the MFMAs.  Same products in the same order as k_gemm_nt_sk (wave w owns k = 32 w .. 32 w + 31 of every chunk, in
+// steps of two): bit-identical results.  Plain row-major operands only (16-byte aligned rows, K % 128 == 0).
+// Selected by yolat_debug_gemm_sk_dma (tools/exp/lds_dma_bench.py: 0 = VGPR-staged kernel, 4 / 8 = waves of this one).
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void yl_glds16(const void* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc), "s"(lds_dst)
+               : "memory");
+}
+template <int NW>      // waves per workgroup: each owns 128 / NW of every chunk's k (NW = 8: two waves per SIMD, one's MFMAs under the other's reads)
+__global__ void __launch_bounds__(64 * NW) k_gemm_nt_sk_dma(const float* __restrict__ A, long lda, int rowsA,
+                                                           const float* __restrict__ B, long ldb, int rowsB, Epilogue ep,
+                                                           int M, int N, int K, long long* stamps) {
+  constexpr int BT = 32, BK = 128, NP = 32 / NW, NG = 32 / NW;      // DMA pieces / 16-byte granules per wave and chunk
+  __shared__ __attribute__((aligned(16))) float smem[2][2][BT * BK];        // [stage][A | B][row][128]: 64 KB
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l31 = lane & 31, lhi = lane >> 5;
+  int rt_, ct_;
+  yl_xcd_tile(rt_, ct_);
+  const int row0 = rt_ * BT, col0 = ct_ * BT;
+  const EpiPre pre = epi_prefetch(ep, row0, col0 + l31, M, N);
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const unsigned lds0 = (unsigned)(size_t)&smem[0][0][0];
+  // this wave's pieces of a stage: piece i = NP wave + j -> operand i >> 4, row pair i & 15; lane -> (row, granule)
+  const float* src[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int i = NP * wave + j, op = i >> 4, pair = i & 15;
+    const int r = 2 * pair + (lane >> 5), g = (lane & 31) ^ (r & 15);
+    src[j] = op == 0 ? A + (long)yl_min(row0 + r, rowsA - 1) * lda + 4 * g : B + (long)yl_min(col0 + r, rowsB - 1) * ldb + 4 * g;
+  }
+  auto stage = [&](int s, int k0) {
+#pragma unroll
+    for (int j = 0; j < NP; ++j) {
+      const int i = NP * wave + j, op = i >> 4, pair = i & 15;
+      yl_glds16(src[j] + k0, lds0 + (unsigned)(((s * 2 + op) * BT * BK + pair * 256) * 4));
+    }
+  };
+  auto compute = [&](int s) {
+    const float* As = &smem[s][0][0];
+    const float* Bs = &smem[s][1][0];
+#pragma unroll
+    for (int gi = 0; gi < NG; ++gi) {
+      const int g = NG * wave + gi, pos = g ^ (l31 & 15);
+      const float4 a4 = *reinterpret_cast<const float4*>(As + l31 * BK + 4 * pos);
+      const float4 b4 = *reinterpret_cast<const float4*>(Bs + l31 * BK + 4 * pos);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lhi ? a4.y : a4.x, lhi ? b4.y : b4.x, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_32x32x2f32(lhi ? a4.w : a4.z, lhi ? b4.w : b4.z, acc, 0, 0, 0);
+    }
+  };
+  const int nch = K / BK;
+  long long t0 = 0, t_wait = 0, t_comp = 0;
+  const bool st_on = stamps != nullptr && tid == 0;
+  stage(0, 0);
+  for (int kc = 0; kc < nch; ++kc) {
+    long long ta = 0, tb = 0, tc = 0;
+    if (kc + 1 < nch) {
+      stage((kc + 1) & 1, (kc + 1) * BK);
+      if (st_on) ta = clock64();
+      // this chunk's pieces have landed; the next chunk's stay in flight
+      if (NP == 8) asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+    } else {
+      if (st_on) ta = clock64();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // every wave's pieces of the chunk are in LDS
+    if (st_on) tb = clock64();
+    compute(kc & 1);
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");     // the stage may be overwritten (two iterations on)
+    if (st_on) { tc = clock64(); t_wait += tb - ta; t_comp += tc - tb; if (kc == 0) t0 = ta; }
+  }
+  if (st_on) {
+    const long o = 3 * (blockIdx.x + (long)gridDim.x * blockIdx.y);
+    stamps[o] = t_wait; stamps[o + 1] = t_comp; stamps[o + 2] = clock64() - t0;
+  }
+  // fixed-order reduction of the NW K-partials: waves 1.. park theirs in LDS, wave 0 adds them in wave order
+  float* red = &smem[0][0][0];   // [NW - 1][16][64]
+  if (wave > 0) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[((wave - 1) * 16 + r) * 64 + lane] = acc[r];
+  }
+  __syncthreads();
+  if (wave == 0) {
+#pragma unroll
+    for (int w = 0; w < NW - 1; ++w)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[r] += red[(w * 16 + r) * 64 + lane];
+    wave_epilogue(acc, row0, col0 + l31, lhi, ep, M, N, pre);
+  }
+}
+int yl_gemm_sk_dma_on();
+long long* yl_gemm_sk_dma_stamps();
+
+// ------------------------------------------------------------------------------------------------
 // TN GEMM (weight gradients):  P[s][n][k] = sum_{r in split s} Y[r][n] * A[r][k]
 // Output tile 64(n) x 64(k); 64 rows per LDS stage (32 MFMAs per wave between barriers; 32-row stages left the
 // N-row weight gradients latency bound: 97 us for [64,64] over 200 k rows); grid = (n tiles, k tiles, splits).

@@ -2,6 +2,14 @@
 // Entry points: yolat_linear_fwd, yolat_linear_fwd_wt, yolat_linear_bwd_w, yolat_bn_finalize,
 // yolat_bn_eval_coeffs, yolat_scale_shift_relu, yolat_bn_relu_bwd.
 #include "common.hpp"
+#include <type_traits>
+
+// switch of the LDS-DMA skinny GEMM (tools/exp/lds_dma_bench.py, tests; not part of the C ABI header)
+static int g_sk_dma = -1;      // -1: automatic (8-wave LDS-DMA kernel for K >= 1024), 0: never, 4 / 8: always (where it applies)
+static long long* g_sk_dma_stamps = nullptr;
+int yl_gemm_sk_dma_on() { return g_sk_dma; }
+long long* yl_gemm_sk_dma_stamps() { return g_sk_dma_stamps; }
+extern "C" void yolat_debug_gemm_sk_dma(int on, long long* stamps) { g_sk_dma = on; g_sk_dma_stamps = stamps; }
 
 // ------------------------------------------------------------------------------------------------
 // GEMM dispatch
@@ -17,6 +25,23 @@ static int launch_gemm_nt(const AL& A, const BL& B, const Epilogue& ep, long M, 
   if (K >= 256 && tiles64 < 160) {
     // few rows, long K: split K across the 4 waves of a 32x32-tile workgroup
     dim3 grid(yl_cdiv(M, 32), yl_cdiv(N, 32));
+    bool dma = false;
+    if constexpr (std::is_same<AL, DenseOp>::value && std::is_same<BL, DenseOp>::value && !NFAST) {
+      // the LDS-DMA experiment (common.hpp k_gemm_nt_sk_dma): plain operands with 16-byte rows, whole 128-deep chunks
+      // measured at the cfg-2 classifier (P = 400, tools/exp/lds_dma_bench.py): 2304 -> 512: 20.7 us VGPR-staged, 20.1 us
+      // LDS-DMA with 4 waves, 18.6 us with 8; 512 -> 256 (4 chunks): 8.9 / 9.2 / 9.3 us — the DMA pipeline needs a long K
+      const int mode = yl_gemm_sk_dma_on() < 0 ? (K >= 1024 ? 8 : 0) : yl_gemm_sk_dma_on();
+      if (mode && A.vec && B.vec && K % 128 == 0 && A.cols >= K && B.cols >= K) {
+        dma = true;
+        if (mode == 8)
+          hipLaunchKernelGGL(k_gemm_nt_sk_dma<8>, grid, dim3(512), 0, st, A.p, A.ld, A.rows, B.p, B.ld, B.rows, ep, (int)M,
+                             (int)N, (int)K, yl_gemm_sk_dma_stamps());
+        else
+          hipLaunchKernelGGL(k_gemm_nt_sk_dma<4>, grid, dim3(256), 0, st, A.p, A.ld, A.rows, B.p, B.ld, B.rows, ep, (int)M,
+                             (int)N, (int)K, yl_gemm_sk_dma_stamps());
+      }
+    }
+    if (!dma)
     hipLaunchKernelGGL((k_gemm_nt_sk<AL, BL, NFAST>), grid, dim3(256), 0, st, A, B, ep, (int)M,
                        (int)N, (int)K);
   } else if (N <= 64 || tiles128 < 2048) {
