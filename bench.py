@@ -314,7 +314,15 @@ def executed_pricing(label, rec, precision, shape):
         ex_by = N * 128 * s + E * 24.0 + (2.0 if s == 4.0 else 1.5) * N * 64 * 4.0 + 4.0 * N
     t_b = ex_by / (PEAK_HBM_GBS * 1e9)
     x6 = _runs_as_bf16x6(label, precision, shape)
-    if x6:
+    if label.startswith("conv_local") and shape is not None:
+        # the one-launch conv stack (csrc/conv_local.hip) issues 24 v_mfma_f32_32x32x16_bf16 per 32 edges and layer (8 of
+        # them identity products that transpose / add the gathered rows, 2 the attr term, 2 the shift, 8 the second Linear,
+        # 4 the mean aggregation) = 24 576 flops per edge against 2 (4 C + C C) = 8 704 algorithmic ones, and the node side
+        # as issued; the stage's byte count is already what it has to move (x, ids, e_attr in; feats + pooled rows out)
+        N, E, P = shape
+        ex_fl = fl * (24576.0 * E + 32768.0 * N) / (8704.0 * E + 32768.0 * N)
+        ex_peak, pipe = PEAK_MFMA_BF16_TFLOPS, "bf16 MFMA (24 per 32 edges and layer, 8.7 of 24.6 kflop per edge algorithmic)"
+    elif x6:
         ex_fl, ex_peak, pipe = 6.0 * fl, PEAK_MFMA_BF16_TFLOPS, "bf16 MFMA (fp32 GEMM as six exact-split bf16 products)"
     elif alg_peak == PEAK_MFMA_BF16_TFLOPS:
         ex_fl, ex_peak, pipe = fl, PEAK_MFMA_BF16_TFLOPS, "bf16 MFMA"

@@ -28,6 +28,9 @@ STAGES = {
 
 # bf16-storage forward (bf16_eval.hip YL_HSTAGE names; round 3)
 STAGES_BF16 = {
+    # round 5: the one-launch proposal-local conv stack (the per-layer edge / node launches behind it are dead, gated launches
+    # on such a batch: their rows in the PMC files are not the stages' traffic and are dropped below)
+    "conv_local_bf16[all conv layers + pooling prologue, one launch]": ("k_conv_local_h", [CS + "common.hpp", CS + "conv_local.hip"], "all"),
     "edge_uv_mlp2_mean_bf16[E x (U+V+attr) -> 64 -> 64 -> mean]": ("k_edge_chain_h", [CS + "common.hpp", CS + "edge_chain.hip"], "all"),
     "fusion_gemm_bf16+segmax[N x 128 -> 1024 -> P] | super[P x 128 -> 1024]": ("k_hfusion_rows8<128", [CS + "common.hpp", CS + "segmax.hpp", CS + "fusion_h8.hip"], "all"),
     "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> 128+64+64]": ("k_hgemm_node3", [CS + "common.hpp", CS + "bf16_eval.hip"], "all"),
@@ -98,6 +101,10 @@ def main():
                       "launch_pick": pick,
                       "file": "profiles/%s_pmc_fetch.txt + profiles/%s_pmc_write.txt" % (prefix, prefix),
                       "sources": srcs, "source_digest": digest(srcs)}
+    if "conv_local_bf16[all conv layers + pooling prologue, one launch]" in ent:
+        for stage in list(ent):
+            if stage.startswith("edge_uv_mlp2_mean_bf16") or stage.startswith("node_uv_bf16"):
+                del ent[stage]
     json.dump(table, open(path, "w"), indent=1, sort_keys=True)
     print(json.dumps(ent, indent=1))
 
