@@ -1584,6 +1584,23 @@ def test_bn_apply_edge_sums_equals_apply_then_sums(N, E, half):
     dH, dUV, dwc4, db = outs[0]
     assert torch.equal(dH, dH_ref)
     assert torch.equal(dUV, dUV_ref)
+    # ---- and against an fp64 restatement of the op itself (autograd of torch_nn.py:58-66 on the rows, then the two
+    # per-node sums of torch_vertex.py:331's factorised backward), not only against the kernels it replaced:
+    #   dH = scale (dA [z > 0] - c1 - xhat c2),  z = H1 scale + shift,  xhat = (H1 - mean) invstd
+    Yd, dZd = H1.double(), dA.double()
+    z = Yd * scale.double() + shift.double()
+    xhat = (Yd - mean.double()) * invstd.double()
+    want_dH = scale.double() * (dZd * (z > 0) - coef[:64].double() - xhat * coef[64:].double())
+    sure = z.abs() > 1e-4                                   # (an activation on the ReLU kink may mask either way in fp32)
+    tol = (2.0 ** -7 if half else 2e-6) * want_dH.abs() + (2e-2 if half else 2e-5)
+    assert bool((((dH.double() - want_dH).abs() <= tol) | ~sure).all())
+    stored = dH.double()
+    want_dU = torch.zeros(N, 64, dtype=torch.float64, device="cuda").index_add_(0, g.dst[:E].long(), stored)
+    want_dV = torch.zeros(N, 64, dtype=torch.float64, device="cuda").index_add_(0, g.src[:E].long(), stored)
+    mag = torch.zeros(N, 64, dtype=torch.float64, device="cuda").index_add_(0, g.dst[:E].long(), stored.abs()) + \
+        torch.zeros(N, 64, dtype=torch.float64, device="cuda").index_add_(0, g.src[:E].long(), stored.abs())
+    assert bool(((dUV[:, :64].double() - want_dU).abs() <= 4e-6 * mag + 1e-6).all())
+    assert bool(((dUV[:, 64:].double() - want_dV).abs() <= 4e-6 * mag + 1e-6).all())
     assert float((dwc4.double().cpu() - ref_w).abs().max()) <= 2e-6 * max(float(ref_w.abs().max()), 1e-3) * max(1.0, E ** 0.5 / 30)
     assert float((db.double().cpu() - ref_b).abs().max()) <= 2e-6 * float(ref_b.abs().max() + E ** 0.5)
     for a, b in zip(outs[0], outs[1]):
@@ -1623,6 +1640,20 @@ def test_linear64_row_stream_is_bit_identical_to_the_tile_kernel(M, pro):
     Ain = torch.relu(A.double() * sc.double() + sh.double()) if pro else A.double()
     ref = Ain @ W.double().t() + b.double()
     assert float((Y.double() - ref).abs().max()) <= 2e-5 * float(ref.abs().max())
+    # the BatchNorm partial statistics against fp64 too: per 32-row group (sum, M2 about the group's mean) of the
+    # pre-epilogue values — what yolat_bn_finalize reduces (include/yolat_hip.h, yolat_linear_fwd)
+    pad = ngrp * 32 - M
+    refp = torch.cat([ref, torch.zeros(pad, 64, dtype=torch.float64, device="cuda")]) if pad else ref
+    valid = torch.cat([torch.ones(M, 1, dtype=torch.float64, device="cuda"),
+                       torch.zeros(pad, 1, dtype=torch.float64, device="cuda")]) if pad else torch.ones(M, 1, dtype=torch.float64, device="cuda")
+    grp = refp.view(ngrp, 32, 64)
+    vg = valid.view(ngrp, 32, 1)
+    cnt = vg.sum(1)
+    want_sum = (grp * vg).sum(1)
+    want_m2 = (((grp - want_sum[:, None, :] / cnt[:, None, :]) ** 2) * vg).sum(1)
+    got = st.view(-1)[:2 * 64 * ngrp].view(ngrp, 64, 2).double()
+    assert float((got[..., 0] - want_sum).abs().max()) <= 2e-5 * float(want_sum.abs().max())
+    assert float((got[..., 1] - want_m2).abs().max()) <= 1e-4 * float(want_m2.abs().max())
 
 
 @pytest.mark.parametrize("M,K,acc", [(70001, 64, False), (70001, 64, True), (131072 + 33, 128, True), (65536, 128, False)])
