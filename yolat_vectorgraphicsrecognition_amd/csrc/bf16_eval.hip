@@ -362,18 +362,18 @@ static __global__ void __launch_bounds__(256) k_hgemm_node3(NodeUvH a) {
   else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
   else hgemm_tile<1, 1, HOp>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0, smem);
 }
-// the same as the fall-back of the one-launch conv stack (conv_local.hip): dead unless the gate word holds its value; a few
-// hundred persistent workgroups walk the row tiles, so that the dead launch is a boundary, not a dispatch of 12 500 workgroups
+// the same as the fall-back of the one-launch conv stack (conv_local.hip): dead unless the gate word holds its value.  (A
+// persistent-grid form — a few hundred workgroups looping over the row tiles, so that the dead launch dispatches fewer
+// workgroups — made the compiler keep 233 registers around the loop, or spill 140 under a bound: the live fall-back then
+// ran at half speed; laundering the loop variable did not change that, and the tile as a real (noinline) call spilled
+// 560 bytes per lane.  The full grid costs ~4 us per dead launch instead of ~2.)
 static __global__ void __launch_bounds__(256) k_hgemm_node3_gated(NodeUvH a, YlGate gate) {
   __shared__ __attribute__((aligned(16))) u16 smem[HTileSmem<1, 1>::elems];
   if (yl_gate_dead(gate)) return;
-  const int y = blockIdx.y, ntile = (a.N + 63) >> 6;
-  for (int x = blockIdx.x; x < ntile; x += gridDim.x) {
-    if (y < 2) hgemm_tile<1, 1, HOp>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y, smem);
-    else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
-    else hgemm_tile<1, 1, HOp>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0, smem);
-    if (x + (int)gridDim.x < ntile) __syncthreads();
-  }
+  const int x = blockIdx.x, y = blockIdx.y;
+  if (y < 2) hgemm_tile<1, 1, HOp>(a.af, a.wuv, a.euv, a.N, 2 * a.C, a.Cin, x, y, smem);
+  else if (y == 2) hgemm_tile<1, 1, HOp>(a.af, a.wr, a.er, a.N, a.C, a.Cin, x, 0, smem);
+  else hgemm_tile<1, 1, HOp>(a.as, a.wn, a.en, a.N, a.C, a.Cin, x, 0, smem);
 }
 
 static Epilogue plain_epilogue() {
@@ -870,7 +870,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
       a.en.Yh = s_slot(l); a.en.ldy = ld_slot(l);
       a.N = (int)N; a.C = (int)C; a.Cin = 64;
       const int ntile = yl_cdiv(N, 64);
-      if (gate.p) hipLaunchKernelGGL(k_hgemm_node3_gated, dim3(ntile > 128 ? 128 : ntile, 4), dim3(256), 0, st, a, gate);
+      if (gate.p) hipLaunchKernelGGL(k_hgemm_node3_gated, dim3(ntile, 4), dim3(256), 0, st, a, gate);
       else hipLaunchKernelGGL(k_hgemm_node3, dim3(ntile, 4), dim3(256), 0, st, a);
       YL_LAUNCH_CHECK();
       });
@@ -891,7 +891,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
                   : "pool_prepare_bf16[max(feats), mean(fsup), zero]", 2.0 * N * D, 4.0 * N * D + 4.0 * P * (F + 2 * D), {
   for (int64_t p0 = 0; p0 < P; p0 += 65535) {
     const int64_t np = (P - p0) < 65535 ? (P - p0) : 65535;
-    hipLaunchKernelGGL(k_pool_prepare_h, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)(gate.p && np > 128 ? 128 : np)), dim3(256), 0,
+    hipLaunchKernelGGL(k_pool_prepare_h, dim3(yl_cdiv(F + 2 * D, 256), (unsigned)(gate.p && np > 1024 ? 1024 : np)), dim3(256), 0,
                        st, p.feats, p.fsup, D, (int)D, (int)F, p.seg_ptr + p0, p.Z + p0 * ZW, ZW, gate, (int)np);
     YL_LAUNCH_CHECK();
   }

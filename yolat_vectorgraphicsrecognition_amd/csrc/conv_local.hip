@@ -118,6 +118,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
   __shared__ int rp_s[T + 4];
   __shared__ int gseg_s[CL_GMAX + 1], grow_s[CL_GMAX + 1];
   __shared__ __attribute__((aligned(16))) float shift_s[256];                  // the coming node phase's shifts
+  __shared__ int stop_s;                 // the flag word as thread 0 saw it at this tile's start (workgroup-uniform exit)
   __shared__ __attribute__((aligned(16))) cl_u32x4 ef_s[12 * 64];              // the layer's edge-phase fragments
 
   const int tid0 = threadIdx.x;
@@ -194,8 +195,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
     r2 = av[0]; r3 = av[1];
   };
 
+  // a proposal of the group that cannot fit a tile is known now: raise the flag before any work is done (the other
+  // workgroups stop at their next check, below)
+  for (int i = tid0; i < np; i += NT)
+    if (gseg_s[i + 1] - gseg_s[i] > T || grow_s[i + 1] - grow_s[i] > ET || gseg_s[i + 1] < gseg_s[i]) *a.flag = a.flag_val;
   int p0, p1;
   next_tile(0, p0, p1);
+  bool first_tile = true;
   cl_u32x4& pre0 = af[0][2];
   cl_u32x4& pre1 = af[0][3];
   cl_u32x4& pre2 = af[1][2];
@@ -253,8 +259,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) af[nt_][ks] = ap[(nt_ * 4 + ks) * 64];
     }
+    // another workgroup (or an earlier tile of this one) has found the batch unfit: the gated per-layer launches will redo
+    // everything, so stop after at most one tile instead of finishing ~230 us of work that is thrown away.  (An L2-served
+    // load: a plain one could be answered by this CU's L1 for ever.)
+    if (tid == 0) stop_s = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     CL_STAMP();      // 1: tile loads landed + LDS written
     cl_lds_barrier();
+    if (stop_s == a.flag_val) return;
 
     // ---- the wave's two edge streams: node boundaries nb[0..NS] (edge-balanced, node-aligned, <= 16 nodes each)
     int ns[3], sb[3];
@@ -388,8 +399,10 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
             }
         }
       }
+      if (first_tile && tid == 0) stop_s = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       CL_STAMP();    // 3 + 5 l: node phase done (before barrier)
       cl_lds_barrier();     // UV, R, s of this layer and its edge fragments are complete; every read of f is done
+      if (first_tile && stop_s == a.flag_val) return;    // (a workgroup's first tile checks at every layer: all start together)
       CL_STAMP();    // 4 + 5 l: node barrier passed
       if (tid < 256) shift_s[tid] = sh_nx;  // read after the edge phase's closing barrier
       // the next node phase's copy of the edge fragments (next layer, or layer 0 of the next tile): a phase ahead
@@ -680,6 +693,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
     cl_lds_barrier();       // the tiles are dead: the next tile may be written
     p0 = pn0;
     p1 = pn1;
+    first_tile = false;
   }
 #undef CL_STAMP
 }

@@ -372,7 +372,7 @@ bool yl_node3_smallk_ok(const NodeUv& a) {             // ... and where it beats
 }
 int yl_node3_smallk(const NodeUv& a, hipStream_t st, YlGate gate) {
   const int nb = yl_cdiv(a.N, N3_ROWS * N3_ITERS);
-  if (gate.p) hipLaunchKernelGGL(k_node3_smallk_gated, dim3(nb < 512 ? nb : 512), dim3(256), 0, st, a, gate, nb);
+  if (gate.p) hipLaunchKernelGGL(k_node3_smallk_gated, dim3(nb < 2048 ? nb : 2048), dim3(256), 0, st, a, gate, nb);
   else hipLaunchKernelGGL(k_node3_smallk, dim3(yl_cdiv(a.N, N3_ROWS * N3_ITERS)), dim3(256), 0, st, a);
   YL_LAUNCH_CHECK();
   return 0;
