@@ -1030,22 +1030,39 @@ def main():
 
         # the same hand-over OFF this thread: data.DeviceLoader (csrc/loader.hip: native worker thread, ring of pinned /
         # device slots, copy stream + events) collates and copies batch i + 1 while batch i's forward is enqueued and runs
-        def loader_rate():
+        # nstreams > 1: consecutive batches are drawn and consumed under different streams (the loader hands a slot back
+        # behind an event on the stream its batch was drawn on), so forwards of consecutive batches overlap on the GPU the
+        # way `multi_stream` overlaps resident ones — and the hand-over (cold operands, the event packets between
+        # forwards: ~6 + 3 us of a one-stream hand-over by kernel trace) hides behind them
+        def loader_rate(nstreams=1):
+            streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else None
+
             def run(n):
-                loader = yv.DeviceLoader(([cpu_item] for _ in range(n)), slots=3)
-                with torch.no_grad():
-                    for b, sl in loader:
-                        model(b, sl)
+                loader = yv.DeviceLoader(([cpu_item] for _ in range(n)), slots=nstreams + 2)
+                try:
+                    with torch.no_grad():
+                        k = 0
+                        if streams:
+                            torch.cuda.set_stream(streams[0])
+                        for b, sl in loader:
+                            model(b, sl)
+                            k += 1
+                            if streams:
+                                torch.cuda.set_stream(streams[k % nstreams])
+                finally:
+                    if streams:
+                        torch.cuda.set_stream(torch.cuda.default_stream())
                 torch.cuda.synchronize()
                 loader.close()
-            run(40)
+            run(60)
             rates = []
             for _ in range(5):
                 t2 = time.perf_counter()
-                run(200)
-                rates.append(n_graphs * 200 / (time.perf_counter() - t2))
+                run(300)
+                rates.append(n_graphs * 300 / (time.perf_counter() - t2))
             return sorted(rates)[2]
         h2d_loader = loader_rate()
+        h2d_loader3 = loader_rate(3)
         # merged mode with the batch resident: one forward at a time on the prepared graph
         b, sl = yv.collate_to_device([cpu_item], csr=True)
         for _ in range(5):
@@ -1059,7 +1076,10 @@ def main():
         torch.cuda.synchronize()
         merged_ms = (time.perf_counter() - t2) / nh * 1e3
         csr_mode = {"h2d_inclusive_graphs_per_sec": h2d_csr, "h2d_inclusive_graphs_per_sec_device_loader": h2d_loader,
+                    "h2d_inclusive_graphs_per_sec_device_loader_3_streams": h2d_loader3,
                     "ms_per_forward_resident": merged_ms,
+                    "device_loader_over_resident_one_stream": h2d_loader * merged_ms * 1e-3 / n_graphs,
+                    "device_loader_3_streams_over_resident_one_stream": h2d_loader3 * merged_ms * 1e-3 / n_graphs,
                     "note": "per-item CSR cached on the dataset item (host, once), merged by offset-add at collate "
                             "(yolat_collate_csr_pack), forward on the prepared graph (yolat_forward_eval_csr); the "
                             "headline keeps csr_rebuilt_each_step = true"}
@@ -1188,6 +1208,7 @@ def main():
             "csr_merged_ms": pick(line, "csr_merged_mode", "ms_per_forward_resident"),
             "csr_merged_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec"),
             "loader_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec_device_loader"),
+            "loader3_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec_device_loader_3_streams"),
             "h2d_inclusive_gps": pick(line, "h2d_inclusive_graphs_per_sec"), "multi_stream_gps": pick(line, "multi_stream", "value"),
             "floorplans_ms": pick(line, "floorplans_sized", "ms_per_forward"),
             "floorplans_x_cpu": pick(line, "floorplans_sized", "speedup_vs_cpu_one_at_a_time"),

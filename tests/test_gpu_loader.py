@@ -103,3 +103,36 @@ def test_device_loader_close_with_batches_in_flight_and_host_keys():
     l2 = yv.DeviceLoader(lists[:2], slots=2)
     assert sum(1 for _ in l2) == 2
     l2.close()
+
+
+def test_device_loader_round_robin_over_three_streams_soak():
+    """consecutive batches drawn (and consumed) under three different streams: the slot of a batch is handed back behind an
+    event on ITS stream — 600 batches, no host synchronisation, logits equal the synchronous hand-over"""
+    yv = _yv()
+    lists = _lists(yv, 5, seed0=140)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 7).cuda().eval()
+    want = []
+    with torch.no_grad():
+        for items in lists:
+            b, sl = yv.collate_to_device(items, csr=True)
+            want.append(model(b, sl)[0].clone())
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    seq = [(3 * i + i // 7) % len(lists) for i in range(600)]
+    loader = yv.DeviceLoader((lists[i] for i in seq), slots=5)
+    outs = []
+    try:
+        with torch.no_grad():
+            k = 0
+            torch.cuda.set_stream(streams[0])
+            for batch, slices in loader:
+                outs.append((seq[k], model(batch, slices)[0]))
+                k += 1
+                torch.cuda.set_stream(streams[k % 3])
+    finally:
+        torch.cuda.set_stream(torch.cuda.default_stream())
+    torch.cuda.synchronize()
+    assert len(outs) == 600
+    bad = [k for k, (i, o) in enumerate(outs) if not torch.equal(o, want[i])]
+    assert not bad, "batches %s differ from the synchronous hand-over" % bad[:10]
+    loader.close()

@@ -134,6 +134,10 @@ class SparseCADGCN(nn.Module):
         pre = data.__dict__.get("_yolat_graph") if hasattr(data, "__dict__") else None
         if pre is not None:
             # the batch carries a prepared graph (data.collate_to_device(csr=True)); x / bbox are device tensors already
+            xref = data.__dict__.get("_yolat_x") if not need_graph else None
+            if xref is not None:
+                # a DeviceLoader batch in the eval forward: x's address / row stride / rows / device, no tensor view
+                return {"x": None, "xref": xref, "bbox": data.bbox, "g": pre, "prepared": True}
             x = data.x if data.x.dtype == torch.float32 else data.x.float()
             return {"x": x, "bbox": data.bbox, "g": pre, "prepared": True}
         cache = getattr(data, "_yolat_stage", None)
@@ -177,9 +181,10 @@ class SparseCADGCN(nn.Module):
             ug = self.__dict__.get("_yolat_use_graph")
             if ug is not None:
                 plan.use_graph = ug
-            self._yolat_plan = plan          # the plan of the most recent forward (status checks)
+            self.__dict__["_yolat_plan"] = plan      # the plan of the most recent forward (status checks); not through
+            #                                          nn.Module.__setattr__: 3 us of a 100 us hand-over
             if st.get("prepared"):
-                pred_cls = plan.run_prepared(st["x"], st["g"])
+                pred_cls = plan.run_prepared(st["x"], st["g"], st.get("xref"))
             else:
                 pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])
             st["plan_status"] = plan

@@ -18,6 +18,8 @@ from itertools import product
 import ctypes
 import os
 
+import struct
+
 import numpy as np
 import torch
 
@@ -130,7 +132,7 @@ def _source_key(item, names):
     out = []
     for k in names:
         t = d.get(k)
-        out.append(None if t is None else (t.data_ptr(), t._version, tuple(t.shape)))
+        out.append(None if t is None else (t.data_ptr(), t._version, t.shape))
     return tuple(out)
 
 
@@ -387,29 +389,111 @@ def collate_to_device(data_list, device="cuda", csr=False):
     return batch, slices
 
 
-class _Thunk(object):
-    __slots__ = ("fn",)
+_UNPACK_I64 = struct.Struct("q").unpack_from
 
-    def __init__(self, fn):
-        self.fn = fn
+
+class _BatchState(object):
+    """What a DeviceLoader batch is made from on demand: the slot's device buffer, the field offsets, the slices (bytes
+    copied out of the slot at draw time) and the host items."""
+    __slots__ = ("mem", "offs", "sl_bytes", "items", "ship", "tkeys", "rest", "B", "sl", "host", "slices", "names")
+
+    def __init__(self, mem, offs, sl_bytes, items, ship, tkeys, rest, B):
+        self.mem, self.offs, self.sl_bytes = mem, offs, sl_bytes
+        self.items, self.ship, self.tkeys, self.rest, self.B = items, ship, tkeys, rest, B
+        self.sl = None
+        self.host = None
+        self.slices = None
+        self.names = None
+
+    def slice_rows(self):
+        if self.sl is None:
+            nk = len(self.ship)
+            self.sl = np.frombuffer(self.sl_bytes, dtype=np.int64).reshape(nk, self.B + 1).copy()
+        return self.sl
+
+    def all_names(self):
+        if self.names is None:
+            self.names = tuple(k for k in self.ship) + tuple(self.rest)
+        return self.names
+
+    def tensor(self, k):
+        """view of the device buffer for shipped key k"""
+        f = self.ship.index(k)
+        t = self.items[0].__dict__[k]
+        _, _, buf, typed = self.mem
+        b = typed.get(t.dtype)
+        if b is None:
+            b = typed[t.dtype] = (buf.view(t.dtype), t.element_size())
+        b, es = b
+        B = self.B
+        rows = _UNPACK_I64(self.sl_bytes, 8 * (f * (B + 1) + B))[0]
+        tail = tuple(t.shape[1:])
+        if len(tail) == 1:                       # one tensor operation instead of slice + view
+            return b.as_strided((rows, tail[0]), (tail[0], 1), self.offs[f] // es)
+        n = rows
+        for d_ in tail:
+            n *= d_
+        o = self.offs[f] // es
+        return b[o:o + n].view((rows,) + tail)
+
+    def host_keys(self):
+        if self.host is None:
+            hb, hs = self.items[0].__class__(), {}
+            for k in self.tkeys:                     # the fix-up of host-resident edge tensors needs the node slices
+                hs[k] = self.slices[k]
+            _collate_host_keys(self.items, self.rest, hb, hs)
+            self.host = (hb, hs)
+        return self.host
+
+    def make_slices(self, k):
+        if k in self.ship:
+            return torch.from_numpy(self.slice_rows()[self.ship.index(k)])
+        if k in self.tkeys:
+            ends = np.zeros(self.B + 1, dtype=np.int64)
+            np.cumsum([it[k].shape[0] for it in self.items], out=ends[1:])
+            return torch.from_numpy(ends)
+        if k in self.rest:
+            return self.host_keys()[1][k]
+        raise KeyError(k)
 
 
 class _LazySlices(dict):
     """`slices` of a DeviceLoader batch: a dict whose values are produced on first access (the forward never reads them)."""
+    _st = None
 
-    def __getitem__(self, k):
-        v = dict.__getitem__(self, k)
-        if isinstance(v, _Thunk):
-            v = v.fn()
-            dict.__setitem__(self, k, v)
+    def __missing__(self, k):
+        st = self._st
+        if st is None:
+            raise KeyError(k)
+        v = st.make_slices(k)
+        dict.__setitem__(self, k, v)
         return v
+
+    def _names(self):
+        st = self._st
+        return () if st is None else tuple(st.tkeys) + tuple(st.rest)
+
+    def __contains__(self, k):
+        return dict.__contains__(self, k) or k in self._names()
 
     def get(self, k, default=None):
         return self[k] if k in self else default
 
     def _all(self):
-        for k in list(dict.keys(self)):
+        for k in self._names():
             self[k]
+
+    def keys(self):
+        self._all()
+        return dict.keys(self)
+
+    def __iter__(self):
+        self._all()
+        return dict.__iter__(self)
+
+    def __len__(self):
+        self._all()
+        return dict.__len__(self)
 
     def items(self):
         self._all()
@@ -425,25 +509,30 @@ class _LazySlices(dict):
 
 
 class _LazyBatch(Data):
-    """The batch of a DeviceLoader: attributes listed in `_lazy` (views of the device buffer other than x, host-side keys)
-    are produced on first access."""
+    """The batch of a DeviceLoader: the views of the device buffer and the host-side keys are produced on first access."""
 
     def __init__(self):
         pass
 
     def __getattr__(self, name):               # only reached when the normal look-up fails
-        lz = self.__dict__.get("_lazy")
-        if lz is not None and name in lz:
-            v = lz.pop(name)()
+        st = self.__dict__.get("_lazy")
+        if st is not None and name[0] != "_":
+            if name in st.ship:
+                v = st.tensor(name)
+            elif name in st.rest:
+                v = st.host_keys()[0][name]
+            else:
+                raise AttributeError(name)
             self.__dict__[name] = v
             return v
         raise AttributeError(name)
 
     @property
     def keys(self):
-        lz = self.__dict__.get("_lazy")
-        for name in list(lz or ()):
-            getattr(self, name)
+        st = self.__dict__.get("_lazy")
+        if st is not None:
+            for name in st.all_names():
+                getattr(self, name)
         return Data.keys.fget(self)
 
 
@@ -466,8 +555,10 @@ class DeviceLoader(object):
     Every batch is what ``collate_to_device(items, csr=True)`` returns (bit-identical: same native call), i.e. it carries
     the merged destination-sorted graph (``item_csr`` of each item, cached on the item) instead of edge / e_attr /
     bbox_idx.  A batch's tensors live in the loader's ring of ``slots`` device buffers: they are valid until ``slots - 1``
-    further batches have been drawn, and everything that reads them must have been ENQUEUED on the current stream by the
-    time the next batch is drawn (the loader then hands the slot back behind an event on that stream)."""
+    further batches have been drawn, and everything that reads them must have been ENQUEUED, on the stream that was current
+    when the batch was drawn, by the time the next batch is drawn (the loader then hands the slot back behind an event on
+    that stream).  Consecutive batches may be drawn under different streams (``torch.cuda.set_stream`` between draws): their
+    forwards then overlap on the GPU and the hand-over disappears behind them (``slots`` >= streams + 2)."""
 
     def __init__(self, batches, device="cuda", slots=3):
         from ._lib import lib
@@ -480,8 +571,13 @@ class DeviceLoader(object):
             self._h = lib.yolat_loader_create(self._slots)
         if not self._h:
             raise RuntimeError("yolat_loader_create failed")
+        from . import ops
+        from ._lib import check, LoaderBatch
+        self._lib, self._check, self._LoaderBatch = lib, check, LoaderBatch
+        self._stream, self._from_buffer = ops._stream, ops.PackedGraph.from_buffer
         self._pending = []          # submitted, not yet drawn: (items, ship, tkeys, rest, pointer array)
         self._held = None           # slot of the batch the consumer holds
+        self._held_stream = None    # ... and the stream it was drawn on (its readers are enqueued there)
         self._mem = {}              # slot -> (ptr, capacity, tensor)
         self._done = False
 
@@ -489,7 +585,6 @@ class DeviceLoader(object):
         return self
 
     def _submit_one(self):
-        from ._lib import lib, check
         if self._done:
             return False
         try:
@@ -499,98 +594,78 @@ class DeviceLoader(object):
             return False
         items = list(items)
         first = items[0]
-        keys = first.keys
-        tkeys = [k for k in keys if isinstance(first[k], torch.Tensor) and first[k].dim() > 0 and k in _DEVICE_KEYS]
-        rest = [k for k in keys if k not in tkeys]
-        ship = tuple(k for k in tkeys if k not in _CSR_SKIP)
-        ptrs = (ctypes.c_void_p * len(items))(*[ctypes.addressof(_item_desc(it, ship)) for it in items])
-        check(lib.yolat_loader_submit(self._h, ptrs, len(items)), "yolat_loader_submit")
+        # the split of the keys (device tensors / host-side rest) is cached on the item beside its descriptor
+        split = first.__dict__.get("_yolat_keysplit")
+        names = tuple(k for k, v in first.__dict__.items() if v is not None and k[0] != "_")
+        if split is None or split[0] != names:
+            tkeys = [k for k in names if isinstance(first[k], torch.Tensor) and first[k].dim() > 0 and k in _DEVICE_KEYS]
+            rest = [k for k in names if k not in tkeys]
+            ship = tuple(k for k in tkeys if k not in _CSR_SKIP)
+            split = first.__dict__["_yolat_keysplit"] = (names, tkeys, rest, ship)
+        _, tkeys, rest, ship = split
+        if len(items) == 1:
+            ptrs = (ctypes.c_void_p * 1)(ctypes.addressof(_item_desc(first, ship)))
+        else:
+            ptrs = (ctypes.c_void_p * len(items))(*[ctypes.addressof(_item_desc(it, ship)) for it in items])
+        rc = self._lib.yolat_loader_submit(self._h, ptrs, len(items))
+        if rc != 0:
+            self._check(rc, "yolat_loader_submit")
         self._pending.append((items, ship, tkeys, rest, ptrs))
         return True
 
     def __next__(self):
-        from . import ops
-        from ._lib import lib, check, LoaderBatch
-        stream = ops._stream()
-        if self._held is not None:       # the consumer is done ENQUEUEING on the previous batch
-            check(lib.yolat_loader_release(self._h, self._held, stream), "yolat_loader_release")
+        lib = self._lib
+        stream = self._stream()
+        if self._held is not None:       # the consumer is done ENQUEUEING on the previous batch — on the stream it drew it on
+            rc = lib.yolat_loader_release(self._h, self._held, self._held_stream)
             self._held = None
-        while len(self._pending) < self._slots - 1 and self._submit_one():
+            if rc != 0:
+                self._check(rc, "yolat_loader_release")
+        pending = self._pending
+        while len(pending) < self._slots - 1 and self._submit_one():
             pass
-        if not self._pending:
+        if not pending:
             raise StopIteration
-        items, ship, tkeys, rest, _ptrs = self._pending.pop(0)
-        out = LoaderBatch()
-        check(lib.yolat_loader_next(self._h, stream, ctypes.byref(out)), "yolat_loader_next")
-        self._held = int(out.slot)
-        while len(self._pending) < self._slots - 1 and self._submit_one():      # keep the worker busy under the forward
+        items, ship, tkeys, rest, _ptrs = pending.pop(0)
+        out = self._LoaderBatch()
+        rc = lib.yolat_loader_next(self._h, stream, ctypes.byref(out))
+        if rc != 0:
+            self._check(rc, "yolat_loader_next")
+        slot = self._held = out.slot
+        self._held_stream = stream
+        while len(pending) < self._slots - 1 and self._submit_one():      # keep the worker busy under the forward
             pass
         B, nk = len(items), len(ship)
-        mem = self._mem.get(self._held)
-        if mem is None or mem[0] != out.device or mem[1] < out.total:
-            t = torch.as_tensor(_DeviceMemory(out.device, out.total), device=self._device)
-            mem = self._mem[self._held] = (out.device, int(out.total), t)
-        dbuf = mem[2][:int(out.total)]
-        sl = np.ctypeslib.as_array(out.slices, shape=(nk * (B + 1) + 1,))[:nk * (B + 1)].reshape(nk, B + 1).copy()
-        offs = [int(out.off[i]) for i in range(nk + 6)]
-        first = items[0]
-        # Only what every forward reads is made eagerly (x, the prepared graph); the other batched tensors, the slices and
-        # the host-side keys are produced on first access — a hand-over is bound by this thread's Python, ~10 us per
-        # tensor view / small tensor
+        total = out.total
+        mem = self._mem.get(slot)
+        if mem is None or mem[0] != out.device or mem[1] < total:
+            t = torch.as_tensor(_DeviceMemory(out.device, total), device=self._device)
+            mem = self._mem[slot] = (out.device, int(total), t, {})
+        # Nothing but the prepared graph is made eagerly: the forward needs addresses only (x's travels as a number in
+        # `_yolat_x`), and every tensor view / slices tensor / host-side key costs this thread 2-10 us of Python — a
+        # hand-over is bound by exactly that.  The slices are copied out of the slot now (it is rewritten later).
+        st = _BatchState(mem, out.off[:nk + 6], ctypes.string_at(out.slices, 8 * nk * (B + 1)), items, ship, tkeys, rest, B)
         batch = _LazyBatch()
+        bd = batch.__dict__
+        bd["_lazy"] = st
         slices = _LazySlices()
-        typed = {}
-
-        def view(o, dtype, shape):
-            b = typed.get(dtype)
-            if b is None:
-                b = typed[dtype] = dbuf.view(dtype)
-            es = b.element_size()
-            n = 1
-            for d_ in shape:
-                n *= d_
-            return b[o // es:o // es + n].view(shape)
-
-        lazy = batch.__dict__["_lazy"] = {}
-        for f, k in enumerate(ship):
-            t = first[k]
-            make = (lambda o=offs[f], dt=t.dtype, shp=(int(sl[f, B]),) + tuple(t.shape[1:]): view(o, dt, shp))
-            if k == "x":
-                batch.x = make()
-            else:
-                lazy[k] = make
-            dict.__setitem__(slices, k, _Thunk(lambda f=f: torch.from_numpy(sl[f])))
-        for k in tkeys:
-            if k not in slices:
-                def ends_of(k=k):
-                    ends = np.zeros(B + 1, dtype=np.int64)
-                    np.cumsum([it[k].shape[0] for it in items], out=ends[1:])
-                    return torch.from_numpy(ends)
-                dict.__setitem__(slices, k, _Thunk(ends_of))
-        if rest:
-            host = {}
-
-            def host_keys():
-                if not host:
-                    hb, hs = first.__class__(), {}
-                    for k in tkeys:                     # the fix-up of host-resident edge tensors needs the node slices
-                        hs[k] = slices[k]
-                    _collate_host_keys(items, rest, hb, hs)
-                    host["b"], host["s"] = hb, hs
-                return host
-            for k in rest:
-                lazy[k] = (lambda k=k: host_keys()["b"][k])
-                dict.__setitem__(slices, k, _Thunk(lambda k=k: host_keys()["s"][k]))
-        g = ops.PackedGraph.from_buffer(dbuf, offs[nk:nk + 6], int(out.N), int(out.E), int(out.P))
-        batch.__dict__["_yolat_graph"] = g
-        batch.__dict__["_device_buffer"] = dbuf
+        slices._st = st
+        st.slices = slices
+        offs = st.offs
+        N = out.N
+        bd["_yolat_graph"] = self._from_buffer(mem[2], offs[nk:nk + 6], N, out.E, out.P)
+        if ship and ship[0] == "x":
+            x0 = items[0].x
+            if x0.dtype == torch.float32 and x0.dim() == 2:
+                bd["_yolat_x"] = (out.device + offs[0], int(x0.shape[1]), N, self._device)
+        bd["_device_buffer"] = mem[2]
         return batch, slices
 
     def close(self):
         from ._lib import lib
         if getattr(self, "_h", None):
             if self._held is not None:
-                lib.yolat_loader_release(self._h, self._held, ops_stream_or_zero())
+                lib.yolat_loader_release(self._h, self._held, self._held_stream)
                 self._held = None
             # draw (and hand back) what the worker has already been given: it may hold pointers into the items
             from ._lib import LoaderBatch

@@ -5,12 +5,13 @@ the ``yolat_model_eval`` descriptor with device pointers and owns a grow-only wo
 is then a single ctypes call; the C++ side enqueues graph pre-processing and all layers back to back.
 """
 import ctypes
+import operator
 import os
 
 import torch
 
 from . import ops
-from ._lib import lib, check, ModelEval, ModelEvalBf16, YOLAT_MAX_LAYERS
+from ._lib import lib, check, ModelEval, ModelEvalBf16, GraphCsr, YOLAT_MAX_LAYERS
 
 # skip the memset of the CSR-build counters when the plan's workspace was last used by a forward of the same shape
 # (yolat_forward_eval_primed, include/yolat_hip.h); module flag, False: always the self-contained call
@@ -37,6 +38,9 @@ def _fold(bn, dev):
     return coef
 
 
+_VERSION_OF = operator.attrgetter("_version")
+
+
 class EvalPlan(object):
     """precision: "fp32" (default) or "bf16" — bf16 STORAGE of the node activations / weights with fp32
     accumulation (csrc/bf16_eval.hip, yolat_forward_eval_bf16), the mode of the large-graph configuration."""
@@ -60,7 +64,7 @@ class EvalPlan(object):
         self.use_graph = False      # model.use_hip_graphs(True) turns the captured-graph replay on
 
     def _version_key(self):
-        return tuple([t._version for t in self._tensors]) + (self._tensors[0].data_ptr(), ops.weight_epoch())
+        return tuple(map(_VERSION_OF, self._tensors)) + (self._tensors[0].data_ptr(), ops.weight_epoch())
 
     def _build(self):
         self._desc_key += 1
@@ -298,7 +302,7 @@ class EvalPlan(object):
                 return out
         return self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
 
-    def run_prepared(self, x, g):
+    def run_prepared(self, x, g, xref=None):
         """The forward on a prepared device graph (ops.Graph; yolat_forward_eval_csr / _bf16_csr): no COO -> CSR
         conversion inside the call.  (hipGraph replay of this path was measured and dropped twice: batches arrive in fresh
         allocations, so captured graphs rarely match — 4.3 k vs 6.2 k graphs/s H2D-inclusive at cfg 2, round 3; keyed by the
@@ -320,24 +324,35 @@ class EvalPlan(object):
                 self._need.clear()
             self._need[(N, E, P, self._desc_key)] = need
         if self._ws is None or self._ws.numel() < need:
-            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=x.device)
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._tensors[0].device)
             self._graphs.clear()
         self._primed = None
-        return self._launch_prepared(x, g)
+        return self._launch_prepared(x, g, xref)
 
-    def _launch_prepared(self, x, g):
-        from ._lib import GraphCsr
+    def _launch_prepared(self, x, g, xref=None):
+        """xref = (address, row stride, rows, device) of a dense fp32 x that exists only as a range of a loader slot
+        (data.DeviceLoader): the hand-over is bound by this thread's Python, a tensor view costs what a launch costs"""
         N, E, P = g.N, g.E, g.P
         gc = GraphCsr(*g.device_pointers())
-        logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
-        if self._desc_h is not None:
-            check(lib.yolat_forward_eval_bf16_csr(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x), ctypes.byref(gc),
-                                                  N, E, P, logits.data_ptr(), logits.stride(0), self._ws.data_ptr(),
-                                                  self._ws.numel(), ops._stream()), "yolat_forward_eval_bf16_csr")
+        if xref is not None:
+            xp, ldx, rows, dev = xref
+            if rows != N:
+                raise ValueError("x has %d rows, the prepared graph %d nodes" % (rows, N))
         else:
-            check(lib.yolat_forward_eval_csr(ctypes.byref(self._desc), ops._f(x, "x"), ops._ld(x), ctypes.byref(gc), N, E, P,
-                                             logits.data_ptr(), logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
-                                             ops._stream()), "yolat_forward_eval_csr")
+            xp, ldx, dev = ops._f(x, "x"), ops._ld(x), x.device
+        logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=dev)
+        ws = self._ws
+        if self._desc_h is not None:
+            rc = lib.yolat_forward_eval_bf16_csr(ctypes.byref(self._desc_h), xp, ldx, ctypes.byref(gc),
+                                                 N, E, P, logits.data_ptr(), logits.stride(0), ws.data_ptr(),
+                                                 ws.numel(), ops._stream())
+            if rc != 0:
+                check(rc, "yolat_forward_eval_bf16_csr")
+        else:
+            rc = lib.yolat_forward_eval_csr(ctypes.byref(self._desc), xp, ldx, ctypes.byref(gc), N, E, P,
+                                            logits.data_ptr(), logits.stride(0), ws.data_ptr(), ws.numel(), ops._stream())
+            if rc != 0:
+                check(rc, "yolat_forward_eval_csr")
         return logits
 
     def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
