@@ -695,10 +695,18 @@ static __global__ void __launch_bounds__(512, (CH == 32 ? 4 : 2)) k_fus_da_mfma(
       int4 a0, a1;
       float4 g0, g1;
       if (in_lds) {
+        // (explicit LDS address space: left to itself the compiler selects between the LDS and the global POINTER and issues
+        // flat loads — they count on vmcnt AND lgkmcnt, and every wait for them drained the weight prefetches in flight)
+        typedef int ft_i32x4 __attribute__((ext_vector_type(4)));
+        typedef float ft_f32x4 __attribute__((ext_vector_type(4)));
+        typedef const __attribute__((address_space(3))) ft_i32x4* lds_i4;
+        typedef const __attribute__((address_space(3))) ft_f32x4* lds_f4;
         const int* ap = &argS[buf][pl * PS + 16 * ks + 8 * lhi];
         const float* gp = &gmS[buf][pl * PS + 16 * ks + 8 * lhi];
-        a0 = *reinterpret_cast<const int4*>(ap); a1 = *reinterpret_cast<const int4*>(ap + 4);
-        g0 = *reinterpret_cast<const float4*>(gp); g1 = *reinterpret_cast<const float4*>(gp + 4);
+        const ft_i32x4 x0 = *(lds_i4)ap, x1 = *(lds_i4)(ap + 4);
+        const ft_f32x4 y0 = *(lds_f4)gp, y1 = *(lds_f4)(gp + 4);
+        a0 = make_int4(x0.x, x0.y, x0.z, x0.w); a1 = make_int4(x1.x, x1.y, x1.z, x1.w);
+        g0 = make_float4(y0.x, y0.y, y0.z, y0.w); g1 = make_float4(y1.x, y1.y, y1.z, y1.w);
       } else {
         const long o = pbase + ch * CH + 16 * ks;
         a0 = *reinterpret_cast<const int4*>(arg + o); a1 = *reinterpret_cast<const int4*>(arg + o + 4);
