@@ -196,5 +196,5 @@ def test_bench_line_with_two_ranks_launched_the_way_the_driver_launches_them():
     pr = d["participation"]
     assert pr["ranks_seen"] == 2 and pr["world_size"] == 2 and pr["backend"] == "gloo"
     assert len(pr["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in pr["per_rank_ms_per_step"])
-    assert max(pr["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-6) + 1e-9
+    assert max(pr["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-6) + 1e-5       # (the record rounds to 1e-5 ms)
     assert sorted(r_["rank"] for r_ in pr["ranks"]) == [0, 1]
