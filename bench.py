@@ -667,6 +667,8 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
         return trainer.step(data, slices)
 
     t, n = _timed_loop(step, budget_s, lo=5, hi=100, warm=4)
+    from yolat_vectorgraphicsrecognition_amd import engine as _eng
+    side_probe = dict(_eng.SIDE_PROBE.get(torch.cuda.current_device(), {})) or None
     # per-op times with every launch on ONE stream: with the weight gradients and node branches on the second stream
     # (the default, which `ms_per_step` above is measured with) the HIP events around an op also cover whatever the other
     # stream runs beside it, and per-op times stop meaning anything (profiles/r04_train_cfg3_kernel_stats.txt)
@@ -691,7 +693,7 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
     top = sorted(table.items(), key=lambda kv: -kv[1]["ms_total"])[:6]
     rec = {"workload": "cfg%s train step (fwd+CE+bwd+Adam), %d graph(s) per step, %s" %
                        (cfg, n_graphs, "fp32" if precision == "fp32" else "bf16 storage of the per-edge tensors"),
-           "nodes": N, "edges": E, "proposals": P, "steps_timed": n, "ms_per_step": t * 1e3,
+           "nodes": N, "edges": E, "proposals": P, "steps_timed": n, "ms_per_step": t * 1e3, "side_stream_probe": side_probe,
            "graphs_per_sec": n_graphs / t,
            "whole_step": {"algorithmic_GFLOP": 3.0 * fwd / 1e9, "TFLOPs": 3.0 * fwd / t / 1e12,
                           "frac_of_fp32_mfma_peak": 3.0 * fwd / t / 1e12 / PEAK_MFMA_F32_TFLOPS,

@@ -769,3 +769,20 @@ def test_training_step_releases_its_activations_without_the_cyclic_collector():
     finally:
         gc.enable()
     assert max(levels) - min(levels) <= 64 * 1024, levels
+
+
+def test_side_stream_probe_picks_a_stream_that_runs_beside_the_current_one():
+    """engine._pick_side_stream: streams share a few hardware queues, and a side stream that lands on the current stream's
+    queue serialises the backward's two branches (the train step then takes its one-stream time).  Whatever number of pool
+    streams the process has drawn before, the probe must end on a candidate whose spin overlaps the current stream's."""
+    from yolat_vectorgraphicsrecognition_amd import engine, ops
+    if getattr(torch.cuda, "_sleep", None) is None:
+        pytest.skip("torch.cuda._sleep is not available")
+    keep = []
+    for drawn in range(5):
+        keep.append(torch.cuda.Stream())
+        cur = ops.current_stream_object()
+        s = engine._pick_side_stream(cur)
+        pr = engine.SIDE_PROBE[cur.device_index]
+        assert s is not None and pr["pair_over_alone"], pr
+        assert pr["pair_over_alone"][-1] < 1.5, "no concurrent stream among 8 candidates: %s" % pr
