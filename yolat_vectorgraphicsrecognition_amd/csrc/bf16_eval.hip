@@ -116,11 +116,18 @@ __device__ __forceinline__ void hgemm_tile(const AL& A, const HOp& B, const Epil
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-  u32x4 ra[NA * AL::NR], rb[NB];
+  // PF K steps of operands in flight (round 5): with one, a long-K classifier tile kept 64 KB per CU on the way and ran at
+  // the latency of its loads (1.2 us per K step for 256 cycles of MFMA per wave)
+  constexpr int PF = 2;        // (3: 150 registers, no faster)
+  u32x4 ra[PF][NA * AL::NR], rb[PF][NB];
 #pragma unroll
-  for (int t = 0; t < NA; ++t) A.load(row0 + sr + 32 * t, sc, ra + t * AL::NR);
+  for (int q = 0; q < PF; ++q)
+    if (64 * q < K) {
 #pragma unroll
-  for (int t = 0; t < NB; ++t) B.load(col0 + sr + 32 * t, sc, rb + t);
+      for (int t = 0; t < NA; ++t) A.load(row0 + sr + 32 * t, 64 * q + sc, ra[q] + t * AL::NR);
+#pragma unroll
+      for (int t = 0; t < NB; ++t) B.load(col0 + sr + 32 * t, 64 * q + sc, rb[q] + t);
+    }
 
   EpiPre pre[TM][TN];
 #pragma unroll
@@ -129,18 +136,19 @@ __device__ __forceinline__ void hgemm_tile(const AL& A, const HOp& B, const Epil
     for (int j = 0; j < TN; ++j)
       pre[i][j] = epi_prefetch(ep, row0 + (wm * TM + i) * 32, col0 + (wn * TN + j) * 32 + l31, M, N);
 
-  for (int k0 = 0; k0 < K; k0 += 64) {
+  // one K step: stage the registers of step k0, refill them with step k0 + 64 PF, MFMAs
+  auto kstep = [&](int k0, u32x4* qa, u32x4* qb) {
 #pragma unroll
     for (int t = 0; t < NA; ++t)
-      *reinterpret_cast<u32x4*>(As + (sr + 32 * t) * YL_HRS + sc) = AL::pack(ra + t * AL::NR);
+      *reinterpret_cast<u32x4*>(As + (sr + 32 * t) * YL_HRS + sc) = AL::pack(qa + t * AL::NR);
 #pragma unroll
-    for (int t = 0; t < NB; ++t) *reinterpret_cast<u32x4*>(Bs + (sr + 32 * t) * YL_HRS + sc) = rb[t];
+    for (int t = 0; t < NB; ++t) *reinterpret_cast<u32x4*>(Bs + (sr + 32 * t) * YL_HRS + sc) = qb[t];
     __syncthreads();
-    if (k0 + 64 < K) {                      // next K step in flight while the MFMAs below run
+    if (k0 + 64 * PF < K) {                 // PF steps ahead, in flight while the MFMAs below run
 #pragma unroll
-      for (int t = 0; t < NA; ++t) A.load(row0 + sr + 32 * t, k0 + 64 + sc, ra + t * AL::NR);
+      for (int t = 0; t < NA; ++t) A.load(row0 + sr + 32 * t, k0 + 64 * PF + sc, qa + t * AL::NR);
 #pragma unroll
-      for (int t = 0; t < NB; ++t) B.load(col0 + sr + 32 * t, k0 + 64 + sc, rb + t);
+      for (int t = 0; t < NB; ++t) B.load(col0 + sr + 32 * t, k0 + 64 * PF + sc, qb + t);
     }
 #pragma unroll
     for (int ks = 0; ks < 4; ++ks) {
@@ -158,6 +166,11 @@ __device__ __forceinline__ void hgemm_tile(const AL& A, const HOp& B, const Epil
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[i], b[j], acc[i][j], 0, 0, 0);
     }
     __syncthreads();
+  };
+  for (int k0 = 0; k0 < K; k0 += 64 * PF) {
+#pragma unroll
+    for (int q = 0; q < PF; ++q)
+      if (k0 + 64 * q < K) kstep(k0 + 64 * q, ra[q], rb[q]);
   }
   static_assert(TM <= 2 && TN <= 2, "epilogue expansion covers up to 2x2 sub-tiles");
   // the operand tiles are dead after the loop's closing barrier: every wave stages its stores in its own 4.5 KB of them
