@@ -395,14 +395,13 @@ _UNPACK_I64 = struct.Struct("q").unpack_from
 class _BatchState(object):
     """What a DeviceLoader batch is made from on demand: the slot's device buffer, the field offsets, the slices (bytes
     copied out of the slot at draw time) and the host items."""
-    __slots__ = ("mem", "offs", "sl_bytes", "items", "ship", "tkeys", "rest", "B", "sl", "host", "slices", "names")
+    __slots__ = ("mem", "offs", "sl_bytes", "items", "ship", "tkeys", "rest", "B", "sl", "host", "names")
 
     def __init__(self, mem, offs, sl_bytes, items, ship, tkeys, rest, B):
         self.mem, self.offs, self.sl_bytes = mem, offs, sl_bytes
         self.items, self.ship, self.tkeys, self.rest, self.B = items, ship, tkeys, rest, B
         self.sl = None
         self.host = None
-        self.slices = None
         self.names = None
 
     def slice_rows(self):
@@ -440,7 +439,7 @@ class _BatchState(object):
         if self.host is None:
             hb, hs = self.items[0].__class__(), {}
             for k in self.tkeys:                     # the fix-up of host-resident edge tensors needs the node slices
-                hs[k] = self.slices[k]
+                hs[k] = self.make_slices(k)
             _collate_host_keys(self.items, self.rest, hb, hs)
             self.host = (hb, hs)
         return self.host
@@ -649,8 +648,7 @@ class DeviceLoader(object):
         bd = batch.__dict__
         bd["_lazy"] = st
         slices = _LazySlices()
-        slices._st = st
-        st.slices = slices
+        slices._st = st                 # (one direction only: no reference cycle per batch)
         offs = st.offs
         N = out.N
         bd["_yolat_graph"] = self._from_buffer(mem[2], offs[nk:nk + 6], N, out.E, out.P)
