@@ -960,19 +960,23 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   });
   {
     Epilogue e = plain_epilogue();
-    e.bias = m->bc1; e.scale = m->sc1; e.shift = m->tc1; e.relu = 1; e.Y = p.c1; e.ldy = m->H1;
+    // the hidden activations of the classifier cross HBM as bf16 (in the fp32-sized buffers c1 / c2): the next Linear rounds
+    // its rows to bf16 while staging anyway (FOp::pack — the same round-to-nearest-even), so the logits are the same bits
+    u16* const c1h = reinterpret_cast<u16*>(p.c1);
+    u16* const c2h = reinterpret_cast<u16*>(p.c2);
+    e.bias = m->bc1; e.scale = m->sc1; e.shift = m->tc1; e.relu = 1; e.Y = nullptr; e.Yh = c1h; e.ldy = m->H1;
     snprintf(nm, sizeof nm, "cls1_bf16[P x %ld -> %ld]", ZW, (long)m->H1);
-    YL_HSTAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * (P * ZW + P * m->H1) + 2.0 * ZW * m->H1,
+    YL_HSTAGE(nm, 2.0 * P * ZW * m->H1, 4.0 * P * ZW + 2.0 * P * m->H1 + 2.0 * ZW * m->H1,
               { YL_TRY(launch_hgemm(FOp{p.Z, ZW, (int)P}, HOp{mh->Wc1, ZW, (int)m->H1}, e, P, m->H1, ZW, st)); });
-    e.bias = m->bc2; e.scale = m->sc2; e.shift = m->tc2; e.Y = p.c2; e.ldy = m->H2;
+    e.bias = m->bc2; e.scale = m->sc2; e.shift = m->tc2; e.Yh = c2h; e.ldy = m->H2;
     snprintf(nm, sizeof nm, "cls2_bf16[P x %ld -> %ld]", (long)m->H1, (long)m->H2);
-    YL_HSTAGE(nm, 2.0 * P * m->H1 * m->H2, 4.0 * (P * m->H1 + P * m->H2) + 2.0 * m->H1 * m->H2,
-              { YL_TRY(launch_hgemm(FOp{p.c1, m->H1, (int)P}, HOp{mh->Wc2, m->H1, (int)m->H2}, e, P, m->H2, m->H1, st)); });
+    YL_HSTAGE(nm, 2.0 * P * m->H1 * m->H2, 2.0 * (P * m->H1 + P * m->H2) + 2.0 * m->H1 * m->H2,
+              { YL_TRY(launch_hgemm(HOp{c1h, m->H1, (int)P}, HOp{mh->Wc2, m->H1, (int)m->H2}, e, P, m->H2, m->H1, st)); });
     e = plain_epilogue();
     e.bias = m->bc3; e.Y = logits; e.ldy = ld_logits;
     snprintf(nm, sizeof nm, "cls3_bf16[P x %ld -> %d]", (long)m->H2, (int)m->n_classes);
-    YL_HSTAGE(nm, 2.0 * P * m->H2 * m->n_classes, 4.0 * (P * m->H2 + P * m->n_classes) + 2.0 * m->H2 * m->n_classes, {
-      YL_TRY(launch_hgemm(FOp{p.c2, m->H2, (int)P}, HOp{mh->Wc3, m->H2, (int)m->n_classes}, e, P, m->n_classes, m->H2, st));
+    YL_HSTAGE(nm, 2.0 * P * m->H2 * m->n_classes, 2.0 * P * m->H2 + 4.0 * P * m->n_classes + 2.0 * m->H2 * m->n_classes, {
+      YL_TRY(launch_hgemm(HOp{c2h, m->H2, (int)P}, HOp{mh->Wc3, m->H2, (int)m->n_classes}, e, P, m->n_classes, m->H2, st));
     });
   }
   return 0;
