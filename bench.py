@@ -999,6 +999,7 @@ def main():
 
     h2d_inclusive = None
     csr_mode = None
+    coo_loader = None
     if args.mode == "fwd" and rank == 0:
         # PCIe-inclusive rate (never `value`): the batch starts as CPU tensors, goes through
         # data.collate_to_device (one pinned staging buffer, one async H2D copy, offset fix-up on the device)
@@ -1036,11 +1037,11 @@ def main():
         # behind an event on the stream its batch was drawn on), so forwards of consecutive batches overlap on the GPU the
         # way `multi_stream` overlaps resident ones — and the hand-over (cold operands, the event packets between
         # forwards: ~6 + 3 us of a one-stream hand-over by kernel trace) hides behind them
-        def loader_rate(nstreams=1):
+        def loader_rate(nstreams=1, csr=True):
             streams = [torch.cuda.Stream() for _ in range(nstreams)] if nstreams > 1 else None
 
             def run(n):
-                loader = yv.DeviceLoader(([cpu_item] for _ in range(n)), slots=nstreams + 2)
+                loader = yv.DeviceLoader(([cpu_item] for _ in range(n)), slots=nstreams + 2, csr=csr)
                 try:
                     with torch.no_grad():
                         k = 0
@@ -1065,6 +1066,9 @@ def main():
             return sorted(rates)[2]
         h2d_loader = loader_rate()
         h2d_loader3 = loader_rate(3)
+        # COO mode through the loader (raw index tensors, fix-up by the native worker, CSR rebuilt on the device by every
+        # forward = the headline's work per graph) against the one-stream resident rate of that work
+        h2d_loader_coo = loader_rate(1, csr=False)
         # merged mode with the batch resident: one forward at a time on the prepared graph
         b, sl = yv.collate_to_device([cpu_item], csr=True)
         for _ in range(5):
@@ -1077,6 +1081,9 @@ def main():
                 model(b, sl)
         torch.cuda.synchronize()
         merged_ms = (time.perf_counter() - t2) / nh * 1e3
+        coo_loader = {"h2d_inclusive_graphs_per_sec_device_loader": h2d_loader_coo,
+                      "resident_one_stream_graphs_per_sec": n_graphs / (latency_ms * 1e-3) if latency_ms else None,
+                      "device_loader_over_resident_one_stream": h2d_loader_coo * latency_ms * 1e-3 / n_graphs if latency_ms else None}
         csr_mode = {"h2d_inclusive_graphs_per_sec": h2d_csr, "h2d_inclusive_graphs_per_sec_device_loader": h2d_loader,
                     "h2d_inclusive_graphs_per_sec_device_loader_3_streams": h2d_loader3,
                     "ms_per_forward_resident": merged_ms,
@@ -1165,6 +1172,7 @@ def main():
             "ms_per_forward": latency_ms,
             "h2d_inclusive_graphs_per_sec": h2d_inclusive,
             "csr_merged_mode": csr_mode,
+            "coo_mode_device_loader": coo_loader,
             "single_stream_graphs_per_sec": (n_graphs * world / (latency_ms * 1e-3)) if latency_ms else None,
             "higher_is_better": True,
             "scaling": "weak",
@@ -1211,6 +1219,8 @@ def main():
             "csr_merged_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec"),
             "loader_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec_device_loader"),
             "loader3_h2d_gps": pick(line, "csr_merged_mode", "h2d_inclusive_graphs_per_sec_device_loader_3_streams"),
+            "loader_coo_h2d_gps": pick(line, "coo_mode_device_loader", "h2d_inclusive_graphs_per_sec_device_loader"),
+            "loader_coo_over_resident": pick(line, "coo_mode_device_loader", "device_loader_over_resident_one_stream"),
             "h2d_inclusive_gps": pick(line, "h2d_inclusive_graphs_per_sec"), "multi_stream_gps": pick(line, "multi_stream", "value"),
             "floorplans_ms": pick(line, "floorplans_sized", "ms_per_forward"),
             "floorplans_x_cpu": pick(line, "floorplans_sized", "speedup_vs_cpu_one_at_a_time"),

@@ -571,7 +571,12 @@ typedef struct {
   int64_t n_keys;
   yolat_span key[YOLAT_MAX_KEYS];
   int64_t rows[YOLAT_MAX_KEYS];
-  yolat_item_csr csr;
+  yolat_item_csr csr;                   /* all zero: the batch carries no prepared graph (COO mode, below)               */
+  /* COO mode (round 5): keys shipped as raw int64 index tensors get the reference's offset fix-up (train.py:238-258)
+   * while they are copied: fix[k] = 1: every element += the rows of key `node_key` in the items before this one (edge:
+   * += slices['pos'][i]), 2: += the rows of key `prop_key` before it (bbox_idx: += slices['labels'][i]), 0: copied as is. */
+  int32_t fix[YOLAT_MAX_KEYS];
+  int32_t node_key, prop_key;
 } yolat_item_desc;
 int yolat_collate_batch(const yolat_item_desc* const* items, int64_t B, void* dst, int64_t cap, int64_t* off,
                         int64_t* total, int64_t* slices, int64_t* totals);

@@ -136,3 +136,33 @@ def test_device_loader_round_robin_over_three_streams_soak():
     bad = [k for k, (i, o) in enumerate(outs) if not torch.equal(o, want[i])]
     assert not bad, "batches %s differ from the synchronous hand-over" % bad[:10]
     loader.close()
+
+
+def test_device_loader_coo_mode_matches_collate_to_device_and_the_reference_fixup():
+    """csr=False: the raw edge / e_attr / bbox_idx tensors travel, with the offset fix-up of train.py:238-258 applied by the
+    native worker while it copies them — tensors equal collate_to_device(items) (device-side fix-up) AND host collate +
+    fixup_offsets (the reference's loops); the forward (CSR rebuilt on the device) gives the same logits"""
+    yv = _yv()
+    lists = _lists(yv, 8, seed0=300)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 11).cuda().eval()
+    loader = yv.DeviceLoader(lists, slots=3, csr=False)
+    n = 0
+    with torch.no_grad():
+        for (batch, slices), items in zip(loader, lists):
+            wb, ws = yv.collate_to_device(items)
+            hb, hs = yv.collate(items)
+            hb = yv.fixup_offsets(hb, hs)
+            assert getattr(batch, "_yolat_graph", None) is None
+            for k in ("x", "pos", "edge", "e_attr", "bbox_idx", "bbox", "stat_feats", "labels"):
+                if k in wb.keys:
+                    a = batch[k]
+                    assert a.is_cuda and a.dtype == wb[k].dtype and a.shape == wb[k].shape, k
+                    assert torch.equal(a, wb[k]), k
+                    assert torch.equal(a.cpu(), hb[k]), k
+                    assert torch.equal(torch.as_tensor(slices[k]), torch.as_tensor(ws[k])), k
+            got = model(batch, slices)[0]
+            want = model(wb, ws)[0]
+            assert torch.equal(got, want)
+            n += 1
+    assert n == len(lists)
+    loader.close()

@@ -70,7 +70,8 @@ YOLAT_MAX_KEYS = 8
 
 class ItemDesc(ctypes.Structure):
     """yolat_item_desc"""
-    _fields_ = [("n_keys", c_i64), ("key", Span * YOLAT_MAX_KEYS), ("rows", c_i64 * YOLAT_MAX_KEYS), ("csr", ItemCsr)]
+    _fields_ = [("n_keys", c_i64), ("key", Span * YOLAT_MAX_KEYS), ("rows", c_i64 * YOLAT_MAX_KEYS), ("csr", ItemCsr),
+                ("fix", ctypes.c_int32 * YOLAT_MAX_KEYS), ("node_key", ctypes.c_int32), ("prop_key", ctypes.c_int32)]
 
 
 class LoaderBatch(ctypes.Structure):

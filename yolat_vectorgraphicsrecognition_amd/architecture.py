@@ -140,6 +140,10 @@ class SparseCADGCN(nn.Module):
                 return {"x": None, "xref": xref, "bbox": data.bbox, "g": pre, "prepared": True}
             x = data.x if data.x.dtype == torch.float32 else data.x.float()
             return {"x": x, "bbox": data.bbox, "g": pre, "prepared": True}
+        raw = data.__dict__.get("_yolat_raw") if (not need_graph and hasattr(data, "__dict__")) else None
+        if raw is not None:
+            # a DeviceLoader batch in COO mode in the eval forward: addresses only (plan.run_raw), no tensor views
+            return {"raw": raw, "bbox": data.bbox, "g": None}
         cache = getattr(data, "_yolat_stage", None)
         key = (data.x.data_ptr(), data.x._version, data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
                data.bbox_idx._version, data.e_attr.data_ptr(), data.e_attr._version, data.bbox.data_ptr(),
@@ -183,7 +187,9 @@ class SparseCADGCN(nn.Module):
                 plan.use_graph = ug
             self.__dict__["_yolat_plan"] = plan      # the plan of the most recent forward (status checks); not through
             #                                          nn.Module.__setattr__: 3 us of a 100 us hand-over
-            if st.get("prepared"):
+            if st.get("raw") is not None:
+                pred_cls = plan.run_raw(st["raw"])
+            elif st.get("prepared"):
                 pred_cls = plan.run_prepared(st["x"], st["g"], st.get("xref"))
             else:
                 pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])

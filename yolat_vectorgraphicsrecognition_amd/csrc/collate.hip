@@ -151,10 +151,31 @@ extern "C" int yolat_collate_batch(const yolat_item_desc* const* items, int64_t 
     for (int64_t b = 0; b < B; ++b) {
       const yolat_span& sp = items[b]->key[k];
       if (sp.bytes < 0 || (sp.bytes > 0 && !sp.ptr)) return YOLAT_E_INVALID;
-      if (sp.bytes) memcpy(w, sp.ptr, (size_t)sp.bytes);
+      const int fx = items[b]->fix[k];
+      if (fx == 0) {
+        if (sp.bytes) memcpy(w, sp.ptr, (size_t)sp.bytes);
+      } else {
+        // an int64 index tensor with the offset of its item added on the way (train.py:238-258)
+        const int64_t ok = fx == 1 ? items[b]->node_key : (fx == 2 ? items[b]->prop_key : -1);
+        if (ok < 0 || ok >= nk || sp.bytes % 8 != 0) return YOLAT_E_INVALID;
+        const int64_t add = slices[ok * (B + 1) + b];
+        const int64_t* in = reinterpret_cast<const int64_t*>(sp.ptr);
+        int64_t* out = reinterpret_cast<int64_t*>(w);
+        const int64_t n = sp.bytes / 8;
+        for (int64_t i = 0; i < n; ++i) out[i] = in[i] + add;
+      }
       w += sp.bytes;
     }
   }
+  // COO mode: no item carries a prepared graph (all csr members zero) — the six graph fields stay empty
+  bool any_csr = false, all_csr = true;
+  for (int64_t b = 0; b < B; ++b) {
+    const bool has = items[b]->csr.N > 0 || items[b]->csr.row_ptr != nullptr;
+    any_csr = any_csr || has;
+    all_csr = all_csr && has;
+  }
+  if (!any_csr) return 0;
+  if (!all_csr) return YOLAT_E_INVALID;
   std::vector<yolat_item_csr> cs((size_t)B);
   for (int64_t b = 0; b < B; ++b) cs[(size_t)b] = items[b]->csr;
   return yolat_collate_csr_pack(cs.data(), B, reinterpret_cast<int32_t*>(base + off[nk + 0]),

@@ -179,16 +179,18 @@ def item_csr(item):
     return c
 
 
-def _item_desc(item, ship):
-    """The cached yolat_item_desc of a dataset item: pointers / sizes of its dense arrays in `ship` order + its CSR."""
-    d = item.__dict__.get("_yolat_desc")
-    key = _source_key(item, tuple(ship) + ("edge", "e_attr", "bbox_idx"))
+def _item_desc(item, ship, csr=True):
+    """The cached yolat_item_desc of a dataset item: pointers / sizes of its dense arrays in `ship` order + its CSR
+    (csr=True), or — COO mode — no CSR and the offset fix-up of the int64 index keys (train.py:238-258: keys containing
+    'edge' += the image's node offset, 'bbox_idx' += its proposal offset) described for the native collate."""
+    slot = "_yolat_desc" if csr else "_yolat_desc_coo"
+    d = item.__dict__.get(slot)
+    key = _source_key(item, tuple(ship) + (("edge", "e_attr", "bbox_idx") if csr else ()))
     if d is not None and d[0] == ship and len(d) > 3 and d[3] == key:
         return d[1]
     from ._lib import ItemDesc
     if len(ship) > 8:
-        raise ValueError("collate_to_device(csr=True) ships at most 8 dense keys")
-    c = item_csr(item)
+        raise ValueError("the native collate ships at most 8 dense keys")
     desc = ItemDesc()
     desc.n_keys = len(ship)
     keep = []
@@ -199,8 +201,19 @@ def _item_desc(item, ship):
         keep.append(t)
         desc.key[f].ptr, desc.key[f].bytes = t.data_ptr(), t.numel() * t.element_size()
         desc.rows[f] = t.shape[0]
-    desc.csr = c["struct"]
-    item.__dict__["_yolat_desc"] = (ship, desc, keep, key)
+    if csr:
+        desc.csr = item_csr(item)["struct"]
+    else:
+        desc.node_key = ship.index("pos") if "pos" in ship else ship.index("x")
+        desc.prop_key = ship.index("labels") if "labels" in ship else ship.index("bbox")
+        for f, k in enumerate(ship):
+            if item[k].dtype == torch.int64 and "edge" in k:
+                desc.fix[f] = 1
+            elif "bbox_idx" in k:
+                if item[k].dtype != torch.int64:
+                    raise TypeError("bbox_idx must be int64")
+                desc.fix[f] = 2
+    item.__dict__[slot] = (ship, desc, keep, key)
     return desc
 
 
@@ -553,13 +566,15 @@ class DeviceLoader(object):
 
     Every batch is what ``collate_to_device(items, csr=True)`` returns (bit-identical: same native call), i.e. it carries
     the merged destination-sorted graph (``item_csr`` of each item, cached on the item) instead of edge / e_attr /
-    bbox_idx.  A batch's tensors live in the loader's ring of ``slots`` device buffers: they are valid until ``slots - 1``
+    bbox_idx.  ``csr=False`` (COO mode): what ``collate_to_device(items)`` returns — edge / e_attr / bbox_idx travel with
+    the offset fix-up of train.py:238-258 applied by the worker while it copies them; the forward rebuilds the CSR on the
+    device (and ``predict`` works on such a batch).  A batch's tensors live in the loader's ring of ``slots`` device buffers: they are valid until ``slots - 1``
     further batches have been drawn, and everything that reads them must have been ENQUEUED, on the stream that was current
     when the batch was drawn, by the time the next batch is drawn (the loader then hands the slot back behind an event on
     that stream).  Consecutive batches may be drawn under different streams (``torch.cuda.set_stream`` between draws): their
     forwards then overlap on the GPU and the hand-over disappears behind them (``slots`` >= streams + 2)."""
 
-    def __init__(self, batches, device="cuda", slots=3):
+    def __init__(self, batches, device="cuda", slots=3, csr=True):
         from ._lib import lib
         if slots < 2:
             raise ValueError("DeviceLoader needs at least two slots")
@@ -575,6 +590,7 @@ class DeviceLoader(object):
         self._lib, self._check, self._LoaderBatch = lib, check, LoaderBatch
         self._stream, self._from_buffer = ops._stream, ops.PackedGraph.from_buffer
         self._pending = []          # submitted, not yet drawn: (items, ship, tkeys, rest, pointer array)
+        self._csr = bool(csr)
         self._held = None           # slot of the batch the consumer holds
         self._held_stream = None    # ... and the stream it was drawn on (its readers are enqueued there)
         self._mem = {}              # slot -> (ptr, capacity, tensor)
@@ -602,10 +618,13 @@ class DeviceLoader(object):
             ship = tuple(k for k in tkeys if k not in _CSR_SKIP)
             split = first.__dict__["_yolat_keysplit"] = (names, tkeys, rest, ship)
         _, tkeys, rest, ship = split
+        csr = self._csr
+        if not csr:
+            ship = tuple(tkeys)          # COO mode: the raw index tensors travel, fixed up by the native collate
         if len(items) == 1:
-            ptrs = (ctypes.c_void_p * 1)(ctypes.addressof(_item_desc(first, ship)))
+            ptrs = (ctypes.c_void_p * 1)(ctypes.addressof(_item_desc(first, ship, csr)))
         else:
-            ptrs = (ctypes.c_void_p * len(items))(*[ctypes.addressof(_item_desc(it, ship)) for it in items])
+            ptrs = (ctypes.c_void_p * len(items))(*[ctypes.addressof(_item_desc(it, ship, csr)) for it in items])
         rc = self._lib.yolat_loader_submit(self._h, ptrs, len(items))
         if rc != 0:
             self._check(rc, "yolat_loader_submit")
@@ -651,13 +670,39 @@ class DeviceLoader(object):
         slices._st = st                 # (one direction only: no reference cycle per batch)
         offs = st.offs
         N = out.N
-        bd["_yolat_graph"] = self._from_buffer(mem[2], offs[nk:nk + 6], N, out.E, out.P)
-        if ship and ship[0] == "x":
+        if self._csr:
+            bd["_yolat_graph"] = self._from_buffer(mem[2], offs[nk:nk + 6], N, out.E, out.P)
+        if self._csr and ship and ship[0] == "x":
             x0 = items[0].x
             if x0.dtype == torch.float32 and x0.dim() == 2:
                 bd["_yolat_x"] = (out.device + offs[0], int(x0.shape[1]), N, self._device)
+        if not self._csr:
+            self._raw_fast_path(bd, items[0], ship, st, out.device)
         bd["_device_buffer"] = mem[2]
         return batch, slices
+
+    def _raw_fast_path(self, bd, first, ship, st, base):
+        """COO mode: the eval forward's operands as addresses (architecture._stage / plan.run_raw) when the batch has the
+        reference's layout: x [N, C] fp32, edge [E, 2] int64, e_attr [E, 4] fp32, bbox_idx [N] int64, bbox rows = proposals"""
+        need = ("x", "edge", "e_attr", "bbox_idx", "bbox")
+        if any(k not in ship for k in need):
+            return
+        d = first.__dict__
+        x0, e0, a0, b0 = d["x"], d["edge"], d["e_attr"], d["bbox_idx"]
+        if (x0.dtype != torch.float32 or x0.dim() != 2 or e0.dtype != torch.int64 or e0.dim() != 2 or e0.shape[1] != 2 or
+                a0.dtype != torch.float32 or a0.dim() != 2 or a0.shape[1] != 4 or b0.dtype != torch.int64 or b0.dim() != 1):
+            return
+        B = st.B
+
+        def rows(k):
+            return _UNPACK_I64(st.sl_bytes, 8 * (ship.index(k) * (B + 1) + B))[0]
+
+        def addr(k):
+            return base + st.offs[ship.index(k)]
+        N, E, P = rows("x"), rows("edge"), rows("bbox")
+        if rows("bbox_idx") != N or rows("e_attr") != E:
+            return
+        bd["_yolat_raw"] = (addr("x"), int(x0.shape[1]), addr("edge"), 2, 1, addr("e_attr"), addr("bbox_idx"), N, E, P, self._device)
 
     def close(self):
         from ._lib import lib

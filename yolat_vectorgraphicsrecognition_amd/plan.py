@@ -302,6 +302,48 @@ class EvalPlan(object):
                 return out
         return self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
 
+    def run_raw(self, raw):
+        """The forward on a DeviceLoader batch in COO mode, described by addresses instead of tensor views:
+        raw = (x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, device) — every tensor view costs this thread
+        what a launch costs, and the hand-over is bound by exactly that (data.DeviceLoader)."""
+        key = self._version_key()
+        if key != self._key:
+            self._build()
+            self._key = key
+            self._graphs.clear()
+        xp, ldx, ep, se, sc, ap, bp, N, E, P, dev = raw
+        nk = ("raw", N, E, P, self._desc_key)
+        need = self._need.get(nk)
+        if need is None:
+            if self._desc_h is not None:
+                need = int(lib.yolat_forward_eval_bf16_workspace_bytes(ctypes.byref(self._desc_h), N, E, P))
+            else:
+                need = int(lib.yolat_forward_eval_workspace_bytes(ctypes.byref(self._desc), N, E, P))
+            if len(self._need) > 64:
+                self._need.clear()
+            self._need[nk] = need
+        if self._ws is None or self._ws.numel() < need:
+            self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._tensors[0].device)
+            self._graphs.clear()
+        logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=dev)
+        stream = ops._stream()
+        bf16 = self._desc_h is not None
+        pk = (self._ws.data_ptr(), self._desc_key, N, E, P, stream, "bf16") if bf16 else (self._ws.data_ptr(), self._desc_key, N, E, P, stream)
+        primed = PRIMED_WS and self._primed == pk
+        self._primed = None
+        if bf16:
+            fn = lib.yolat_forward_eval_bf16_primed if primed else lib.yolat_forward_eval_bf16
+            rc = fn(ctypes.byref(self._desc_h), xp, ldx, ep, se, sc, ap, bp, N, E, P, logits.data_ptr(), logits.stride(0),
+                    self._ws.data_ptr(), self._ws.numel(), self._status.data_ptr(), stream)
+        else:
+            fn = lib.yolat_forward_eval_primed if primed else lib.yolat_forward_eval
+            rc = fn(ctypes.byref(self._desc), xp, ldx, ep, se, sc, ap, bp, N, E, P, logits.data_ptr(), logits.stride(0),
+                    self._ws.data_ptr(), self._ws.numel(), self._status.data_ptr(), stream)
+        if rc != 0:
+            check(rc, "yolat_forward_eval")
+        self._primed = pk
+        return logits
+
     def run_prepared(self, x, g, xref=None):
         """The forward on a prepared device graph (ops.Graph; yolat_forward_eval_csr / _bf16_csr): no COO -> CSR
         conversion inside the call.  (hipGraph replay of this path was measured and dropped twice: batches arrive in fresh
