@@ -303,8 +303,11 @@ def bf16_grads_vs_fp64_oracle(g16, g64, g64p, name):
     g64p = the same float64 oracle on node features carrying bf16-sized noise: the oracle's own statement of what ONE
     2^-9 relative perturbation of stored values is worth for that tensor (the network is discontinuous: per-proposal
     arg-max, ReLU gates); the bf16 step rounds at every stored [E,64] activation and gradient of every layer, hence the
-    factor 4 (measured: with 2.5 one tensor of ~50 exceeds the bound by 6 - 18 % on the 4-block fixture and at cfg 5, all
-    others pass).  2e-2 = the bf16 term: ~5 stored roundings of 2^-9 between a gradient and its tensor.
+    factor 4 (measured, tools/exp/bf16_grad_bound_which_tensor.py on the 4-block fixture: the tensor that needs more than
+    2.5 is `prediction_cls.1.1.bias` — the BatchNorm shift of the classifier's second block — at 3.0; next
+    `prediction_cls.1.0.weight` 2.5, `prediction_cls.0.1.weight` 2.3, every conv-layer tensor <= 1.4: the classifier sits
+    behind the per-proposal arg-max of ALL layers, so its gradients collect every layer's rounding while the probe perturbs
+    the input once).  2e-2 = the bf16 term: ~5 stored roundings of 2^-9 between a gradient and its tensor.
     The one exception, as in tests/test_gpu_configs.py::_grad_check_per_tensor: a MATHEMATICALLY ZERO gradient (the bias
     of a Linear in front of a BatchNorm, |g64| < 1e-9 gmax) is a random walk of rounding errors over E rows,
     sqrt(E) * 2^-9 * rms(dY) — bounded by 4e-2 of the largest tensor rms."""
