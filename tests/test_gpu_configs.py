@@ -6,6 +6,8 @@ caches the HIP kernels bypass (round-2 review items):
   cfg 4  Diagrams-style batch (32 graphs, K=22): Trainer.step, loss / gradients vs the oracle on the same batch
   cfg 5  N=200k / E=1.2M / n_blocks=4: training step — determinism, finiteness, block-diagonal consistency
 """
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -161,7 +163,7 @@ def test_cfg3_full_size_train_step_matches_oracle_and_is_deterministic():
     # every tensor at its own scale against the float64 oracle (floor = that tensor's fp32-vs-fp64 oracle gap)
     g32 = {n: p.grad.detach().double() for n, p in ref.named_parameters()}
     _, _, g64 = _oracle_grads(optkw, 33, data, torch.float64)
-    _grad_check_per_tensor(runs[0][2], g64, g32, 5e-3, "cfg 3")
+    _grad_check_per_tensor(runs[0][2], g64, g32, 3e-3, "cfg 3")
     # the same step through the trainer (flat buffers + one-kernel Adam): same loss, finite parameters afterwards
     m3 = _model(yv, optkw, 33)
     tr = yv.Trainer(m3, opt, lr=2.5e-4, weight_decay=1e-5)
@@ -189,7 +191,7 @@ def test_cfg4_diagrams_batch_train_step_matches_oracle():
     hip_grads = {n: tr.flat.grad_views[id(p)] for n, p in model.named_parameters()}
     g32 = {n: p.grad.detach().double() for n, p in ref.named_parameters()}
     _, _, g64 = _oracle_grads(optkw, 44, data, torch.float64)
-    _grad_check_per_tensor(hip_grads, g64, g32, 5e-3, "cfg 4")
+    _grad_check_per_tensor(hip_grads, g64, g32, 3e-3, "cfg 4")
     moved = sum(int(not torch.equal(before[n], p.detach())) for n, p in model.named_parameters())
     assert moved == len(before)
     for n, b in model.named_buffers():
@@ -205,7 +207,7 @@ def _oracle_grads(optkw, seed, data, dtype):
     return logits, loss, {n: p.grad.detach().double() for n, p in ref.named_parameters()}
 
 
-def _grad_check_per_tensor(model_grads, g64, g32, rtol, name, gap_factor=4.0):
+def _grad_check_per_tensor(model_grads, g64, g32, rtol, name, gap_factor=2.0):
     """Every gradient tensor against the float64 oracle at ITS OWN scale: |d| <= rtol * max|g64_n| + gap_factor * gap_n
     with gap_n = max|g32_n - g64_n|, the distance between the fp32 and the fp64 run of the same CPU oracle on that very
     tensor — what fp32 arithmetic (summation order, near-tie arg-max / ReLU decisions) is worth for it.  No floor taken
@@ -214,7 +216,8 @@ def _grad_check_per_tensor(model_grads, g64, g32, rtol, name, gap_factor=4.0):
     front of a BatchNorm: its float64 value is ~1e-17, every fp32 implementation returns the rounding noise of a sum
     over E / N / P rows (measured, gpurun_out/r03a/gap_cfg*.txt: device 3e-9 .. 7e-7, fp32 CPU oracle 1e-9 .. 4e-7 at
     gmax 8e-2) — for those tensors alone the tolerance is the absolute noise level 2e-5 * gmax, a hundredth of the old
-    floor."""
+    floor.  Round 5: rtol 5e-3 -> 3e-3 and gap_factor 4 -> 2 — with the old pair the largest err / tol of any tensor was
+    0.30 (cfg 3), 0.22 (cfg 4), 0.45 (cfg 5: prediction_cls.0.0.weight); YOLAT_TEST_REPORT_GRAD_MARGINS=1 prints them."""
     gmax = max(float(g.abs().max()) for g in g64.values())
     worst = []
     for n, g in model_grads.items():
@@ -227,6 +230,9 @@ def _grad_check_per_tensor(model_grads, g64, g32, rtol, name, gap_factor=4.0):
             tol += 2e-5 * gmax
         worst.append((err / max(tol, 1e-300), n, err, scale, gap))
     worst.sort(reverse=True)
+    if os.environ.get("YOLAT_TEST_REPORT_GRAD_MARGINS"):          # (how much of the tolerance each check uses: tuning aid)
+        print("\n%s: per-tensor gradient check, largest err / tol: %s" % (
+            name, "; ".join("%s %.2f (err %.2e, scale %.2e, gap %.2e)" % (w[1], w[0], w[2], w[3], w[4]) for w in worst[:4])))
     bad = [w for w in worst if w[0] > 1.0]
     assert not bad, "%s: %s" % (name, "; ".join("%s err %.3e scale %.3e fp32-vs-fp64 gap %.3e" % (w[1], w[2], w[3], w[4])
                                                 for w in bad[:6]))
@@ -278,7 +284,7 @@ def test_cfg5_full_size_train_step_matches_oracle():
     assert float((out[0].detach().cpu() - l32_logits).abs().max()) <= 5e-4 * float(l32_logits.abs().max())
     _, l64, g64 = _oracle_grads(optkw, 55, data, torch.float64)
     assert abs(float(loss.detach()) - float(l64)) <= RTOL_FWD * abs(float(l64))
-    _grad_check_per_tensor(grads, g64, g32, 5e-3, "cfg 5")
+    _grad_check_per_tensor(grads, g64, g32, 3e-3, "cfg 5")
     m16 = _model(yv, optkw, 55).train()
     m16.set_train_precision("bf16")
     data._yolat_stage = None
