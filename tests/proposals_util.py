@@ -14,6 +14,14 @@ CASES = {
 }
 
 
+# seeds of Python's `random` and numpy's global generator for the do_mixup runs (reference side and this repo's side)
+MIXUP_SEEDS = {"diagram_like": 202, "floorplan_mini": 101}
+MIXUP_CASES = {
+    "diagram_like": CASES["diagram_like"],
+    "floorplan_mini": dict(seed=21, n_cc=3, pts=(7, 10), lattice=4, step=10, n_classes=17, control=2, extra_edges=3),
+}
+
+
 def synth_graph_dict(seed, n_cc, pts, lattice, step, n_classes, control, extra_edges):
     """Components on disjoint patches of the unit square; points sit on a jittered-free lattice (many repeated x / y
     values: the distinct-value grid is much smaller than the point count), edges = a random spanning path plus extra

@@ -1,8 +1,8 @@
 """Box-proposal generation — the dataset-side producer of the hot path's input.
 
 ``get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step, n_classes)`` mirrors
-``SESYDFloorPlan._get_proposal`` (/root/reference/Datasets/graph_dict3.py:309-789, without the random ``mixup``
-augmentation of :364-365): same arguments, same 14-tuple
+``SESYDFloorPlan._get_proposal`` (/root/reference/Datasets/graph_dict3.py:309-789, with the optional random ``mixup``
+augmentation of :354-355, :791-907): same arguments, same 14-tuple
 
     pos, is_super, is_control, edge, edge_super, e_attr, e_attr_super, labels, bbox_idx, bbox, bbox_targets,
     stat_feats, has_obj, roots
@@ -88,8 +88,78 @@ def proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step):
     return out
 
 
-def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classes=17, normalize_bbox=True):
-    """graph_dict3.py:309-789 (do_mixup = False).  graph_dict: the pickled per-SVG dict of
+def mixup(cc, pos, edge, edge_super, e_attr, e_attr_super, is_super):
+    """The reference's `mixup` augmentation, graph_dict3.py:791-907 (called at :354-355 when the dataset is built with
+    do_mixup): for EVERY component i a partner j is drawn (Python's global `random`), both are brought into the unit square
+    (same scale on both axes: the larger extent), the partner is pushed to the right of / below the first by a random offset
+    (numpy's global RNG), and the pair becomes one NEW component appended behind the existing nodes — its shape edges are
+    the two components' edges renumbered, its super edges theirs plus the complete bipartite set between the two (attributes:
+    zeros, 6 columns).  The draws are made with the same calls in the same order as the reference makes them (per component:
+    random.choice(range(n)), random.choice([True, False]), two np.random.random()), so that a caller who seeds the two
+    global generators the way a reference run does gets the reference's arrays bit for bit (tests/test_proposals.py).
+    Like the reference, a component without a shape edge or without a super edge cannot be mixed (np.stack of nothing):
+    ValueError."""
+    import random
+    n_nodes = pos.shape[0]
+    owner = np.zeros(n_nodes, dtype=np.int64)
+    for ci, cluster in enumerate(cc):
+        owner[np.asarray(cluster, dtype=np.int64)] = ci
+    edge = np.asarray(edge)
+    edge_super = np.asarray(edge_super)
+    e_owner = owner[edge[:, 0]] if edge.size else np.zeros(0, np.int64)
+    s_owner = owner[edge_super[:, 0]] if edge_super.size else np.zeros(0, np.int64)
+    edges_of = [np.nonzero(e_owner == ci)[0] for ci in range(len(cc))]          # original order inside a component
+    sedges_of = [np.nonzero(s_owner == ci)[0] for ci in range(len(cc))]
+
+    def unit(p):
+        lo = np.array([p[:, 0].min(0), p[:, 1].min(0)])
+        ex, ey = p[:, 0].max(0) - lo[0], p[:, 1].max(0) - lo[1]
+        d = ex if ex > ey else ey
+        return (p - lo) / np.array([d, d])
+
+    def renumber(rows, old_ids, new_ids):
+        table = {}
+        for o, nw in zip(old_ids, new_ids):
+            table[o] = nw
+        return np.array([[table[a], table[b]] for a, b in rows])
+
+    offset = n_nodes
+    add_cc, add_pos, add_edge, add_sedge, add_attr, add_sattr, add_super = [], [], [], [], [], [], []
+    for ci in range(len(cc)):
+        cj = random.choice(range(len(cc)))
+        first, second = cc[ci], cc[cj]
+        if edges_of[ci].size == 0 or edges_of[cj].size == 0 or sedges_of[ci].size == 0 or sedges_of[cj].size == 0:
+            raise ValueError("need at least one array to stack")        # np.stack([]) in the reference, :838-845
+        p0, p1 = unit(pos[first]), unit(pos[second])
+        if random.choice([True, False]):
+            tx = 1 + np.random.random() * 0.1
+            ty = np.random.random()
+        else:
+            tx = np.random.random()
+            ty = 1 + 0.1 * np.random.random()
+        p1[:, 0] += tx
+        p1[:, 1] += ty
+        ids0 = offset + np.arange(len(first))
+        ids1 = offset + len(first) + np.arange(len(second))
+        cross = [[a, b] for a in ids0 for b in ids1]
+        e0, e1 = renumber(edge[edges_of[ci]], first, ids0), renumber(edge[edges_of[cj]], second, ids1)
+        s0, s1 = renumber(edge_super[sedges_of[ci]], first, ids0), renumber(edge_super[sedges_of[cj]], second, ids1)
+        add_pos.append(np.concatenate([p0, p1], axis=0))
+        add_super.append(np.concatenate([is_super[first], is_super[second]], axis=0))
+        add_cc.append(list(ids0) + list(ids1))
+        add_edge.append(np.concatenate([e0, e1], axis=0))
+        add_sedge.append(np.concatenate([s0, s1, cross], axis=0))
+        add_attr.append(np.concatenate([e_attr[edges_of[ci]], e_attr[edges_of[cj]]], axis=0))
+        add_sattr.append(np.zeros((s0.shape[0] + s1.shape[0] + len(cross), 6)))
+        offset += len(first) + len(second)
+    return (cc + add_cc, np.concatenate([pos] + add_pos, axis=0), np.concatenate([edge] + add_edge, axis=0),
+            np.concatenate([edge_super] + add_sedge, axis=0), np.concatenate([e_attr] + add_attr, axis=0),
+            np.concatenate([e_attr_super] + add_sattr, axis=0), np.concatenate([is_super] + add_super, axis=0))
+
+
+def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classes=17, normalize_bbox=True, do_mixup=False):
+    """graph_dict3.py:309-789; do_mixup: the augmentation of :354-355 / :791-907 (`mixup` above; off in the published
+    recipe, README.md:47,52).  graph_dict: the pickled per-SVG dict of
     utils/svg_utils/build_graph_bbox.py:351-370 ('cc', 'pos'/'spatial', 'edge'/{'shape','super'},
     'edge_attr'/{'shape','super'}, 'attr'/{'is_super','is_control'}, 'img_width', 'img_height')."""
     cc = graph_dict["cc"]
@@ -117,6 +187,9 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
     cc = [[int(o2n[i]) for i in cluster] for cluster in cc]
     pos = pos[not_control]
     is_super = is_super[not_control]
+    if do_mixup:
+        cc, pos, edge, edge_super, e_attr, e_attr_super, is_super = mixup(cc, pos, edge, edge_super, e_attr, e_attr_super,
+                                                                          is_super)
 
     w = proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step)
     count = w["cc_of"].shape[0]
