@@ -166,3 +166,20 @@ def test_device_loader_coo_mode_matches_collate_to_device_and_the_reference_fixu
             n += 1
     assert n == len(lists)
     loader.close()
+
+
+def test_predict_on_a_coo_mode_loader_batch_equals_predict_on_the_synchronous_batch():
+    """two-pass inference (arch:139-356) cuts sub-graphs out of the raw edge list: it runs on a csr=False loader batch (lazy
+    tensor views, lazily collated `roots`) and returns what it returns for collate_to_device(items)"""
+    yv = _yv()
+    lists = _lists(yv, 3, seed0=410, with_roots=True)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 13).cuda().eval()
+    loader = yv.DeviceLoader(lists, slots=3, csr=False)
+    with torch.no_grad():
+        for (batch, slices), items in zip(loader, lists):
+            wb, ws = yv.collate_to_device(items)
+            got = model.predict(batch, slices)
+            want = model.predict(wb, ws)
+            assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
+            assert list(got[3]) == list(want[3]) and list(got[4]) == list(want[4])
+    loader.close()

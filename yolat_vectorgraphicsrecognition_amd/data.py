@@ -523,8 +523,11 @@ class _LazySlices(dict):
 class _LazyBatch(Data):
     """The batch of a DeviceLoader: the views of the device buffer and the host-side keys are produced on first access."""
 
-    def __init__(self):
-        pass
+    def __init__(self, *args, **kwargs):
+        # the loader builds it empty (attributes appear on first access); code that makes a NEW batch of the same class —
+        # predict()'s sub-batches: `data.__class__(x=..., pos=...)`, arch:180 — gets a plain attribute bag
+        if args or kwargs:
+            Data.__init__(self, *args, **kwargs)
 
     def __getattr__(self, name):               # only reached when the normal look-up fails
         st = self.__dict__.get("_lazy")
