@@ -183,3 +183,28 @@ def test_predict_on_a_coo_mode_loader_batch_equals_predict_on_the_synchronous_ba
             assert torch.equal(got[0], want[0]) and torch.equal(got[1], want[1])
             assert list(got[3]) == list(want[3]) and list(got[4]) == list(want[4])
     loader.close()
+
+
+@pytest.mark.parametrize("csr", [True, False])
+def test_training_step_on_a_loader_batch_equals_the_step_on_the_synchronous_batch(csr):
+    """Trainer.step reads x / labels / the graph (prepared or raw) off the lazy batch: same loss and same updated parameters as
+    on collate_to_device's batch"""
+    yv = _yv()
+    items = _lists(yv, 3, seed0=520)[2]
+    opt = yv.Opt()
+
+    def run(batch, slices):
+        model = gu.fill_state_(yv.SparseCADGCN(opt), 17).cuda()
+        tr = yv.Trainer(model, opt, lr=1e-3, weight_decay=1e-5)
+        loss = float(tr.step(batch, slices))
+        torch.cuda.synchronize()
+        return loss, [p.detach().clone() for p in model.parameters()]
+
+    loader = yv.DeviceLoader([items], slots=2, csr=csr)
+    batch, slices = next(loader)
+    l1, p1 = run(batch, slices)
+    loader.close()
+    wb, ws = yv.collate_to_device(items, csr=csr)
+    l2, p2 = run(wb, ws)
+    assert l1 == l2
+    assert all(torch.equal(a, b) for a, b in zip(p1, p2))
