@@ -43,6 +43,7 @@ typedef void* yolat_stream_t; /* hipStream_t */
 #define YOLAT_STATUS_EDGE_RANGE  1 /* an edge endpoint is outside [0,N)      */
 #define YOLAT_STATUS_SEG_UNSORTED 2 /* bbox_idx is not non-decreasing        */
 #define YOLAT_STATUS_SEG_RANGE   4 /* bbox_idx value outside [0,P)           */
+#define YOLAT_STATUS_NOT_LOCAL   8 /* a batch the caller vouched for as proposal-local (yolat_locality) is not */
 
 /* A-operand "prologue": the consumer applies  a' = a*scale[k] + shift[k]; if (relu) a' = max(a',0)
  * while loading, so BatchNorm1d+ReLU outputs (gcn_lib/sparse/torch_nn.py:58-66) need not be
@@ -679,6 +680,35 @@ int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* m, const void* pack
                                 const yolat_graph_csr* g, int64_t N, int64_t E, int64_t P, uint16_t* feats,
                                 int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag, yolat_stream_t stream);
 
+/* ABI 6.  The locality property of a batch, decided BEFORE the forward is enqueued (integer structure: once per batch
+ * version).  The reference stores a proposal's edges as one contiguous block (Datasets/graph_dict3.py:725 `new_edge.append`
+ * per proposal, :752-764 per-proposal edge ranges, :732 sorted bbox_idx) and never lets an edge leave its proposal
+ * (:582-600,733); a batch like that, whose proposals fit a tile, needs neither the global COO -> CSR build nor the gated
+ * per-layer fall-back launches: each tile of the conv kernel sorts its <= 1024 edges by destination in LDS (stable).
+ *   yolat_batch_locality: info[4] (device int32) = { YOLAT_LOC_* violations, nodes of the largest proposal, edges of the
+ *     largest proposal, YOLAT_STATUS_* bits of malformed ids }; workspace of yolat_batch_locality_workspace_bytes.
+ *   yolat_locality: the same on the host (known = 1 once examined), handed to yolat_forward_eval_bf16_loc:
+ *     known and fitting (yolat_conv_local_fits) -> local prep + ONE conv launch, no gated launches; a violation the device
+ *       still finds (the caller's information was stale) raises YOLAT_STATUS_NOT_LOCAL in *status, the logits are invalid;
+ *     known and unfit -> the per-layer path directly;   NULL / known = 0 -> found out on the device (gated fall-back).
+ *   yolat_conv_stack_local_bf16_coo: yolat_conv_stack_local_bf16 on the raw edge list of a vouched batch (op tests).  */
+#define YOLAT_LOC_UNGROUPED 1 /* the edge list is not grouped by proposal (bbox_idx[dst] decreases along it) */
+#define YOLAT_LOC_CROSSING  2 /* an edge joins nodes of two proposals                                        */
+#define YOLAT_LOC_MALFORMED 4 /* ids out of range / bbox_idx unsorted (the YOLAT_STATUS_* conditions)         */
+typedef struct yolat_locality {
+  int32_t known, flags, max_nodes, max_edges;
+} yolat_locality;
+size_t yolat_batch_locality_workspace_bytes(int64_t N, int64_t E, int64_t P);
+int yolat_batch_locality(const int64_t* edge, int64_t stride_e, int64_t stride_c, const int64_t* bbox_idx, int64_t N,
+                         int64_t E, int64_t P, int32_t* info, void* workspace, size_t workspace_bytes,
+                         yolat_stream_t stream);
+int yolat_conv_local_fits(const yolat_locality* loc, int64_t P);
+int yolat_conv_stack_local_bf16_coo(const yolat_model_eval_bf16* m, const void* pack, const float* x, int64_t ldx,
+                                    const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                                    const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, uint16_t* feats,
+                                    int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag, int32_t* status,
+                                    void* workspace, size_t workspace_bytes, yolat_stream_t stream);
+
 /* The edge stage of the bf16-storage forward on its own (op tests, benchmarks): factorised edge MLP + mean
  * aggregation of one conv layer, gcn_lib/sparse/torch_vertex.py:319-337 in eval mode.
  *   UV [N, ld_uv] bf16: per-node products U' | V' with layer 1's folded BatchNorm applied (node-side epilogue);
@@ -707,6 +737,13 @@ int yolat_forward_eval_bf16_primed(const yolat_model_eval_bf16* m, const float* 
                                    int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                                    int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                                    size_t workspace_bytes, int32_t* status, yolat_stream_t stream);
+/* yolat_forward_eval_bf16 with the batch's locality decided by the caller (yolat_locality above; NULL = unknown) and the
+ * `primed` promise as a flag; g != NULL: the prepared-graph form (edge / e_attr / bbox_idx unused) */
+int yolat_forward_eval_bf16_loc(const yolat_model_eval_bf16* m, const float* x, int64_t ldx, const int64_t* edge,
+                                int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
+                                const yolat_graph_csr* g, int64_t N, int64_t E, int64_t P, float* logits,
+                                int64_t ld_logits, void* workspace, size_t workspace_bytes, int32_t* status,
+                                const yolat_locality* loc, int primed, yolat_stream_t stream);
 /* the same forward on a prepared device graph (yolat_graph_csr above) */
 int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* m, const float* x, int64_t ldx, const yolat_graph_csr* g,
                                 int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,

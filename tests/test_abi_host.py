@@ -44,7 +44,7 @@ def test_ctypes_signatures_match_header():
 
 
 def test_abi_version_and_strerror():
-    assert _lib.lib.yolat_abi_version() == 5
+    assert _lib.lib.yolat_abi_version() == 6
     assert b"invalid" in _lib.lib.yolat_strerror(-1)
     assert _lib.lib.yolat_strerror(0) == b"ok"
 

@@ -81,6 +81,12 @@ class LoaderBatch(ctypes.Structure):
                 ("rc", ctypes.c_int32)]
 
 
+class Locality(ctypes.Structure):
+    """yolat_locality"""
+    _fields_ = [("known", ctypes.c_int32), ("flags", ctypes.c_int32), ("max_nodes", ctypes.c_int32),
+                ("max_edges", ctypes.c_int32)]
+
+
 class GraphCsr(ctypes.Structure):
     """yolat_graph_csr"""
     _fields_ = [("row_ptr", c_p), ("src", c_p), ("dst", c_p), ("attr", c_p), ("seg_ptr", c_p), ("node_seg", c_p)]
@@ -258,6 +264,14 @@ SIGNATURES = {
                                              c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_forward_eval_bf16_primed": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_batch_locality_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "yolat_batch_locality": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_sz, c_p]),
+    "yolat_conv_local_fits": (c_int, [ctypes.POINTER(Locality), c_i64]),
+    "yolat_conv_stack_local_bf16_coo": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p,
+                                                 c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_sz, c_p]),
+    "yolat_forward_eval_bf16_loc": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p,
+                                            ctypes.POINTER(GraphCsr), c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p,
+                                            ctypes.POINTER(Locality), c_int, c_p]),
 }
 
 

@@ -599,12 +599,12 @@ int yl_edge_chain_bf16(const uint16_t* UV, int64_t ld_uv, const int32_t* src_csr
                        uint16_t* f_out, int64_t ld_fo, hipStream_t st, YlGate gate);
 
 bool yl_conv_local_model_ok(const yolat_model_eval_bf16* mh);
-int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const float* x, int64_t ldx, const int32_t* row_ptr,
-                       const int32_t* src, const int32_t* dst, const float* attr, const int32_t* seg_ptr, int64_t N,
-                       int64_t E, int64_t P, uint16_t* feats, int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag,
+int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const float* x, int64_t ldx, const YlLocalIn& in,
+                       int64_t N, int64_t E, int64_t P, uint16_t* feats, int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag,
                        int32_t flag_val, hipStream_t st);
 // YOLAT_CONV_LOCAL: 0 = never, 1 = batches with >= 1024 proposals (default), 2 = every batch
 // (read per call: tests flip it in-process)
+static __global__ void k_zero_word(int* p) { if (threadIdx.x == 0) *p = 0; }
 static int yl_conv_local_mode() {
   const char* e = getenv("YOLAT_CONV_LOCAL");
   return (e && e[0] >= '0' && e[0] <= '3') ? e[0] - '0' : 1;      // (3: measurement only — forced, WITHOUT the gated fall-back)
@@ -672,7 +672,7 @@ struct PlanH {
   int* row_ptr; int* perm; int* src; int* dst; float* attr; int* work; int* seg_ptr; int* node_seg;
   u16* UV; float* root; u16* f_tmp[YOLAT_MAX_LAYERS]; u16* s_tmp[YOLAT_MAX_LAYERS];
   u16* feats; u16* fsup; float* Z; float* c1; float* c2;
-  int* local_flag;
+  int* local_flag; int* eptr;
   size_t bytes;
 };
 PlanH carve_h(const yolat_model_eval* m, long N, long E, long P, void* ws) {
@@ -691,6 +691,7 @@ PlanH carve_h(const yolat_model_eval* m, long N, long E, long P, void* ws) {
   p.feats = c.take<u16>(N * D); p.fsup = c.take<u16>(N * D);
   p.Z = c.take<float>(P * 2 * (F + D)); p.c1 = c.take<float>(P * m->H1); p.c2 = c.take<float>(P * m->H2);
   p.local_flag = c.take<int>(64);
+  p.eptr = c.take<int>(P + 1);
   p.bytes = c.off + 256;
   return p;
 }
@@ -753,7 +754,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
                                   int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                                   int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                                   size_t workspace_bytes, int32_t* status, yolat_stream_t stream, const yolat_graph_csr* g,
-                                  bool primed = false);
+                                  bool primed = false, const yolat_locality* loc = nullptr);
 
 extern "C" int yolat_forward_eval_bf16(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
                                        const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
@@ -787,11 +788,27 @@ extern "C" int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* mh, cons
                                 logits, ld_logits, workspace, workspace_bytes, &unused_status, stream, g);
 }
 
+extern "C" int yolat_forward_eval_bf16_loc(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx,
+                                           const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                                           const int64_t* bbox_idx, const yolat_graph_csr* g, int64_t N, int64_t E,
+                                           int64_t P, float* logits, int64_t ld_logits, void* workspace,
+                                           size_t workspace_bytes, int32_t* status, const yolat_locality* loc, int primed,
+                                           yolat_stream_t stream) {
+  if (g != nullptr) {
+    if (!g->row_ptr || !g->seg_ptr || !g->node_seg || (E > 0 && (!g->src || !g->dst || !g->attr))) return YOLAT_E_INVALID;
+    if (!status) return YOLAT_E_INVALID;
+    return forward_eval_bf16_impl(mh, x, ldx, nullptr, 0, 0, nullptr, reinterpret_cast<const int64_t*>(g->node_seg), N, E, P,
+                                  logits, ld_logits, workspace, workspace_bytes, status, stream, g, false, loc);
+  }
+  return forward_eval_bf16_impl(mh, x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, logits, ld_logits,
+                                workspace, workspace_bytes, status, stream, nullptr, primed != 0, loc);
+}
+
 static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* x, int64_t ldx, const int64_t* edge,
                                   int64_t stride_e, int64_t stride_c, const float* e_attr, const int64_t* bbox_idx,
                                   int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, void* workspace,
                                   size_t workspace_bytes, int32_t* status, yolat_stream_t stream,
-                                  const yolat_graph_csr* g, bool primed) {
+                                  const yolat_graph_csr* g, bool primed, const yolat_locality* loc) {
   if (!x || !bbox_idx || !logits || !workspace || !status || N <= 0 || E < 0 || P <= 0) return YOLAT_E_INVALID;
   YL_TRY(model_ok(mh));
   if (N > (1LL << 23) || E > (1LL << 29)) return YOLAT_E_UNSUPPORTED;     // 32-bit element offsets in the gathers
@@ -823,14 +840,30 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   a0.euv.scale = mh->uv_scale[0]; a0.euv.shift = mh->uv_shift[0];
   a0.en.Y = nullptr; a0.en.Yh = s_slot(0); a0.en.ldy = ld_slot(0);
   const int local_mode = yl_conv_local_mode();
+  const bool known = loc != nullptr && loc->known != 0;
+  const bool fits = known && yolat_conv_local_fits(loc, P) != 0;
+  // (a batch known NOT to have the property goes straight to the per-layer launches)
   const bool local = local_mode != 0 && mh->conv_local != nullptr && yl_conv_local_model_ok(mh) &&
-                     yl_node3_smallk_shape_ok(a0) && D % 8 == 0 && ZW % 4 == 0 && (local_mode >= 2 || P >= 1024);
+                     yl_node3_smallk_shape_ok(a0) && D % 8 == 0 && ZW % 4 == 0 && (local_mode >= 2 || P >= 1024) &&
+                     (!known || fits) && (g != nullptr || E == 0 || yl_aligned16(e_attr) || !fits);
+  // vouched: the caller examined the batch (yolat_batch_locality / the host collate) — no gated fall-back launches, and
+  // for a COO batch no global destination sort either: the tiles sort their edges themselves
+  const bool vouched = local && fits;
   YlGate gate{nullptr, 0};
+  int flag_val = 0;
   if (local) {
-    static std::atomic<int> epoch_counter{0x10000};
-    int epoch = ++epoch_counter;
-    if (epoch == 0) epoch = ++epoch_counter;
-    gate.p = p.local_flag; gate.val = epoch;
+    // the word the conv kernel raises: a fresh value per forward instead of a reset launch.  High bit set: the workspace
+    // is re-carved per shape and may hold stale int32 index data (< 2^30) at this address, which must never look raised
+    static std::atomic<unsigned> epoch_counter{0};
+    flag_val = (int)(0x80000000u | (++epoch_counter & 0x7FFFFFFFu));
+    if (!vouched) { gate.p = p.local_flag; gate.val = flag_val; }
+    hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing((hipStream_t)stream, &cap) == hipSuccess && cap != hipStreamCaptureStatusNone) {
+      // a captured forward replays with THIS value: a replay on an unfit batch would leave the word raised for every later
+      // replay (the fall-back would run for fit batches too) — reset it inside the graph (a kernel, not a memset node: §4)
+      hipLaunchKernelGGL(k_zero_word, dim3(1), dim3(64), 0, (hipStream_t)stream, p.local_flag);
+      YL_LAUNCH_CHECK();
+    }
   }
 
   // ---- graph structure + node side of layer 0 (fp32 MFMA on the raw K = Cin0 features, bf16 / fp32 outputs)
@@ -838,7 +871,11 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   YL_HSTAGE("graph_prep[csr+attr+segments] + node_uv[layer 0, bf16 out]", 8.0 * N * m->conv[0].Cin * C,
             16.0 * E + 12.0 * E + 32.0 * E + 12.0 * N + 4.0 * N * m->conv[0].Cin + 2.0 * N * 3 * C + 4.0 * N * C, {
     const NodeUv& a = a0;
-    if (local) {
+    if (vouched) {
+      if (g == nullptr)
+        YL_TRY(yl_local_prep(edge, stride_e, stride_c, bbox_idx, N, E, P, p.seg_ptr, p.node_seg, p.eptr, status, nullptr, true,
+                             st));
+    } else if (local) {
       if (g == nullptr)
         YL_TRY(yl_graph_prepare_impl(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, p.row_ptr, p.perm, p.src, p.dst,
                                      p.attr, p.seg_ptr, p.node_seg, p.work, status, nullptr, primed, stream));
@@ -860,13 +897,21 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
     // bytes: what the stack has to move — x, ids, e_attr in; feats + the pooled rows out
     YL_HSTAGE("conv_local_bf16[all conv layers + pooling prologue, one launch]", fl,
               4.0 * N * cv0.Cin + 8.0 * E + 16.0 * E + 4.0 * N + 2.0 * N * D + 4.0 * P * (F + 2 * D), {
-      YL_TRY(yl_conv_local_bf16(mh, mh->conv_local, x, ldx, p.row_ptr, p.src, p.dst, p.attr, p.seg_ptr, N, E, P, p.feats, D,
-                                p.Z, ZW, p.local_flag, gate.val, st));
+      YlLocalIn in{};
+      in.seg_ptr = p.seg_ptr;
+      if (vouched && g == nullptr) {
+        in.attr = e_attr; in.edge = edge; in.se = stride_e; in.sc = stride_c; in.eptr = p.eptr;
+      } else {
+        in.row_ptr = p.row_ptr; in.src = p.src; in.dst = p.dst; in.attr = p.attr;
+      }
+      in.status = vouched ? status : nullptr;
+      YL_TRY(yl_conv_local_bf16(mh, mh->conv_local, x, ldx, in, N, E, P, p.feats, D, p.Z, ZW, p.local_flag, flag_val, st));
     });
     // the fall-back's layer-0 node side (dead unless the flag was raised)
-    if (local_mode != 3) YL_TRY(yl_node3_smallk(a0, st, gate));
+    if (local_mode != 3 && !vouched) YL_TRY(yl_node3_smallk(a0, st, gate));
   }
-  for (int l = 0; l < m->n_blocks && !(local && local_mode == 3); ++l) {
+  const bool no_layers = local && (local_mode == 3 || vouched);
+  for (int l = 0; l < m->n_blocks && !no_layers; ++l) {
     const yolat_conv_eval& cv = m->conv[l];
     if (l > 0) {
       snprintf(nm, sizeof nm, "node_uv_bf16[UV | lin_r | mlp_node, N x 64 -> %ld+%ld+%ld]%s", 2 * C, C, C,
@@ -899,7 +944,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
   }
 
   // ---- pooling prologue, fusion block (+ per-proposal max) | fusion_block_super, classifier
-  if (!(local && local_mode == 3))
+  if (!no_layers)
   YL_HSTAGE(local ? "pool_prepare_bf16[max(feats), mean(fsup), zero] (gated fall-back)"
                   : "pool_prepare_bf16[max(feats), mean(fsup), zero]", 2.0 * N * D, 4.0 * N * D + 4.0 * P * (F + 2 * D), {
   for (int64_t p0 = 0; p0 < P; p0 += 65535) {

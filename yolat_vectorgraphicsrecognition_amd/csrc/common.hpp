@@ -936,6 +936,18 @@ bool yl_profile_on();
 void yl_stage_begin(const char* name, double flops, double bytes, yolat_stream_t stream);
 void yl_stage_end(yolat_stream_t stream);
 
+// inputs of the one-launch conv stack (conv_local.hip): a prepared destination-sorted graph (row_ptr / src / dst / attr in
+// CSR order), or — edge != nullptr — the raw COO list (attr in COO order) with per-proposal edge ranges eptr
+struct YlLocalIn {
+  const int32_t *row_ptr, *src, *dst; const float* attr; const int32_t* seg_ptr;
+  const int64_t* edge; int64_t se, sc; const int32_t* eptr;
+  int32_t* status;         // non-null: the caller vouched for the batch, a violation is reported as YOLAT_STATUS_NOT_LOCAL
+};
+// seg_ptr / node_seg / eptr of a COO batch grouped by proposal + YOLAT_LOC_* violations (conv_local.hip)
+int yl_local_prep(const int64_t* edge, int64_t se, int64_t sc, const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P,
+                  int32_t* seg_ptr, int32_t* node_seg, int32_t* eptr, int32_t* status, int32_t* info, bool vouched,
+                  hipStream_t st);
+
 // yolat_graph_prepare with an optional co-scheduled node-side GEMM set (graph.hip)
 int yl_graph_prepare_impl(const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
                           const int64_t* bbox_idx, int64_t E, int64_t N, int64_t P, int32_t* row_ptr, int32_t* perm,

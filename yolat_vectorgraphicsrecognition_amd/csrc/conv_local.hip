@@ -85,6 +85,10 @@ __device__ __forceinline__ unsigned cl_sel2(unsigned mask, int pos) {
 struct ClArgs {
   const float* x; int ldx; int cin0;
   const int* row_ptr; const int* src; const int* dst; const float* attr; const int* seg_ptr;
+  // COO instantiation (the tile sorts its edges by destination in LDS): the raw edge list (int64 pairs, element strides
+  // se / sc as in yolat_forward_eval), e_attr in COO order through `attr`, eptr [P + 1] = first edge of each proposal
+  const long long* edge; long se, sc; const int* eptr;
+  int* status;           // when the caller vouched for the batch: a violation found here is an input error (YOLAT_STATUS_NOT_LOCAL)
   int N, E, P, G0;
   int L, lo;
   const unsigned char* pack;
@@ -105,9 +109,13 @@ __device__ __forceinline__ float cl_quad_xor2(float v) {
 
 // NW waves per workgroup: tiles of T = 16 NW nodes / ET = 128 NW edges.  NW = 4: 256 threads, 77 KB of LDS, two workgroups
 // per CU; NW = 8: 512 threads, 141 KB, one per CU (two waves per SIMD either way).
-template <int NW>
+// COO: the tile's edges come in the caller's order (grouped by proposal: eptr) and are counting-sorted by destination in
+// LDS, stable — the summation order of the destination-sorted form (graph.hip) — so the global COO -> CSR build
+// (count, scan, fill, rank-and-emit: 4 launches over E) disappears from the forward.
+template <int NW, bool COO>
 __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
   constexpr int T = 16 * NW, ET = 128 * NW, NT = 64 * NW, NS = 2 * NW;
+  constexpr int LOGT = (NW == 8) ? 7 : 6;          // T = 1 << LOGT
   constexpr int NE = (768 + NT - 1) / NT;          // 16-byte pieces of the edge fragments per thread
   __shared__ __attribute__((aligned(16))) unsigned char uv_s[T * CL_UVB];
   __shared__ __attribute__((aligned(16))) unsigned char r_s[T * CL_RB];
@@ -120,6 +128,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
   __shared__ __attribute__((aligned(16))) float shift_s[256];                  // the coming node phase's shifts
   __shared__ int stop_s;                 // the flag word as thread 0 saw it at this tile's start (workgroup-uniform exit)
   __shared__ __attribute__((aligned(16))) cl_u32x4 ef_s[12 * 64];              // the layer's edge-phase fragments
+  // COO: in-degree of every tile node inside each 64-edge chunk of the tile's edge list (one byte each; all zero between
+  // tiles: the scan below clears what it reads).  The chunk bases [2 NW][T] u16 live in the (still unused) UV tile.
+  __shared__ __attribute__((aligned(16))) unsigned char cnt_s[COO ? 2 * NW * T : 16];
 
   const int tid0 = threadIdx.x;
   const int wv = __builtin_amdgcn_readfirstlane(tid0 >> 6);
@@ -130,8 +141,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
   for (int i = tid0; i <= np; i += NT) {
     const int s = a.seg_ptr[p_lo + i];
     gseg_s[i] = s;
-    grow_s[i] = a.row_ptr[yl_min(yl_max(s, 0), a.N)];
+    if constexpr (COO) grow_s[i] = yl_min(yl_max(a.eptr[p_lo + i], 0), a.E);
+    else grow_s[i] = a.row_ptr[yl_min(yl_max(s, 0), a.N)];
   }
+  if constexpr (COO)
+    for (int i = tid0; i < 2 * NW * T / 4; i += NT) reinterpret_cast<unsigned*>(cnt_s)[i] = 0u;
   if (tid0 < 256) shift_s[tid0] = reinterpret_cast<const float*>(a.pack + CL_EDGE_BYTES + CL_NODE_BYTES)[tid0];
   // node-phase weight fragments of this wave's output group, one phase ahead.  Layer 0 uses [.][0..1] only: while no
   // fragments are in flight (last layer -> next tile) the other four hold the NEXT tile's raw loads (pre0..3 below)
@@ -162,15 +176,21 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
 
   // greedy tile: the first proposals [q0, q1) from `from` on with <= T nodes and <= ET edges; a proposal that does not
   // fit (or an unsorted segment table) raises the flag (the gated per-layer path then runs) and is skipped
+  // the batch does not have the property: tell the gated per-layer launches (or, when the caller vouched for it, the status word)
+  auto raise = [&]() {
+    *a.flag = a.flag_val;
+    if (a.status != nullptr) atomicOr(a.status, YOLAT_STATUS_NOT_LOCAL);
+  };
   auto next_tile = [&](int from, int& q0, int& q1) {
     q0 = from;
     q1 = from;
     while (q0 < np) {
       const int sg = gseg_s[q0], rg = grow_s[q0];
       q1 = q0;
-      while (q1 < np && gseg_s[q1 + 1] - sg <= T && grow_s[q1 + 1] - rg <= ET && gseg_s[q1 + 1] >= gseg_s[q1]) ++q1;
+      while (q1 < np && gseg_s[q1 + 1] - sg <= T && grow_s[q1 + 1] - rg <= ET && gseg_s[q1 + 1] >= gseg_s[q1] &&
+             grow_s[q1 + 1] >= grow_s[q1]) ++q1;
       if (q1 > q0) return;
-      if (tid0 == 0) *a.flag = a.flag_val;
+      if (tid0 == 0) raise();
       ++q0;
     }
   };
@@ -178,7 +198,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
   auto issue_tile_loads = [&](int q0, int q1, cl_u32x4& r0, cl_u32x4& r1, cl_u32x4& r2, cl_u32x4& r3) {
     const int tid = cl_opaque(tid0);
     const int n0 = gseg_s[q0], nt = gseg_s[q1] - n0, e0 = grow_s[q0], et = grow_s[q1] - e0;
-    r0.x = (unsigned)a.row_ptr[n0 + yl_min(tid, nt)];
+    if constexpr (!COO) r0.x = (unsigned)a.row_ptr[n0 + yl_min(tid, nt)];
+    else r0.x = 0u;
     unsigned xv[2], dv[2], sv[2];
     cl_u32x4 av[2];
 #pragma unroll
@@ -186,8 +207,13 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
       const int i = tid + NT * t, n = i >> 3, k = i & 7;
       xv[t] = __float_as_uint(a.x[(long)yl_min(n0 + n, a.N - 1) * a.ldx + yl_min(k, a.cin0 - 1)]);
       const int ec = yl_min(e0 + yl_min(i, et > 0 ? et - 1 : 0), a.E > 0 ? a.E - 1 : 0);
-      dv[t] = (unsigned)a.dst[ec];
-      sv[t] = (unsigned)a.src[ec];
+      if constexpr (COO) {          // (ids are < 2^31 wherever they are valid: the low halves decide)
+        dv[t] = (unsigned)a.edge[(long)ec * a.se + a.sc];
+        sv[t] = (unsigned)a.edge[(long)ec * a.se];
+      } else {
+        dv[t] = (unsigned)a.dst[ec];
+        sv[t] = (unsigned)a.src[ec];
+      }
       av[t] = *reinterpret_cast<const cl_u32x4*>(a.attr + 4l * ec);
     }
     r0.y = xv[0]; r0.z = xv[1]; r0.w = dv[0];
@@ -198,7 +224,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
   // a proposal of the group that cannot fit a tile is known now: raise the flag before any work is done (the other
   // workgroups stop at their next check, below)
   for (int i = tid0; i < np; i += NT)
-    if (gseg_s[i + 1] - gseg_s[i] > T || grow_s[i + 1] - grow_s[i] > ET || gseg_s[i + 1] < gseg_s[i]) *a.flag = a.flag_val;
+    if (gseg_s[i + 1] - gseg_s[i] > T || grow_s[i + 1] - grow_s[i] > ET || gseg_s[i + 1] < gseg_s[i] ||
+        grow_s[i + 1] < grow_s[i]) raise();
   int p0, p1;
   next_tile(0, p0, p1);
   bool first_tile = true;
@@ -227,6 +254,81 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
         const float v = a.x[(long)yl_min(n0 + n, a.N - 1) * a.ldx + yl_min(k, a.cin0 - 1)];
         xs[i] = (n < nt && k < a.cin0) ? v : 0.f;
       }
+    } else if constexpr (COO) {
+      // The tile's edges arrive in the caller's order.  Stable counting sort by destination, all in LDS:
+      //   rank   a lane's rank among the lanes of its 64-edge chunk with the same destination: LOGT ballots, no loop over
+      //          values; the first lane of each group stores the group's size -> cnt_s[chunk][node]
+      //   scan   (wave 0, two nodes per lane) running sum over the chunks per node -> chunk bases, in-degrees; exclusive
+      //          scan over the nodes -> rp_s (the tile's row_ptr); base_s[chunk][node] = row start + edges of earlier chunks
+      //   emit   edge -> slot base_s[chunk][dst] + rank: packed ids and the e_attr fragment
+      float* xs = reinterpret_cast<float*>(f_s);
+      unsigned short* base_s = reinterpret_cast<unsigned short*>(uv_s);
+      const unsigned xv[2] = {pre0.y, pre0.z}, dv[2] = {pre0.w, pre1.x}, sv[2] = {pre1.y, pre1.z};
+      bool bad = false;
+      int dd[2], rk[2];
+      bool okk[2];
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const int i = tid + NT * t, n = i >> 3, k = i & 7;
+        xs[i] = (n < nt && k < a.cin0) ? __uint_as_float(xv[t]) : 0.f;
+        const int d = (int)dv[t] - n0, sr = (int)sv[t] - n0;
+        const bool ok = i < et && (unsigned)sr < (unsigned)nt && (unsigned)d < (unsigned)nt;
+        bad |= (i < et) && !ok;
+        unsigned long long m = __ballot(ok);
+#pragma unroll
+        for (int b = 0; b < LOGT; ++b) {
+          const bool bit = (d >> b) & 1;
+          const unsigned long long bal = __ballot(bit);
+          m &= bit ? bal : ~bal;
+        }
+        const int r = __popcll(m & ((1ull << lane) - 1ull));
+        if (ok && r == 0) cnt_s[(wv + NW * t) * T + d] = (unsigned char)__popcll(m);
+        dd[t] = d; rk[t] = r; okk[t] = ok;
+      }
+      if (bad) raise();
+      cl_lds_barrier();
+      if (wv == 0 && 2 * lane < T) {
+        unsigned run0 = 0, run1 = 0, bq[2 * NW];
+#pragma unroll
+        for (int c = 0; c < 2 * NW; ++c) {
+          unsigned short* cp = reinterpret_cast<unsigned short*>(cnt_s + c * T + 2 * lane);
+          const unsigned v = *cp;
+          *cp = 0;
+          bq[c] = run0 | (run1 << 16);
+          run0 += v & 0xFFu;
+          run1 += v >> 8;
+        }
+        const int tot = (int)(run0 + run1);
+        int incl = tot;
+#pragma unroll
+        for (int off = 1; off < T / 2; off <<= 1) {
+          const int nb = __shfl_up(incl, off);
+          if (lane >= off) incl += nb;
+        }
+        const unsigned rp0 = (unsigned)(incl - tot), rp1 = rp0 + run0;
+        rp_s[2 * lane] = (int)rp0;
+        rp_s[2 * lane + 1] = (int)rp1;
+        if (2 * lane + 2 == T) rp_s[T] = incl;
+#pragma unroll
+        for (int c = 0; c < 2 * NW; ++c)
+          *reinterpret_cast<unsigned*>(base_s + c * T + 2 * lane) = ((bq[c] & 0xFFFFu) + rp0) | (((bq[c] >> 16) + rp1) << 16);
+      }
+      cl_lds_barrier();
+#pragma unroll
+      for (int t = 0; t < 2; ++t) {
+        const cl_u32x4 qa = t ? pre3 : pre2;
+        const float4 q = __builtin_bit_cast(float4, qa);
+        if (okk[t]) {
+          const int pos = (int)base_s[(wv + NW * t) * T + dd[t]] + rk[t];
+          const int sr = (int)sv[t] - n0;
+          idx_s[pos] = (unsigned)dd[t] | ((unsigned)sr << 8);
+          const unsigned h01 = yl_pack_bf16(q.x, q.y), h23 = yl_pack_bf16(q.z, q.w);
+          const unsigned l01 = yl_pack_bf16(q.x - yl_bf16_lo(h01), q.y - yl_bf16_hi(h01));
+          const unsigned l23 = yl_pack_bf16(q.z - yl_bf16_lo(h23), q.w - yl_bf16_hi(h23));
+          const cl_u32x4 fr = {h01, h23, l01, l23};
+          ab_s[pos] = fr;
+        }
+      }
     } else {
       if (tid <= nt) rp_s[tid] = (int)pre0.x - e0;
       float* xs = reinterpret_cast<float*>(f_s);
@@ -250,7 +352,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
           ab_s[i] = fr;
         }
       }
-      if (bad) *a.flag = a.flag_val;
+      if (bad) raise();
     }
     {   // layer 0's node-phase fragments (two k-steps): in flight under the barrier and the stream set-up
       const cl_u32x4* ap = reinterpret_cast<const cl_u32x4*>(a.pack + CL_EDGE_BYTES) + (grp * 8) * 64 + lane;
@@ -823,19 +925,142 @@ extern "C" int yolat_conv_local_pack(const yolat_model_eval_bf16* mh, void* dst,
   return 0;
 }
 
-// launch on a prepared (destination-sorted) graph; *flag = flag_val when the gated per-layer path must run
-int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const float* x, int64_t ldx, const int32_t* row_ptr,
-                       const int32_t* src, const int32_t* dst, const float* attr, const int32_t* seg_ptr, int64_t N,
-                       int64_t E, int64_t P, uint16_t* feats, int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag,
+// ------------------------------------------------------------------------------------------------
+// Proposal structure of a COO batch, without the global destination sort (what the COO instantiation needs instead of
+// yolat_graph_prepare): seg_ptr / node_seg from bbox_idx, eptr [P + 1] = first edge of every proposal from the edge
+// list — valid when the list is GROUPED by proposal (bbox_idx[dst] non-decreasing along it: Datasets/graph_dict3.py:725
+// appends a proposal's edges as one block, :752-764 keeps per-proposal edge ranges) — and the violations of the
+// locality property as flag bits (YOLAT_LOC_*).  One thread per node and per edge.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ void __launch_bounds__(256) k_local_prep(const long long* __restrict__ edge, long se, long sc,
+                                                    const long long* __restrict__ bbox_idx, int N, int E, int P,
+                                                    int* __restrict__ seg_ptr, int* __restrict__ node_seg,
+                                                    int* __restrict__ eptr, int* status, int* info, int vouched) {
+  const int t = blockIdx.x * 256 + threadIdx.x;
+  auto seg_of = [&](long n, bool flag) -> int {
+    long b = bbox_idx[n];
+    if (b < 0 || b >= P) {
+      if (flag) atomicOr(status, YOLAT_STATUS_SEG_RANGE);
+      b = b < 0 ? 0 : P - 1;
+    }
+    return (int)b;
+  };
+  if (t < N) {
+    const int cur = seg_of(t, true);
+    const int prev = t > 0 ? seg_of(t - 1, false) : -1;
+    node_seg[t] = cur;
+    if (cur < prev) atomicOr(status, YOLAT_STATUS_SEG_UNSORTED);
+    else for (int p = prev + 1; p <= cur; ++p) seg_ptr[p] = t;
+    if (t == N - 1) for (int p = cur + 1; p <= P; ++p) seg_ptr[p] = N;
+  }
+  if (t < E) {
+    auto node_of = [&](long e, long col, bool flag) -> long {
+      long v = edge[e * se + col * sc];
+      if (v < 0 || v >= N) {
+        if (flag) atomicOr(status, YOLAT_STATUS_EDGE_RANGE);
+        v = v < 0 ? 0 : N - 1;
+      }
+      return v;
+    };
+    const int pd = seg_of(node_of(t, 1, true), false), ps = seg_of(node_of(t, 0, true), false);
+    const int prev = t > 0 ? seg_of(node_of(t - 1, 1, false), false) : -1;
+    int bad = 0;
+    if (ps != pd) bad |= YOLAT_LOC_CROSSING;
+    if (pd < prev) bad |= YOLAT_LOC_UNGROUPED;
+    else for (int p = prev + 1; p <= pd; ++p) eptr[p] = t;
+    if (t == E - 1) for (int p = pd + 1; p <= P; ++p) eptr[p] = E;
+    if (bad) {
+      if (info) atomicOr(info, bad);
+      if (vouched) atomicOr(status, YOLAT_STATUS_NOT_LOCAL);
+    }
+  }
+  if (E == 0) for (int p = t; p <= P; p += gridDim.x * 256) eptr[p] = 0;
+}
+
+// info[1] = nodes of the largest proposal, info[2] = edges of the largest proposal (info zeroed by the caller)
+__global__ void __launch_bounds__(256) k_local_sizes(const int* __restrict__ seg_ptr, const int* __restrict__ eptr, int P,
+                                                     int* info) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  int n = 0, e = 0;
+  if (p < P) { n = seg_ptr[p + 1] - seg_ptr[p]; e = eptr[p + 1] - eptr[p]; }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) { n = yl_max(n, __shfl_xor(n, off)); e = yl_max(e, __shfl_xor(e, off)); }
+  if ((threadIdx.x & 63) == 0) { atomicMax(info + 1, n); atomicMax(info + 2, e); }
+}
+__global__ void k_local_info_zero(int* info) { if (threadIdx.x < 4) info[threadIdx.x] = 0; }
+__global__ void k_local_info_fold(const int* status, int* info) { if (threadIdx.x == 0) info[3] = status[0]; }
+}  // namespace
+
+int yl_local_prep(const int64_t* edge, int64_t se, int64_t sc, const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P,
+                  int32_t* seg_ptr, int32_t* node_seg, int32_t* eptr, int32_t* status, int32_t* info, bool vouched,
+                  hipStream_t st) {
+  const long n = N > E ? N : E;
+  hipLaunchKernelGGL(k_local_prep, dim3(yl_cdiv(n > 0 ? n : 1, 256)), dim3(256), 0, st,
+                     reinterpret_cast<const long long*>(edge), (long)se, (long)sc, reinterpret_cast<const long long*>(bbox_idx),
+                     (int)N, (int)E, (int)P, seg_ptr, node_seg, eptr, status, info, vouched ? 1 : 0);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+// tile shape the launcher will pick for a batch of P proposals: nodes / edges a proposal may have
+static void yl_conv_local_tile(int64_t P, int* nw, int* t_nodes, int* t_edges) {
+  const int w = (g_cl_nw == 4 || g_cl_nw == 8) ? g_cl_nw : (P >= 2048 ? 8 : 4);
+  *nw = w; *t_nodes = 16 * w; *t_edges = 128 * w;
+}
+
+extern "C" size_t yolat_batch_locality_workspace_bytes(int64_t N, int64_t E, int64_t P) {
+  if (N <= 0 || E < 0 || P <= 0) return 0;
+  return (size_t)(2 * (P + 1) + N + 64) * sizeof(int32_t) + 1024;
+}
+
+extern "C" int yolat_batch_locality(const int64_t* edge, int64_t stride_e, int64_t stride_c, const int64_t* bbox_idx,
+                                    int64_t N, int64_t E, int64_t P, int32_t* info, void* workspace,
+                                    size_t workspace_bytes, yolat_stream_t stream) {
+  if (!bbox_idx || !info || !workspace || N <= 0 || E < 0 || P <= 0 || (E > 0 && !edge)) return YOLAT_E_INVALID;
+  if (N >= (1LL << 30) || E >= (1LL << 30) || P >= (1LL << 30)) return YOLAT_E_UNSUPPORTED;
+  if (workspace_bytes < yolat_batch_locality_workspace_bytes(N, E, P)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  int32_t* seg_ptr = reinterpret_cast<int32_t*>(base);
+  int32_t* eptr = seg_ptr + (P + 1);
+  int32_t* node_seg = eptr + (P + 1);
+  int32_t* scratch_status = node_seg + N;
+  hipLaunchKernelGGL(k_local_info_zero, dim3(1), dim3(64), 0, st, info);
+  hipLaunchKernelGGL(k_local_info_zero, dim3(1), dim3(64), 0, st, scratch_status);
+  YL_LAUNCH_CHECK();
+  int rc = yl_local_prep(edge, stride_e, stride_c, bbox_idx, N, E, P, seg_ptr, node_seg, eptr, scratch_status, info, false, st);
+  if (rc != 0) return rc;
+  hipLaunchKernelGGL(k_local_sizes, dim3(yl_cdiv(P, 256)), dim3(256), 0, st, seg_ptr, eptr, (int)P, info);
+  // malformed ids (status bits of the scratch word) make the batch unfit as well: info[3] carries them
+  hipLaunchKernelGGL(k_local_info_fold, dim3(1), dim3(64), 0, st, scratch_status, info);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_conv_local_fits(const yolat_locality* loc, int64_t P) {
+  if (!loc || !loc->known || loc->flags != 0) return 0;
+  int nw, tn, te;
+  yl_conv_local_tile(P, &nw, &tn, &te);
+  return (loc->max_nodes <= tn && loc->max_edges <= te) ? 1 : 0;
+}
+
+// launch on a prepared (destination-sorted) graph, or — in.edge != nullptr — on the raw COO list with per-proposal edge
+// ranges (yl_local_prep); *flag = flag_val when the batch turns out not to have the property
+int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const float* x, int64_t ldx, const YlLocalIn& in,
+                       int64_t N, int64_t E, int64_t P, uint16_t* feats, int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag,
                        int32_t flag_val, hipStream_t st) {
   const yolat_model_eval* m = mh->base;
   ClArgs a;
   a.x = x; a.ldx = (int)ldx; a.cin0 = (int)m->conv[0].Cin;
-  a.row_ptr = row_ptr; a.src = src; a.dst = dst; a.attr = attr; a.seg_ptr = seg_ptr;
+  a.row_ptr = in.row_ptr; a.src = in.src; a.dst = in.dst; a.attr = in.attr; a.seg_ptr = in.seg_ptr;
+  a.edge = reinterpret_cast<const long long*>(in.edge); a.se = (long)in.se; a.sc = (long)in.sc; a.eptr = in.eptr;
+  a.status = in.status;
   a.N = (int)N; a.E = (int)E; a.P = (int)P;
   // 8-wave workgroups (128-node tiles, one per CU) once there are enough proposals to give each of 256 workgroups a few
   // tiles; 4-wave workgroups (64-node tiles, two per CU) below that
-  int nw = g_cl_nw == 4 || g_cl_nw == 8 ? g_cl_nw : (P >= 2048 ? 8 : 4);
+  int nw, tn, te;
+  yl_conv_local_tile(P, &nw, &tn, &te);
   const long slots = nw == 8 ? 256 : 512;          // one round: one 8-wave / two 4-wave workgroups per CU
   long g0 = (P + slots - 1) / slots;
   if (g0 < 4) g0 = 4;
@@ -849,8 +1074,15 @@ int yl_conv_local_bf16(const yolat_model_eval_bf16* mh, const void* pack, const 
   a.flag = flag; a.flag_val = flag_val;
   a.abl = g_cl_abl;
   a.stamps = g_cl_stamps;
-  if (nw == 8) hipLaunchKernelGGL(k_conv_local_h<8>, dim3((unsigned)((P + g0 - 1) / g0)), dim3(512), 0, st, a);
-  else hipLaunchKernelGGL(k_conv_local_h<4>, dim3((unsigned)((P + g0 - 1) / g0)), dim3(256), 0, st, a);
+  const dim3 grid((unsigned)((P + g0 - 1) / g0));
+  const bool coo = in.edge != nullptr && E > 0;
+  if (coo) {
+    if (nw == 8) hipLaunchKernelGGL((k_conv_local_h<8, true>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_local_h<4, true>), grid, dim3(256), 0, st, a);
+  } else {
+    if (nw == 8) hipLaunchKernelGGL((k_conv_local_h<8, false>), grid, dim3(512), 0, st, a);
+    else hipLaunchKernelGGL((k_conv_local_h<4, false>), grid, dim3(256), 0, st, a);
+  }
   YL_LAUNCH_CHECK();
   return 0;
 }
@@ -866,8 +1098,38 @@ extern "C" int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* mh, cons
   if (ld_feats < D || ld_feats % 8 != 0 || (((uintptr_t)feats) & 15) != 0 || ldz < 2 * (m->F + D) || ldz % 4 != 0 ||
       !yl_aligned16(Z) || (E > 0 && !yl_aligned16(g->attr)) || N >= (1LL << 30) || E >= (1LL << 30))
     return YOLAT_E_UNSUPPORTED;
-  return yl_conv_local_bf16(mh, pack, x, ldx, g->row_ptr, g->src, g->dst, g->attr, g->seg_ptr, N, E, P, feats, ld_feats, Z,
-                            ldz, flag, 1, (hipStream_t)stream);
+  YlLocalIn in{};
+  in.row_ptr = g->row_ptr; in.src = g->src; in.dst = g->dst; in.attr = g->attr; in.seg_ptr = g->seg_ptr;
+  return yl_conv_local_bf16(mh, pack, x, ldx, in, N, E, P, feats, ld_feats, Z, ldz, flag, 1, (hipStream_t)stream);
+}
+
+// The same launch on the RAW edge list (COO order, grouped by proposal): the proposal structure comes from
+// yl_local_prep into `workspace` ((2 (P + 1) + N) int32), the tiles sort their edges in LDS.
+extern "C" int yolat_conv_stack_local_bf16_coo(const yolat_model_eval_bf16* mh, const void* pack, const float* x, int64_t ldx,
+                                               const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
+                                               const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, uint16_t* feats,
+                                               int64_t ld_feats, float* Z, int64_t ldz, int32_t* flag, int32_t* status,
+                                               void* workspace, size_t workspace_bytes, yolat_stream_t stream) {
+  if (!mh || !mh->base || !pack || !x || !bbox_idx || !feats || !Z || !flag || !status || !workspace || N <= 0 || E < 0 ||
+      P <= 0 || (E > 0 && (!edge || !e_attr)))
+    return YOLAT_E_INVALID;
+  if (!yl_conv_local_model_ok(mh)) return YOLAT_E_UNSUPPORTED;
+  const yolat_model_eval* m = mh->base;
+  const long D = m->C * m->n_blocks_out;
+  if (ld_feats < D || ld_feats % 8 != 0 || (((uintptr_t)feats) & 15) != 0 || ldz < 2 * (m->F + D) || ldz % 4 != 0 ||
+      !yl_aligned16(Z) || (E > 0 && !yl_aligned16(e_attr)) || N >= (1LL << 30) || E >= (1LL << 30))
+    return YOLAT_E_UNSUPPORTED;
+  if (workspace_bytes < yolat_batch_locality_workspace_bytes(N, E, P)) return YOLAT_E_INVALID;
+  char* base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  int32_t* seg_ptr = reinterpret_cast<int32_t*>(base);
+  int32_t* eptr = seg_ptr + (P + 1);
+  int32_t* node_seg = eptr + (P + 1);
+  hipStream_t st = (hipStream_t)stream;
+  YlLocalIn in{};
+  in.attr = e_attr; in.seg_ptr = seg_ptr; in.edge = edge; in.se = stride_e; in.sc = stride_c; in.eptr = eptr; in.status = status;
+  int rc = yl_local_prep(edge, stride_e, stride_c, bbox_idx, N, E, P, seg_ptr, node_seg, eptr, status, nullptr, true, st);
+  if (rc != 0) return rc;
+  return yl_conv_local_bf16(mh, pack, x, ldx, in, N, E, P, feats, ld_feats, Z, ldz, flag, 1, st);
 }
 
 // tuning / debug hook (tests, tools/exp/conv_local_bench.py): waves per workgroup (4 | 8, 0 = automatic), proposals per

@@ -227,7 +227,7 @@ extern "C" int yolat_dropout_bwd(const float* dZ, int64_t lddz, int64_t M, int64
   return 0;
 }
 
-extern "C" int yolat_abi_version(void) { return 5; }
+extern "C" int yolat_abi_version(void) { return 6; }
 
 extern "C" const char* yolat_strerror(int code) {
   if (code == 0) return "ok";

@@ -12,7 +12,7 @@ import torch
 from ._lib import lib, check
 
 STATS_ROWS = 32
-STATUS_EDGE_RANGE, STATUS_SEG_UNSORTED, STATUS_SEG_RANGE = 1, 2, 4
+STATUS_EDGE_RANGE, STATUS_SEG_UNSORTED, STATUS_SEG_RANGE, STATUS_NOT_LOCAL = 1, 2, 4, 8
 
 # The HIP kernels write parameters and BatchNorm buffers through raw pointers, which torch's per-tensor `_version`
 # counters never see.  Every wrapper below that modifies model state (Adam step, running-statistic updates) bumps
@@ -163,6 +163,9 @@ class Graph(object):
             raise ValueError("bbox_idx is not non-decreasing")
         if s & STATUS_SEG_RANGE:
             raise IndexError("bbox_idx contains a proposal id outside [0, P)")
+        if s & STATUS_NOT_LOCAL:
+            raise ValueError("a batch handed over as proposal-local (yolat_locality) is not: an edge leaves its proposal, "
+                             "the edge list is not grouped by proposal, or a proposal does not fit a tile")
         return True
 
 

@@ -11,7 +11,9 @@ import os
 import torch
 
 from . import ops
-from ._lib import lib, check, ModelEval, ModelEvalBf16, GraphCsr, YOLAT_MAX_LAYERS
+import weakref
+
+from ._lib import lib, check, ModelEval, ModelEvalBf16, GraphCsr, Locality, YOLAT_MAX_LAYERS
 
 # skip the memset of the CSR-build counters when the plan's workspace was last used by a forward of the same shape
 # (yolat_forward_eval_primed, include/yolat_hip.h); module flag, False: always the self-contained call
@@ -21,6 +23,11 @@ PRIMED_WS = True
 # bf16 plan: all conv layers + the pooling prologue in ONE launch for proposal-local batches (csrc/conv_local.hip; the
 # per-layer launches stay enqueued as its gated fall-back).  False: the per-layer launches only.
 CONV_LOCAL = True
+
+# bf16 plan: examine a resident batch once per batch version (yolat_batch_locality: one extra launch pair + one host read)
+# so that a proposal-local batch runs WITHOUT the global COO -> CSR build and without the gated fall-back launches, and an
+# unfit one goes straight to the per-layer path.  False: every forward finds out on the device (the gated form).
+LOCALITY_CACHE = True
 
 
 def _x6_on(default=True):
@@ -61,6 +68,7 @@ class EvalPlan(object):
         self._need = {}           # (N, E, P, descriptor build) -> workspace bytes of the prepared-graph forward
         self._primed = None        # (workspace, descriptor build, N, E, P, stream) of the last completed direct launch
         self._desc_key = 0
+        self._loc = {}             # batch version -> (weakrefs, Locality): the locality property, examined once
         self.use_graph = False      # model.use_hip_graphs(True) turns the captured-graph replay on
 
     def _version_key(self):
@@ -276,6 +284,34 @@ class EvalPlan(object):
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
 
+    def locality(self, edge, bbox_idx, N, E, P, se, sc):
+        """The batch's locality record (yolat_locality), examined on the device ONCE per batch version: the key is the
+        identity, storage address and `_version` of the two index tensors — the invalidation rule of the model's stage
+        cache, so an in-place edit (`edge[5, 0] = ...`) is seen.  The record holds weak references to the tensors it
+        was taken from: an address recycled for another tensor never matches.  Returns None when the one-launch conv
+        stack is not a candidate for this model / batch size (nothing to decide: no examination, no host read)."""
+        if not LOCALITY_CACHE or self._desc_h is None or not self._desc_h.conv_local:
+            return None
+        mode = os.environ.get("YOLAT_CONV_LOCAL", "1")
+        if mode == "0" or (mode not in ("2", "3") and P < 1024):
+            return None
+        key = (id(edge), edge.data_ptr(), edge._version, id(bbox_idx), bbox_idx.data_ptr(), bbox_idx._version, N, E, P, se, sc)
+        ent = self._loc.get(key)
+        if ent is not None and ent[0]() is edge and ent[1]() is bbox_idx:
+            return ent[2]
+        need = int(lib.yolat_batch_locality_workspace_bytes(N, E, P))
+        ws = torch.empty(need + 16, dtype=torch.uint8, device=bbox_idx.device)
+        info = torch.empty(4, dtype=torch.int32, device=bbox_idx.device)
+        check(lib.yolat_batch_locality(ops._i(edge, torch.int64, "edge") if E > 0 else None, se, sc,
+                                       ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, info.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), ops._stream()), "yolat_batch_locality")
+        flags, mn, me, bad = info.tolist()             # the one host read per batch version
+        loc = Locality(1, int(flags) | (4 if bad else 0), int(mn), int(me))
+        if len(self._loc) >= 16:
+            self._loc.pop(next(iter(self._loc)))
+        self._loc[key] = (weakref.ref(edge), weakref.ref(bbox_idx), loc)
+        return loc
+
     def run(self, x, edge, e_attr, bbox_idx, num_proposals):
         key = self._version_key()
         if key != self._key:
@@ -403,15 +439,19 @@ class EvalPlan(object):
             stream = ops._stream()
             capturing = torch.cuda.is_current_stream_capturing()
             key = (self._ws.data_ptr(), self._desc_key, N, E, P, stream, "bf16")
-            primed = PRIMED_WS and not capturing and self._primed == key
+            loc = None if capturing else self.locality(edge, bbox_idx, N, E, P, se, sc)
+            vouched = loc is not None and lib.yolat_conv_local_fits(ctypes.byref(loc), P) != 0
+            # (a vouched forward does not touch the CSR-build counters: it neither needs nor keeps the `primed` promise)
+            primed = PRIMED_WS and not capturing and not vouched and self._primed == key
             self._primed = None
-            fn = lib.yolat_forward_eval_bf16_primed if primed else lib.yolat_forward_eval_bf16
-            check(fn(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x),
-                     ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
-                     ops._i(bbox_idx, torch.int64, "bbox_idx"), N, E, P, logits.data_ptr(),
-                     logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
-                     self._status.data_ptr(), stream), "yolat_forward_eval_bf16")
-            if not capturing:
+            check(lib.yolat_forward_eval_bf16_loc(ctypes.byref(self._desc_h), ops._f(x, "x"), ops._ld(x),
+                                                  ops._i(edge, torch.int64, "edge"), se, sc, ops._f(e_attr, "e_attr"),
+                                                  ops._i(bbox_idx, torch.int64, "bbox_idx"), None, N, E, P,
+                                                  logits.data_ptr(), logits.stride(0), self._ws.data_ptr(),
+                                                  self._ws.numel(), self._status.data_ptr(),
+                                                  ctypes.byref(loc) if loc is not None else None, 1 if primed else 0,
+                                                  stream), "yolat_forward_eval_bf16")
+            if not capturing and not vouched:
                 self._primed = key
             return logits
         # the workspace is this plan's own: when its previous use was a forward of the same shape on the same stream,
