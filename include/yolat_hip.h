@@ -686,7 +686,8 @@ int yolat_conv_stack_local_bf16(const yolat_model_eval_bf16* m, const void* pack
  * (:582-600,733); a batch like that, whose proposals fit a tile, needs neither the global COO -> CSR build nor the gated
  * per-layer fall-back launches: each tile of the conv kernel sorts its <= 1024 edges by destination in LDS (stable).
  *   yolat_batch_locality: info[4] (device int32) = { YOLAT_LOC_* violations, nodes of the largest proposal, edges of the
- *     largest proposal, YOLAT_STATUS_* bits of malformed ids }; workspace of yolat_batch_locality_workspace_bytes.
+ *     largest proposal (by edge RANGES: meaningful when the list is grouped), YOLAT_STATUS_* bits of malformed ids };
+ *     workspace of yolat_batch_locality_workspace_bytes.
  *   yolat_locality: the same on the host (known = 1 once examined), handed to yolat_forward_eval_bf16_loc:
  *     known and fitting (yolat_conv_local_fits) -> local prep + ONE conv launch, no gated launches; a violation the device
  *       still finds (the caller's information was stale) raises YOLAT_STATUS_NOT_LOCAL in *status, the logits are invalid;
@@ -703,6 +704,10 @@ int yolat_batch_locality(const int64_t* edge, int64_t stride_e, int64_t stride_c
                          int64_t E, int64_t P, int32_t* info, void* workspace, size_t workspace_bytes,
                          yolat_stream_t stream);
 int yolat_conv_local_fits(const yolat_locality* loc, int64_t P);
+/* the record of ONE dataset item, on the host (collate.hip); a batch of items has the OR of the flags and the maxima of the
+ * sizes (collate keeps the order and adds per-image offsets, train.py:238-258) */
+int yolat_item_locality_host(const int64_t* edge, int64_t stride_e, int64_t stride_c, const int64_t* bbox_idx, int64_t E,
+                             int64_t N, int64_t P, yolat_locality* out);
 int yolat_conv_stack_local_bf16_coo(const yolat_model_eval_bf16* m, const void* pack, const float* x, int64_t ldx,
                                     const int64_t* edge, int64_t stride_e, int64_t stride_c, const float* e_attr,
                                     const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P, uint16_t* feats,

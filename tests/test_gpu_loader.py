@@ -208,3 +208,123 @@ def test_training_step_on_a_loader_batch_equals_the_step_on_the_synchronous_batc
     l2, p2 = run(wb, ws)
     assert l1 == l2
     assert all(torch.equal(a, b) for a, b in zip(p1, p2))
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 6: the locality record travels with the batch (decided on the host from the items, data.batch_locality), and the
+# lifetime / shortcut rules of loader batches.
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _stage_names(fn):
+    import ctypes
+    from yolat_vectorgraphicsrecognition_amd._lib import lib
+    lib.yolat_profile_reset()
+    lib.yolat_profile_enable(1)
+    try:
+        out = fn()
+        torch.cuda.synchronize()
+    finally:
+        lib.yolat_profile_enable(0)
+    names = []
+    buf = ctypes.create_string_buffer(128)
+    ms, calls, fl, by = ctypes.c_float(), ctypes.c_int(), ctypes.c_double(), ctypes.c_double()
+    for i in range(lib.yolat_profile_count()):
+        lib.yolat_profile_get(i, buf, 128, ctypes.byref(ms), ctypes.byref(calls), ctypes.byref(fl), ctypes.byref(by))
+        names.append(buf.value.decode())
+    lib.yolat_profile_reset()
+    return out, names
+
+
+def test_host_locality_of_items_equals_the_device_examination_of_the_batch():
+    """data.batch_locality (yolat_item_locality_host per item, merged) against yolat_batch_locality on the collated batch:
+    the same flags and sizes, for clean items, an item with a crossing edge and an item whose edge list is not grouped"""
+    import ctypes
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd._lib import lib, check
+    from yolat_vectorgraphicsrecognition_amd import data as D
+    items = [yv.synth_graph(num_proposals=40 + 5 * j, nodes_lo=3, nodes_hi=20 + j, edge_factor=1.7, seed=60 + j) for j in range(4)]
+    bad1 = yv.synth_graph(num_proposals=30, nodes_lo=3, nodes_hi=12, seed=70)
+    bad1.edge = bad1.edge.clone()
+    bad1.edge[4, 0] = bad1.x.shape[0] - 1
+    bad2 = yv.synth_graph(num_proposals=30, nodes_lo=3, nodes_hi=12, seed=71)
+    bad2.edge = torch.cat([bad2.edge[1:], bad2.edge[:1]], 0)
+    bad2.e_attr = torch.cat([bad2.e_attr[1:], bad2.e_attr[:1]], 0)
+    for lst in (items, items[:1], [items[0], bad1, items[1]], [bad2, items[2]]):
+        host = D.batch_locality(lst)
+        batch, _ = yv.collate_to_device(lst)
+        N, E, P = batch.x.shape[0], batch.edge.shape[0], batch.bbox.shape[0]
+        ws = torch.empty(int(lib.yolat_batch_locality_workspace_bytes(N, E, P)) + 16, dtype=torch.uint8, device="cuda")
+        info = torch.empty(4, dtype=torch.int32, device="cuda")
+        check(lib.yolat_batch_locality(batch.edge.data_ptr(), 2, 1, batch.bbox_idx.data_ptr(), N, E, P, info.data_ptr(),
+                                       ws.data_ptr(), ws.numel(), torch.cuda.current_stream().cuda_stream), "locality")
+        flags, mn, me, st = info.tolist()
+        assert (host.known, host.flags, host.max_nodes) == (1, flags, mn) and st == 0
+        if not flags & 1:            # (per-proposal edge RANGES only exist for a grouped list)
+            assert host.max_edges == me
+    # cached on the item, invalidated by an in-place edit of the edge list
+    rec = D.item_locality(items[0])
+    assert D.item_locality(items[0]) is rec
+    items[0].edge[0, 0] = items[0].x.shape[0] - 1
+    assert D.item_locality(items[0])[0] & 2
+
+
+@pytest.mark.parametrize("csr", [True, False])
+def test_bf16_forward_on_loader_batches_takes_the_one_launch_stack_without_gated_launches(csr):
+    """a bf16 model on DeviceLoader / collate_to_device batches of >= 1024 proposals: the locality record comes with the
+    batch, so the forward is local prep (COO mode) or nothing (CSR mode) + ONE conv launch — no gated fall-back launches, no
+    device-side examination — and its logits equal the resident forward's bit for bit"""
+    yv = _yv()
+    import os
+    lists = [[yv.synth_graph(num_proposals=420 + 30 * i + 10 * j, nodes_lo=3, nodes_hi=25, edge_factor=1.6,
+                             seed=900 + 10 * i + j) for j in range(3)] for i in range(4)]
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(n_classes=17, n_blocks=3, n_blocks_out=2)), 2).cuda().eval()
+    model.set_eval_precision("bf16")
+    n = 0
+    for (batch, slices), items in zip(yv.DeviceLoader(lists, slots=3, csr=csr), lists):
+        with torch.no_grad():
+            examined = len(model.__dict__["_yolat_plan"]._loc) if "_yolat_plan" in model.__dict__ else 0
+            got, names = _stage_names(lambda: model(batch, slices)[0].clone())
+            sync, names_sync = _stage_names(lambda: model(*yv.collate_to_device(items, csr=csr))[0].clone())
+            assert len(model._yolat_plan._loc) == examined          # the record came with the batch: nothing examined
+            host = yv.collate(items)
+            yv.fixup_offsets(*host)
+            for k in ("x", "edge", "e_attr", "bbox_idx", "bbox"):
+                setattr(host[0], k, getattr(host[0], k).cuda())
+            want = model(*host)[0].clone()
+        for nm in (names, names_sync):
+            assert any(s.startswith("conv_local") for s in nm), nm
+            assert not any("gated" in s for s in nm), nm
+        assert torch.equal(got, want) and torch.equal(sync, want)
+        n += 1
+    assert n == len(lists)
+    model._yolat_plan.check_status()
+
+
+def test_a_loader_batch_outlives_the_loop_that_drew_it_and_sees_reassigned_tensors():
+    """(1) the last batch of `for batch, sl in DeviceLoader(...)` is used after the loop — its tensors live in
+    slot buffers the loader owns, so the batch keeps the loader alive; (2) a caller that re-assigns a shipped key before the
+    forward gets the forward on ITS tensor, not on the slot data captured at draw time."""
+    import gc
+    yv = _yv()
+    lists = _lists(yv, 4)
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt()), 3).cuda().eval()
+    for csr in (True, False):
+        last = None
+        for batch, slices in yv.DeviceLoader(lists, slots=2, csr=csr):
+            last = (batch, slices)
+        gc.collect()
+        torch.cuda.synchronize()
+        junk = [torch.full((1 << 20,), 7.0, device="cuda") for _ in range(8)]        # recycle whatever was freed
+        with torch.no_grad():
+            got = model(*last)[0].clone()
+            want = model(*yv.collate_to_device(lists[-1], csr=csr))[0]
+        assert torch.equal(got, want)
+        del junk
+        # (2) re-assignment of x: the forward reads the new tensor
+        batch, slices = last
+        batch.x = batch.x * 0.5
+        assert "_yolat_x" not in batch.__dict__ and "_yolat_raw" not in batch.__dict__
+        ref_b, ref_s = yv.collate_to_device(lists[-1], csr=csr)
+        ref_b.x = ref_b.x * 0.5
+        with torch.no_grad():
+            assert torch.equal(model(batch, slices)[0], model(ref_b, ref_s)[0])

@@ -267,6 +267,7 @@ SIGNATURES = {
     "yolat_batch_locality_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "yolat_batch_locality": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_sz, c_p]),
     "yolat_conv_local_fits": (c_int, [ctypes.POINTER(Locality), c_i64]),
+    "yolat_item_locality_host": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, ctypes.POINTER(Locality)]),
     "yolat_conv_stack_local_bf16_coo": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p,
                                                  c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p, c_p, c_sz, c_p]),
     "yolat_forward_eval_bf16_loc": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p,

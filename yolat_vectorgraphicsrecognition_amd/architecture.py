@@ -137,13 +137,14 @@ class SparseCADGCN(nn.Module):
             xref = data.__dict__.get("_yolat_x") if not need_graph else None
             if xref is not None:
                 # a DeviceLoader batch in the eval forward: x's address / row stride / rows / device, no tensor view
-                return {"x": None, "xref": xref, "bbox": data.bbox, "g": pre, "prepared": True}
+                return {"x": None, "xref": xref, "bbox": data.bbox, "g": pre, "prepared": True,
+                        "loc": data.__dict__.get("_yolat_loc")}
             x = data.x if data.x.dtype == torch.float32 else data.x.float()
-            return {"x": x, "bbox": data.bbox, "g": pre, "prepared": True}
+            return {"x": x, "bbox": data.bbox, "g": pre, "prepared": True, "loc": data.__dict__.get("_yolat_loc")}
         raw = data.__dict__.get("_yolat_raw") if (not need_graph and hasattr(data, "__dict__")) else None
         if raw is not None:
             # a DeviceLoader batch in COO mode in the eval forward: addresses only (plan.run_raw), no tensor views
-            return {"raw": raw, "bbox": data.bbox, "g": None}
+            return {"raw": raw, "bbox": data.bbox, "g": None, "loc": data.__dict__.get("_yolat_loc")}
         cache = getattr(data, "_yolat_stage", None)
         key = (data.x.data_ptr(), data.x._version, data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
                data.bbox_idx._version, data.e_attr.data_ptr(), data.e_attr._version, data.bbox.data_ptr(),
@@ -188,11 +189,18 @@ class SparseCADGCN(nn.Module):
             self.__dict__["_yolat_plan"] = plan      # the plan of the most recent forward (status checks); not through
             #                                          nn.Module.__setattr__: 3 us of a 100 us hand-over
             if st.get("raw") is not None:
-                pred_cls = plan.run_raw(st["raw"])
+                pred_cls = plan.run_raw(st["raw"], st.get("loc"))
             elif st.get("prepared"):
-                pred_cls = plan.run_prepared(st["x"], st["g"], st.get("xref"))
+                pred_cls = plan.run_prepared(st["x"], st["g"], st.get("xref"), st.get("loc"))
             else:
-                pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0])
+                # a batch from collate_to_device carries its locality record, decided on the host from the items: valid
+                # for exactly the (edge, bbox_idx) tensors it was taken for
+                loc = data.__dict__.get("_yolat_loc") if hasattr(data, "__dict__") else None
+                if loc is not None:
+                    e_t, b_t = st["edge"], st["bbox_idx"]
+                    loc = loc[1] if (isinstance(loc, tuple) and
+                                     loc[0] == (e_t.data_ptr(), e_t._version, b_t.data_ptr(), b_t._version)) else None
+                pred_cls = plan.run(st["x"], st["edge"], st["e_attr"], st["bbox_idx"], st["bbox"].shape[0], loc)
             st["plan_status"] = plan
         else:
             st = self._stage(data)

@@ -89,6 +89,44 @@ extern "C" int yolat_item_csr_host(const int64_t* edge, int64_t stride_e, int64_
   return 0;
 }
 
+// The locality record of ONE dataset item on the host (the twin of yolat_batch_locality): is its edge list grouped by
+// proposal (Datasets/graph_dict3.py:725,752-764), does every edge stay inside its proposal (:582-600,733), how large is the
+// largest proposal.  A batch of items inherits the OR of the flags and the maxima: collate adds per-image offsets
+// (train.py:238-258) and keeps the order, so the batch's list is grouped iff every item's is.  Computed once per item and
+// cached with it (data.item_locality), like the item's CSR.
+extern "C" int yolat_item_locality_host(const int64_t* edge, int64_t stride_e, int64_t stride_c, const int64_t* bbox_idx,
+                                        int64_t E, int64_t N, int64_t P, yolat_locality* out) {
+  if (!out || N <= 0 || E < 0 || P <= 0 || !bbox_idx || (E > 0 && !edge)) return YOLAT_E_INVALID;
+  if (N >= (1LL << 30) || E >= (1LL << 30) || P >= (1LL << 30)) return YOLAT_E_UNSUPPORTED;
+  int flags = 0;
+  std::vector<int32_t> nn((size_t)P, 0), ne((size_t)P, 0);
+  int64_t prev = -1;
+  for (int64_t n = 0; n < N; ++n) {
+    int64_t b = bbox_idx[n];
+    if (b < 0 || b >= P) { flags |= YOLAT_LOC_MALFORMED; b = b < 0 ? 0 : P - 1; }
+    if (b < prev) flags |= YOLAT_LOC_MALFORMED;
+    prev = b;
+    ++nn[(size_t)b];
+  }
+  auto seg = [&](int64_t v) -> int64_t {
+    if (v < 0 || v >= N) { flags |= YOLAT_LOC_MALFORMED; v = v < 0 ? 0 : N - 1; }
+    int64_t b = bbox_idx[v];
+    return b < 0 ? 0 : (b >= P ? P - 1 : b);
+  };
+  prev = -1;
+  for (int64_t e = 0; e < E; ++e) {
+    const int64_t ps = seg(edge[e * stride_e]), pd = seg(edge[e * stride_e + stride_c]);
+    if (ps != pd) flags |= YOLAT_LOC_CROSSING;
+    if (pd < prev) flags |= YOLAT_LOC_UNGROUPED;
+    prev = pd;
+    ++ne[(size_t)pd];
+  }
+  int32_t mn = 0, me = 0;
+  for (int64_t p = 0; p < P; ++p) { mn = nn[(size_t)p] > mn ? nn[(size_t)p] : mn; me = ne[(size_t)p] > me ? ne[(size_t)p] : me; }
+  out->known = 1; out->flags = flags; out->max_nodes = mn; out->max_edges = me;
+  return 0;
+}
+
 extern "C" int yolat_collate_csr_pack(const yolat_item_csr* items, int64_t B, int32_t* row_ptr, int32_t* src, int32_t* dst,
                                       float* attr, int32_t* seg_ptr, int32_t* node_seg) {
   if (!items || B <= 0 || !row_ptr || !seg_ptr || !node_seg) return YOLAT_E_INVALID;

@@ -179,6 +179,43 @@ def item_csr(item):
     return c
 
 
+def item_locality(item):
+    """The locality record (``yolat_locality``) of ONE dataset item, computed once by the library's host code
+    (``yolat_item_locality_host``) and cached on the item like its CSR: is the edge list grouped by proposal
+    (Datasets/graph_dict3.py:725,752-764), does every edge stay inside its proposal (:582-600,733), nodes / edges of the
+    largest proposal.  Returns (flags, max_nodes, max_edges)."""
+    c = item.__dict__.get("_yolat_loc_item")
+    key = _source_key(item, ("edge", "bbox_idx")) + (int(item.x.shape[0]), int(item.bbox.shape[0]))
+    if c is not None and c[0] == key:
+        return c[1]
+    from ._lib import lib, check, Locality
+    edge, bidx = item.edge, item.bbox_idx.contiguous()
+    if edge.dtype != torch.long or bidx.dtype != torch.long:
+        raise TypeError("item_locality: edge / bbox_idx must be int64 (Datasets/graph_dict3.py:1049-1066)")
+    N, E, P = int(item.x.shape[0]), int(edge.shape[0]), int(item.bbox.shape[0])
+    loc = Locality()
+    check(lib.yolat_item_locality_host(edge.data_ptr() if E > 0 else None, edge.stride(0) if E > 0 else 2,
+                                       edge.stride(1) if (E > 0 and edge.dim() == 2) else 1, bidx.data_ptr(), E, N, P,
+                                       ctypes.byref(loc)), "yolat_item_locality_host")
+    rec = (int(loc.flags), int(loc.max_nodes), int(loc.max_edges))
+    item.__dict__["_yolat_loc_item"] = (key, rec)
+    return rec
+
+
+def batch_locality(items):
+    """The batch's record from its items': collate keeps the order of the items and of their edges and adds per-image
+    offsets (train.py:238-258), so the batch's edge list is grouped / local iff every item's is, and its largest proposal
+    is the largest of the items'."""
+    from ._lib import Locality
+    flags = mn = me = 0
+    for it in items:
+        f, n, e = item_locality(it)
+        flags |= f
+        mn = n if n > mn else mn
+        me = e if e > me else me
+    return Locality(1, flags, mn, me)
+
+
 def _item_desc(item, ship, csr=True):
     """The cached yolat_item_desc of a dataset item: pointers / sizes of its dense arrays in `ship` order + its CSR
     (csr=True), or — COO mode — no CSR and the offset fix-up of the int64 index keys (train.py:238-258: keys containing
@@ -299,6 +336,7 @@ def _collate_csr(data_list, device, tkeys, ship, batch, slices):
     # the merged CSR stays six offsets into the device buffer until somebody asks for the arrays (ops.PackedGraph)
     g = ops.PackedGraph.from_buffer(dbuf, [off[nk + i] for i in range(6)], Nt, Et, Pt)
     batch.__dict__["_yolat_graph"] = g
+    batch.__dict__["_yolat_loc"] = batch_locality(data_list)       # decided on the host, before any forward is enqueued
     batch._device_buffer = dbuf
     return batch, slices
 
@@ -399,6 +437,9 @@ def collate_to_device(data_list, device="cuda", csr=False):
                                   dv["node_ptr"].data_ptr(), dv["node_off"].data_ptr(), dv["prop_off"].data_ptr(), B,
                                   ops._stream()), "yolat_fixup_offsets")
     batch._device_buffer = dbuf
+    # the locality record travels with the tensors it describes: (edge, bbox_idx) storage + version, checked by the forward
+    e_t, b_t = dv["edge"], dv["bbox_idx"]
+    batch.__dict__["_yolat_loc"] = ((e_t.data_ptr(), e_t._version, b_t.data_ptr(), b_t._version), batch_locality(data_list))
     return batch, slices
 
 
@@ -529,6 +570,20 @@ class _LazyBatch(Data):
         if args or kwargs:
             Data.__init__(self, *args, **kwargs)
 
+    def __setattr__(self, name, value):
+        # the eval fast paths read a loader batch through addresses captured at draw time (`_yolat_x`, `_yolat_raw`) and a
+        # locality record taken from the host items: a caller that re-assigns a shipped key (`batch.x = norm(batch.x)`,
+        # `batch.edge = ...`) must get the forward on ITS tensors — drop the shortcuts, the regular staged path takes over
+        d = self.__dict__
+        if name[0] != "_" and ("_yolat_x" in d or "_yolat_raw" in d or "_yolat_loc" in d):
+            st = d.get("_lazy")
+            if st is not None and name in st.ship:
+                d.pop("_yolat_x", None)
+                d.pop("_yolat_raw", None)
+                if name in ("edge", "bbox_idx"):
+                    d.pop("_yolat_loc", None)
+        d[name] = value
+
     def __getattr__(self, name):               # only reached when the normal look-up fails
         st = self.__dict__.get("_lazy")
         if st is not None and name[0] != "_":
@@ -631,7 +686,7 @@ class DeviceLoader(object):
         rc = self._lib.yolat_loader_submit(self._h, ptrs, len(items))
         if rc != 0:
             self._check(rc, "yolat_loader_submit")
-        self._pending.append((items, ship, tkeys, rest, ptrs))
+        self._pending.append((items, ship, tkeys, rest, ptrs, batch_locality(items)))
         return True
 
     def __next__(self):
@@ -647,9 +702,13 @@ class DeviceLoader(object):
             pass
         if not pending:
             raise StopIteration
-        items, ship, tkeys, rest, _ptrs = pending.pop(0)
+        # (the entry — host items, descriptors, pointer array — stays referenced until the worker has handed the batch over:
+        # it reads them until yolat_loader_next returns)
+        ent = pending[0]
+        items, ship, tkeys, rest, _ptrs, loc = ent
         out = self._LoaderBatch()
         rc = lib.yolat_loader_next(self._h, stream, ctypes.byref(out))
+        pending.pop(0)
         if rc != 0:
             self._check(rc, "yolat_loader_next")
         slot = self._held = out.slot
@@ -682,6 +741,8 @@ class DeviceLoader(object):
         if not self._csr:
             self._raw_fast_path(bd, items[0], ship, st, out.device)
         bd["_device_buffer"] = mem[2]
+        bd["_yolat_loc"] = loc           # prepared graph / slot addresses: nothing the consumer edits in place
+        bd["_loader"] = self             # the slot buffers are the loader's: a batch keeps it (and them) alive
         return batch, slices
 
     def _raw_fast_path(self, bd, first, ship, st, base):
@@ -716,10 +777,14 @@ class DeviceLoader(object):
             # draw (and hand back) what the worker has already been given: it may hold pointers into the items
             from ._lib import LoaderBatch
             while self._pending:
-                self._pending.pop(0)
+                # the worker may still be reading this entry's items / descriptors (the header requires them alive until
+                # yolat_loader_next has returned the batch): drop it only afterwards
+                ent = self._pending[0]
                 out = LoaderBatch()
                 if lib.yolat_loader_next(self._h, ops_stream_or_zero(), ctypes.byref(out)) == 0:
                     lib.yolat_loader_release(self._h, int(out.slot), ops_stream_or_zero())
+                self._pending.pop(0)
+                del ent
             torch.cuda.synchronize(self._device)
             lib.yolat_loader_destroy(self._h)
             self._h = None

@@ -284,16 +284,25 @@ class EvalPlan(object):
         if self._status is None:
             self._status = torch.zeros(1, dtype=torch.int32, device=dev)
 
+    def _local_candidate(self, P):
+        """would yolat_forward_eval_bf16 consider the one-launch conv stack for a batch of P proposals?  (the model's
+        shapes packed, YOLAT_CONV_LOCAL — read per call like the C side does — and its P >= 1024 rule)"""
+        if self._desc_h is None or not self._desc_h.conv_local:
+            return False
+        mode = os.environ.get("YOLAT_CONV_LOCAL", "1")
+        return mode != "0" and (mode in ("2", "3") or P >= 1024)
+
+    def _vouched(self, loc, P):
+        return (loc is not None and self._local_candidate(P) and
+                lib.yolat_conv_local_fits(ctypes.byref(loc), P) != 0)
+
     def locality(self, edge, bbox_idx, N, E, P, se, sc):
         """The batch's locality record (yolat_locality), examined on the device ONCE per batch version: the key is the
         identity, storage address and `_version` of the two index tensors — the invalidation rule of the model's stage
         cache, so an in-place edit (`edge[5, 0] = ...`) is seen.  The record holds weak references to the tensors it
         was taken from: an address recycled for another tensor never matches.  Returns None when the one-launch conv
         stack is not a candidate for this model / batch size (nothing to decide: no examination, no host read)."""
-        if not LOCALITY_CACHE or self._desc_h is None or not self._desc_h.conv_local:
-            return None
-        mode = os.environ.get("YOLAT_CONV_LOCAL", "1")
-        if mode == "0" or (mode not in ("2", "3") and P < 1024):
+        if not LOCALITY_CACHE or not self._local_candidate(P):
             return None
         key = (id(edge), edge.data_ptr(), edge._version, id(bbox_idx), bbox_idx.data_ptr(), bbox_idx._version, N, E, P, se, sc)
         ent = self._loc.get(key)
@@ -312,7 +321,9 @@ class EvalPlan(object):
         self._loc[key] = (weakref.ref(edge), weakref.ref(bbox_idx), loc)
         return loc
 
-    def run(self, x, edge, e_attr, bbox_idx, num_proposals):
+    def run(self, x, edge, e_attr, bbox_idx, num_proposals, loc=None):
+        """loc: the batch's locality record when the caller has it (decided on the host by the collate); None: the plan
+        examines a resident batch itself, once per batch version (`locality`)"""
         key = self._version_key()
         if key != self._key:
             self._build()
@@ -336,9 +347,9 @@ class EvalPlan(object):
             out = self._run_graph(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
             if out is not None:
                 return out
-        return self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc)
+        return self._launch(x, edge, e_attr, bbox_idx, N, E, P, se, sc, loc)
 
-    def run_raw(self, raw):
+    def run_raw(self, raw, loc=None):
         """The forward on a DeviceLoader batch in COO mode, described by addresses instead of tensor views:
         raw = (x, ldx, edge, stride_e, stride_c, e_attr, bbox_idx, N, E, P, device) — every tensor view costs this thread
         what a launch costs, and the hand-over is bound by exactly that (data.DeviceLoader)."""
@@ -368,9 +379,14 @@ class EvalPlan(object):
         primed = PRIMED_WS and self._primed == pk
         self._primed = None
         if bf16:
-            fn = lib.yolat_forward_eval_bf16_primed if primed else lib.yolat_forward_eval_bf16
-            rc = fn(ctypes.byref(self._desc_h), xp, ldx, ep, se, sc, ap, bp, N, E, P, logits.data_ptr(), logits.stride(0),
-                    self._ws.data_ptr(), self._ws.numel(), self._status.data_ptr(), stream)
+            vouched = self._vouched(loc, P)
+            primed = primed and not vouched
+            rc = lib.yolat_forward_eval_bf16_loc(ctypes.byref(self._desc_h), xp, ldx, ep, se, sc, ap, bp, None, N, E, P,
+                                                 logits.data_ptr(), logits.stride(0), self._ws.data_ptr(), self._ws.numel(),
+                                                 self._status.data_ptr(), ctypes.byref(loc) if loc is not None else None,
+                                                 1 if primed else 0, stream)
+            if vouched:
+                pk = None
         else:
             fn = lib.yolat_forward_eval_primed if primed else lib.yolat_forward_eval
             rc = fn(ctypes.byref(self._desc), xp, ldx, ep, se, sc, ap, bp, N, E, P, logits.data_ptr(), logits.stride(0),
@@ -380,7 +396,7 @@ class EvalPlan(object):
         self._primed = pk
         return logits
 
-    def run_prepared(self, x, g, xref=None):
+    def run_prepared(self, x, g, xref=None, loc=None):
         """The forward on a prepared device graph (ops.Graph; yolat_forward_eval_csr / _bf16_csr): no COO -> CSR
         conversion inside the call.  (hipGraph replay of this path was measured and dropped twice: batches arrive in fresh
         allocations, so captured graphs rarely match — 4.3 k vs 6.2 k graphs/s H2D-inclusive at cfg 2, round 3; keyed by the
@@ -405,9 +421,9 @@ class EvalPlan(object):
             self._ws = torch.empty(int(need * 1.25) + 4096, dtype=torch.uint8, device=self._tensors[0].device)
             self._graphs.clear()
         self._primed = None
-        return self._launch_prepared(x, g, xref)
+        return self._launch_prepared(x, g, xref, loc)
 
-    def _launch_prepared(self, x, g, xref=None):
+    def _launch_prepared(self, x, g, xref=None, loc=None):
         """xref = (address, row stride, rows, device) of a dense fp32 x that exists only as a range of a loader slot
         (data.DeviceLoader): the hand-over is bound by this thread's Python, a tensor view costs what a launch costs"""
         N, E, P = g.N, g.E, g.P
@@ -421,9 +437,10 @@ class EvalPlan(object):
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=dev)
         ws = self._ws
         if self._desc_h is not None:
-            rc = lib.yolat_forward_eval_bf16_csr(ctypes.byref(self._desc_h), xp, ldx, ctypes.byref(gc),
-                                                 N, E, P, logits.data_ptr(), logits.stride(0), ws.data_ptr(),
-                                                 ws.numel(), ops._stream())
+            rc = lib.yolat_forward_eval_bf16_loc(ctypes.byref(self._desc_h), xp, ldx, None, 0, 0, None, None, ctypes.byref(gc),
+                                                 N, E, P, logits.data_ptr(), logits.stride(0), ws.data_ptr(), ws.numel(),
+                                                 self._status.data_ptr(), ctypes.byref(loc) if loc is not None else None, 0,
+                                                 ops._stream())
             if rc != 0:
                 check(rc, "yolat_forward_eval_bf16_csr")
         else:
@@ -433,14 +450,15 @@ class EvalPlan(object):
                 check(rc, "yolat_forward_eval_csr")
         return logits
 
-    def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc):
+    def _launch(self, x, edge, e_attr, bbox_idx, N, E, P, se, sc, loc=None):
         logits = torch.empty(P, self._desc.n_classes, dtype=torch.float32, device=x.device)
         if self._desc_h is not None:
             stream = ops._stream()
             capturing = torch.cuda.is_current_stream_capturing()
             key = (self._ws.data_ptr(), self._desc_key, N, E, P, stream, "bf16")
-            loc = None if capturing else self.locality(edge, bbox_idx, N, E, P, se, sc)
-            vouched = loc is not None and lib.yolat_conv_local_fits(ctypes.byref(loc), P) != 0
+            if loc is None and not capturing:
+                loc = self.locality(edge, bbox_idx, N, E, P, se, sc)
+            vouched = self._vouched(loc, P)
             # (a vouched forward does not touch the CSR-build counters: it neither needs nor keeps the `primed` promise)
             primed = PRIMED_WS and not capturing and not vouched and self._primed == key
             self._primed = None
