@@ -14,6 +14,12 @@ CASES = {
 }
 
 
+# the timed case of bench.py's `proposals` leg and of tests/golden/time_reference.py (the reference's own _get_proposal on
+# the same dict): nine dense components, 877 proposals / 9.8 k proposal nodes — the size of a Floorplans drawing
+TIMING_CASE = dict(seed=31, n_cc=9, pts=(22, 30), lattice=6, step=10, n_classes=17, control=4, extra_edges=8)
+# ... and of the `nms` leg: 625 boxes x 16 classes = 10 000 candidates at conf_thres 0 (train.py:448)
+NMS_TIMING = dict(seed=17, n=625, nc=16)
+
 # seeds of Python's `random` and numpy's global generator for the do_mixup runs (reference side and this repo's side)
 MIXUP_SEEDS = {"diagram_like": 202, "floorplan_mini": 101}
 MIXUP_CASES = {

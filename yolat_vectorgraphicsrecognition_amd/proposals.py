@@ -157,9 +157,12 @@ def mixup(cc, pos, edge, edge_super, e_attr, e_attr_super, is_super):
             np.concatenate([e_attr_super] + add_sattr, axis=0), np.concatenate([is_super] + add_super, axis=0))
 
 
-def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classes=17, normalize_bbox=True, do_mixup=False):
+def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classes=17, normalize_bbox=True, do_mixup=False,
+                 stat_feats=True):
     """graph_dict3.py:309-789; do_mixup: the augmentation of :354-355 / :791-907 (`mixup` above; off in the published
-    recipe, README.md:47,52).  graph_dict: the pickled per-SVG dict of
+    recipe, README.md:47,52).  stat_feats=False skips the 13 per-proposal statistics of :644-705 (an O(sum deg^2) Python
+    loop over neighbour pairs) and returns zeros in their place: the model never reads them (arch:87 `dim_stat = 0`, :112
+    copies them to the device unused); the default keeps the reference's output.  graph_dict: the pickled per-SVG dict of
     utils/svg_utils/build_graph_bbox.py:351-370 ('cc', 'pos'/'spatial', 'edge'/{'shape','super'},
     'edge_attr'/{'shape','super'}, 'attr'/{'is_super','is_control'}, 'img_width', 'img_height')."""
     cc = graph_dict["cc"]
@@ -204,7 +207,7 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
         valid_of_cc.append(valid)
 
     new_pos, new_is_super, new_edge, new_edge_super, new_e_attr, new_e_attr_super = [], [], [], [], [], []
-    labels, has_objs, bbox_idx, new_bbox, bbox_targets, stat_feats = [], [], [], [], [], []
+    labels, has_objs, bbox_idx, new_bbox, bbox_targets, stat_feats_out = [], [], [], [], [], []
     slice_pos, slice_edge, slice_super = [0], [0], [0]
     offset = 0
     for p in range(count):
@@ -232,6 +235,27 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
         has_obj = 1 if ios[idx_gt] > 0.7 else 0
         # :644-705 — angle statistics over pairs of neighbours of every node
         k = pos_bbox.shape[0]
+        if not stat_feats:
+            if normalize_bbox:
+                pos_bbox = (pos_bbox - [min_x, min_y]) / [max_x - min_x, max_y - min_y]
+            slice_pos.append(slice_pos[-1] + k)
+            slice_edge.append(slice_edge[-1] + edge_bbox.shape[0])
+            slice_super.append(slice_super[-1] + edge_super_bbox.shape[0])
+            new_pos.append(pos_bbox)
+            new_is_super.append(is_super[idxs, :])
+            new_edge.append(edge_bbox)
+            if edge_super_bbox.shape[0] > 0:
+                new_edge_super.append(edge_super_bbox)
+            new_e_attr.append(e_attr_bbox)
+            new_e_attr_super.append(e_attr_super_bbox)
+            labels.append(label)
+            has_objs.append(has_obj)
+            bbox_idx += [p] * k
+            offset += k
+            new_bbox.append([min_x, min_y, max_x, max_y])
+            bbox_targets.append(bbox_target)
+            stat_feats_out.append(np.zeros((1, 13)))
+            continue
         adj = [set() for _ in range(k)]
         for a, b in edge_bbox:
             adj[a - offset].add(b - offset)
@@ -275,7 +299,7 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
         offset += k
         new_bbox.append([min_x, min_y, max_x, max_y])
         bbox_targets.append(bbox_target)
-        stat_feats.append(stat_feat)
+        stat_feats_out.append(stat_feat)
 
     # :756-781 — per component: the largest-area proposal is the root, the others its children
     roots = []
@@ -302,5 +326,5 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
     return (pos_out, np.concatenate(new_is_super, axis=0), np.zeros((pos_out.shape[0], 1)),
             np.concatenate(new_edge, axis=0), np.concatenate(new_edge_super, axis=0),
             np.concatenate(new_e_attr, axis=0), np.concatenate(new_e_attr_super, axis=0), labels,
-            np.array(bbox_idx), bb, np.concatenate(bbox_targets, axis=0), np.concatenate(stat_feats, axis=0),
+            np.array(bbox_idx), bb, np.concatenate(bbox_targets, axis=0), np.concatenate(stat_feats_out, axis=0),
             has_objs, roots)

@@ -175,6 +175,14 @@ def _load_checkpoint_file(path, trust_pickle):
         t = getattr(getattr(np, "dtypes", None), tname, None)
         if t is not None:
             allow.append(t)
+    # torch releases before the (callable, "qualified name") form of safe_globals reject the tuples when the context is
+    # entered: probe once and keep the plain callables as the baseline there, instead of reporting a TypeError of the allow
+    # list as "the checkpoint does not load"
+    try:
+        with torch.serialization.safe_globals(allow):
+            pass
+    except (TypeError, ValueError, AttributeError):
+        allow = [a for a in allow if not isinstance(a, tuple)]
     try:
         with torch.serialization.safe_globals(allow):
             return torch.load(path, map_location="cpu", weights_only=True)
