@@ -684,12 +684,34 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
 
     t, n = _timed_loop(step, budget_s, lo=5, hi=100, warm=4)
     from yolat_vectorgraphicsrecognition_amd import engine as _eng
+    from yolat_vectorgraphicsrecognition_amd import trainer as _trn
+    plan_steps = trainer.plan_steps
+    # host side of a step: the time trainer.step() takes to RETURN (enqueue only; the GPU is drained outside the timed
+    # region), through the one-call plan (yolat_train_step) and through the Python schedule it replaces
+    def host_ms(flag):
+        old = _trn.TRAIN_PLAN
+        _trn.TRAIN_PLAN = flag
+        try:
+            step()
+            torch.cuda.synchronize()
+            ts = []
+            for _ in range(9):
+                t0 = time.perf_counter()
+                step()
+                ts.append(time.perf_counter() - t0)
+                torch.cuda.synchronize()
+        finally:
+            _trn.TRAIN_PLAN = old
+        ts.sort()
+        return ts[len(ts) // 2] * 1e3
+    host_plan, host_python = host_ms(True), host_ms(False)
     side_probe = dict(_eng.SIDE_PROBE.get(torch.cuda.current_device(), {})) or None
     # per-op times with every launch on ONE stream: with the weight gradients and node branches on the second stream
     # (the default, which `ms_per_step` above is measured with) the HIP events around an op also cover whatever the other
     # stream runs beside it, and per-op times stop meaning anything (profiles/r04_train_cfg3_kernel_stats.txt)
     side = yv.engine.SIDE_STREAM
     yv.engine.SIDE_STREAM = False
+    _trn.TRAIN_PLAN = False              # the op table times the ops.* entry points: the Python schedule issues them
     try:
         for _ in range(2):
             step()
@@ -699,6 +721,7 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
             table = timer.summary()
     finally:
         yv.engine.SIDE_STREAM = side
+        _trn.TRAIN_PLAN = True
     roof = roofline_entry(table, None, precision)
     roof["note"] = ("dominant op of the step by HIP-event time, all launches on one stream (ops.* entry points; each is one "
                     "or a few launches)")
@@ -710,6 +733,10 @@ def train_config_record(yv, gu, cfg, precision="fp32", budget_s=5.0, cpu=True):
     rec = {"workload": "cfg%s train step (fwd+CE+bwd+Adam), %d graph(s) per step, %s" %
                        (cfg, n_graphs, "fp32" if precision == "fp32" else "bf16 storage of the per-edge tensors"),
            "nodes": N, "edges": E, "proposals": P, "steps_timed": n, "ms_per_step": t * 1e3, "side_stream_probe": side_probe,
+           "one_call_plan": {"steps_through_yolat_train_step": plan_steps, "host_ms_per_step": round(host_plan, 4),
+                             "host_ms_per_step_python_schedule": round(host_python, 4),
+                             "note": "ms_per_step is measured through the plan when steps_through_yolat_train_step > 0; host "
+                                     "ms = time for Trainer.step to return, GPU drained between steps"},
            "graphs_per_sec": n_graphs / t,
            "whole_step": {"algorithmic_GFLOP": 3.0 * fwd / 1e9, "TFLOPs": 3.0 * fwd / t / 1e12,
                           "frac_of_fp32_mfma_peak": 3.0 * fwd / t / 1e12 / PEAK_MFMA_F32_TFLOPS,
@@ -1346,7 +1373,8 @@ def main():
             return round(d, 4) if isinstance(d, float) else d
         line["summary"] = {
             "graphs_per_sec": round(line["value"], 1), "ms_per_forward": pick(line, "ms_per_forward"),
-            "train_cfg3_ms": pick(line, "train_cfg3", "ms_per_step"), "cfg5_fp32_ms": pick(line, "cfg5_fp32", "ms_per_forward"),
+            "train_cfg3_ms": pick(line, "train_cfg3", "ms_per_step"),
+            "train_cfg3_host_ms": pick(line, "train_cfg3", "one_call_plan", "host_ms_per_step"), "cfg5_fp32_ms": pick(line, "cfg5_fp32", "ms_per_forward"),
             "cfg5_bf16_ms": pick(line, "cfg5_bf16", "ms_per_forward"),
             "train_cfg5_fp32_ms": pick(line, "train_cfg5_fp32", "ms_per_step"),
             "train_cfg5_bf16_ms": pick(line, "train_cfg5_bf16", "ms_per_step"),

@@ -755,6 +755,52 @@ int yolat_forward_eval_bf16_csr(const yolat_model_eval_bf16* m, const float* x, 
                                 size_t workspace_bytes, yolat_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI 6.  The training step as ONE native call (train_plan.hip): the loop body of cad_recognition/train.py:263-284 —
+ * forward (architecture3cc_rpn_gp_iter2.py:106-137), CrossEntropyLoss (arch:363), backward, Adam (train.py:212) — enqueued
+ * from C on `stream` (+ the weight gradients and node branches on `side_stream`, NULL = one stream): the schedule engine.py
+ * issues from Python, the same kernels on the same operands in the same order per stream, so the results are bit-identical.
+ *   yolat_train_model: pointers into ONE flat parameter buffer (param_base) and its gradient twin (grad_base, same
+ *     offsets: trainer.FlatParams); BatchNorm running statistics / counters are updated in place.
+ *   Shapes: n_filters C = 64, n_blocks_out = 2, biases and BatchNorm on every layer, no dropout, E >= N; `half` != 0:
+ *     bfloat16 storage of the per-edge tensors where E >= 2 N.  Anything else: YOLAT_E_UNSUPPORTED (the caller keeps its
+ *     own schedule).
+ *   Batch: the collated COO arrays (edge / e_attr / bbox_idx; the destination-sorted form is built inside the call), or a
+ *     prepared graph g.  labels [P] int64.  logits [P, ld_logits] and loss [1] are written; *status as yolat_graph_prepare.
+ *   phases (bit mask): 1 = graph + forward + loss + backward of the classifier and the fusion blocks — on return every
+ *     gradient of the parameters BEHIND the conv layers (the "head" bucket of the data-parallel exchange) is final on
+ *     `stream`; 2 = backward of the conv layers (all gradients final on `stream`); 4 = Adam (yolat_adam_args).  A caller that
+ *     exchanges gradients issues its collectives between the calls; 7 = the whole step.  The workspace
+ *     (yolat_train_step_workspace_bytes, 256-byte aligned) carries the step's state between the calls.                  */
+typedef struct yolat_train_lin { const float* W; const float* b; } yolat_train_lin;
+typedef struct yolat_train_bn {
+  const float* gamma; const float* beta; float* running_mean; float* running_var; int64_t* num_batches_tracked;
+  float momentum, eps;
+} yolat_train_bn;
+typedef struct yolat_train_conv {
+  int64_t Cin;
+  yolat_train_lin nn0; yolat_train_bn bn1; yolat_train_lin nn3; yolat_train_bn bn4;   /* gconv.nn.{0,1,3,4}   */
+  yolat_train_lin lin_r; yolat_train_lin node; yolat_train_bn bn_node;                /* lin_r, mlp_node.{0,1} */
+} yolat_train_conv;
+typedef struct yolat_train_model {
+  int32_t n_blocks, n_blocks_out, n_classes, half;
+  int64_t C, F, H1, H2;
+  yolat_train_conv conv[YOLAT_MAX_LAYERS];
+  yolat_train_lin fus; yolat_train_bn fus_bn; yolat_train_lin fus_s; yolat_train_bn fus_s_bn;
+  yolat_train_lin c1; yolat_train_bn c1_bn; yolat_train_lin c2; yolat_train_bn c2_bn; yolat_train_lin c3;
+  const float* param_base; float* grad_base;
+} yolat_train_model;
+typedef struct yolat_adam_args {
+  float* exp_avg; float* exp_avg_sq; int64_t n; int64_t step;
+  float lr, beta1, beta2, eps, weight_decay, grad_scale;
+} yolat_adam_args;
+size_t yolat_train_step_workspace_bytes(const yolat_train_model* m, int64_t N, int64_t E, int64_t P);
+int yolat_train_step(const yolat_train_model* m, const float* x, int64_t ldx, const int64_t* edge, int64_t stride_e,
+                     int64_t stride_c, const float* e_attr, const int64_t* bbox_idx, const yolat_graph_csr* g,
+                     const int64_t* labels, int64_t N, int64_t E, int64_t P, float* logits, int64_t ld_logits, float* loss,
+                     void* workspace, size_t workspace_bytes, int32_t* status, const yolat_adam_args* adam, int phases,
+                     yolat_stream_t stream, yolat_stream_t side_stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-processing: torchvision.ops.nms(boxes, scores, iou_threshold) as called by the
  * reference's non_max_suppression (cad_recognition/train.py:34-121 at :105; detect.py:118).
  * boxes [n,4] fp32 (x1,y1,x2,y2; 16-byte aligned), scores [n] fp32.  keep[0 .. *num_keep) = indices of the kept

@@ -130,6 +130,26 @@ def test_cfg1_floorplans_sized_eval_forward_matches_oracle():
     model.set_eval_precision("fp32")
     rms = float(((g16 - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())
     assert rms < 1e-2, rms
+    assert float((g16 - want).abs().max()) <= 1.5e-2 * float(want.abs().max())
+    assert float((g16.argmax(1) == want.argmax(1)).float().mean()) >= 0.99
+    # ... and through the one-launch conv stack (P = 2000 takes it by default; forced here for clarity): the same contract
+    import os
+    old_mode = os.environ.get("YOLAT_CONV_LOCAL")
+    os.environ["YOLAT_CONV_LOCAL"] = "2"
+    try:
+        model.set_eval_precision("bf16")
+        with torch.no_grad():
+            data._yolat_stage = None
+            g16 = model(data, slices)[0].cpu()
+        model.set_eval_precision("fp32")
+    finally:
+        if old_mode is None:
+            os.environ.pop("YOLAT_CONV_LOCAL", None)
+        else:
+            os.environ["YOLAT_CONV_LOCAL"] = old_mode
+    assert float(((g16 - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt()) < 1e-2
+    assert float((g16 - want).abs().max()) <= 1.5e-2 * float(want.abs().max())
+    assert float((g16.argmax(1) == want.argmax(1)).float().mean()) >= 0.99
 
 
 def test_cfg3_full_size_train_step_matches_oracle_and_is_deterministic():
@@ -243,7 +263,7 @@ def test_cfg5_full_size_eval_forward_matches_oracle():
     """BASELINE.json configs[4] at FULL size (N=200k / E=1.2M / P=8000, n_blocks=4) against the CPU oracle at full size —
     the size at which the persistent wave-specialised edge kernel (bf16x6 layer 2), the bf16x6 node side and the
     rider-less fusion launch are the auto-selected variants.  fp32: per element 1e-4 (arch:106-137); bf16 storage:
-    <= 1e-2 rms of the logits, element-wise maximum 3e-2, arg-max agreement."""
+    <= 1e-2 rms of the logits, element-wise maximum 1.5e-2, arg-max agreement >= 0.99."""
     yv = _yv()
     data, slices, optkw, _ = yv.config("5")
     N, E, P = data.x.shape[0], data.edge.shape[0], data.bbox.shape[0]
@@ -262,10 +282,15 @@ def test_cfg5_full_size_eval_forward_matches_oracle():
     with torch.no_grad():
         g16 = model(data, slices)[0].cpu()
     model.set_eval_precision("fp32")
+    # <= 1e-2 (rms, of the logits' scale); the element-wise maximum and the arg-max agreement are held to what
+    # round 6 measured with margin (tools/exp/bf16_contract.py, profiles/r06_bf16_contract.txt: max 0.5-1.2e-2, agreement
+    # >= 0.9976 over cfg 1 / 2 / 4 / 5 and two weight seeds; every flipped row is a near-tie of the fp32 logits, top-2 gap
+    # <= 4e-3 of the scale).  The messages' bf16 rounding in front of the aggregation MFMA of the one-launch conv stack is not
+    # the dominant term: the per-layer launches (fp32 messages into the mean) measure the same.
     rms = float(((g16 - want) ** 2).mean().sqrt() / (want ** 2).mean().sqrt())
     assert rms < 1e-2, rms
-    assert float((g16 - want).abs().max()) <= 3e-2 * float(want.abs().max())
-    assert float((g16.argmax(1) == want.argmax(1)).float().mean()) > 0.97
+    assert float((g16 - want).abs().max()) <= 1.5e-2 * float(want.abs().max())
+    assert float((g16.argmax(1) == want.argmax(1)).float().mean()) >= 0.99
 
 
 def test_cfg5_full_size_train_step_matches_oracle():

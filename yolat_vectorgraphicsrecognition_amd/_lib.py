@@ -87,6 +87,38 @@ class Locality(ctypes.Structure):
                 ("max_edges", ctypes.c_int32)]
 
 
+class TrainLin(ctypes.Structure):
+    """yolat_train_lin"""
+    _fields_ = [("W", c_p), ("b", c_p)]
+
+
+class TrainBn(ctypes.Structure):
+    """yolat_train_bn"""
+    _fields_ = [("gamma", c_p), ("beta", c_p), ("running_mean", c_p), ("running_var", c_p), ("num_batches_tracked", c_p),
+                ("momentum", c_f), ("eps", c_f)]
+
+
+class TrainConv(ctypes.Structure):
+    """yolat_train_conv"""
+    _fields_ = [("Cin", c_i64), ("nn0", TrainLin), ("bn1", TrainBn), ("nn3", TrainLin), ("bn4", TrainBn), ("lin_r", TrainLin),
+                ("node", TrainLin), ("bn_node", TrainBn)]
+
+
+class TrainModel(ctypes.Structure):
+    """yolat_train_model"""
+    _fields_ = [("n_blocks", ctypes.c_int32), ("n_blocks_out", ctypes.c_int32), ("n_classes", ctypes.c_int32),
+                ("half", ctypes.c_int32), ("C", c_i64), ("F", c_i64), ("H1", c_i64), ("H2", c_i64),
+                ("conv", TrainConv * YOLAT_MAX_LAYERS), ("fus", TrainLin), ("fus_bn", TrainBn), ("fus_s", TrainLin),
+                ("fus_s_bn", TrainBn), ("c1", TrainLin), ("c1_bn", TrainBn), ("c2", TrainLin), ("c2_bn", TrainBn),
+                ("c3", TrainLin), ("param_base", c_p), ("grad_base", c_p)]
+
+
+class AdamArgs(ctypes.Structure):
+    """yolat_adam_args"""
+    _fields_ = [("exp_avg", c_p), ("exp_avg_sq", c_p), ("n", c_i64), ("step", c_i64), ("lr", c_f), ("beta1", c_f),
+                ("beta2", c_f), ("eps", c_f), ("weight_decay", c_f), ("grad_scale", c_f)]
+
+
 class GraphCsr(ctypes.Structure):
     """yolat_graph_csr"""
     _fields_ = [("row_ptr", c_p), ("src", c_p), ("dst", c_p), ("attr", c_p), ("seg_ptr", c_p), ("node_seg", c_p)]
@@ -264,6 +296,10 @@ SIGNATURES = {
                                              c_i64, c_i64, c_p, c_i64, c_p, c_i64, c_p, c_p]),
     "yolat_forward_eval_bf16_primed": (c_int, [ctypes.POINTER(ModelEvalBf16), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, c_i64,
                                         c_i64, c_i64, c_p, c_i64, c_p, c_sz, c_p, c_p]),
+    "yolat_train_step_workspace_bytes": (c_sz, [ctypes.POINTER(TrainModel), c_i64, c_i64, c_i64]),
+    "yolat_train_step": (c_int, [ctypes.POINTER(TrainModel), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, ctypes.POINTER(GraphCsr),
+                                 c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_sz, c_p, ctypes.POINTER(AdamArgs), c_int, c_p,
+                                 c_p]),
     "yolat_batch_locality_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "yolat_batch_locality": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_sz, c_p]),
     "yolat_conv_local_fits": (c_int, [ctypes.POINTER(Locality), c_i64]),

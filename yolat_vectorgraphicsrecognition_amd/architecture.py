@@ -145,6 +145,16 @@ class SparseCADGCN(nn.Module):
         if raw is not None:
             # a DeviceLoader batch in COO mode in the eval forward: addresses only (plan.run_raw), no tensor views
             return {"raw": raw, "bbox": data.bbox, "g": None, "loc": data.__dict__.get("_yolat_loc")}
+        st = SparseCADGCN._stage_tensors(data)
+        if need_graph and st["g"] is None:
+            st["g"] = ops.build_graph(st["edge"], st["e_attr"], st["bbox_idx"], st["x"].shape[0],
+                                      st["bbox"].shape[0])
+        return st
+
+    @staticmethod
+    def _stage_tensors(data):
+        """the H2D half of `_stage`: device copies of x / edge / e_attr / bbox_idx / bbox, cached on the batch object and
+        invalidated by in-place edits (`_version`) or re-assignment (`data_ptr`) of any of them"""
         cache = getattr(data, "_yolat_stage", None)
         key = (data.x.data_ptr(), data.x._version, data.edge.data_ptr(), data.edge._version, data.bbox_idx.data_ptr(),
                data.bbox_idx._version, data.e_attr.data_ptr(), data.e_attr._version, data.bbox.data_ptr(),
@@ -161,11 +171,7 @@ class SparseCADGCN(nn.Module):
                 data._yolat_stage = cache
             except AttributeError:
                 pass
-        st = cache[1]
-        if need_graph and st["g"] is None:
-            st["g"] = ops.build_graph(st["edge"], st["e_attr"], st["bbox_idx"], st["x"].shape[0],
-                                      st["bbox"].shape[0])
-        return st
+        return cache[1]
 
     def forward(self, data, slices=None):
         """arch:106-137.  Preconditions the dataset guarantees (Datasets/graph_dict3.py:594-600,732):

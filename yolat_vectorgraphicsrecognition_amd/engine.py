@@ -233,13 +233,21 @@ def _pick_side_stream(cur):
     return best[1]
 
 
+def side_stream_for(cur):
+    """the side stream of `cur`'s device (picked by the probe on first use) — also what trainer.TrainPlan hands to
+    yolat_train_step"""
+    ent = _SIDE.get(cur.device_index)
+    if ent is None:
+        ent = _SIDE[cur.device_index] = {"stream": _pick_side_stream(cur), "dirty": False}
+    return ent["stream"]
+
+
 def _on_side(fn, keep):
     if not SIDE_STREAM or torch.cuda.is_current_stream_capturing():
         return fn()
     cur = ops.current_stream_object()
-    ent = _SIDE.get(cur.device_index)
-    if ent is None:
-        ent = _SIDE[cur.device_index] = {"stream": _pick_side_stream(cur), "dirty": False}
+    side_stream_for(cur)
+    ent = _SIDE[cur.device_index]
     side = ent["stream"]
     side.wait_stream(cur)
     _set = torch._C._cuda_setStream

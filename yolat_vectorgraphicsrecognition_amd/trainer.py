@@ -254,6 +254,209 @@ def allreduce_mean_(flat_grad):
     return 1.0
 
 
+# The training step as ONE native call per phase (csrc/train_plan.hip, yolat_train_step): the schedule of engine.model_fwd /
+# model_bwd enqueued from C.  Module flag; False (or a model / batch outside the plan's shapes): the Python schedule.
+TRAIN_PLAN = True
+
+
+class TrainPlan(object):
+    """Descriptor (pointers into the flat parameter / gradient buffers + BatchNorm buffers), grow-only workspace and status
+    word of yolat_train_step for one Trainer.  `step_phases` enqueues phases of one training step on the current stream
+    (+ the side stream engine.py uses); results are bit-identical to the Python schedule (tests/test_gpu_train_plan.py)."""
+
+    def __init__(self, trainer):
+        self.trainer = trainer
+        self.model = trainer.model
+        self._key = None
+        self._desc = None
+        self._ws = None
+        self._status = None
+        self._need = {}
+        self.last = None           # (logits, loss) of the most recent step
+
+    # -- eligibility --------------------------------------------------------------------------------------------------
+    @staticmethod
+    def schedule_is_default():
+        """the plan restates engine.py's DEFAULT schedule: any flipped module flag (the tests flip them to cross-check
+        schedules against each other) hands the step back to Python"""
+        from . import engine
+        return (engine.FACTORISED_TRAIN and engine.FUSED_FUSION_TRAIN and engine.FUSED_BN_CSR_BWD and
+                engine.FUSED_BN_APPLY_SUMS and engine.FACT_FWD_RATIO == 2.0 and engine.FACT_BWD_RATIO == 1.0 and
+                not engine._FAULT_EARLY_HEAD_EXCHANGE and not ops.X6_TRAIN_ROWS and
+                ops.X6_TRAIN_GEMM == (os.environ.get("YOLAT_STRICT_FP32", "0") != "1"))
+
+    def model_fits(self):
+        from . import engine
+        m = self.model
+        net = getattr(m, "cls_net", None)
+        if net is None or m.classifier != "softmax":
+            return False
+        try:
+            convs = engine.model_convs(net)
+            m1, m2, m3 = m.prediction_cls[0], m.prediction_cls[1], m.prediction_cls[2]
+            if engine._drop_p(m2) > 0 or len(list(m3.children())) != 1:
+                return False
+            for cv in convs:
+                if cv.nn[0].bias is None or cv.nn[3].bias is None or cv.lin_r.bias is None or cv.mlp_node[0].bias is None:
+                    return False
+                if not isinstance(cv.nn[1], torch.nn.BatchNorm1d) or not isinstance(cv.nn[4], torch.nn.BatchNorm1d):
+                    return False
+            for blk in (net.fusion_block, net.fusion_block_super, m1, m2):
+                if blk[0].bias is None or not isinstance(blk[1], torch.nn.BatchNorm1d):
+                    return False
+            return m3[0].bias is not None and net.n_blocks_out == 2 and convs[0].nn[0].out_features == 64
+        except (AttributeError, IndexError, TypeError):
+            return False
+
+    # -- descriptor ---------------------------------------------------------------------------------------------------
+    def _tensors(self):
+        return [self.trainer.flat.param, self.trainer.flat.grad] + list(self.model.buffers())
+
+    def _build(self):
+        from . import engine
+        from ._lib import TrainModel
+        m, flat = self.model, self.trainer.flat
+        net = m.cls_net
+        convs = engine.model_convs(net)
+        d = TrainModel()
+        d.n_blocks, d.n_blocks_out, d.n_classes = net.n_blocks, net.n_blocks_out, m.n_classes
+        d.half = 1 if m.__dict__.get("_yolat_train_precision", "fp32") == "bf16" else 0
+        d.C = convs[0].nn[0].out_features
+        d.F = net.fusion_block[0].out_features
+        d.H1, d.H2 = m.prediction_cls[0][0].out_features, m.prediction_cls[1][0].out_features
+        base, end = flat.param.data_ptr(), flat.param.data_ptr() + 4 * flat.numel
+
+        def lin(dst, mod):
+            for t in (mod.weight, mod.bias):
+                if not (base <= t.data_ptr() < end) or not t.is_contiguous():
+                    raise ValueError("parameter outside the flat buffer")
+            dst.W, dst.b = mod.weight.data_ptr(), mod.bias.data_ptr()
+
+        def bn(dst, mod):
+            for t in (mod.weight, mod.bias):
+                if not (base <= t.data_ptr() < end):
+                    raise ValueError("parameter outside the flat buffer")
+            dst.gamma, dst.beta = mod.weight.data_ptr(), mod.bias.data_ptr()
+            track = mod.track_running_stats and mod.running_mean is not None
+            dst.running_mean = mod.running_mean.data_ptr() if track else None
+            dst.running_var = mod.running_var.data_ptr() if track else None
+            dst.num_batches_tracked = mod.num_batches_tracked.data_ptr() if mod.num_batches_tracked is not None else None
+            dst.momentum = 0.1 if mod.momentum is None else float(mod.momentum)
+            dst.eps = float(mod.eps)
+
+        for l, cv in enumerate(convs):
+            c = d.conv[l]
+            c.Cin = cv.in_channels
+            lin(c.nn0, cv.nn[0]); bn(c.bn1, cv.nn[1]); lin(c.nn3, cv.nn[3]); bn(c.bn4, cv.nn[4])
+            lin(c.lin_r, cv.lin_r); lin(c.node, cv.mlp_node[0]); bn(c.bn_node, cv.mlp_node[1])
+        lin(d.fus, net.fusion_block[0]); bn(d.fus_bn, net.fusion_block[1])
+        lin(d.fus_s, net.fusion_block_super[0]); bn(d.fus_s_bn, net.fusion_block_super[1])
+        m1, m2, m3 = m.prediction_cls[0], m.prediction_cls[1], m.prediction_cls[2]
+        lin(d.c1, m1[0]); bn(d.c1_bn, m1[1]); lin(d.c2, m2[0]); bn(d.c2_bn, m2[1]); lin(d.c3, m3[0])
+        d.param_base, d.grad_base = flat.param.data_ptr(), flat.grad.data_ptr()
+        self._desc = d
+        self._need.clear()
+        if self._status is None:
+            self._status = torch.zeros(1, dtype=torch.int32, device=flat.param.device)
+
+    def prepare(self):
+        """(Re)builds the descriptor when a tensor it points at has moved; returns False when the model is outside the plan."""
+        key = tuple(t.data_ptr() for t in self._tensors()) + (self.model.__dict__.get("_yolat_train_precision", "fp32"),)
+        if key != self._key:
+            if not self.model_fits():
+                self._desc = None
+            else:
+                try:
+                    self._build()
+                except ValueError:
+                    self._desc = None
+            self._key = key
+        return self._desc is not None
+
+    # -- one step -----------------------------------------------------------------------------------------------------
+    def stage(self, data):
+        """device operands of the step: (x, edge-or-None, strides, e_attr, bbox_idx, prepared graph-or-None, labels, N, E, P)"""
+        model = self.model
+        pre = data.__dict__.get("_yolat_graph") if hasattr(data, "__dict__") else None
+        if pre is not None:
+            x = data.x if data.x.dtype == torch.float32 else data.x.float()
+            P = pre.P
+            ops_in = (x, None, 0, 0, None, None, pre, pre.N, pre.E, P)
+        else:
+            st = model._stage_tensors(data)
+            x, edge = st["x"], st["edge"]
+            if edge.dim() != 2 or (edge.shape[1] != 2 and edge.shape[0] != 2):
+                raise ValueError("edge must be [E,2] or [2,E]")
+            if edge.shape[1] == 2 and not (edge.shape[0] == 2 and edge.stride(0) == 1):
+                E, se, sc = edge.shape[0], edge.stride(0), edge.stride(1)
+            else:
+                E, se, sc = edge.shape[1], edge.stride(1), edge.stride(0)
+            e_attr = st["e_attr"] if st["e_attr"].is_contiguous() else st["e_attr"].contiguous()
+            ops_in = (x, edge, se, sc, e_attr, st["bbox_idx"], None, x.shape[0], E, st["bbox"].shape[0])
+        labels = data.labels
+        if not labels.is_cuda and labels.numel():
+            lo, hi = int(labels.min()), int(labels.max())
+            if lo < 0 or hi >= model.n_classes:
+                raise IndexError("Target %d is out of bounds." % (lo if lo < 0 else hi))
+        return ops_in + (labels.cuda(non_blocking=True),)
+
+    def run(self, staged, phases, adam=None):
+        """Enqueue `phases` (bit mask, yolat_train_step) of the step on `staged`; returns False when the C side declines the
+        shapes (nothing was enqueued; only possible with phase 1)."""
+        import ctypes
+        from . import engine
+        from ._lib import lib, check, GraphCsr, AdamArgs
+        x, edge, se, sc, e_attr, bbox_idx, g, N, E, P, labels = staged
+        d = self._desc
+        if E < N or E <= 0:
+            return False
+        nk = (N, E, P)
+        need = self._need.get(nk)
+        if need is None:
+            need = int(lib.yolat_train_step_workspace_bytes(ctypes.byref(d), N, E, P))
+            if need == 0:
+                return False
+            if len(self._need) > 64:
+                self._need.clear()
+            self._need[nk] = need
+        if self._ws is None or self._ws.numel() < need + 256:
+            if phases & 1 == 0:
+                raise RuntimeError("TrainPlan: the workspace of phase 1 is gone")
+            self._ws = torch.empty(int(need * 1.1) + 4096, dtype=torch.uint8, device=x.device)
+        ws_ptr = (self._ws.data_ptr() + 255) // 256 * 256
+        ws_bytes = self._ws.numel() - (ws_ptr - self._ws.data_ptr())
+        if phases & 1:
+            K = self.model.n_classes
+            self.last = (torch.empty(P, K, dtype=torch.float32, device=x.device),
+                         torch.empty(1, dtype=torch.float32, device=x.device))
+        logits, loss = self.last
+        cur = ops.current_stream_object()
+        side = engine.side_stream_for(cur) if engine.SIDE_STREAM else None
+        gc = GraphCsr(*g.device_pointers()) if g is not None else None
+        aa = None
+        if adam is not None:
+            aa = AdamArgs(*adam)
+        rc = lib.yolat_train_step(ctypes.byref(d), ops._f(x, "x"), ops._ld(x),
+                                  ops._i(edge, torch.int64, "edge") if edge is not None else None, se, sc,
+                                  ops._f(e_attr, "e_attr") if e_attr is not None else None,
+                                  ops._i(bbox_idx, torch.int64, "bbox_idx") if bbox_idx is not None else None,
+                                  ctypes.byref(gc) if gc is not None else None, ops._i(labels, torch.int64, "labels"), N, E, P,
+                                  logits.data_ptr(), logits.stride(0), loss.data_ptr(), ws_ptr, ws_bytes,
+                                  self._status.data_ptr() if g is None else g.status.data_ptr(),
+                                  ctypes.byref(aa) if aa is not None else None, int(phases), cur.cuda_stream,
+                                  side.cuda_stream if side is not None else None)
+        if rc == -2 and phases & 1:
+            return False
+        check(rc, "yolat_train_step")
+        ops.bump_weight_epoch()       # BatchNorm running statistics (phase 1) / parameters (phase 4) changed behind torch's back
+        return True
+
+    def check_status(self):
+        g = ops.Graph()
+        g.status = self._status
+        return ops.Graph.check_status(g)
+
+
 class Trainer(object):
     def __init__(self, model, opt, lr=2.5e-4, weight_decay=1e-5, precision=None, check_inputs_every=0,
                  force_exchange=None, exchange_premul=None):
@@ -279,6 +482,69 @@ class Trainer(object):
         # side stream of the backward) stays unscaled and changes the result.  It makes the ordering of the exchange
         # observable in a process group of ONE rank, where SUM is the identity (tests/test_gpu_dist.py).
         self.exchange_premul = None if exchange_premul is None else float(exchange_premul)
+        self.plan = TrainPlan(self)
+        self.plan_steps = 0                 # steps that went through yolat_train_step (diagnostics, tests, bench.py)
+
+    def _adam_args(self, scale):
+        o = self.optimizer
+        g = o.param_groups[0]
+        return (o.exp_avg.data_ptr(), o.exp_avg_sq.data_ptr(), self.flat.numel, o.step_count, float(g["lr"]),
+                float(g["betas"][0]), float(g["betas"][1]), float(g["eps"]), float(g["weight_decay"]), float(scale))
+
+    def _plan_step(self, data):
+        """The step through yolat_train_step; returns the loss tensor, or None when the plan declines (nothing enqueued)."""
+        plan = self.plan
+        if not (TRAIN_PLAN and TrainPlan.schedule_is_default() and plan.prepare()):
+            return None
+        staged = plan.stage(data)
+        grouped = dist.is_available() and dist.is_initialized()
+        world = dist.get_world_size() if grouped else 1
+        exchange = self.exchange_gradients and grouped and (world > 1 or self.force_exchange)
+        check = self._steps == 0 or (self.check_inputs_every > 0 and self._steps % self.check_inputs_every == 0)
+        self.model.train()
+        self.optimizer.zero_grad()
+        self.model.__dict__["_yolat_plan"] = plan if staged[6] is None else staged[6]
+        if not exchange and not check:
+            # the whole step in ONE call: graph + forward + loss + backward + Adam
+            self.optimizer.step_count += 1
+            if not plan.run(staged, 7, self._adam_args(1.0)):
+                self.optimizer.step_count -= 1
+                return None
+            self.flat.grads_ready = True
+            self._steps += 1
+            self.plan_steps += 1
+            return plan.last[1][0]
+        if not plan.run(staged, 1):
+            return None
+        premul = self.exchange_premul if exchange else None
+        scale = 1.0
+
+        def reduce_(bucket, async_op):
+            if premul is not None:
+                bucket.mul_(premul)
+            return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=async_op)
+
+        if exchange and self.flat.conv_end > 0:
+            handles = [reduce_(self.flat.grad[self.flat.conv_end:], True)]      # the head bucket, final after phase 1
+            plan.run(staged, 2)
+            handles.append(reduce_(self.flat.grad[:self.flat.conv_end], True))
+            for h in handles:
+                h.wait()
+            scale = 1.0 / world
+        else:
+            plan.run(staged, 2)
+            if exchange:
+                reduce_(self.flat.grad, False)
+                scale = 1.0 / world
+        if premul is not None:
+            scale /= premul
+        self.flat.grads_ready = True
+        if check:
+            self.model.check_last_status()      # raises before the update is applied
+        self._steps += 1
+        self.plan_steps += 1
+        self.optimizer.step(grad_scale=scale)
+        return plan.last[1][0]
 
     def step(self, data, slices=None):
         """One training step on this rank's batch.  Returns the (device) loss tensor."""
@@ -286,6 +552,9 @@ class Trainer(object):
         if engine._FAULT_EARLY_HEAD_EXCHANGE and self.exchange_premul is None:
             raise RuntimeError("engine._FAULT_EARLY_HEAD_EXCHANGE is set outside its test (a leaked fault-injection flag): "
                                "the head bucket would be exchanged before its gradients exist")
+        loss = self._plan_step(data)
+        if loss is not None:
+            return loss.detach()
         self.model.train()
         self.optimizer.zero_grad()
         out = self.model(data, slices)
