@@ -54,3 +54,37 @@ e.record()
 torch.cuda.synchronize()
 print("conv_local COO cfg %s abl %d: %.1f us per launch (local prep included), flag %d status %d"
       % (cfg, abl, s.elapsed_time(e) / reps * 1e3, int(flag.item()), int(status.item())))
+
+# ---- in-kernel phase stamps (s_memtime, shader cycles) of the first two tiles of every workgroup: CL_STAMPS=1
+if os.environ.get("CL_STAMPS", "0") == "1":
+    import numpy as np
+    nwg = 4096
+    stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
+    lib.yolat_conv_local_tune(int(os.environ.get("CL_NW", "0")), 0, abl, stamps.data_ptr())
+    if os.environ.get("CL_CSR", "0") == "1":
+        from yolat_vectorgraphicsrecognition_amd import ops
+        from yolat_vectorgraphicsrecognition_amd._lib import GraphCsr
+        g = ops.build_graph(edge, ea, bb, N, P)
+        gc = GraphCsr(*g.device_pointers())
+        check(lib.yolat_conv_stack_local_bf16(ctypes.byref(h), h.conv_local, x.data_ptr(), x.stride(0), ctypes.byref(gc), N, E, P,
+                                              feats.data_ptr(), D, Z.data_ptr(), Z.stride(0), flag.data_ptr(), st))
+    else:
+        run()
+    torch.cuda.synchronize()
+    lib.yolat_conv_local_tune(0, 0, 0, None)
+    st_ = stamps.cpu().numpy().reshape(nwg, 64)
+    st_ = st_[st_[:, 0] != 0]
+    L = base.n_blocks
+    per_tile = 3 + 5 * L
+    names = ["tile load (+ sort)", "stream set-up"]
+    for l in range(L):
+        names += ["L%d node phase" % l, "L%d node barrier" % l, "L%d mean-pool + steps" % l, "L%d finalize+barrier" % l, "L%d outputs" % l]
+    for tile in range(2):
+        seg = st_[:, tile * per_tile:(tile + 1) * per_tile + 1].astype(np.float64)
+        seg = seg[(seg != 0).all(1)]
+        d = np.diff(seg, axis=1)
+        print("%s tile %d: %d workgroups, total %.0f cycles (to next tile start)"
+              % ("CSR" if os.environ.get("CL_CSR", "0") == "1" else "COO", tile, len(seg), (seg[:, -1] - seg[:, 0]).mean()))
+        for i, nme in enumerate(names + ["zero Z + barrier"]):
+            if i < d.shape[1]:
+                print("   %-24s mean %7.0f  p10 %7.0f  p90 %7.0f" % (nme, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))

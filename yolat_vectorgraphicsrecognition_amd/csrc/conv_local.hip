@@ -245,6 +245,7 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
     next_tile(p1, pn0, pn1);
 
     // ---- tile -> LDS: row_ptr (tile-local), x rows, packed edge ids, e_attr fragments
+    int coo_clear[2] = {-1, -1};       // COO: the cnt_s entries this lane wrote (cleared behind the barrier below)
     if (a.E == 0) {                    // (no edge arrays to read from)
       if (tid <= nt) rp_s[tid] = 0;
       float* xs = reinterpret_cast<float*>(f_s);
@@ -258,8 +259,9 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
       // The tile's edges arrive in the caller's order.  Stable counting sort by destination, all in LDS:
       //   rank   a lane's rank among the lanes of its 64-edge chunk with the same destination: LOGT ballots, no loop over
       //          values; the first lane of each group stores the group's size -> cnt_s[chunk][node]
-      //   scan   (wave 0, two nodes per lane) running sum over the chunks per node -> chunk bases, in-degrees; exclusive
-      //          scan over the nodes -> rp_s (the tile's row_ptr); base_s[chunk][node] = row start + edges of earlier chunks
+      //   scan   (every wave, two nodes per lane) running sum over the chunks per node -> chunk bases, in-degrees;
+      //          exclusive DPP scan over the nodes -> rp_s (the tile's row_ptr); base_s[chunk][node] = row start + edges of
+      //          earlier chunks, each wave for its own two chunks
       //   emit   edge -> slot base_s[chunk][dst] + rank: packed ids and the e_attr fragment
       float* xs = reinterpret_cast<float*>(f_s);
       unsigned short* base_s = reinterpret_cast<unsigned short*>(uv_s);
@@ -287,33 +289,43 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
       }
       if (bad) raise();
       cl_lds_barrier();
-      if (wv == 0 && 2 * lane < T) {
-        unsigned run0 = 0, run1 = 0, bq[2 * NW];
+      // EVERY wave runs the chunk walk and the node scan (the same LDS reads, redundantly: no second workgroup barrier, no
+      // wave that works while seven wait) and keeps the bases of its OWN two chunks; lane l holds nodes 2 l, 2 l + 1
+      {
+        const bool act = 2 * lane < T;
+        unsigned run0 = 0, run1 = 0, mine[2] = {0u, 0u};
 #pragma unroll
         for (int c = 0; c < 2 * NW; ++c) {
-          unsigned short* cp = reinterpret_cast<unsigned short*>(cnt_s + c * T + 2 * lane);
-          const unsigned v = *cp;
-          *cp = 0;
-          bq[c] = run0 | (run1 << 16);
+          const unsigned v = act ? *reinterpret_cast<const unsigned short*>(cnt_s + c * T + 2 * lane) : 0u;
+          if (c == wv) mine[0] = run0 | (run1 << 16);
+          if (c == wv + NW) mine[1] = run0 | (run1 << 16);
           run0 += v & 0xFFu;
           run1 += v >> 8;
         }
         const int tot = (int)(run0 + run1);
+        // inclusive wave scan through DPP (row shifts, then the row totals broadcast down: no LDS round trips)
         int incl = tot;
-#pragma unroll
-        for (int off = 1; off < T / 2; off <<= 1) {
-          const int nb = __shfl_up(incl, off);
-          if (lane >= off) incl += nb;
-        }
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x111, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x112, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x114, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x118, 0xF, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x142, 0xA, 0xF, false);
+        incl += __builtin_amdgcn_update_dpp(0, incl, 0x143, 0xC, 0xF, false);
         const unsigned rp0 = (unsigned)(incl - tot), rp1 = rp0 + run0;
-        rp_s[2 * lane] = (int)rp0;
-        rp_s[2 * lane + 1] = (int)rp1;
-        if (2 * lane + 2 == T) rp_s[T] = incl;
+        if (act) {
+          if (wv == 0) {
+            rp_s[2 * lane] = (int)rp0;
+            rp_s[2 * lane + 1] = (int)rp1;
+            if (2 * lane + 2 == T) rp_s[T] = incl;
+          }
 #pragma unroll
-        for (int c = 0; c < 2 * NW; ++c)
-          *reinterpret_cast<unsigned*>(base_s + c * T + 2 * lane) = ((bq[c] & 0xFFFFu) + rp0) | (((bq[c] >> 16) + rp1) << 16);
+          for (int t = 0; t < 2; ++t)
+            *reinterpret_cast<unsigned*>(base_s + (wv + NW * t) * T + 2 * lane) =
+                ((mine[t] & 0xFFFFu) + rp0) | (((mine[t] >> 16) + rp1) << 16);
+        }
       }
-      cl_lds_barrier();
+      // (the wave reads back rows of base_s it wrote itself: LDS operations of a wave complete in order)
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
         const cl_u32x4 qa = t ? pre3 : pre2;
@@ -329,6 +341,8 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
           ab_s[pos] = fr;
         }
       }
+      coo_clear[0] = okk[0] && rk[0] == 0 ? wv * T + dd[0] : -1;
+      coo_clear[1] = okk[1] && rk[1] == 0 ? (wv + NW) * T + dd[1] : -1;
     } else {
       if (tid <= nt) rp_s[tid] = (int)pre0.x - e0;
       float* xs = reinterpret_cast<float*>(f_s);
@@ -368,6 +382,11 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
     CL_STAMP();      // 1: tile loads landed + LDS written
     cl_lds_barrier();
     if (stop_s == a.flag_val) return;
+    if constexpr (COO) {               // every wave has finished its chunk walk: the counters go back to zero for the next tile
+#pragma unroll
+      for (int t = 0; t < 2; ++t)
+        if (coo_clear[t] >= 0) cnt_s[coo_clear[t]] = 0;
+    }
 
     // ---- the wave's two edge streams: node boundaries nb[0..NS] (edge-balanced, node-aligned, <= 16 nodes each)
     int ns[3], sb[3];
@@ -483,22 +502,37 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
         for (int rb = 0; rb < 2; ++rb) {
           const int n = 64 * rbp + 32 * rb + l31;
 #pragma unroll
-          for (int nt_ = 0; nt_ < 2; ++nt_)
+          for (int nt_ = 0; nt_ < 2; ++nt_) {
+            if (grp == 2) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-              const int ch = 32 * nt_ + 8 * q + 4 * lhi;
-              const float v0 = acc[rb][nt_][4 * q], v1 = acc[rb][nt_][4 * q + 1], v2 = acc[rb][nt_][4 * q + 2],
-                          v3 = acc[rb][nt_][4 * q + 3];
-              if (grp < 2) {
-                cl_u32x2 o = {yl_pack_bf16(v0, v1), yl_pack_bf16(v2, v3)};
-                *reinterpret_cast<cl_u32x2*>(uv_s + n * CL_UVB + 128 * grp + 2 * ch) = o;
-              } else if (grp == 2) {
-                *reinterpret_cast<float4*>(r_s + n * CL_RB + 4 * ch) = make_float4(v0, v1, v2, v3);
-              } else {
-                cl_u32x2 o = {cl_relu_pk(yl_pack_bf16(v0, v1)), cl_relu_pk(yl_pack_bf16(v2, v3))};
-                *reinterpret_cast<cl_u32x2*>(s_s + n * CL_FB + 2 * ch) = o;
+              for (int q = 0; q < 4; ++q) {
+                const int ch = 32 * nt_ + 8 * q + 4 * lhi;
+                *reinterpret_cast<float4*>(r_s + n * CL_RB + 4 * ch) =
+                    make_float4(acc[rb][nt_][4 * q], acc[rb][nt_][4 * q + 1], acc[rb][nt_][4 * q + 2], acc[rb][nt_][4 * q + 3]);
+              }
+            } else {
+              // bf16 rows: a lane holds channels 8 q + 4 lhi .. + 3 (8 bytes) for q = 0..3.  Written like that, the 32 rows
+              // of a half-wave fall on 8 bank groups (row strides of 272 / 144 bytes step 4 banks): 4-way conflicts on every
+              // store (profiles/r06_conv_local_lds_by_phase_before.txt: 1.7 conflict cycles per LDS instruction in this
+              // phase).  The two lanes of a node (l31, l31 + 32) trade halves through v_permlane32_swap instead: each ends
+              // up with 8 CONSECUTIVE channels twice and stores 16 bytes — 8 rows per pass, 4 banks each: conflict-free.
+              unsigned pk[4][2];
+#pragma unroll
+              for (int q = 0; q < 4; ++q) {
+                pk[q][0] = yl_pack_bf16(acc[rb][nt_][4 * q], acc[rb][nt_][4 * q + 1]);
+                pk[q][1] = yl_pack_bf16(acc[rb][nt_][4 * q + 2], acc[rb][nt_][4 * q + 3]);
+                if (grp == 3) { pk[q][0] = cl_relu_pk(pk[q][0]); pk[q][1] = cl_relu_pk(pk[q][1]); }
+              }
+              unsigned char* row = (grp == 3) ? (s_s + n * CL_FB) : (uv_s + n * CL_UVB + 128 * grp);
+#pragma unroll
+              for (int j = 0; j < 2; ++j) {
+                const cl_u32x2 s0 = __builtin_amdgcn_permlane32_swap(pk[j][0], pk[j + 2][0], false, false);
+                const cl_u32x2 s1 = __builtin_amdgcn_permlane32_swap(pk[j][1], pk[j + 2][1], false, false);
+                const cl_u32x4 o = {s0.x, s1.x, s0.y, s1.y};     // channels 32 nt + 8 j + 16 lhi .. + 7
+                *reinterpret_cast<cl_u32x4*>(row + 2 * (32 * nt_ + 8 * j + 16 * lhi)) = o;
               }
             }
+          }
         }
       }
       if (first_tile && tid == 0) stop_s = __hip_atomic_load(a.flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -731,16 +765,25 @@ __global__ void __launch_bounds__(64 * NW, 2) k_conv_local_h(const ClArgs a) {
           const int deg = my_rp1 - my_rp0;
           const float inv = 1.f / (float)(deg > 1 ? deg : 1);
 #pragma unroll
-          for (int nb = 0; nb < 2; ++nb)
+          for (int nb = 0; nb < 2; ++nb) {
+            const f32x16& ag = nb ? agg1 : agg0;
+            unsigned pk[4][2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
               const int ch = 32 * nb + 8 * q + 4 * lhi;
               const float4 rt = *reinterpret_cast<const float4*>(r_s + my_node * CL_RB + 4 * ch);
-              const f32x16& ag = nb ? agg1 : agg0;
-              cl_u32x2 o = {yl_pack_bf16(fmaf(ag[4 * q], inv, rt.x), fmaf(ag[4 * q + 1], inv, rt.y)),
-                            yl_pack_bf16(fmaf(ag[4 * q + 2], inv, rt.z), fmaf(ag[4 * q + 3], inv, rt.w))};
-              *reinterpret_cast<cl_u32x2*>(f_s + my_node * CL_FB + 2 * ch) = o;
+              pk[q][0] = yl_pack_bf16(fmaf(ag[4 * q], inv, rt.x), fmaf(ag[4 * q + 1], inv, rt.y));
+              pk[q][1] = yl_pack_bf16(fmaf(ag[4 * q + 2], inv, rt.z), fmaf(ag[4 * q + 3], inv, rt.w));
             }
+            // (the lanes l31 / l31 + 32 of a node trade halves: 16-byte stores, see the node phase)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const cl_u32x2 s0 = __builtin_amdgcn_permlane32_swap(pk[j][0], pk[j + 2][0], false, false);
+              const cl_u32x2 s1 = __builtin_amdgcn_permlane32_swap(pk[j][1], pk[j + 2][1], false, false);
+              const cl_u32x4 o = {s0.x, s1.x, s0.y, s1.y};
+              *reinterpret_cast<cl_u32x4*>(f_s + my_node * CL_FB + 2 * (32 * nb + 8 * j + 16 * lhi)) = o;
+            }
+          }
         }
       }
       cl_lds_barrier();     // f of this layer is complete; every gather of UV / R is done
