@@ -228,11 +228,12 @@ inline float* grad_of(const yolat_train_model* m, const float* p) {
   return p ? m->grad_base + (p - m->param_base) : nullptr;
 }
 
-// ops.linear_fwd (fp32 operands)
+// ops.linear_fwd (fp32 operands).  pack != NULL: the bf16x6 path may be taken; prepacked: its weight image was produced
+// earlier in this step (the side stream's weight-only preparation) — the same kernel on the same weights, issued sooner
 int lin_fwd(const float* A, long lda, long M, long K, const float* asc, const float* ash, int arelu, const float* W,
-            const float* bias, long Nout, float* Y, long ldy, float* stats, uint16_t* pack, hipStream_t st) {
+            const float* bias, long Nout, float* Y, long ldy, float* stats, uint16_t* pack, bool prepacked, hipStream_t st) {
   if (pack && x6_fwd(A, lda, M, K, Nout, asc != nullptr, stats != nullptr, bias != nullptr)) {
-    TP_TRY(yolat_gemm_x6_pack(W, K, Nout, K, nullptr, pack, st));
+    if (!prepacked) TP_TRY(yolat_gemm_x6_pack(W, K, Nout, K, nullptr, pack, st));
     return yolat_gemm_x6_stats(A, lda, M, K, pack, bias, Nout, Y, ldy, stats, st);
   }
   return yolat_linear_fwd(A, lda, M, K, asc, ash, arelu, W, K, bias, Nout, nullptr, nullptr, 0, Y, ldy, 0, stats, st);
@@ -240,9 +241,9 @@ int lin_fwd(const float* A, long lda, long M, long K, const float* asc, const fl
 
 // ops.linear_fwd_wt (fp32): Y (+)= A . Wt, Wt [K, Nout] row-major
 int lin_wt(const float* A, long lda, long M, long K, const float* Wt, long Nout, float* Y, long ldy, int accumulate,
-           uint16_t* pack, float* work, hipStream_t st) {
+           uint16_t* pack, bool prepacked, float* work, hipStream_t st) {
   if (pack && x6_wt(A, lda, M, K, Nout, accumulate != 0)) {
-    TP_TRY(yolat_gemm_x6_pack_t(Wt, Nout, Nout, K, pack, st));
+    if (!prepacked) TP_TRY(yolat_gemm_x6_pack_t(Wt, Nout, Nout, K, pack, st));
     return yolat_gemm_x6(A, lda, M, K, pack, nullptr, 0, Nout, Y, ldy, work, st);
   }
   return yolat_linear_fwd_wt(A, lda, M, K, Wt, Nout, Nout, Y, ldy, accumulate, st);
@@ -313,6 +314,20 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
       TP_TRY(yolat_graph_prepare(edge, stride_e, stride_c, e_attr, bbox_idx, E, N, P, b.row_ptr, b.perm, b.src, b.dst, b.attr,
                                  b.seg_ptr, b.node_seg, b.gwork, status, st));
     }
+    // ---- work that depends on the weights or the graph only, off the critical path: the side stream takes it now, the
+    // forward's join (before the per-proposal mean) is long past it.  (The Python schedule issues the same launches where
+    // their results are first needed, on the main stream; same kernels, same operands.)
+    {
+      hipStream_t ss = S.fork();
+      if (x6_fwd(b.Z, ZW, P, ZW, H1, false, true, true)) TP_TRY(yolat_gemm_x6_pack(m->c1.W, ZW, H1, ZW, nullptr, b.c1pack, ss));
+      if (x6_wt(b.d2, H2, P, H2, H1, false)) TP_TRY(yolat_gemm_x6_pack_t(m->c2.W, H1, H1, H2, b.p2, ss));
+      if (x6_wt(b.d1, H1, P, H1, ZW, false)) TP_TRY(yolat_gemm_x6_pack_t(m->c1.W, ZW, ZW, H1, b.p1, ss));
+      for (long l = 0; l < L; ++l)
+        if (!b.cv[l].fact_fwd) TP_TRY(yolat_conv_split_w1(m->conv[l].nn0.W, m->conv[l].Cin, C, b.cv[l].wuv_b, b.cv[l].wc4_b, ss));
+      // CSC by source + 1 / deg for the backward (ops.Graph.ensure_csc / inv_deg)
+      TP_TRY(yolat_inv_degree(row_ptr, N, b.inv_deg, ss));
+      TP_TRY(yolat_csc_by_source(src, E, N, b.col_ptr, b.slots, b.cwork, ss));
+    }
     // ================================ forward ================================
     Lazy s{x, ldx, nullptr, nullptr, 0};
     const float* f = x;
@@ -371,13 +386,13 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
     S.join();                          // the node branches (fsup, sup_coef) were computed on the side stream
     float* sup = b.Z + 2 * F + D;
     TP_TRY(yolat_segment_mean_fwd(b.fsup, D, D, b.sup_coef, b.sup_coef + D, 1, seg_ptr, P, sup, ZW, st));
-    TP_TRY(lin_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->fus_s.W, m->fus_s.b, F, b.fs_y, F, b.fs_st, nullptr, st));
+    TP_TRY(lin_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->fus_s.W, m->fus_s.b, F, b.fs_y, F, b.fs_st, nullptr, false, st));
     TP_TRY(finalize(b.fs_st, P, F, m->fus_s_bn, b.fs_c, b.fs_c + F, b.fs_c + 2 * F, b.fs_c + 3 * F, st));
     TP_TRY(yolat_scale_shift_relu(b.fs_y, F, P, F, b.fs_c, b.fs_c + F, 1, b.Z + F + D, ZW, st));
     // classifier (arch:91-93,128)
-    TP_TRY(lin_fwd(b.Z, ZW, P, ZW, nullptr, nullptr, 0, m->c1.W, m->c1.b, H1, b.c1y, H1, b.c1st, b.c1pack, st));
+    TP_TRY(lin_fwd(b.Z, ZW, P, ZW, nullptr, nullptr, 0, m->c1.W, m->c1.b, H1, b.c1y, H1, b.c1st, b.c1pack, true, st));
     TP_TRY(finalize(b.c1st, P, H1, m->c1_bn, b.c1c, b.c1c + H1, b.c1c + 2 * H1, b.c1c + 3 * H1, st));
-    TP_TRY(lin_fwd(b.c1y, H1, P, H1, b.c1c, b.c1c + H1, 1, m->c2.W, m->c2.b, H2, b.c2y, H2, b.c2st, nullptr, st));
+    TP_TRY(lin_fwd(b.c1y, H1, P, H1, b.c1c, b.c1c + H1, 1, m->c2.W, m->c2.b, H2, b.c2y, H2, b.c2st, nullptr, false, st));
     TP_TRY(finalize(b.c2st, P, H2, m->c2_bn, b.c2c, b.c2c + H2, b.c2c + 2 * H2, b.c2c + 3 * H2, st));
     TP_TRY(yolat_linear_fwd(b.c2y, H2, P, H2, b.c2c, b.c2c + H2, 1, m->c3.W, H2, m->c3.b, K, nullptr, nullptr, 0, logits, ld_logits,
                             0, nullptr, st));
@@ -405,13 +420,13 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
                              grad_of(m, m->c2_bn.gamma), grad_of(m, m->c2_bn.beta), 0, b.d2, H2, b.w2bn, st));
     TP_TRY(yolat_linear_bwd_w(b.d2, H2, P, H2, b.c1y, H1, H1, b.c1c, b.c1c + H1, 1, grad_of(m, m->c2.W), H1, grad_of(m, m->c2.b), 0,
                               b.w2w, S.fork()));
-    TP_TRY(lin_wt(b.d2, H2, P, H2, m->c2.W, H1, b.d1, H1, 0, b.p2, b.x2w, st));
+    TP_TRY(lin_wt(b.d2, H2, P, H2, m->c2.W, H1, b.d1, H1, 0, b.p2, true, b.x2w, st));
     // prediction_cls.0
     TP_TRY(yolat_bn_relu_bwd(b.d1, H1, b.c1y, H1, P, H1, m->c1_bn.gamma, b.c1c + 2 * H1, b.c1c + 3 * H1, b.c1c, b.c1c + H1, 1,
                              grad_of(m, m->c1_bn.gamma), grad_of(m, m->c1_bn.beta), 0, b.d1, H1, b.w1bn, st));
     TP_TRY(yolat_linear_bwd_w(b.d1, H1, P, H1, b.Z, ZW, ZW, nullptr, nullptr, 0, grad_of(m, m->c1.W), ZW, grad_of(m, m->c1.b), 0,
                               b.w1w, S.fork()));
-    TP_TRY(lin_wt(b.d1, H1, P, H1, m->c1.W, ZW, b.dZ, ZW, 0, b.p1, b.x1w, st));
+    TP_TRY(lin_wt(b.d1, H1, P, H1, m->c1.W, ZW, b.dZ, ZW, 0, b.p1, true, b.x1w, st));
     // fusion_block_super: input sup = Z[:, 2F+D:], post-activation output Z[:, F+D:2F+D]
     float* d_sup = b.dZ + 2 * F + D;
     float* dz_fs = b.dZ + F + D;
@@ -438,9 +453,7 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
 
   if (phases & 2) {
     // ================================ backward: conv layers, last to first ================================
-    // CSC by source + 1 / deg (ops.Graph.ensure_csc / inv_deg: built on first use in the Python schedule)
-    TP_TRY(yolat_inv_degree(row_ptr, N, b.inv_deg, st));
-    TP_TRY(yolat_csc_by_source(src, E, N, b.col_ptr, b.slots, b.cwork, st));
+    // (CSC by source, 1 / deg and the weight splits were prepared by phase 1 on the side stream, joined at its end)
     float* d_f_next = nullptr;
     float* d_s_next = nullptr;
     for (long l = L - 1; l >= 0; --l) {
@@ -500,10 +513,7 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
                                       v.coef1, row_ptr, attr, N, v.dUV, 2 * C, v.dwc4, grad_of(m, cv.nn0.b), v.w_apply, st));
       // first edge Linear through the per-node products (ops.edge_lin1_bwd_factorised with partial = (dUV, dWc4))
       const float* wuv = v.wuv;
-      if (!v.fact_fwd) {
-        TP_TRY(yolat_conv_split_w1(cv.nn0.W, Cin, C, v.wuv_b, v.wc4_b, st));
-        wuv = v.wuv_b;
-      }
+      if (!v.fact_fwd) wuv = v.wuv_b;
       TP_TRY(yolat_edge_uv_sums_v(v.dA1, C, v.half ? 1 : 0, b.col_ptr, b.slots, N, C, v.dUV, 2 * C, st));
       {
         hipStream_t ss = S.fork();
