@@ -1007,6 +1007,15 @@ def train_dp_record(yv, gu, rank, world, steps, warmup):
     for _ in range(max(warmup, 3)):
         step()
     t_step = timed(step, steps, "step")
+    # the same step with ONE all-reduce of the whole flat gradient after the backward (YOLAT_DP_BUCKETS=1: fewer, larger
+    # collectives — xGMI rings are per-link bound), every rank in the same order
+    os.environ["YOLAT_DP_BUCKETS"] = "1"
+    try:
+        for _ in range(2):
+            step()
+        t_one = timed(step, steps)
+    finally:
+        os.environ.pop("YOLAT_DP_BUCKETS", None)
     trainer.exchange_gradients = False
     for _ in range(2):
         step()
@@ -1025,6 +1034,8 @@ def train_dp_record(yv, gu, rank, world, steps, warmup):
             "proposals_rank0": int(data.bbox.shape[0]), "ms_per_step": t_step * 1e3,
             "graphs_per_sec": n_graphs * world / t_step, "ms_per_step_without_exchange": t_local * 1e3,
             "exchange_cost_ms_after_overlap": (t_step - t_local) * 1e3, "allreduce_bytes": nbytes,
+            "ms_per_step_one_bucket": t_one * 1e3, "exchange_cost_ms_one_bucket": (t_one - t_local) * 1e3,
+            "steps_through_yolat_train_step": trainer.plan_steps,
             "allreduce_alone_ms": t_ar * 1e3, "allreduce_alone_GBs": nbytes / t_ar / 1e9, "steps": steps,
             "collective": "2 async SUM all-reduces per step (fusion+classifier bucket during the conv backward, conv "
                           "bucket after it) over %s" % dist.get_backend(),

@@ -801,6 +801,35 @@ int yolat_train_step(const yolat_train_model* m, const float* x, int64_t ldx, co
                      yolat_stream_t stream, yolat_stream_t side_stream);
 
 /* ------------------------------------------------------------------------------------------
+ * ABI 6.  predict() in one submission (subgraph.hip): SparseCADGCN.predict, architecture3cc_rpn_gp_iter2.py:139-356.
+ * In eval mode every proposal's logits are a row of ONE forward over the whole batch (a proposal sees only its own nodes
+ * and edges), so the root pass / has_object / child pass of the reference (:259-281) reduce to integer selection on the
+ * device: no host round trip between the passes, one read at the end.
+ *   yolat_predict_tree: the proposal tree of the batch, flattened on the host once (device int32 arrays): per root its
+ *     global proposal row and (idx_pos start, end, idx_edge start, end) as global ranges; child_ptr [R + 1] into the same
+ *     for the children; image_root_ptr [B + 1] = first root of every image.
+ *   yolat_predict_select: out[0] = rows of the result, out[1] = 0 when the tree's ranges ARE its proposals' node / edge
+ *     ranges and no edge leaves its proposal (else != 0: the one-forward shortcut does not apply — duplicated or foreign
+ *     ranges, the reference's KeyError cases — and the caller runs the two-pass extraction), out[4 .. 4 + B] =
+ *     slice_image_bbox, out[4 + B + 1 ..] = the proposal row of every output row (slice_bbox): per image the roots, then
+ *     the children of the roots whose arg-max (first maximum) is class K - 1.  out: 4 + B + 1 + R + Ctot int32.
+ *   yolat_predict_gather: out_cls [total, K] = logits[rows], out_bbox [total, 4] = the rows' boxes enlarged by 5 % about
+ *     their centre with the reference's fp32 steps (:341-346).                                                           */
+typedef struct yolat_predict_tree {
+  int64_t R, Ctot, B;
+  const int32_t *root_row, *root_range;      /* [R], [R, 4]       */
+  const int32_t *child_ptr;                  /* [R + 1]           */
+  const int32_t *child_row, *child_range;    /* [Ctot], [Ctot, 4] */
+  const int32_t *image_root_ptr;             /* [B + 1]           */
+} yolat_predict_tree;
+size_t yolat_predict_select_workspace_bytes(int64_t N, int64_t P, int64_t R);
+int yolat_predict_select(const float* logits, int64_t ld_logits, int64_t P, int64_t K, const int64_t* edge, int64_t stride_e,
+                         int64_t stride_c, const int64_t* bbox_idx, int64_t N, int64_t E, const yolat_predict_tree* tree,
+                         int32_t* out, void* workspace, size_t workspace_bytes, yolat_stream_t stream);
+int yolat_predict_gather(const float* logits, int64_t ld_logits, int64_t P, int64_t K, const float* bbox, const int32_t* rows,
+                         int64_t total, float* out_cls, float* out_bbox, yolat_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------
  * Post-processing: torchvision.ops.nms(boxes, scores, iou_threshold) as called by the
  * reference's non_max_suppression (cad_recognition/train.py:34-121 at :105; detect.py:118).
  * boxes [n,4] fp32 (x1,y1,x2,y2; 16-byte aligned), scores [n] fp32.  keep[0 .. *num_keep) = indices of the kept

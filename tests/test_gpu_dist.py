@@ -46,12 +46,23 @@ def _worker(rank, world, port, outdir):
     dist.destroy_process_group()
 
 
-def test_dp_train_step_two_ranks_matches_single_process_average(tmp_path):
+@pytest.mark.parametrize("buckets", ["2", "1"])
+def test_dp_train_step_two_ranks_matches_single_process_average(tmp_path, buckets):
+    """(buckets: YOLAT_DP_BUCKETS — two async all-reduces, the head bucket issued between the phases of the one-call
+    training step, or ONE all-reduce of the whole flat gradient after the backward; the same result)"""
     sys.path.insert(0, os.path.dirname(HERE))
     import yolat_vectorgraphicsrecognition_amd as yv
     import golden_util as gu
     port = _free_port()
-    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    old_env = os.environ.get("YOLAT_DP_BUCKETS")
+    os.environ["YOLAT_DP_BUCKETS"] = buckets
+    try:
+        mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    finally:
+        if old_env is None:
+            os.environ.pop("YOLAT_DP_BUCKETS", None)
+        else:
+            os.environ["YOLAT_DP_BUCKETS"] = old_env
     r0, r1 = np.load(tmp_path / "rank0.npz"), np.load(tmp_path / "rank1.npz")
     np.testing.assert_array_equal(r0["param"], r1["param"])           # replicas stay bit-identical
     # single process: same start (rank 0's weights), gradient = mean of the two ranks' gradients, same Adam

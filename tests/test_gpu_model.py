@@ -786,3 +786,78 @@ def test_side_stream_probe_picks_a_stream_that_runs_beside_the_current_one():
         pr = engine.SIDE_PROBE[cur.device_index]
         assert s is not None and pr["pair_over_alone"], pr
         assert pr["pair_over_alone"][-1] < 1.5, "no concurrent stream among 8 candidates: %s" % pr
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# Round 6: predict() in one submission (csrc/subgraph.hip: yolat_predict_select / yolat_predict_gather) against the two-pass
+# sub-graph extraction it replaces (arch:139-356, :259-281 has_object, :317-328 interleaving, :341-346 box enlargement)
+# ----------------------------------------------------------------------------------------------------------------------
+
+def _predict_both(yv, model, data, slices):
+    from yolat_vectorgraphicsrecognition_amd import architecture as A
+    with torch.no_grad():
+        A.PREDICT_ONE_SUBMISSION = True
+        one = model.predict(data, slices)
+        A.PREDICT_ONE_SUBMISSION = False
+        try:
+            two = model.predict(data, slices)
+        finally:
+            A.PREDICT_ONE_SUBMISSION = True
+    return one, two
+
+
+@pytest.mark.parametrize("n_graphs,precision", [(1, "fp32"), (3, "fp32"), (2, "bf16")])
+def test_predict_one_submission_equals_the_two_pass_extraction(n_graphs, precision):
+    """several images per batch, roots with and without objects: the same rows in the same order (slice_bbox,
+    slice_image_bbox bit-exact), the same boxes bit for bit, logits within the forward's tolerance (the two paths run the
+    same kernels on differently composed batches), and no sub-graph extraction launches on the one-submission path"""
+    yv = _yv()
+    data, slices = yv.synth_batch(n_graphs, 21, num_proposals=300, nodes_lo=4, nodes_hi=30, edge_factor=1.3, with_roots=True)
+    model = _model(yv, dict(n_classes=17, n_blocks=2, n_blocks_out=2), 3).eval()
+    # make "has object" (class n_classes - 1) a frequent arg-max so that the child pass has work
+    with torch.no_grad():
+        model.prediction_cls[2][0].bias[model.n_classes - 1] += 1.5
+    model.set_eval_precision(precision)
+    one, two = _predict_both(yv, model, data, slices)
+    assert one[2] is None and one[5] is None
+    np.testing.assert_array_equal(np.array([int(v) for v in one[3]]), np.array([int(v) for v in two[3]]))
+    assert [int(v) for v in one[4]] == [int(v) for v in two[4]]
+    n_roots = len(data.roots)
+    assert n_roots < len(one[3]) < data.bbox.shape[0] + 1          # some, not all, children were selected
+    assert torch.equal(one[1], two[1])                             # boxes: the same fp32 steps
+    tol = RTOL_FWD if precision == "fp32" else 2e-2
+    scale = float(two[0].abs().max())
+    assert float((one[0] - two[0]).abs().max()) <= tol * scale
+    assert one[0].shape == two[0].shape and one[0].is_cuda
+
+
+def test_predict_falls_back_when_the_tree_is_not_made_of_its_proposals():
+    """a tree node whose idx_pos range covers TWO proposals (nothing a dataset builds, but what the reference's loops would
+    happily cut out): the device finds the mismatch, the call runs the two-pass extraction and returns its result"""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd import architecture as A
+    data, slices = yv.synth_batch(1, 23, num_proposals=120, nodes_lo=4, nodes_hi=20, edge_factor=1.3, with_roots=True)
+    root = data.roots[0]
+    nxt = data.roots[1]
+    root.value["idx_pos"] = (root.value["idx_pos"][0], nxt.value["idx_pos"][1]) if nxt.value["idx_pos"][0] >= root.value["idx_pos"][1] \
+        else root.value["idx_pos"]
+    model = _model(yv, dict(n_classes=17, n_blocks=2, n_blocks_out=2), 4).eval()
+    calls = []
+    orig = model._predict_two_pass
+    model._predict_two_pass = lambda d, s: calls.append(1) or orig(d, s)
+    try:
+        with torch.no_grad():
+            try:
+                out = model.predict(data, slices)
+            except KeyError:
+                out = None                                       # (the widened range may cut an edge: the reference's KeyError)
+    finally:
+        del model._predict_two_pass
+    assert calls == [1]
+    # and an edge between two proposals: the reference raises KeyError (o2n lookup), so does this path via the fall-back
+    data2, slices2 = yv.synth_batch(1, 24, num_proposals=120, nodes_lo=4, nodes_hi=20, edge_factor=1.3, with_roots=True)
+    data2.edge = data2.edge.clone()
+    data2.edge[0, 0] = data2.x.shape[0] - 1
+    with torch.no_grad():
+        with pytest.raises(KeyError):
+            model.predict(data2, slices2)

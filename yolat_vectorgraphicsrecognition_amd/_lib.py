@@ -119,6 +119,12 @@ class AdamArgs(ctypes.Structure):
                 ("beta2", c_f), ("eps", c_f), ("weight_decay", c_f), ("grad_scale", c_f)]
 
 
+class PredictTree(ctypes.Structure):
+    """yolat_predict_tree"""
+    _fields_ = [("R", c_i64), ("Ctot", c_i64), ("B", c_i64), ("root_row", c_p), ("root_range", c_p), ("child_ptr", c_p),
+                ("child_row", c_p), ("child_range", c_p), ("image_root_ptr", c_p)]
+
+
 class GraphCsr(ctypes.Structure):
     """yolat_graph_csr"""
     _fields_ = [("row_ptr", c_p), ("src", c_p), ("dst", c_p), ("attr", c_p), ("seg_ptr", c_p), ("node_seg", c_p)]
@@ -300,6 +306,10 @@ SIGNATURES = {
     "yolat_train_step": (c_int, [ctypes.POINTER(TrainModel), c_p, c_i64, c_p, c_i64, c_i64, c_p, c_p, ctypes.POINTER(GraphCsr),
                                  c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_p, c_p, c_sz, c_p, ctypes.POINTER(AdamArgs), c_int, c_p,
                                  c_p]),
+    "yolat_predict_select_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
+    "yolat_predict_select": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_i64, c_i64, c_p, c_i64, c_i64,
+                                     ctypes.POINTER(PredictTree), c_p, c_p, c_sz, c_p]),
+    "yolat_predict_gather": (c_int, [c_p, c_i64, c_i64, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p]),
     "yolat_batch_locality_workspace_bytes": (c_sz, [c_i64, c_i64, c_i64]),
     "yolat_batch_locality": (c_int, [c_p, c_i64, c_i64, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_sz, c_p]),
     "yolat_conv_local_fits": (c_int, [ctypes.POINTER(Locality), c_i64]),

@@ -99,6 +99,11 @@ class _ModelFn(torch.autograd.Function):
         return (None, None, None) + tuple(sink.out.get(id(p)) for p in params)
 
 
+# predict(): one forward over the whole batch + integer selection on the device (csrc/subgraph.hip, yolat_predict_select);
+# False: always the two-pass sub-graph extraction (module flag; the tests run both)
+PREDICT_ONE_SUBMISSION = True
+
+
 class SparseCADGCN(nn.Module):
     def __init__(self, opt, n_edges=3, edge_max_pool=None, expand_ratio=0.25):
         super(SparseCADGCN, self).__init__()
@@ -222,6 +227,96 @@ class SparseCADGCN(nn.Module):
         return True if last is None else last.check_status()
 
     def predict(self, data, slices):
+        """arch:139-356.  Eval mode, softmax classifier, a batch with its raw edge list: ONE forward over the whole batch
+        + integer selection on the device (`_predict_one_submission`: no host round trip between the two passes of the
+        reference, one read at the end); when the tree of the batch is not made of the ranges of its own proposals — or in
+        any other mode — the two-pass extraction (`_predict_two_pass`).  Same 6-tuple either way."""
+        if PREDICT_ONE_SUBMISSION and not self.training and self.classifier == "softmax":
+            out = self._predict_one_submission(data, slices)
+            if out is not None:
+                return out
+        return self._predict_two_pass(data, slices)
+
+    def _predict_one_submission(self, data, slices):
+        """One forward over the whole batch, then yolat_predict_select / yolat_predict_gather (csrc/subgraph.hip): in eval
+        mode the logits of a proposal depend only on its own nodes and edges, so the root pass and the child pass of the
+        reference are rows of the same forward; `has_object` (:259-281), the per-image interleaving (:317-328) and the 5 %
+        box enlargement (:341-346) are device kernels.  Returns None when the shortcut does not apply (the device found
+        tree ranges that are not the ranges of the proposals, or an edge between proposals: the duplicate / KeyError
+        cases of the reference) — the caller then runs the two-pass extraction."""
+        import ctypes
+        import numpy as np
+        from ._lib import lib, check, PredictTree
+        from .data import flatten_tree
+        d = data.__dict__ if hasattr(data, "__dict__") else {}
+        if d.get("_yolat_graph") is not None:
+            return None                                  # prepared-CSR batch: no raw edge list to validate the tree against
+        with torch.no_grad():
+            logits, bbox = self.forward(data, slices)
+        raw = d.get("_yolat_raw")
+        if raw is not None:
+            _, _, ep, se, sc, _, bp, N, E, P, dev = raw
+        else:
+            st = self._stage_tensors(data)
+            edge, bidx = st["edge"], st["bbox_idx"]
+            if edge.dim() != 2 or edge.shape[1] != 2:
+                return None
+            ep, bp = ops._i(edge, torch.int64, "edge"), ops._i(bidx, torch.int64, "bbox_idx")
+            se, sc = edge.stride(0), edge.stride(1)
+            N, E, P, dev = st["x"].shape[0], edge.shape[0], bbox.shape[0], logits.device
+        # the flattened tree, on the device once per batch object (keyed by the identity of the tree and the image offsets)
+        key = (id(data.roots), len(data.roots), tuple(int(v) for v in slices["roots"]), tuple(int(v) for v in slices["pos"]),
+               tuple(int(v) for v in slices["edge"]), tuple(int(v) for v in slices["bbox"]))
+        ent = d.get("_yolat_tree")
+        if ent is None or ent[0] != key:
+            ft = flatten_tree(data, slices)
+            order = ("root_row", "root_range", "child_ptr", "child_row", "child_range", "image_root_ptr")
+            flat = np.concatenate([ft[k].reshape(-1) for k in order])
+            buf = torch.from_numpy(flat).to(dev, non_blocking=True)
+            offs, o = {}, 0
+            for k in order:
+                offs[k] = o
+                o += ft[k].size
+            ent = (key, ft, buf, offs)
+            try:
+                data.__dict__["_yolat_tree"] = ent
+            except AttributeError:
+                pass
+        _, ft, buf, offs = ent
+        R, Ctot, B = ft["R"], ft["Ctot"], ft["B"]
+        t = PredictTree()
+        t.R, t.Ctot, t.B = R, Ctot, B
+        base = buf.data_ptr()
+        for k in ("root_row", "root_range", "child_ptr", "child_row", "child_range", "image_root_ptr"):
+            setattr(t, k, base + 4 * offs[k])
+        K = logits.shape[1]
+        out = torch.empty(4 + B + 1 + R + Ctot, dtype=torch.int32, device=dev)
+        ws = torch.empty(int(lib.yolat_predict_select_workspace_bytes(N, P, R)) + 16, dtype=torch.uint8, device=dev)
+        stream = ops._stream()
+        check(lib.yolat_predict_select(logits.data_ptr(), logits.stride(0), P, K, ep if E > 0 else None, se, sc, bp, N, E,
+                                       ctypes.byref(t), out.data_ptr(), ws.data_ptr(), ws.numel(), stream),
+              "yolat_predict_select")
+        plan = self.__dict__.get("_yolat_plan")
+        if getattr(plan, "_status", None) is not None:    # the forward's input-validity word rides along in out[2]
+            out[2:3].copy_(plan._status)
+        host = out.cpu().numpy()                          # the ONE host read of the call (synchronises)
+        if int(host[2]) != 0:
+            self.check_last_status()                      # raises IndexError / ValueError like the forward's own check
+        if int(host[1]) != 0:
+            return None
+        total = int(host[0])
+        slice_image_bbox = [int(v) for v in host[4:4 + B + 1]]
+        slice_bbox = torch.from_numpy(host[4 + B + 1:4 + B + 1 + total].astype(np.int64))
+        pred_cls = torch.empty(total, K, dtype=torch.float32, device=dev)
+        pred_bbox = torch.empty(total, 4, dtype=torch.float32, device=dev)
+        bb = bbox if (bbox.dtype == torch.float32 and bbox.is_contiguous()) else bbox.float().contiguous()
+        check(lib.yolat_predict_gather(logits.data_ptr(), logits.stride(0), P, K, bb.data_ptr(),
+                                       out.data_ptr() + 4 * (4 + B + 1), total, pred_cls.data_ptr(), pred_bbox.data_ptr(),
+                                       stream), "yolat_predict_gather")
+        pred_cls._yolat_keep = (out, logits, bb)
+        return pred_cls, pred_bbox, None, slice_bbox, slice_image_bbox, None
+
+    def _predict_two_pass(self, data, slices):
         """Two-pass root/children inference, arch:139-356: forward on the sub-batch of all root
         proposals; proposals classified as class ``n_classes-1`` get their children evaluated in a
         second forward; per image the root rows are followed by the child rows; boxes are enlarged by

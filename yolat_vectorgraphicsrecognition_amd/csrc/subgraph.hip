@@ -204,3 +204,188 @@ extern "C" int yolat_fixup_offsets(int64_t* edge, int64_t E, const int64_t* edge
   YL_LAUNCH_CHECK();
   return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// predict() in ONE submission (round 6).  Reference: SparseCADGCN.predict, architecture3cc_rpn_gp_iter2.py:139-356 — pass 1
+// over the root proposals, `has_object` (:259-281: arg-max == n_classes - 1) decides which roots get their children
+// evaluated in pass 2, per image the root rows are followed by the child rows (:317-328).
+//
+// In eval mode a proposal's logits depend on nothing but its own nodes and edges (BatchNorm on running statistics,
+// block-diagonal adjacency, per-proposal pooling: Datasets/graph_dict3.py:582-600,733), so the logits of every root and
+// every child are rows of ONE forward over the whole batch, and the second pass's SIZE no longer has to reach the host
+// before anything can be enqueued.  What is left of the two passes is integer work on the device:
+//   k_predict_validate  the tree's (idx_pos, idx_edge) ranges must be exactly its proposals' node / edge ranges (seg_ptr /
+//                       eptr of yl_local_prep) and no edge may leave its proposal — otherwise the sub-batches of the
+//                       reference are NOT the proposals of the batch (duplicates, foreign edges -> its KeyError) and the
+//                       caller falls back to the two-pass extraction (flag in out[1])
+//   k_predict_select    has_object per root (first maximum), exclusive scan of the selected children, per image offsets
+//                       (slice_image_bbox), and the proposal row of every output row (slice_bbox) in the reference's order
+//   k_predict_gather    logits / boxes of those rows, boxes enlarged by 5 % about their centre (:341-346, same fp32 steps)
+// One host read (out[]: total, flag, slice_image_bbox, rows) ends the call.
+// ------------------------------------------------------------------------------------------------
+int yl_local_prep(const int64_t* edge, int64_t se, int64_t sc, const int64_t* bbox_idx, int64_t N, int64_t E, int64_t P,
+                  int32_t* seg_ptr, int32_t* node_seg, int32_t* eptr, int32_t* status, int32_t* info, bool vouched,
+                  hipStream_t st);
+
+static __global__ void k_predict_zero(int* p, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) p[i] = 0;
+}
+
+static __global__ void __launch_bounds__(256) k_predict_validate(yolat_predict_tree t, const int* __restrict__ seg_ptr,
+                                                                 const int* __restrict__ eptr, int P, const int* info,
+                                                                 const int* status, int* out) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  const long R = t.R, C = t.Ctot;
+  if (i == 0 && (info[0] != 0 || status[0] != 0)) atomicOr(out + 1, 2);
+  if (i >= R + C) return;
+  const bool root = i < R;
+  const long j = root ? i : i - R;
+  const int row = root ? t.root_row[j] : t.child_row[j];
+  const int* rg = (root ? t.root_range : t.child_range) + 4 * j;       // pos_s, pos_e, edge_s, edge_e
+  bool ok = row >= 0 && row < P;
+  if (ok) ok = rg[0] == seg_ptr[row] && rg[1] == seg_ptr[row + 1] && rg[2] == eptr[row] && rg[3] == eptr[row + 1];
+  if (!ok) atomicOr(out + 1, 1);
+}
+
+// one workgroup: R roots (a few thousand at most per batch)
+static __global__ void __launch_bounds__(1024) k_predict_select(yolat_predict_tree t, const float* __restrict__ logits, long ld,
+                                                                int K, int P, int* sel_off, int* out) {
+  __shared__ int wsum[16];
+  __shared__ int carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int R = (int)t.R, B = (int)t.B;
+  if (tid == 0) carry_s = 0;
+  __syncthreads();
+  for (int r0 = 0; r0 < R; r0 += 1024) {
+    const int r = r0 + tid;
+    int n = 0;
+    if (r < R) {
+      const int row = t.root_row[r];
+      if (row >= 0 && row < P) {
+        const float* z = logits + (long)row * ld;
+        float best = z[0];
+        int arg = 0;
+        for (int k = 1; k < K; ++k) {
+          const float v = z[k];
+          if (v > best) { best = v; arg = k; }
+        }
+        if (arg == K - 1) n = t.child_ptr[r + 1] - t.child_ptr[r];
+      }
+    }
+    int incl = n;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int nb = __shfl_up(incl, off);
+      if (lane >= off) incl += nb;
+    }
+    if (lane == 63) wsum[wave] = incl;
+    __syncthreads();
+    int woff = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; ++w) {
+      const int s = wsum[w];
+      if (w < wave) woff += s;
+      total += s;
+    }
+    const int carry = carry_s;
+    if (r < R) sel_off[r] = carry + woff + incl - n;
+    __syncthreads();
+    if (tid == 0) carry_s = carry + total;
+    __syncthreads();
+  }
+  if (tid == 0) sel_off[R] = carry_s;
+  __syncthreads();
+  const int total_children = carry_s;
+  int* image_off = out + 4;                      // [B + 1]
+  int* rows = out + 4 + B + 1;                   // [R + Ctot]
+  for (int i = tid; i <= B; i += 1024) {
+    const int r = t.image_root_ptr[i];
+    image_off[i] = r + sel_off[r];
+  }
+  if (tid == 0) out[0] = R + total_children;
+  for (int r = tid; r < R; r += 1024) {
+    int lo = 0, hi = B;                          // image of root r: largest i with image_root_ptr[i] <= r
+    while (hi - lo > 1) {
+      const int mid = (lo + hi) >> 1;
+      if (t.image_root_ptr[mid] <= r) lo = mid; else hi = mid;
+    }
+    const int r_lo = t.image_root_ptr[lo], r_hi = t.image_root_ptr[lo + 1];
+    const int base = r_lo + sel_off[r_lo];
+    rows[base + (r - r_lo)] = t.root_row[r];
+    const int n = sel_off[r + 1] - sel_off[r];
+    const int c0 = t.child_ptr[r];
+    const int cb = base + (r_hi - r_lo) + (sel_off[r] - sel_off[r_lo]);
+    for (int j = 0; j < n; ++j) rows[cb + j] = t.child_row[c0 + j];
+  }
+}
+
+static __global__ void __launch_bounds__(256) k_predict_gather(const float* __restrict__ logits, long ld, int K,
+                                                               const float* __restrict__ bbox, const int* __restrict__ rows,
+                                                               int total, int P, float* out_cls, float* out_bbox) {
+  const long i = (long)blockIdx.x * 256 + threadIdx.x;
+  if (i >= (long)total * (K + 4)) return;
+  const int r = (int)(i / (K + 4)), c = (int)(i - (long)r * (K + 4));
+  int row = rows[r];
+  row = row < 0 ? 0 : (row >= P ? P - 1 : row);
+  if (c < K) { out_cls[(long)r * K + c] = logits[(long)row * ld + c]; return; }
+  const float x1 = bbox[4l * row], y1 = bbox[4l * row + 1], x2 = bbox[4l * row + 2], y2 = bbox[4l * row + 3];
+  // arch:341-346: w = (x2 - x1) * 1.05, h = ..., cx = (x2 + x1) / 2, cy = ...; [cx - w/2, cy - h/2, cx + w/2, cy + h/2]
+  const float w = (x2 - x1) * 1.05f, h = (y2 - y1) * 1.05f, cx = (x2 + x1) / 2.f, cy = (y2 + y1) / 2.f;
+  const int k = c - K;
+  out_bbox[4l * r + k] = k == 0 ? cx - w / 2.f : (k == 1 ? cy - h / 2.f : (k == 2 ? cx + w / 2.f : cy + h / 2.f));
+}
+
+extern "C" size_t yolat_predict_select_workspace_bytes(int64_t N, int64_t P, int64_t R) {
+  if (N <= 0 || P <= 0 || R < 0) return 0;
+  return (size_t)(2 * (P + 1) + N + (R + 1) + 64) * sizeof(int32_t) + 1024;
+}
+
+extern "C" int yolat_predict_select(const float* logits, int64_t ld_logits, int64_t P, int64_t K, const int64_t* edge,
+                                    int64_t stride_e, int64_t stride_c, const int64_t* bbox_idx, int64_t N, int64_t E,
+                                    const yolat_predict_tree* tree, int32_t* out, void* workspace, size_t workspace_bytes,
+                                    yolat_stream_t stream) {
+  if (!logits || !bbox_idx || !tree || !out || !workspace || P <= 0 || K <= 0 || N <= 0 || E < 0 || (E > 0 && !edge) ||
+      ld_logits < K)
+    return YOLAT_E_INVALID;
+  const yolat_predict_tree& t = *tree;
+  if (t.R < 0 || t.Ctot < 0 || t.B < 0 || !t.image_root_ptr || !t.child_ptr ||
+      (t.R > 0 && (!t.root_row || !t.root_range)) || (t.Ctot > 0 && (!t.child_row || !t.child_range)))
+    return YOLAT_E_INVALID;
+  if (N >= (1LL << 30) || E >= (1LL << 30) || P >= (1LL << 30) || t.R + t.Ctot >= (1LL << 30)) return YOLAT_E_UNSUPPORTED;
+  if (workspace_bytes < yolat_predict_select_workspace_bytes(N, P, t.R)) return YOLAT_E_INVALID;
+  hipStream_t st = (hipStream_t)stream;
+  char* base = reinterpret_cast<char*>(((uintptr_t)workspace + 255) & ~(uintptr_t)255);
+  int32_t* seg_ptr = reinterpret_cast<int32_t*>(base);
+  int32_t* eptr = seg_ptr + (P + 1);
+  int32_t* node_seg = eptr + (P + 1);
+  int32_t* sel_off = node_seg + N;
+  int32_t* info = sel_off + (t.R + 1);           // [4] locality flags, then [1] status bits of malformed ids
+  int32_t* status = info + 4;
+  hipLaunchKernelGGL(k_predict_zero, dim3(1), dim3(64), 0, st, info, 8);
+  hipLaunchKernelGGL(k_predict_zero, dim3(1), dim3(64), 0, st, out, 4);
+  YL_LAUNCH_CHECK();
+  int rc = yl_local_prep(edge, stride_e, stride_c, bbox_idx, N, E, P, seg_ptr, node_seg, eptr, status, info, false, st);
+  if (rc != 0) return rc;
+  if (t.R + t.Ctot > 0) {
+    hipLaunchKernelGGL(k_predict_validate, dim3(yl_cdiv(t.R + t.Ctot, 256)), dim3(256), 0, st, t, seg_ptr, eptr, (int)P, info,
+                       status, out);
+    YL_LAUNCH_CHECK();
+  }
+  hipLaunchKernelGGL(k_predict_select, dim3(1), dim3(1024), 0, st, t, logits, (long)ld_logits, (int)K, (int)P, sel_off, out);
+  YL_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int yolat_predict_gather(const float* logits, int64_t ld_logits, int64_t P, int64_t K, const float* bbox,
+                                    const int32_t* rows, int64_t total, float* out_cls, float* out_bbox,
+                                    yolat_stream_t stream) {
+  if (total < 0 || P <= 0 || K <= 0 || ld_logits < K) return YOLAT_E_INVALID;
+  if (total == 0) return 0;
+  if (!logits || !bbox || !rows || !out_cls || !out_bbox) return YOLAT_E_INVALID;
+  if (total * (K + 4) >= (1LL << 40)) return YOLAT_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_predict_gather, dim3(yl_cdiv(total * (K + 4), 256)), dim3(256), 0, (hipStream_t)stream, logits,
+                     (long)ld_logits, (int)K, bbox, rows, (int)total, (int)P, out_cls, out_bbox);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

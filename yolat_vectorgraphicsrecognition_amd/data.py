@@ -879,6 +879,39 @@ def select_tree_ranges(data, slices, has_object=None):
     return as64(pos_s), as64(pos_e), as64(edge_s), as64(edge_e), slice_bbox, image_off
 
 
+def flatten_tree(data, slices):
+    """The batch's proposal tree as flat int32 arrays for the one-submission predict (yolat_predict_tree): per root and
+    per child the global proposal row and its (idx_pos, idx_edge) ranges with the image offsets added (arch:153-164,
+    277-296), `child_ptr` [R + 1], `image_root_ptr` [B + 1].  O(#tree nodes) host work, once per batch (cached by the
+    caller: the tree of a dataset item never changes, Datasets/graph_dict3.py:745-767)."""
+    roots = data.roots
+    slice_root = [int(v) for v in slices["roots"]]
+    B = len(slice_root) - 1
+    root_row, root_rng, child_ptr, child_row, child_rng, image_ptr = [], [], [0], [], [], [0]
+    for i in range(B):
+        off_pos, off_edge, off_bbox = int(slices["pos"][i]), int(slices["edge"][i]), int(slices["bbox"][i])
+        int(slices["edge_super"][i])               # the reference reads it (KeyError if absent)
+        for root in roots[slice_root[i]:slice_root[i + 1]]:
+            v = root.value
+            root_row.append(int(v["idx_bbox"]) + off_bbox)
+            root_rng.append((v["idx_pos"][0] + off_pos, v["idx_pos"][1] + off_pos, v["idx_edge"][0] + off_edge,
+                             v["idx_edge"][1] + off_edge))
+            for ch in root.children:
+                c = ch.value
+                child_row.append(int(c["idx_bbox"]) + off_bbox)
+                child_rng.append((c["idx_pos"][0] + off_pos, c["idx_pos"][1] + off_pos, c["idx_edge"][0] + off_edge,
+                                  c["idx_edge"][1] + off_edge))
+            child_ptr.append(len(child_row))
+        image_ptr.append(len(root_row))
+
+    def i32(a, shape):
+        return np.asarray(a, dtype=np.int64).astype(np.int32).reshape(shape)
+    R, C = len(root_row), len(child_row)
+    return {"R": R, "Ctot": C, "B": B, "root_row": i32(root_row, (R,)), "root_range": i32(root_rng, (R, 4)),
+            "child_ptr": i32(child_ptr, (R + 1,)), "child_row": i32(child_row, (C,)), "child_range": i32(child_rng, (C, 4)),
+            "image_root_ptr": i32(image_ptr, (B + 1,))}
+
+
 def select_tree_nodes(data, slices, has_object=None):
     """`select_tree_ranges` with the ranges expanded on the host: (slice_pos, slice_edge, slice_bbox,
     slice_image_bbox) exactly as the reference's Python lists (used by the CPU cross-checks)."""

@@ -229,6 +229,14 @@ def load_reference_checkpoint(model, checkpoint, optimizer=None, strict=True, tr
     return checkpoint.get("epoch", -1), checkpoint.get("best_value", None)
 
 
+def dp_buckets():
+    """YOLAT_DP_BUCKETS = 2 (default): the head bucket (fusion blocks + classifier, 93 % of the gradient bytes) is
+    all-reduced from inside the backward, under the conv layers' backward, the conv bucket after it; 1: ONE all-reduce of the
+    whole flat gradient after the backward (fewer, larger collectives: xGMI rings are per-link bound) — read per step so
+    that a driver can quote both."""
+    return 1 if os.environ.get("YOLAT_DP_BUCKETS", "2") == "1" else 2
+
+
 def shard_graph_ids(num_graphs, rank, world_size):
     """Round-robin partition of dataset items (graph ids) over ranks — DistributedSampler-style.
     Every edge joins two nodes of the same image (Datasets/graph_dict3.py:594-600), so a shard never
@@ -524,7 +532,7 @@ class Trainer(object):
                 bucket.mul_(premul)
             return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=async_op)
 
-        if exchange and self.flat.conv_end > 0:
+        if exchange and self.flat.conv_end > 0 and dp_buckets() == 2:
             handles = [reduce_(self.flat.grad[self.flat.conv_end:], True)]      # the head bucket, final after phase 1
             plan.run(staged, 2)
             handles.append(reduce_(self.flat.grad[:self.flat.conv_end], True))
@@ -571,7 +579,7 @@ class Trainer(object):
                 bucket.mul_(premul)
             return dist.all_reduce(bucket, op=dist.ReduceOp.SUM, async_op=async_op)
 
-        if exchange and self.flat.conv_end > 0:
+        if exchange and self.flat.conv_end > 0 and dp_buckets() == 2:
             # bucket 1 (fusion blocks + classifier, 93 % of the bytes) is all-reduced while the conv layers'
             # backward still runs; bucket 2 (conv layers) after the backward
             handles = []
