@@ -521,6 +521,13 @@ class EvalPlan(object):
         return static_out.clone()
 
     def check_status(self):
+        """Raises on the input-validity flags of the forwards since the last check.  The word belongs to the plan and the
+        kernels only ever OR into it: a raised condition is cleared here, so one malformed batch does not condemn every later
+        forward of the model."""
         g = ops.Graph()
         g.status = self._status
-        return ops.Graph.check_status(g)
+        try:
+            return ops.Graph.check_status(g)
+        except (IndexError, ValueError):
+            self._status.zero_()
+            raise
