@@ -775,7 +775,8 @@ def _reference_timings():
 def proposals_record(yv):
     """box-proposal generation (Datasets/graph_dict3.py:309-789) on one synthetic per-SVG dict of Floorplans
     size — ms per SVG, split into the native core (yolat_proposals_build: grid windows, de-duplication, edge pick-up,
-    rejection tests) and the Python assembly around it, with and without the 13 unused statistics (:644-705).  HOST code
+    rejection tests) and the per-proposal assembly (yolat_proposals_assemble, round 6; `ms_per_svg_python_assembly_loop` =
+    the Python loop it replaced) + the proposal tree, with and without the 13 unused statistics (:644-705).  HOST code
     (DataLoader workers, cached per SVG :924-929): one thread, like the reference."""
     sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests"))
     import proposals_util as pu
@@ -803,11 +804,13 @@ def proposals_record(yv):
     sedge = o2n[np.asarray(gd["edge"]["super"]).reshape(-1, 2)]
     cc = [[int(o2n[i]) for i in c] for c in gd["cc"]]
     t_core, w = med(lambda: pr.proposal_windows(pos, cc, edge, sedge, step))
+    t_py, _ = med(lambda: pr.get_proposal(gd, gt_bbox, gt_labels, bbox_sampling_step=step, n_classes=n_classes, native=False), 3)
     ref = _reference_timings().get("get_proposal", {})
     rec = {"workload": "one synthetic per-SVG graph dict (proposals_util.TIMING_CASE): %d proposals, %d nodes, %d edges out"
                        % (int(np.asarray(res[9]).shape[0]), int(res[0].shape[0]), int(res[3].shape[0])),
            "ms_per_svg": t_full * 1e3, "ms_per_svg_without_stat_feats": t_nostat * 1e3,
-           "ms_native_core_yolat_proposals_build": t_core * 1e3, "ms_python_assembly": (t_full - t_core) * 1e3,
+           "ms_native_core_yolat_proposals_build": t_core * 1e3, "ms_assembly_and_tree": (t_full - t_core) * 1e3,
+           "ms_per_svg_python_assembly_loop": t_py * 1e3,
            "threads": 1,
            "reference_ms_per_svg_build_container": (ref.get("seconds_per_svg") or 0) * 1e3 or None,
            "reference_proposals": ref.get("proposals"),

@@ -1056,6 +1056,20 @@ int64_t yolat_proposals_total(const yolat_proposals* p, int what);   /* 0 nodes,
 int yolat_proposals_get(const yolat_proposals* p, int64_t* node_ptr, int64_t* node_idx, int64_t* edge_ptr,
                         int64_t* edge_idx, int64_t* sedge_ptr, int64_t* sedge_idx, int64_t* cc_of, double* bbox);
 int yolat_proposals_window_counts(const yolat_proposals* p, int64_t* windows, int64_t* distinct);   /* [n_cc] each */
+/* ABI 6: the per-proposal assembly of _get_proposal (graph_dict3.py:577-753) on the handle's member lists — local
+ * re-indexing (+ running node offset), e_attr rows, label / regression target / has_obj by IoU / IoS against the
+ * ground-truth boxes of the proposal's component (valid_ptr [n_cc + 1] / valid_idx: utils/det_util.py:343-362), the 13
+ * statistics of :644-705 (stat_feats = 0: zeros), positions normalised to the box (normalize != 0, :714).  float64 in the
+ * reference's operation order; outputs sized by yolat_proposals_count / _total: new_pos [nodes, 2], new_is_super
+ * [nodes, sw], new_edge [edges, 2], new_e_attr [edges, aw], new_edge_super [sedges, 2], new_e_attr_super [sedges, asw],
+ * labels / has_obj [count], bbox_idx [nodes], bbox_targets [count, 4], stat [count, 13].                              */
+int yolat_proposals_assemble(const yolat_proposals* p, const double* pos, const double* is_super, int64_t sw,
+                             const int64_t* edge, const double* e_attr, int64_t aw, const int64_t* edge_super,
+                             const double* e_attr_super, int64_t asw, const double* gt_bbox, const int64_t* gt_labels,
+                             const int64_t* valid_ptr, const int64_t* valid_idx, int64_t n_classes, int normalize,
+                             int stat_feats, double* new_pos, double* new_is_super, int64_t* new_edge, double* new_e_attr,
+                             int64_t* new_edge_super, double* new_e_attr_super, int64_t* labels, int64_t* has_obj,
+                             int64_t* bbox_idx, double* bbox_targets, double* stat);
 void yolat_proposals_free(yolat_proposals* p);
 
 #ifdef __cplusplus

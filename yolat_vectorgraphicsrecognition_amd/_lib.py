@@ -276,6 +276,8 @@ SIGNATURES = {
     "yolat_proposals_get": (c_int, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_proposals_window_counts": (c_int, [c_p, c_p, c_p]),
     "yolat_proposals_free": (None, [c_p]),
+    "yolat_proposals_assemble": (c_int, [c_p, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_i64, c_p, c_p, c_p, c_p, c_i64, c_int,
+                                         c_int, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "yolat_collate_pack": (c_int, [c_p, c_p, ctypes.POINTER(Span), c_i64, c_i64]),
     "yolat_item_csr_host": (c_int, [c_p, c_i64, c_i64, c_p, c_p, c_i64, c_i64, c_i64, c_p, c_p, c_p, c_p, c_p, c_p, c_p,
                                      c_p]),

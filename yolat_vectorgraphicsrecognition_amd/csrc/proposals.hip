@@ -238,3 +238,150 @@ extern "C" int yolat_proposals_window_counts(const yolat_proposals* p, int64_t* 
   return 0;
 }
 extern "C" void yolat_proposals_free(yolat_proposals* p) { delete p; }
+
+// ------------------------------------------------------------------------------------------------
+// Round 6: the per-proposal ASSEMBLY of _get_proposal (graph_dict3.py:577-753) as native code too.  Round 5 left it as a
+// Python loop over the proposals (local re-indexing through a dict, label assignment by IoU / IoS against the ground-truth
+// boxes of the component :624-640, the 13 statistics :644-705, normalisation :714): 56 of the 57 ms a Floorplans-sized SVG
+// dict took.  Everything here is float64 arithmetic in the reference's order (no fused multiply-adds) or integer copying;
+// the only latitude is the order in which the angle list is summed for its mean / std (the reference iterates Python sets,
+// :668-670): those two of the 13 statistics agree to 1e-12, everything else bit for bit (tests/test_proposals.py).
+// ------------------------------------------------------------------------------------------------
+#pragma clang fp contract(off)
+extern "C" int yolat_proposals_assemble(const yolat_proposals* p, const double* pos, const double* is_super, int64_t sw,
+                                        const int64_t* edge, const double* e_attr, int64_t aw, const int64_t* edge_super,
+                                        const double* e_attr_super, int64_t asw, const double* gt_bbox,
+                                        const int64_t* gt_labels, const int64_t* valid_ptr, const int64_t* valid_idx,
+                                        int64_t n_classes, int normalize, int stat_feats, double* new_pos,
+                                        double* new_is_super, int64_t* new_edge, double* new_e_attr,
+                                        int64_t* new_edge_super, double* new_e_attr_super, int64_t* labels, int64_t* has_obj,
+                                        int64_t* bbox_idx, double* bbox_targets, double* stat) {
+  if (!p || !pos || !valid_ptr || !labels || !has_obj || !bbox_targets || !stat || sw < 0 || aw < 0 || asw < 0)
+    return YOLAT_E_INVALID;
+  const int64_t count = (int64_t)p->cc_of.size();
+  int64_t off = 0, eoff = 0, soff = 0;
+  std::vector<int64_t> local;                  // global node id -> position inside the proposal (scratch, sparse reset)
+  std::vector<std::vector<int64_t>> adj;
+  std::vector<double> angles;
+  for (int64_t q = 0; q < count; ++q) {
+    const int64_t n0 = p->node_ptr[q], n1 = p->node_ptr[q + 1], k = n1 - n0;
+    const int64_t e0 = p->edge_ptr[q], e1 = p->edge_ptr[q + 1], ne = e1 - e0;
+    const int64_t s0 = p->sedge_ptr[q], s1 = p->sedge_ptr[q + 1], ns = s1 - s0;
+    const double min_x = p->bbox[4 * q], min_y = p->bbox[4 * q + 1], max_x = p->bbox[4 * q + 2], max_y = p->bbox[4 * q + 3];
+    // local ids (a dict in the reference, :582-586: later duplicates win; the native member lists have none)
+    int64_t hi = 0;
+    for (int64_t i = n0; i < n1; ++i) hi = std::max(hi, p->node_idx[i]);
+    if ((int64_t)local.size() <= hi) local.resize((size_t)hi + 1, -1);
+    for (int64_t i = n0; i < n1; ++i) local[(size_t)p->node_idx[i]] = i - n0;
+    auto loc = [&](int64_t g) -> int64_t { return (g >= 0 && g < (int64_t)local.size()) ? local[(size_t)g] : -1; };
+    for (int64_t j = 0; j < ne; ++j) {
+      const int64_t e = p->edge_idx[e0 + j];
+      const int64_t a = loc(edge[2 * e]), b = loc(edge[2 * e + 1]);
+      if (a < 0 || b < 0) return YOLAT_E_INVALID;          // (KeyError in the reference's dict)
+      new_edge[2 * (eoff + j)] = a + off;
+      new_edge[2 * (eoff + j) + 1] = b + off;
+      for (int64_t c = 0; c < aw; ++c) new_e_attr[(eoff + j) * aw + c] = e_attr[e * aw + c];
+    }
+    for (int64_t j = 0; j < ns; ++j) {
+      const int64_t e = p->sedge_idx[s0 + j];
+      const int64_t a = loc(edge_super[2 * e]), b = loc(edge_super[2 * e + 1]);
+      if (a < 0 || b < 0) return YOLAT_E_INVALID;
+      new_edge_super[2 * (soff + j)] = a + off;
+      new_edge_super[2 * (soff + j) + 1] = b + off;
+      for (int64_t c = 0; c < asw; ++c) new_e_attr_super[(soff + j) * asw + c] = e_attr_super[e * asw + c];
+    }
+    // :624-640 — label / regression target / has_obj from the ground-truth boxes that overlap the component
+    {
+      const int64_t cc = p->cc_of[q];
+      const int64_t v0 = valid_ptr[cc], v1 = valid_ptr[cc + 1];
+      double best = 0.0, best_ios = 0.0;
+      int64_t arg = -1;
+      for (int64_t t = v0; t < v1; ++t) {
+        const double* g = gt_bbox + 4 * valid_idx[t];
+        const double ix1 = std::max(min_x, g[0]), iy1 = std::max(min_y, g[1]);
+        const double ix2 = std::min(max_x, g[2]), iy2 = std::min(max_y, g[3]);
+        const double inter = std::max(ix2 - ix1, 0.0) * std::max(iy2 - iy1, 0.0);
+        const double a1 = (max_x - min_x) * (max_y - min_y);
+        const double a2 = (g[2] - g[0]) * (g[3] - g[1]);
+        const double iou = inter / (a1 + a2 - inter + 1e-16), ios = inter / a2;
+        if (arg < 0 || iou > best) { best = iou; best_ios = ios; arg = t; }
+      }
+      if (arg < 0) return YOLAT_E_INVALID;                  // (a component without ground truth: SystemExit upstream)
+      if (best > 0.7) {
+        labels[q] = gt_labels[valid_idx[arg]];
+        for (int c = 0; c < 4; ++c) bbox_targets[4 * q + c] = gt_bbox[4 * valid_idx[arg] + c];
+      } else {
+        labels[q] = n_classes - 1;
+        for (int c = 0; c < 4; ++c) bbox_targets[4 * q + c] = 0.0;
+      }
+      has_obj[q] = best_ios > 0.7 ? 1 : 0;
+    }
+    // :644-705 — the 13 statistics
+    double* st = stat + 13 * q;
+    for (int c = 0; c < 13; ++c) st[c] = 0.0;
+    if (stat_feats) {
+      adj.assign((size_t)k, std::vector<int64_t>());
+      for (int64_t j = 0; j < ne; ++j) {
+        const int64_t a = new_edge[2 * (eoff + j)] - off, b = new_edge[2 * (eoff + j) + 1] - off;
+        adj[(size_t)a].push_back(b);
+        adj[(size_t)b].push_back(a);
+      }
+      angles.clear();
+      int64_t n_less = 0, n_90 = 0, n_more = 0;
+      for (int64_t a = 0; a < k; ++a) {
+        auto& nb = adj[(size_t)a];
+        std::sort(nb.begin(), nb.end());
+        nb.erase(std::unique(nb.begin(), nb.end()), nb.end());
+        const double ax = pos[2 * p->node_idx[n0 + a]], ay = pos[2 * p->node_idx[n0 + a] + 1];
+        for (size_t i = 0; i < nb.size(); ++i)
+          for (size_t j = i + 1; j < nb.size(); ++j) {
+            const double* pi = pos + 2 * p->node_idx[n0 + nb[i]];
+            const double* pj = pos + 2 * p->node_idx[n0 + nb[j]];
+            const double v0x = pi[0] - ax, v0y = pi[1] - ay, v1x = pj[0] - ax, v1y = pj[1] - ay;
+            const double m0 = v0x * v1x, m1 = v0y * v1y;
+            const double dot = m0 + m1;
+            if (dot <= -1e-2) ++n_more;
+            else if (dot >= 1e-2) ++n_less;
+            else if (fabs(dot) < 1e-2) ++n_90;
+            angles.push_back(dot);
+          }
+      }
+      if (angles.empty()) return YOLAT_E_INVALID;           // (the native rejection test keeps only proposals with a pair)
+      double sum = 0.0, mx = angles[0], mn = angles[0];
+      for (double v : angles) { sum += v; mx = std::max(mx, v); mn = std::min(mn, v); }
+      const double mean = sum / (double)angles.size();
+      double var = 0.0;
+      for (double v : angles) var += (v - mean) * (v - mean);
+      var /= (double)angles.size();
+      double am = 0.0, av = 0.0;
+      if (ne > 0 && aw > 0) {
+        for (int64_t j = 0; j < ne; ++j) am += new_e_attr[(eoff + j) * aw + aw - 1];
+        am /= (double)ne;
+        for (int64_t j = 0; j < ne; ++j) {
+          const double d = new_e_attr[(eoff + j) * aw + aw - 1] - am;
+          av += d * d;
+        }
+        av /= (double)ne;
+      } else {
+        am = av = NAN;                                       // (numpy: mean of an empty slice)
+      }
+      st[0] = (double)k; st[1] = (double)ne; st[2] = (double)n_90; st[3] = (double)n_less; st[4] = (double)n_more;
+      st[5] = max_x - min_x; st[6] = max_y - min_y; st[7] = mean; st[8] = mx; st[9] = mn; st[10] = sqrt(var);
+      st[11] = am; st[12] = sqrt(av);
+    }
+    // rows of the proposal: positions (normalised to the box, :714), is_super, bbox_idx
+    const double w = max_x - min_x, h = max_y - min_y;
+    for (int64_t i = 0; i < k; ++i) {
+      const int64_t g = p->node_idx[n0 + i];
+      double x = pos[2 * g], y = pos[2 * g + 1];
+      if (normalize) { x = (x - min_x) / w; y = (y - min_y) / h; }
+      new_pos[2 * (off + i)] = x;
+      new_pos[2 * (off + i) + 1] = y;
+      for (int64_t c = 0; c < sw; ++c) new_is_super[(off + i) * sw + c] = is_super[g * sw + c];
+      bbox_idx[off + i] = q;
+    }
+    for (int64_t i = n0; i < n1; ++i) local[(size_t)p->node_idx[i]] = -1;
+    off += k; eoff += ne; soff += ns;
+  }
+  return 0;
+}

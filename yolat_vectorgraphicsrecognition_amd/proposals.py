@@ -53,8 +53,10 @@ def _ptr(a):
     return a.ctypes.data_as(ctypes.c_void_p) if a is not None and a.size else None
 
 
-def proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step):
-    """The native core on already renumbered inputs.  pos [n,2] float64; cc: list of lists of node ids;
+def proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step, keep_handle=False):
+    """keep_handle: the dict also carries the native handle ("handle", to be freed by the caller with
+    lib.yolat_proposals_free) and the contiguous inputs it was built from — what yolat_proposals_assemble works on.
+    The native core on already renumbered inputs.  pos [n,2] float64; cc: list of lists of node ids;
     edge / edge_super [.,2] int64.  Returns a dict of int64 CSR arrays (node / edge / super-edge members of every
     proposal), `cc_of`, `bbox` [count,4] float64 and the per-component window statistics."""
     pos = np.ascontiguousarray(pos, dtype=np.float64)
@@ -83,7 +85,12 @@ def proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step):
                                       _ptr(out["cc_of"]), _ptr(out["bbox"])), "yolat_proposals_get")
         check(lib.yolat_proposals_window_counts(handle, _ptr(out["windows_per_cc"]), _ptr(out["distinct_per_cc"])),
               "yolat_proposals_window_counts")
-    finally:
+    except Exception:
+        lib.yolat_proposals_free(handle)
+        raise
+    if keep_handle:
+        out["handle"], out["_pos"], out["_edge"], out["_edge_super"] = handle, pos, edge, edge_super
+    else:
         lib.yolat_proposals_free(handle)
     return out
 
@@ -157,8 +164,71 @@ def mixup(cc, pos, edge, edge_super, e_attr, e_attr_super, is_super):
             np.concatenate([e_attr_super] + add_sattr, axis=0), np.concatenate([is_super] + add_super, axis=0))
 
 
+def _assemble_native(w, cc, pos, is_super, e_attr, e_attr_super, gt_bbox, gt_labels, n_classes, normalize_bbox, stat_feats):
+    """graph_dict3.py:573-789 on the native member lists: the per-proposal assembly is ONE call (yolat_proposals_assemble:
+    local re-indexing, IoU / IoS labels, the 13 statistics, normalisation); the proposal tree (:756-781) is built here."""
+    count = int(w["cc_of"].shape[0])
+    pos_c, edge_c, sedge_c = w["_pos"], w["_edge"], w["_edge_super"]
+    gt_bbox = np.ascontiguousarray(np.asarray(gt_bbox, dtype=np.float64).reshape(-1, 4))
+    gt_lab = _i64(np.asarray(gt_labels).reshape(-1))
+    # :573-577 — every component must overlap a ground-truth box
+    valid_ptr, valid_idx = [0], []
+    for cluster in cc:
+        pc = pos[cluster, :]
+        bbox_cc = np.array([pc[:, 0].min(0), pc[:, 1].min(0), pc[:, 0].max(0), pc[:, 1].max(0)])[None, :]
+        valid = intersect_bb_idx(bbox_cc, gt_bbox)
+        if valid.shape[0] == 0:
+            raise SystemExit("cc has no intersect gt bbox")
+        valid_idx.append(valid)
+        valid_ptr.append(valid_ptr[-1] + valid.shape[0])
+    valid_ptr = _i64(np.asarray(valid_ptr))
+    valid_idx = _i64(np.concatenate(valid_idx)) if valid_idx else np.zeros(0, np.int64)
+    is_super = np.ascontiguousarray(np.asarray(is_super, dtype=np.float64).reshape(pos_c.shape[0], -1))
+    e_attr = np.ascontiguousarray(np.asarray(e_attr, dtype=np.float64).reshape(edge_c.shape[0], -1)) if edge_c.shape[0] \
+        else np.zeros((0, np.asarray(e_attr).shape[-1] if np.asarray(e_attr).ndim == 2 else 0))
+    e_attr_super = np.ascontiguousarray(np.asarray(e_attr_super, dtype=np.float64).reshape(sedge_c.shape[0], -1)) \
+        if sedge_c.shape[0] else np.zeros((0, np.asarray(e_attr_super).shape[-1] if np.asarray(e_attr_super).ndim == 2 else 0))
+    sw, aw, asw = is_super.shape[1], e_attr.shape[1], e_attr_super.shape[1]
+    nn_, ne_, ns_ = int(w["node_ptr"][-1]), int(w["edge_ptr"][-1]), int(w["sedge_ptr"][-1])
+    new_pos = np.zeros((nn_, 2)); new_is_super = np.zeros((nn_, sw))
+    new_edge = np.zeros((ne_, 2), np.int64); new_e_attr = np.zeros((ne_, aw))
+    new_edge_super = np.zeros((ns_, 2), np.int64); new_e_attr_super = np.zeros((ns_, asw))
+    labels = np.zeros(count, np.int64); has_obj = np.zeros(count, np.int64); bbox_idx = np.zeros(nn_, np.int64)
+    bbox_targets = np.zeros((count, 4)); stat = np.zeros((count, 13))
+    rc = lib.yolat_proposals_assemble(w["handle"], _ptr(pos_c), _ptr(is_super), sw, _ptr(edge_c), _ptr(e_attr), aw,
+                                      _ptr(sedge_c), _ptr(e_attr_super), asw, _ptr(gt_bbox), _ptr(gt_lab), _ptr(valid_ptr),
+                                      _ptr(valid_idx), int(n_classes), 1 if normalize_bbox else 0, 1 if stat_feats else 0,
+                                      _ptr(new_pos), _ptr(new_is_super), _ptr(new_edge), _ptr(new_e_attr),
+                                      _ptr(new_edge_super), _ptr(new_e_attr_super), _ptr(labels), _ptr(has_obj),
+                                      _ptr(bbox_idx), _ptr(bbox_targets), _ptr(stat))
+    check(rc, "yolat_proposals_assemble")
+    # :756-781 — per component: the largest-area proposal is the root, the others its children
+    roots = []
+    bb = np.array(w["bbox"]).reshape(-1, 4)
+    sp, se, ss = w["node_ptr"], w["edge_ptr"], w["sedge_ptr"]
+    for c in range(len(cc)):
+        members = np.where(w["cc_of"] == c)[0]
+        if members.size == 0:
+            raise ValueError("component %d produced no proposal (np.argmax of an empty array in the reference)" % c)
+        area = (bb[members, 2] - bb[members, 0]) * (bb[members, 3] - bb[members, 1])
+        top = int(np.argmax(area))
+        nodes = []
+        for m in members:
+            t = idxTree()
+            t.value["idx_pos"] = (int(sp[m]), int(sp[m + 1]))
+            t.value["idx_edge"] = (int(se[m]), int(se[m + 1]))
+            t.value["idx_edge_super"] = (int(ss[m]), int(ss[m + 1]))
+            t.value["idx_bbox"] = int(m)
+            nodes.append(t)
+        root = nodes[top]
+        root.children = [t for i, t in enumerate(nodes) if i != top]
+        roots.append(root)
+    return (new_pos, new_is_super, np.zeros((new_pos.shape[0], 1)), new_edge, new_edge_super, new_e_attr, new_e_attr_super,
+            labels.tolist(), bbox_idx, bb, bbox_targets, stat, has_obj.tolist(), roots)
+
+
 def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classes=17, normalize_bbox=True, do_mixup=False,
-                 stat_feats=True):
+                 stat_feats=True, native=True):
     """graph_dict3.py:309-789; do_mixup: the augmentation of :354-355 / :791-907 (`mixup` above; off in the published
     recipe, README.md:47,52).  stat_feats=False skips the 13 per-proposal statistics of :644-705 (an O(sum deg^2) Python
     loop over neighbour pairs) and returns zeros in their place: the model never reads them (arch:87 `dim_stat = 0`, :112
@@ -194,8 +264,14 @@ def get_proposal(graph_dict, gt_bbox, gt_labels, bbox_sampling_step=-1, n_classe
         cc, pos, edge, edge_super, e_attr, e_attr_super, is_super = mixup(cc, pos, edge, edge_super, e_attr, e_attr_super,
                                                                           is_super)
 
-    w = proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step)
+    w = proposal_windows(pos, cc, edge, edge_super, bbox_sampling_step, keep_handle=native)
     count = w["cc_of"].shape[0]
+    if native:
+        try:
+            return _assemble_native(w, cc, pos, is_super, e_attr, e_attr_super, gt_bbox, gt_labels, n_classes, normalize_bbox,
+                                    stat_feats)
+        finally:
+            lib.yolat_proposals_free(w["handle"])
     # :573-577 — every component must overlap a ground-truth box
     valid_of_cc = []
     for c, cluster in enumerate(cc):
