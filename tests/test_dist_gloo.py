@@ -48,6 +48,22 @@ def _worker(rank, world, port, out):
     ok &= torch.allclose(flat.grad, sum(gathered))
     ok &= torch.equal(flat.param, _Flat(0).param)                     # everyone holds rank 0's parameters
     ok &= float(model.bn.running_mean[0]) == 1.0                      # and rank 0's BatchNorm buffers
+    # the two exchange layouts of Trainer.step (YOLAT_DP_BUCKETS): two asynchronous SUM all-reduces of the flat gradient's
+    # [conv_end:] and [:conv_end] ranges (head bucket first, as the one-call step issues them between its phases) give what
+    # ONE all-reduce of the whole buffer gives
+    whole = g_local.clone()
+    dist.all_reduce(whole, op=dist.ReduceOp.SUM)
+    two = g_local.clone()
+    conv_end = 137
+    handles = [dist.all_reduce(two[conv_end:], op=dist.ReduceOp.SUM, async_op=True),
+               dist.all_reduce(two[:conv_end], op=dist.ReduceOp.SUM, async_op=True)]
+    for h in handles:
+        h.wait()
+    ok &= torch.equal(two, whole)
+    os.environ["YOLAT_DP_BUCKETS"] = "1"
+    ok &= trainer.dp_buckets() == 1
+    os.environ.pop("YOLAT_DP_BUCKETS")
+    ok &= trainer.dp_buckets() == 2
     ids = trainer.shard_graph_ids(11, rank, world)
     all_ids = [None] * world
     dist.all_gather_object(all_ids, ids)
