@@ -88,3 +88,21 @@ if os.environ.get("CL_STAMPS", "0") == "1":
         for i, nme in enumerate(names + ["zero Z + barrier"]):
             if i < d.shape[1]:
                 print("   %-24s mean %7.0f  p10 %7.0f  p90 %7.0f" % (nme, d[:, i].mean(), np.percentile(d[:, i], 10), np.percentile(d[:, i], 90)))
+
+# ---- per-wave arrival at the end of layer 1's steps / finalize / barrier (first tile): CL_WAVES=1
+if os.environ.get("CL_WAVES", "0") == "1":
+    import numpy as np
+    nwg = 4096
+    stamps = torch.zeros(nwg * 64, dtype=torch.int64, device=dev)
+    lib.yolat_conv_local_tune(int(os.environ.get("CL_NW", "0")), 0, 16, stamps.data_ptr())
+    run()
+    torch.cuda.synchronize()
+    lib.yolat_conv_local_tune(0, 0, 0, None)
+    st_ = stamps.cpu().numpy().reshape(nwg, 64)
+    st_ = st_[st_[:, 0] != 0][:, 32:56].reshape(-1, 8, 3).astype(np.float64)
+    st_ = st_[(st_ != 0).all((1, 2))]
+    t0 = st_[:, :, 0].min(1, keepdims=True)
+    print("layer 1, first tile, %d workgroups: per wave (cycles after the first wave finished its steps)" % len(st_))
+    for w in range(8):
+        print("   wave %d: steps done %6.0f   finalize done %6.0f   barrier passed %6.0f" % (
+            w, (st_[:, w, 0] - t0[:, 0]).mean(), (st_[:, w, 1] - t0[:, 0]).mean(), (st_[:, w, 2] - t0[:, 0]).mean()))

@@ -8,7 +8,8 @@ import ctypes
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libyolat_hip.so")
+# (YOLAT_LIB_PATH: another build of the same ABI — A/B measurements of one kernel on one box, tools/exp/)
+LIB_PATH = os.environ.get("YOLAT_LIB_PATH") or os.path.join(_HERE, "libyolat_hip.so")
 
 c_p = ctypes.c_void_p
 c_i64 = ctypes.c_int64
