@@ -848,7 +848,7 @@ static int forward_eval_bf16_impl(const yolat_model_eval_bf16* mh, const float* 
                      (!known || fits) && (g != nullptr || E == 0 || yl_aligned16(e_attr) || !fits);
   // vouched: the caller examined the batch (yolat_batch_locality / the host collate) — no gated fall-back launches, and
   // for a COO batch no global destination sort either: the tiles sort their edges themselves
-  const bool vouched = local && fits;
+  const bool vouched = local && fits && (g != nullptr || E > 0);      // (no edges: nothing to sort, the gated form has no cost)
   YlGate gate{nullptr, 0};
   int flag_val = 0;
   if (local) {

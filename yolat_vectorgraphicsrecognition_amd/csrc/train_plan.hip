@@ -15,8 +15,12 @@
 // YOLAT_E_UNSUPPORTED and the caller keeps the Python schedule (trainer.Trainer does).
 //
 // Streams.  `side` != NULL: the weight gradients and the node branches run on it beside the dX chain, forked behind an
-// event on `stream` at every hand-over and joined before the per-proposal mean of the forward, before the head bucket is
-// declared complete and at the end of the backward — engine._on_side / _join_side.  Every temporary has its own range of
+// event on `stream` at every hand-over and joined in front of the classifier, before the head bucket is declared complete
+// and at the end of the backward — engine._on_side / _join_side.  The side stream also takes what the Python schedule
+// leaves on the main one although nothing on the critical path waits for it: weight-only / graph-only preparation at the
+// start of the step, the pooling of feats / the node branches and fusion_block_super beside the fusion block (forward),
+// fusion_block_super's backward and the per-proposal mean's beside the fusion block's backward.  Same kernels, same
+// operands, so the results stay bit-identical; only WHERE a launch waits changes.  Every temporary has its own range of
 // the workspace (nothing is recycled inside a step), so the two streams never share scratch.
 //
 // Phases (for the data-parallel exchange, which stays with the caller's process group): 1 = everything up to the point
@@ -378,17 +382,24 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
       f = of; ldf = ldo;
       s = Lazy{os, ldo, v.cn_scale, v.cn_shift, 1};
     }
+    // Everything between the conv layers and the classifier that does NOT go through the fusion block — the per-proposal max
+    // of feats, the per-proposal mean of the node branches (computed on the side stream anyway) and fusion_block_super on its
+    // P rows — runs on the side stream BESIDE the fusion block (428 us at cfg 3; disjoint column ranges of Z), joined in
+    // front of the classifier.  (The Python schedule issues them on the main stream behind it; same kernels and operands.)
+    {
+      hipStream_t ss = S.fork();       // (behind the last conv layer's aggregation: feats is complete)
+      float* sup = b.Z + 2 * F + D;
+      TP_TRY(yolat_segment_max_fwd(b.feats, D, D, nullptr, nullptr, 0, seg_ptr, P, N, b.Z + F, ZW, b.arg_feat, ss));
+      TP_TRY(yolat_segment_mean_fwd(b.fsup, D, D, b.sup_coef, b.sup_coef + D, 1, seg_ptr, P, sup, ZW, ss));
+      TP_TRY(lin_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->fus_s.W, m->fus_s.b, F, b.fs_y, F, b.fs_st, nullptr, false, ss));
+      TP_TRY(finalize(b.fs_st, P, F, m->fus_s_bn, b.fs_c, b.fs_c + F, b.fs_c + 2 * F, b.fs_c + 3 * F, ss));
+      TP_TRY(yolat_scale_shift_relu(b.fs_y, F, P, F, b.fs_c, b.fs_c + F, 1, b.Z + F + D, ZW, ss));
+    }
     // fusion block over nodes + per-proposal max (arch:61-63,122): fused, no [N, F] activation
     TP_TRY(yolat_fusion_pool_train_fwd(b.feats, D, N, D, m->fus.W, m->fus.b, F, m->fus_bn.gamma, m->fus_bn.beta,
                                        m->fus_bn.running_mean, m->fus_bn.running_var, m->fus_bn.momentum, m->fus_bn.eps, node_seg,
                                        P, b.Z, ZW, b.fus_coef, b.fus_saved, b.fus_work, st));
-    TP_TRY(yolat_segment_max_fwd(b.feats, D, D, nullptr, nullptr, 0, seg_ptr, P, N, b.Z + F, ZW, b.arg_feat, st));
-    S.join();                          // the node branches (fsup, sup_coef) were computed on the side stream
-    float* sup = b.Z + 2 * F + D;
-    TP_TRY(yolat_segment_mean_fwd(b.fsup, D, D, b.sup_coef, b.sup_coef + D, 1, seg_ptr, P, sup, ZW, st));
-    TP_TRY(lin_fwd(sup, ZW, P, D, nullptr, nullptr, 0, m->fus_s.W, m->fus_s.b, F, b.fs_y, F, b.fs_st, nullptr, false, st));
-    TP_TRY(finalize(b.fs_st, P, F, m->fus_s_bn, b.fs_c, b.fs_c + F, b.fs_c + 2 * F, b.fs_c + 3 * F, st));
-    TP_TRY(yolat_scale_shift_relu(b.fs_y, F, P, F, b.fs_c, b.fs_c + F, 1, b.Z + F + D, ZW, st));
+    S.join();                          // Z is complete: node branches, pooled rows, fusion_block_super, the weight packs
     // classifier (arch:91-93,128)
     TP_TRY(lin_fwd(b.Z, ZW, P, ZW, nullptr, nullptr, 0, m->c1.W, m->c1.b, H1, b.c1y, H1, b.c1st, b.c1pack, true, st));
     TP_TRY(finalize(b.c1st, P, H1, m->c1_bn, b.c1c, b.c1c + H1, b.c1c + 2 * H1, b.c1c + 3 * H1, st));
@@ -427,15 +438,20 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
     TP_TRY(yolat_linear_bwd_w(b.d1, H1, P, H1, b.Z, ZW, ZW, nullptr, nullptr, 0, grad_of(m, m->c1.W), ZW, grad_of(m, m->c1.b), 0,
                               b.w1w, S.fork()));
     TP_TRY(lin_wt(b.d1, H1, P, H1, m->c1.W, ZW, b.dZ, ZW, 0, b.p1, true, b.x1w, st));
-    // fusion_block_super: input sup = Z[:, 2F+D:], post-activation output Z[:, F+D:2F+D]
-    float* d_sup = b.dZ + 2 * F + D;
-    float* dz_fs = b.dZ + F + D;
-    TP_TRY(yolat_bn_relu_bwd(dz_fs, ZW, b.fs_y, F, P, F, m->fus_s_bn.gamma, b.fs_c + 2 * F, b.fs_c + 3 * F, b.fs_c, b.fs_c + F, 1,
-                             grad_of(m, m->fus_s_bn.gamma), grad_of(m, m->fus_s_bn.beta), 0, dz_fs, ZW, b.wfsbn, st));
-    TP_TRY(yolat_linear_bwd_w(dz_fs, ZW, P, F, b.Z + 2 * F + D, ZW, D, nullptr, nullptr, 0, grad_of(m, m->fus_s.W), D,
-                              grad_of(m, m->fus_s.b), 0, b.wfsw, S.fork()));
-    TP_TRY(yolat_linear_fwd_wt(dz_fs, ZW, P, F, m->fus_s.W, D, D, d_sup, ZW, 1, st));
-    TP_TRY(yolat_segment_mean_bwd(d_sup, ZW, D, seg_ptr, node_seg, N, b.d_fsup, D, st));
+    // fusion_block_super: input sup = Z[:, 2F+D:], post-activation output Z[:, F+D:2F+D].  Its whole backward and the
+    // per-proposal mean's feed nothing but the node branches' backward chain, which lives on the side stream: so do they,
+    // beside the fusion block's backward (their columns of dZ are disjoint from the ones the main stream reads)
+    {
+      hipStream_t ss = S.fork();
+      float* d_sup = b.dZ + 2 * F + D;
+      float* dz_fs = b.dZ + F + D;
+      TP_TRY(yolat_bn_relu_bwd(dz_fs, ZW, b.fs_y, F, P, F, m->fus_s_bn.gamma, b.fs_c + 2 * F, b.fs_c + 3 * F, b.fs_c, b.fs_c + F, 1,
+                               grad_of(m, m->fus_s_bn.gamma), grad_of(m, m->fus_s_bn.beta), 0, dz_fs, ZW, b.wfsbn, ss));
+      TP_TRY(yolat_linear_bwd_w(dz_fs, ZW, P, F, b.Z + 2 * F + D, ZW, D, nullptr, nullptr, 0, grad_of(m, m->fus_s.W), D,
+                                grad_of(m, m->fus_s.b), 0, b.wfsw, ss));
+      TP_TRY(yolat_linear_fwd_wt(dz_fs, ZW, P, F, m->fus_s.W, D, D, d_sup, ZW, 1, ss));
+      TP_TRY(yolat_segment_mean_bwd(d_sup, ZW, D, seg_ptr, node_seg, N, b.d_fsup, D, ss));
+    }
     // fusion_block + max pooling
     TP_TRY(yolat_segment_max_bwd(b.dZ + F, ZW, D, b.arg_feat, node_seg, N, b.d_feats, D, st));
     auto fus_part = [&](int mask, hipStream_t s) {

@@ -686,7 +686,11 @@ class DeviceLoader(object):
         rc = self._lib.yolat_loader_submit(self._h, ptrs, len(items))
         if rc != 0:
             self._check(rc, "yolat_loader_submit")
-        self._pending.append((items, ship, tkeys, rest, ptrs, batch_locality(items)))
+        try:
+            loc = batch_locality(items)
+        except (AttributeError, TypeError):      # items without the reference's edge / bbox_idx layout: nothing to vouch for
+            loc = None
+        self._pending.append((items, ship, tkeys, rest, ptrs, loc))
         return True
 
     def __next__(self):

@@ -509,7 +509,8 @@ class Trainer(object):
         world = dist.get_world_size() if grouped else 1
         exchange = self.exchange_gradients and grouped and (world > 1 or self.force_exchange)
         check = self._steps == 0 or (self.check_inputs_every > 0 and self._steps % self.check_inputs_every == 0)
-        self.model.train()
+        if not self.model.training:          # (nn.Module.train() walks ~100 modules: not once per step)
+            self.model.train()
         self.optimizer.zero_grad()
         self.model.__dict__["_yolat_plan"] = plan if staged[6] is None else staged[6]
         if not exchange and not check:
