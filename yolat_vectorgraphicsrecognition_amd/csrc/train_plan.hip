@@ -188,8 +188,14 @@ __global__ void k_tp_nbt(NbtList l) {
 // two streams, forked / joined through events (engine._on_side / _join_side)
 struct Streams {
   hipStream_t main, side;
-  hipEvent_t ev_fork, ev_join;
+  hipEvent_t ev_fork, ev_join, ev_mark;
   bool dirty;
+  void mark() {                        // a point of the side stream the main stream can wait for WITHOUT joining everything
+    if (side) (void)hipEventRecord(ev_mark, side);
+  }
+  void wait_mark() {
+    if (side) (void)hipStreamWaitEvent(main, ev_mark, 0);
+  }
   hipStream_t fork() {                 // the side stream, ordered behind everything issued on main so far
     if (!side) return main;
     (void)hipEventRecord(ev_fork, main);
@@ -206,19 +212,22 @@ struct Streams {
 };
 
 // the two events of a (main, side) pair, created once per process and pair of streams
-struct EvCache { hipStream_t m, s; hipEvent_t f, j; };
+struct EvCache { hipStream_t m, s; hipEvent_t f, j, k; };
 EvCache g_ev[8];
 int g_nev = 0;
-bool events_for(hipStream_t m, hipStream_t s, hipEvent_t* f, hipEvent_t* j) {
+bool events_for(hipStream_t m, hipStream_t s, hipEvent_t* f, hipEvent_t* j, hipEvent_t* k) {
   for (int i = 0; i < g_nev; ++i)
-    if (g_ev[i].m == m && g_ev[i].s == s) { *f = g_ev[i].f; *j = g_ev[i].j; return true; }
-  EvCache e{m, s, nullptr, nullptr};
+    if (g_ev[i].m == m && g_ev[i].s == s) { *f = g_ev[i].f; *j = g_ev[i].j; *k = g_ev[i].k; return true; }
+  EvCache e{m, s, nullptr, nullptr, nullptr};
   if (hipEventCreateWithFlags(&e.f, hipEventDisableTiming) != hipSuccess) return false;
   if (hipEventCreateWithFlags(&e.j, hipEventDisableTiming) != hipSuccess) return false;
+  if (hipEventCreateWithFlags(&e.k, hipEventDisableTiming) != hipSuccess) return false;
   const int slot = g_nev < 8 ? g_nev++ : 7;      // (a process uses one or two pairs; the last slot is recycled beyond eight)
-  if (slot == 7 && g_nev == 8 && g_ev[7].f) { (void)hipEventDestroy(g_ev[7].f); (void)hipEventDestroy(g_ev[7].j); }
+  if (slot == 7 && g_nev == 8 && g_ev[7].f) {
+    (void)hipEventDestroy(g_ev[7].f); (void)hipEventDestroy(g_ev[7].j); (void)hipEventDestroy(g_ev[7].k);
+  }
   g_ev[slot] = e;
-  *f = e.f; *j = e.j;
+  *f = e.f; *j = e.j; *k = e.k;
   return true;
 }
 
@@ -288,8 +297,8 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
   S.main = (hipStream_t)stream;
   S.side = (side_stream && side_stream != stream) ? (hipStream_t)side_stream : nullptr;
   S.dirty = false;
-  S.ev_fork = S.ev_join = nullptr;
-  if (S.side && !events_for(S.main, S.side, &S.ev_fork, &S.ev_join)) return YOLAT_E_INVALID;
+  S.ev_fork = S.ev_join = S.ev_mark = nullptr;
+  if (S.side && !events_for(S.main, S.side, &S.ev_fork, &S.ev_join, &S.ev_mark)) return YOLAT_E_INVALID;
   hipStream_t st = S.main;
 
   const int* row_ptr = b.row_ptr; const int* src = b.src; const int* dst = b.dst; const float* attr = b.attr;
