@@ -30,6 +30,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <mutex>
+
 namespace {
 
 struct Carve {
@@ -215,7 +217,9 @@ struct Streams {
 struct EvCache { hipStream_t m, s; hipEvent_t f, j, k; };
 EvCache g_ev[8];
 int g_nev = 0;
+std::mutex g_ev_mu;
 bool events_for(hipStream_t m, hipStream_t s, hipEvent_t* f, hipEvent_t* j, hipEvent_t* k) {
+  std::lock_guard<std::mutex> lock(g_ev_mu);       // (trainers on several devices / host threads share the table)
   for (int i = 0; i < g_nev; ++i)
     if (g_ev[i].m == m && g_ev[i].s == s) { *f = g_ev[i].f; *j = g_ev[i].j; *k = g_ev[i].k; return true; }
   EvCache e{m, s, nullptr, nullptr, nullptr};
@@ -281,7 +285,7 @@ extern "C" int yolat_train_step(const yolat_train_model* m, const float* x, int6
   if (!x || !labels || !logits || !loss || !workspace || !status || N <= 0 || E <= 0 || P <= 0 || (phases & 7) == 0)
     return YOLAT_E_INVALID;
   if (!g && (!edge || !e_attr || !bbox_idx)) return YOLAT_E_INVALID;
-  if ((phases & 4) && !adam) return YOLAT_E_INVALID;
+  if ((phases & 4) && (!adam || !adam->exp_avg || !adam->exp_avg_sq || adam->n <= 0 || adam->step < 1)) return YOLAT_E_INVALID;
   if (E < N || N >= (1LL << 30) || E >= (1LL << 30)) return YOLAT_E_UNSUPPORTED;   // (E >= N: the factorised backward)
   const long C = m->C, F = m->F, D = C * m->n_blocks_out, ZW = 2 * (F + D), L = m->n_blocks, lo = L - m->n_blocks_out;
   const long K = m->n_classes, H1 = m->H1, H2 = m->H2;
