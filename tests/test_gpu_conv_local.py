@@ -529,3 +529,31 @@ def test_a_stale_locality_record_is_reported_in_the_status_word():
             assert int(status.item()) & 8
             with pytest.raises(ValueError, match="proposal-local"):
                 g.check_status()
+
+
+def test_batches_without_edges_and_without_children_take_the_ordinary_paths():
+    """edge cases of the round-6 paths: a batch with NO edges (E = 0: never vouched — nothing to sort; the forward matches the
+    oracle through whichever path the mode picks), and predict() on a tree without children / with a single image"""
+    yv = _yv()
+    optkw = dict(n_classes=17, n_blocks=2, n_blocks_out=2)
+    d = _ragged(yv, 1100, 5, lo=2, hi=6, edges_per_proposal=0)
+    assert d.edge.shape[0] == 0
+    model = _model(yv, optkw, 12)
+    ref = gu.fill_state_(orc.SparseCADGCN(orc.Opt(**optkw)), 12).eval()
+    with torch.no_grad():
+        want = ref(d, None)[0]
+        for mode in (2, 0):
+            with _mode(mode):
+                d.__dict__.pop("_yolat_stage", None)
+                got = model(d, None)[0].clone()
+            mx, rms = _rel(got, want)
+            assert mx <= RTOL_BF16 and rms <= RMS_BF16, (mode, mx, rms)
+    model._yolat_plan.check_status()
+    # predict() with a tree of roots only (no children anywhere): one submission, rows = the roots in order
+    data, slices = yv.synth_batch(2, 31, num_proposals=60, nodes_lo=4, nodes_hi=12, edge_factor=1.4, with_roots=True)
+    for r in data.roots:
+        r.children = []
+    m32 = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 13).cuda().eval()
+    with torch.no_grad():
+        out = m32.predict(data, slices)
+    assert out[0].shape[0] == len(data.roots) == len(out[3]) and out[4][-1] == len(data.roots)

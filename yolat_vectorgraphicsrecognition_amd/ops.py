@@ -64,7 +64,7 @@ def _f(t, name="tensor", allow_none=False):
         raise RuntimeError("%s must be a CUDA (ROCm) tensor — the yolat HIP path has no CPU fallback" % name)
     if t.dtype != torch.float32:
         raise TypeError("%s must be float32, got %s" % (name, t.dtype))
-    if t.dim() >= 1 and t.shape[-1] > 1 and t.stride(-1) != 1:
+    if t.dim() >= 1 and t.shape[-1] > 1 and t.stride(-1) != 1 and t.numel() > 0:      # (an empty tensor's strides mean nothing)
         raise ValueError("%s must be dense along its last dimension" % name)
     return t.data_ptr()
 
@@ -73,7 +73,7 @@ def _h(t, name="tensor"):
     """data_ptr of a bfloat16 CUDA tensor whose last dim is dense (bf16-storage training tensors)."""
     if not t.is_cuda or t.dtype != torch.bfloat16:
         raise TypeError("%s must be a bfloat16 CUDA tensor" % name)
-    if t.dim() >= 1 and t.shape[-1] > 1 and t.stride(-1) != 1:
+    if t.dim() >= 1 and t.shape[-1] > 1 and t.stride(-1) != 1 and t.numel() > 0:      # (an empty tensor's strides mean nothing)
         raise ValueError("%s must be dense along its last dimension" % name)
     return t.data_ptr()
 
