@@ -390,3 +390,74 @@ def test_collate_csr_pack_equals_csr_of_the_collated_batch(golden_dir):
         want_k = np.concatenate([it[k].numpy() for it in items], 0)
         got = buf[foff[f]:foff[f] + want_k.nbytes].view(want_k.dtype).reshape(want_k.shape)
         np.testing.assert_array_equal(got, want_k, err_msg=k)
+
+
+def test_item_locality_host_against_a_numpy_restatement():
+    """yolat_item_locality_host (data.item_locality / batch_locality): flags and sizes against a direct numpy restatement of
+    the property — bbox_idx[dst] non-decreasing along the edge list (grouped by proposal, Datasets/graph_dict3.py:725,752-764),
+    both end points in the same proposal (:582-600,733), nodes / edges of the largest proposal — on clean items, an item with
+    a crossing edge, an ungrouped edge list and malformed ids; merged over a batch by OR / max."""
+    from yolat_vectorgraphicsrecognition_amd import data as D
+
+    def numpy_record(it):
+        bb, e = it.bbox_idx.numpy(), it.edge.numpy()
+        N, P = it.x.shape[0], it.bbox.shape[0]
+        flags = 0
+        if ((bb < 0) | (bb >= P)).any() or (np.diff(bb) < 0).any() or ((e < 0) | (e >= N)).any():
+            flags |= 4
+        ec = np.clip(e, 0, N - 1)
+        owner = np.clip(bb, 0, P - 1)[ec]
+        if (owner[:, 0] != owner[:, 1]).any():
+            flags |= 2
+        if (np.diff(owner[:, 1]) < 0).any():
+            flags |= 1
+        return flags, int(np.bincount(np.clip(bb, 0, P - 1), minlength=P).max()), \
+            int(np.bincount(owner[:, 1], minlength=P).max()) if len(e) else 0
+
+    items = [yv.synth_graph(num_proposals=30 + 7 * j, nodes_lo=3, nodes_hi=15 + j, edge_factor=1.6, seed=300 + j) for j in range(4)]
+    crossing = yv.synth_graph(num_proposals=25, nodes_lo=3, nodes_hi=12, seed=310)
+    crossing.edge = crossing.edge.clone()
+    crossing.edge[3, 0] = crossing.x.shape[0] - 1
+    ungrouped = yv.synth_graph(num_proposals=25, nodes_lo=3, nodes_hi=12, seed=311)
+    perm = torch.randperm(ungrouped.edge.shape[0], generator=torch.Generator().manual_seed(1))
+    ungrouped.edge = ungrouped.edge[perm].contiguous()
+    malformed = yv.synth_graph(num_proposals=25, nodes_lo=3, nodes_hi=12, seed=312)
+    malformed.edge = malformed.edge.clone()
+    malformed.edge[0, 1] = malformed.x.shape[0] + 3
+    for it in items + [crossing, ungrouped, malformed]:
+        got = D.item_locality(it)
+        want = numpy_record(it)
+        assert got[0] == want[0] and got[1] == want[1], (got, want)
+        if not got[0] & 1:
+            assert got[2] == want[2]
+    loc = D.batch_locality(items)
+    recs = [numpy_record(it) for it in items]
+    assert (loc.known, loc.flags, loc.max_nodes, loc.max_edges) == (1, 0, max(r[1] for r in recs), max(r[2] for r in recs))
+    assert D.batch_locality(items + [crossing]).flags == 2
+    assert D.batch_locality([ungrouped] + items).flags & 1
+    # yolat_conv_local_fits: what the forward decides from the record (tile shapes 64 / 512 below 2048 proposals, 128 / 1024 from there)
+    from yolat_vectorgraphicsrecognition_amd._lib import Locality
+    for P, n, e, fits in ((100, 64, 512, 1), (100, 65, 512, 0), (100, 64, 513, 0), (4000, 128, 1024, 1), (4000, 129, 10, 0)):
+        assert _lib.lib.yolat_conv_local_fits(ctypes.byref(Locality(1, 0, n, e)), P) == fits
+    assert _lib.lib.yolat_conv_local_fits(ctypes.byref(Locality(1, 1, 8, 8)), 4000) == 0
+    assert _lib.lib.yolat_conv_local_fits(None, 4000) == 0
+
+
+def test_flatten_tree_lists_what_select_tree_ranges_walks():
+    """data.flatten_tree (the one-submission predict's tree, uploaded once) against data.select_tree_ranges (the two-pass
+    walk of arch:153-164 / :277-296): the same global ranges and proposal rows, roots in order, every root's children behind
+    child_ptr, per-image root offsets."""
+    from yolat_vectorgraphicsrecognition_amd import data as D
+    data, slices = yv.synth_batch(3, 41, num_proposals=40, nodes_lo=3, nodes_hi=12, edge_factor=1.4, with_roots=True)
+    ft = D.flatten_tree(data, slices)
+    ps, pe, es, ee, rows, image_off = D.select_tree_ranges(data, slices)
+    assert ft["R"] == len(rows) == len(data.roots) and ft["B"] == 3
+    np.testing.assert_array_equal(ft["root_row"], np.asarray(rows))
+    np.testing.assert_array_equal(ft["root_range"], np.stack([ps, pe, es, ee], 1))
+    np.testing.assert_array_equal(ft["image_root_ptr"], np.asarray(image_off))
+    has = np.ones(len(data.roots), dtype=bool)
+    ps, pe, es, ee, rows, image_off = D.select_tree_ranges(data, slices, has)
+    assert ft["Ctot"] == len(rows) == int(ft["child_ptr"][-1])
+    np.testing.assert_array_equal(ft["child_row"], np.asarray(rows))
+    np.testing.assert_array_equal(ft["child_range"], np.stack([ps, pe, es, ee], 1))
+    assert [int(ft["child_ptr"][i + 1] - ft["child_ptr"][i]) for i in range(ft["R"])] == [len(r.children) for r in data.roots]
