@@ -209,3 +209,26 @@ def test_bench_line_with_two_ranks_launched_the_way_the_driver_launches_them():
     assert len(pr["per_rank_ms_per_step"]) == 2 and all(t > 0 for t in pr["per_rank_ms_per_step"])
     assert max(pr["per_rank_ms_per_step"]) <= d["ms_per_step"] * (1 + 1e-6) + 1e-5       # (the record rounds to 1e-5 ms)
     assert sorted(r_["rank"] for r_ in pr["ranks"]) == [0, 1]
+
+
+def test_bench_train_dp_record_with_two_ranks_carries_both_exchange_layouts():
+    """the N > 1 line's `train_dp` sub-record (cfg-4 training step with the gradient exchange, two ranks over gloo on this one
+    GPU): the step goes through yolat_train_step with the exchange between its phases, the one-bucket layout
+    (YOLAT_DP_BUCKETS=1) is timed beside the two-bucket one, and the record proves its ranks."""
+    import json
+    import subprocess
+    root = os.path.dirname(HERE)
+    env = dict(os.environ, YOLAT_BENCH_DEVICE="0", YOLAT_BENCH_BACKEND="gloo")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "YOLAT_DP_BUCKETS"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+                        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(root, "bench.py"),
+                        "--gpus", "2", "--steps", "20", "--warmup", "5", "--no-cpu-baseline", "--no-roofline"],
+                       env=env, cwd=root, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-1000:]
+    td = json.loads(lines[0])["train_dp"]
+    assert td["ms_per_step"] > 0 and td["ms_per_step_one_bucket"] > 0 and td["ms_per_step_without_exchange"] > 0
+    assert td["steps_through_yolat_train_step"] > 0
+    assert td["participation"]["ranks_seen"] == 2 and td["participation"]["backend"] == "gloo"
