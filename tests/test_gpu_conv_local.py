@@ -557,3 +557,27 @@ def test_batches_without_edges_and_without_children_take_the_ordinary_paths():
     with torch.no_grad():
         out = m32.predict(data, slices)
     assert out[0].shape[0] == len(data.roots) == len(out[3]) and out[4][-1] == len(data.roots)
+
+
+def test_cfg5_full_size_vouched_forward_equals_the_gated_forward_bit_for_bit():
+    """configs[4] at FULL size: the forward with the locality decided before enqueue (local prep + tile-local sort, no gated
+    launches) against the forward that finds it out on the device (global destination sort + gated fall-back): the same
+    logits bit for bit, and the examination reports the batch's structure (25 nodes / 150 edges per proposal, no violation)."""
+    yv = _yv()
+    from yolat_vectorgraphicsrecognition_amd import plan as plan_mod
+    data, slices, optkw, _ = yv.config("5")
+    for k in ("x", "edge", "e_attr", "bbox_idx", "bbox"):
+        data[k] = data[k].cuda()
+    model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 9).cuda().eval().set_eval_precision("bf16")
+    with torch.no_grad():
+        with _mode(1):
+            vouched = model(data, slices)[0].clone()
+            (loc,) = [v[2] for v in model._yolat_plan._loc.values()]
+            assert (loc.known, loc.flags, loc.max_nodes, loc.max_edges) == (1, 0, 25, 150)
+            plan_mod.LOCALITY_CACHE = False
+            try:
+                gated = model(data, slices)[0].clone()
+            finally:
+                plan_mod.LOCALITY_CACHE = True
+    assert torch.equal(vouched, gated)
+    model._yolat_plan.check_status()

@@ -172,3 +172,17 @@ def test_plan_host_time_per_step_is_a_fraction_of_the_python_schedule():
         finally:
             T.TRAIN_PLAN = True
     assert host[True] < 0.5 * host[False], host
+
+
+@pytest.mark.parametrize("cfg,precision", [("3", "fp32"), ("4", "fp32"), ("5", "fp32"), ("5", "bf16")])
+def test_plan_step_is_bit_identical_at_the_baseline_configurations_full_size(cfg, precision):
+    """BASELINE.json configs[2] / [3] / [4] at FULL size (cfg 3: 4 x 2000 proposals, N ~ 175 k; cfg 4: 32 Diagrams-style
+    graphs; cfg 5: N = 200 k / E = 1.2 M / P = 8000, n_blocks 4): two steps through yolat_train_step against two steps of the
+    Python schedule — loss, flat gradient, parameters, Adam moments, BatchNorm buffers bit for bit.  (The Python schedule's
+    gradients are pinned to the float64 oracle at these sizes by tests/test_gpu_configs.py.)"""
+    yv = _yv()
+    data, slices, optkw, _ = yv.config(cfg)
+    for k in ("x", "edge", "e_attr", "bbox_idx", "bbox", "labels"):
+        data[k] = data[k].cuda()
+    ta, tb = _pair(yv, optkw, 21, precision)
+    _run(yv, ta, tb, [(data, slices)], steps=2)
