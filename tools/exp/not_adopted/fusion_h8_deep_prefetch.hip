@@ -1,0 +1,247 @@
+// fusion_h8.hip — eval fusion block + per-proposal max (architecture3cc_rpn_gp_iter2.py:61-63,122) and
+// fusion_block_super (arch:65-69) for the bf16-storage forward, as ONE launch of an A-in-registers rows kernel (round 3).
+//
+// What it replaces and why (profiles/r01_fwd_cfg5_bf16_kernel_stats_v1.txt, k_hfusion_rows<1,128>: 158 us for 52 GFLOP =
+// 0.14 of the dense bf16 peak): that kernel keeps a 64-row tile of `feats` in LDS and re-streams every 64-column tile of
+// the weights per 64 rows — 800 MB of L2 -> LDS traffic at N = 200 k for a 256 KB weight — and reads 16 KB of LDS
+// fragments for every 8 MFMAs of a wave between two barriers.  Here (the structure of fusion_x6.hip's fp32 kernel, one
+// bf16 part instead of three): a 512-thread workgroup owns 256 rows; every wave keeps ITS 32 rows x K of A as MFMA
+// fragments in 32 registers for all the column tiles it walks; the weights — BatchNorm scale folded into their rows
+// BEFORE the bf16 rounding, the shift is the accumulators' initial value — stream through a double-buffered LDS tile
+// (64 columns x K), the next tile's 16-byte pieces in registers while the current tile's MFMAs and pooling epilogue run;
+// one barrier per column tile; W is streamed once per 256 rows (200 MB).  The pooling epilogue is the run-length integer
+// atomicMax of segmax.hpp (values >= 0: integer order == float order, exact, order-independent).
+// The small problem (fusion_block_super on the P per-proposal means, fp32 rows converted while loading, plain ReLU
+// store) rides in the same launch, its workgroups first.
+#include "segmax.hpp"
+#include <stdlib.h>
+
+typedef unsigned short u16;
+typedef unsigned h8_u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 h8_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct H8Prob {
+  const u16* Ah;        // bf16 rows (NULL -> Af)
+  const float* Af;      // fp32 rows, converted while loading
+  long lda; int N;
+  const u16* W;         // [F, KD] bf16, BatchNorm scale folded into the rows
+  const float* tfold;   // [F] shift (s*b + t)
+  const int* seg;       // != NULL: pooling epilogue into out (pooled matrix); else out[row, col] = relu(.)
+  float* out; long ldo;
+  int F, tm, groups, ng;
+};
+
+template <int KD>
+__global__ void __launch_bounds__(512, 2) k_hfusion_rows8(H8Prob p0, H8Prob p1) {
+  constexpr int KS = KD / 16, RS = KD + 8, CPR = KD / 8;    // k steps, LDS row stride (bf16), 16-byte chunks per row
+  constexpr int NW = 64 * CPR / 512;                        // 16-byte pieces of one W tile per thread
+  static_assert((64 * CPR) % 512 == 0, "W tile / thread mismatch");
+  __shared__ __attribute__((aligned(16))) u16 Ws[2][64 * RS];
+  __shared__ int seg_s[256];
+  // per-column-tile pooled maxima of the workgroup (segmax.hpp) + the shifts of the workgroup's column tiles (tf_s below:
+  // FX_NP * 64 floats = 32 tiles; the launcher never gives a workgroup more)
+  __shared__ int tab_s[2 + 1][FX_NP * 64];
+  static_assert(FX_NP == 32, "tf_s: 32 column tiles per workgroup at most (yl_hfusion_rows8's split)");
+  const int tid = threadIdx.x;
+  const int n1 = p1.tm * p1.groups, n1p = (n1 + 7) & ~7;
+  const int id = blockIdx.x;
+  int logical;
+  if (id < n1p) {
+    if (id >= n1) return;
+    logical = id;
+  } else {
+    // (row tile, column group) pairs, column group fastest, dealt to the XCDs in contiguous ranges
+    const int n0 = p0.tm * p0.groups, j0 = id - n1p;
+    const int chunk = n0 >> 3, rem = n0 & 7;
+    const int xcd = j0 & 7, slot = j0 >> 3;
+    logical = xcd * chunk + (xcd < rem ? xcd : rem) + slot;
+  }
+  const bool small = id < n1p;
+  const u16* const Ah = small ? p1.Ah : p0.Ah;
+  const float* const Af = small ? p1.Af : p0.Af;
+  const long lda = small ? p1.lda : p0.lda;
+  const int N = small ? p1.N : p0.N, F = small ? p1.F : p0.F;
+  const u16* const W = small ? p1.W : p0.W;
+  const float* const tfold = small ? p1.tfold : p0.tfold;
+  const int* const seg = small ? p1.seg : p0.seg;
+  float* const out = small ? p1.out : p0.out;
+  const long ldo = small ? p1.ldo : p0.ldo;
+  const int groups = small ? p1.groups : p0.groups, ng = small ? p1.ng : p0.ng;
+  const int rt = logical / groups, cg = logical % groups;
+  const int tn = (F + 63) >> 6;
+  const int ct0 = cg * ng;
+  const int ngl = yl_min(ng, tn - ct0);
+  if (ngl <= 0) return;
+
+  const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
+  const int row0 = rt * 256 + wave * 32;
+  // ---- this wave's 32 rows of A as MFMA A fragments (lane = row, 8 consecutive k per lane half)
+  h8_bf16x8 Afr[KS];
+  {
+    const long r = yl_min(row0 + l31, N - 1);
+    if (Ah != nullptr) {
+      const u16* ap = Ah + r * lda + 8 * lhi;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) Afr[ks] = __builtin_bit_cast(h8_bf16x8, *reinterpret_cast<const h8_u32x4*>(ap + 16 * ks));
+    } else {
+      const float* ap = Af + r * lda + 8 * lhi;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const float4 a0 = *reinterpret_cast<const float4*>(ap + 16 * ks), a1 = *reinterpret_cast<const float4*>(ap + 16 * ks + 4);
+        const h8_u32x4 v = {yl_pack_bf16(a0.x, a0.y), yl_pack_bf16(a0.z, a0.w), yl_pack_bf16(a1.x, a1.y),
+                            yl_pack_bf16(a1.z, a1.w)};
+        Afr[ks] = __builtin_bit_cast(h8_bf16x8, v);
+      }
+    }
+  }
+  const bool pooling = seg != nullptr;
+  FxTile tile{};
+  if (pooling) {
+    const int row_lo = rt * 256, row_hi = yl_min(row_lo + 256, N);
+    tile = fx_tile(seg, row_lo, row_hi, N);
+    for (int e = tid; e < 2 * FX_NP * 64; e += 512) (&tab_s[0][0])[e] = 0;
+  }
+  FxRuns runs;
+  {
+    const int sv = (pooling && row0 + l31 < N) ? seg[row0 + l31] : -1;
+    if (lhi == 0) seg_s[wave * 32 + l31] = sv;          // read back by the same wave only, after the barrier below
+    fx_seg_runs(sv, lhi, runs);
+  }
+  const int* segs = seg_s + wave * 32;
+  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
+  auto load_w = [&](int ct, h8_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const unsigned r = wr0 + (unsigned)t * (512 / CPR);
+      rw[t] = *reinterpret_cast<const h8_u32x4*>(W + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
+    }
+  };
+  auto store_w = [&](int buf, const h8_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const unsigned r = wr0 + (unsigned)t * (512 / CPR);
+      *reinterpret_cast<h8_u32x4*>(&Ws[buf][r * RS + wk]) = rw[t];
+    }
+  };
+  // Round 6: the W tiles are fetched TWO column tiles ahead.  A 64-column tile is 16 MFMAs per wave (0.3-0.6 us of matrix
+  // pipe per SIMD) while a dependent L2 round trip costs ~1 us on this part under load: with the next tile fetched at the
+  // top of the current one (rounds 3-5) every tile ended in a wait for its successor — 3.3-3.7 k clocks per tile for 1 k of
+  // MFMA.  Two register sets alternate (the loop body is written once and instantiated for both roles, so the register
+  // names stay static): the set stored to LDS after tile j's MFMAs was loaded at the top of tile j - 1.  The shifts of the
+  // workgroup's columns sit in LDS (no global load in the loop but the W pieces), and there is no explicit vmcnt(0) any
+  // more: the wait in front of the LDS store counts only what is younger than the older set.
+  float* const tf_s = reinterpret_cast<float*>(&tab_s[0][0]) + 2 * FX_NP * 64;     // [ngl * 64] shifts, behind the tables
+  for (int e = tid; e < ngl * 64; e += 512) tf_s[e] = tfold[yl_min(ct0 * 64 + e, F - 1)];
+  // the first tile's shifts straight from memory (a one-tile workgroup must not wait for the LDS round trip)
+  const float tf0 = tfold[yl_min(ct0 * 64 + l31, F - 1)], tf1 = tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
+  h8_u32x4 rwA[NW], rwB[NW];
+  load_w(ct0, rwA);
+  load_w(ct0 + yl_min(1, ngl - 1), rwB);               // unconditional, clamped: the compiler counts the loads in flight
+  store_w(0, rwA);
+  // everything the prologue loaded has arrived before the loop starts: a load still pending on the loop's entry edge (the
+  // first tile's shifts) would make the compiler wait at the top of EVERY tile with a count that also covers the previous
+  // tile's drain stores
+  __builtin_amdgcn_s_waitcnt(0x0F70);                    // vmcnt(0)
+  __syncthreads();
+  f32x16 acc0, acc1;                                     // start value = the tile's shifts (set at the end of the tile before)
+#pragma unroll
+  for (int r = 0; r < 16; ++r) { acc0[r] = tf0; acc1[r] = tf1; }
+  // X: the pieces of tile j + 1 (loaded a whole tile ago), Y: receives tile j + 2
+  auto tile_step = [&](int j, h8_u32x4* X, h8_u32x4* Y) {
+    const int ct = ct0 + j, buf = j & 1;
+    const int c0 = ct * 64 + l31, c1 = c0 + 32;
+    // two tiles ahead, unconditionally (past the end: the last tile again, never stored): these NW loads are the youngest
+    // vector-memory operations when X is needed, and the wait in front of the LDS store below is vmcnt(NW), not vmcnt(0)
+    load_w(yl_min(ct + 2, ct0 + ngl - 1), Y);
+    __builtin_amdgcn_sched_barrier(0);                 // HERE: the scheduler otherwise sinks the loads below the MFMAs and
+                                                       // lends their registers to the B fragments in between
+    const u16* wb = &Ws[buf][l31 * RS + 8 * lhi];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const h8_bf16x8 b0 = *reinterpret_cast<const h8_bf16x8*>(wb + 16 * ks);
+      const h8_bf16x8 b1 = *reinterpret_cast<const h8_bf16x8*>(wb + 32 * RS + 16 * ks);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Afr[ks], b0, acc0, 0, 0, 0);
+      acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(Afr[ks], b1, acc1, 0, 0, 0);
+    }
+    // next W tile into the other buffer (its readers finished before the last barrier)
+    if (j + 1 < ngl) store_w(buf ^ 1, X);
+    // the previous column tile's pooled maxima (complete since its closing barrier) go out HERE, behind the wait for X:
+    // vmcnt retires in order, and at the top of the tile (rounds 3-5) these stores were younger than nothing the tile
+    // waits for — every tile waited for the acknowledgement of its own drain
+    if (pooling && j > 0) fx_tab_drain(tab_s[buf ^ 1], tile, out, (unsigned)ldo, ct - 1, F, tid, 512);
+    if (pooling) {
+      fx_segmax2_lds(acc0, acc1, tab_s[buf], out, (unsigned)ldo, segs, tile.seg_base, lhi, (unsigned)c0, (unsigned)l31, c0 < F,
+                     c1 < F, runs);
+    } else {
+      unsigned rb = (unsigned)(row0 + 4 * lhi);
+      asm volatile("" : "+v"(rb));
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const unsigned row = rb + (r & 3) + 8 * (r >> 2);
+        if ((int)row < N) {
+          float* o = out + (unsigned long)row * (unsigned long)ldo;
+          if (c0 < F) o[c0] = fmaxf(acc0[r], 0.f);
+          if (c1 < F) o[c1] = fmaxf(acc1[r], 0.f);
+        }
+      }
+    }
+    {                                                    // the next tile's start values (its shifts)
+      const int jn = yl_min(j + 1, ngl - 1);
+      const float t0 = tf_s[jn * 64 + l31], t1 = tf_s[jn * 64 + 32 + l31];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { acc0[r] = t0; acc1[r] = t1; }
+    }
+    __syncthreads();
+  };
+  for (int j = 0; j < ngl; j += 2) {
+    tile_step(j, rwB, rwA);
+    if (j + 1 < ngl) tile_step(j + 1, rwA, rwB);
+  }
+  if (pooling) fx_tab_drain(tab_s[(ngl - 1) & 1], tile, out, (unsigned)ldo, ct0 + ngl - 1, F, tid, 512);
+}
+
+// A [N, lda] bf16 x Wf [F, D] (folded) with the per-proposal max into pool [*, ld_pool] (columns 0..F), and
+// As [P, lda_s] fp32 x Wfs [F, D] (folded) -> relu -> sup_out [P, ld_sup].  D in {64, 128}; F % 64 == 0.
+int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const uint16_t* Wf, const float* tf,
+                     const int32_t* seg, float* pool, int64_t ld_pool, int64_t F, const float* As, int64_t lda_s, int64_t P,
+                     const uint16_t* Wfs, const float* tfs, float* sup_out, int64_t ld_sup, hipStream_t st) {
+  if ((D != 64 && D != 128) || F % 64 != 0 || N <= 0 || P <= 0) return YOLAT_E_UNSUPPORTED;
+  if (!yl_aligned16(A) || !yl_aligned16(As) || !yl_aligned16(Wf) || !yl_aligned16(Wfs) || lda % 8 != 0 || lda_s % 4 != 0)
+    return YOLAT_E_UNSUPPORTED;
+  const int tn = (int)(F / 64);
+  auto split = [&](long rows, int& tm, int& groups, int& ng, bool is_small) {
+    // column groups by the cost model of fusion_x6.hip: rounds x (1 prologue + tiles per workgroup), 2 workgroups per CU
+    tm = yl_cdiv(rows, 256);
+    long best = -1;
+    groups = 1;
+    for (int g = 1; g <= tn; g *= 2) {
+      const long wgs = (long)tm * g, rounds = (wgs + 511) / 512;
+      const long cost = rounds * (2 + yl_cdiv(tn, g));
+      if (best < 0 || cost < best) { best = cost; groups = g; }
+    }
+    if (is_small) {
+      // the P-row problem's workgroups start first: few of them (each walking several column tiles) so that they do not
+      // hold the first round of CUs back from the N-row problem (measured at cfg 5: 512 one-tile workgroups 104 us,
+      // 32 sixteen-tile workgroups 93 us for the launch)
+      groups = 1;
+      while ((long)tm * groups * 2 <= 128 && groups * 2 <= tn) groups *= 2;
+    }
+    while (yl_cdiv(tn, groups) > 32) groups *= 2;      // the kernel keeps the shifts of <= 32 column tiles in LDS
+    ng = yl_cdiv(tn, groups);
+    groups = yl_cdiv(tn, ng);
+  };
+  H8Prob p0{}, p1{};
+  p0.Ah = A; p0.Af = nullptr; p0.lda = lda; p0.N = (int)N; p0.W = Wf; p0.tfold = tf; p0.seg = seg; p0.out = pool;
+  p0.ldo = ld_pool; p0.F = (int)F;
+  split(N, p0.tm, p0.groups, p0.ng, false);
+  p1.Ah = nullptr; p1.Af = As; p1.lda = lda_s; p1.N = (int)P; p1.W = Wfs; p1.tfold = tfs; p1.seg = nullptr; p1.out = sup_out;
+  p1.ldo = ld_sup; p1.F = (int)F;
+  split(P, p1.tm, p1.groups, p1.ng, true);
+  const long n1p = ((long)p1.tm * p1.groups + 7) & ~7L;
+  const long total = n1p + (long)p0.tm * p0.groups;
+  if (total >= (1LL << 31)) return YOLAT_E_UNSUPPORTED;
+  if (D == 128) hipLaunchKernelGGL(k_hfusion_rows8<128>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  else hipLaunchKernelGGL(k_hfusion_rows8<64>, dim3((unsigned)total), dim3(512), 0, st, p0, p1);
+  YL_LAUNCH_CHECK();
+  return 0;
+}

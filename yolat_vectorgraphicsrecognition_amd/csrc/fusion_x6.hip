@@ -32,22 +32,31 @@ __device__ __forceinline__ unsigned long long fx_key(float z, bool neg, unsigned
   u = (u & 0x80000000u) ? ~u : (u | 0x80000000u);                // order-preserving float -> uint
   return ((unsigned long long)u << 32) | (unsigned long long)(0xFFFFFFFFu - row);
 }
+// Round 6: the run's extreme is tracked as a FLOAT with its register index (xor with the column's sign mask, one compare,
+// two selects per element) and turned into the 64-bit key only where a run ends — the key per element (sign select,
+// order-preserving transform, 64-bit compare + two selects) was ~8 vector instructions per element, a quarter of the
+// kernel's MFMA time at two waves per SIMD.  Same key, same tie rule (strict >: the lowest row of equal values wins);
+// differences only where IEEE comparison and the key order differ: -0 / +0 inside one lane's run count as equal (the
+// lower row wins, as in torch_scatter's `>` walk), and a NaN never replaces a number.
 __device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1, unsigned long long* keys, unsigned ldk,
                                          const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, bool neg0, bool neg1,
                                          unsigned rbase, const FxRuns& sr) {
-  unsigned long long cur0 = 0ull, cur1 = 0ull;
+  const unsigned m0 = neg0 ? 0x80000000u : 0u, m1 = neg1 ? 0x80000000u : 0u;
+  float cur0 = -INFINITY, cur1 = -INFINITY;
+  int at0 = 0, at1 = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    const unsigned row = rbase + (r & 3) + 8 * (r >> 2);
-    const unsigned long long k0 = fx_key(acc0[r], neg0, row), k1 = fx_key(acc1[r], neg1, row);
-    const bool cont = sr.keep[r] != 0.f;
-    cur0 = (cont && cur0 > k0) ? cur0 : k0;
-    cur1 = (cont && cur1 > k1) ? cur1 : k1;
+    const float x0 = __uint_as_float(__float_as_uint(acc0[r]) ^ m0), x1 = __uint_as_float(__float_as_uint(acc1[r]) ^ m1);
+    const bool b0 = x0 > cur0, b1 = x1 > cur1;
+    cur0 = b0 ? x0 : cur0; at0 = b0 ? r : at0;
+    cur1 = b1 ? x1 : cur1; at1 = b1 ? r : at1;
     if ((sr.uflush >> r) & 1u) {
       if ((sr.flush_bits >> r) & 1u) {
         unsigned long long* o = keys + ((unsigned long)(unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldk + c0);
-        if (ok0) atomicMax(o, cur0);
-        if (ok1) atomicMax(o + 32, cur1);
+        if (ok0) atomicMax(o, fx_key(cur0, false, rbase + (at0 & 3) + 8 * (at0 >> 2)));
+        if (ok1) atomicMax(o + 32, fx_key(cur1, false, rbase + (at1 & 3) + 8 * (at1 >> 2)));
+        cur0 = -INFINITY; cur1 = -INFINITY;              // the lane's next row starts a new run
+        at0 = r + 1; at1 = r + 1;
       }
     }
   }

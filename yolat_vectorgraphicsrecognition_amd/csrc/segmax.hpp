@@ -6,10 +6,11 @@
 
 namespace {
 // Run structure of a lane's 16 rows (C/D layout of a 32x32 MFMA tile) from their proposal ids — the same for every
-// column tile: keep[r] = 1 when row r continues the run of row r-1, flush bit r = a run ends at row r (uflush: in
-// some lane of the wave).  The proposal id of a flushed row is re-read from LDS (segs: the wave's 32 ids) — rare,
-// and 16 registers cheaper than keeping the offsets.
-struct FxRuns { float keep[16]; unsigned flush_bits, uflush; };
+// column tile: flush bit r = a run ends at row r (uflush: in some lane of the wave).  A run of row r+1 starts exactly
+// where a run ended at row r, so the running maximum is reset inside the flush block (round 6: one v_max per element
+// instead of a multiply by a keep flag + v_max3, and 16 registers fewer).  The proposal id of a flushed row is re-read
+// from LDS (segs: the wave's 32 ids) — rare, and 16 registers cheaper than keeping the offsets.
+struct FxRuns { unsigned flush_bits, uflush; };
 __device__ __forceinline__ void fx_seg_runs(int segv, int lhi, FxRuns& sr) {
   int sgs[16];
 #pragma unroll
@@ -17,7 +18,6 @@ __device__ __forceinline__ void fx_seg_runs(int segv, int lhi, FxRuns& sr) {
   unsigned fb = 0, uf = 0;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    sr.keep[r] = (r > 0 && sgs[r] == sgs[r - 1]) ? 1.f : 0.f;
     const bool fl = sgs[r] >= 0 && (r == 15 || sgs[r] != sgs[r + 1]);
     fb |= fl ? (1u << r) : 0u;
     uf |= (__builtin_amdgcn_ballot_w64(fl) != 0ull) ? (1u << r) : 0u;
@@ -31,13 +31,14 @@ __device__ __forceinline__ void fx_segmax2(const f32x16& acc0, const f32x16& acc
   float cur0 = 0.f, cur1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    cur0 = fmaxf(fmaxf(cur0 * sr.keep[r], acc0[r]), 0.f);
-    cur1 = fmaxf(fmaxf(cur1 * sr.keep[r], acc1[r]), 0.f);
+    cur0 = fmaxf(cur0, acc0[r]);                       // cur >= 0 always: the ReLU is the start value
+    cur1 = fmaxf(cur1, acc1[r]);
     if ((sr.uflush >> r) & 1u) {
       if ((sr.flush_bits >> r) & 1u) {
         int* o = reinterpret_cast<int*>(pool) + ((unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldpool + c0);
         if (ok0 && cur0 > 0.f) atomicMax(o, __float_as_int(cur0));
         if (ok1 && cur1 > 0.f) atomicMax(o + 32, __float_as_int(cur1));
+        cur0 = 0.f; cur1 = 0.f;                          // the lane's next row starts a new run
       }
     }
   }
@@ -76,8 +77,8 @@ __device__ __forceinline__ void fx_segmax2_lds(const f32x16& acc0, const f32x16&
   float cur0 = 0.f, cur1 = 0.f;
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
-    cur0 = fmaxf(fmaxf(cur0 * sr.keep[r], acc0[r]), 0.f);
-    cur1 = fmaxf(fmaxf(cur1 * sr.keep[r], acc1[r]), 0.f);
+    cur0 = fmaxf(cur0, acc0[r]);
+    cur1 = fmaxf(cur1, acc1[r]);
     if ((sr.uflush >> r) & 1u) {
       if ((sr.flush_bits >> r) & 1u) {
         const int sg = segs[(r & 3) + 8 * (r >> 2) + 4 * lhi];
@@ -90,6 +91,7 @@ __device__ __forceinline__ void fx_segmax2_lds(const f32x16& acc0, const f32x16&
           if (ok0 && cur0 > 0.f) atomicMax(o, __float_as_int(cur0));
           if (ok1 && cur1 > 0.f) atomicMax(o + 32, __float_as_int(cur1));
         }
+        cur0 = 0.f; cur1 = 0.f;
       }
     }
   }
