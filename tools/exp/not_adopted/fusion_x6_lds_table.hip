@@ -18,10 +18,6 @@
 // bf16_eval.hip's rows kernel (values >= 0: int order == float order, exact, order-independent).
 // fusion_block_super (P rows, its own weights, plain relu store) is a second problem of the same launch.
 #include "x6.hpp"
-#ifdef YOLAT_FX_STAMPS
-extern __device__ long long fx_stamps_d[4096 * 32];
-#define FX_EPI_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) fx_stamps_d[blockIdx.x * 32 + 25 + (k)] = wall_clock64(); } while (0)
-#endif
 #include "segmax.hpp"
 #include <algorithm>
 #include <map>
@@ -64,9 +60,10 @@ __device__ __forceinline__ unsigned long long fx_key(float z, bool neg, unsigned
 // kernel's MFMA time at two waves per SIMD.  Same key, same tie rule (strict >: the lowest row of equal values wins);
 // differences only where IEEE comparison and the key order differ: -0 / +0 inside one lane's run count as equal (the
 // lower row wins, as in torch_scatter's `>` walk), and a NaN never replaces a number.
-__device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1, unsigned long long* keys,
-                                         const unsigned off[16], unsigned c0, bool ok0, bool ok1, unsigned m0, unsigned m1,
+__device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1, unsigned long long* keys, unsigned ldk,
+                                         const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, bool neg0, bool neg1,
                                          unsigned rbase, const FxRuns& sr) {
+  const unsigned m0 = neg0 ? 0x80000000u : 0u, m1 = neg1 ? 0x80000000u : 0u;
   float cur0 = -INFINITY, cur1 = -INFINITY;
   int at0 = 0, at1 = 0;
 #pragma unroll
@@ -77,7 +74,7 @@ __device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1,
     cur1 = b1 ? x1 : cur1; at1 = b1 ? r : at1;
     if ((sr.uflush >> r) & 1u) {
       if ((sr.flush_bits >> r) & 1u) {
-        unsigned long long* o = keys + (off[r] + c0);      // (proposal id x F precomputed per row: no LDS read here)
+        unsigned long long* o = keys + ((unsigned long)(unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldk + c0);
         if (ok0) atomicMax(o, fx_key(cur0, false, rbase + (at0 & 3) + 8 * (at0 >> 2)));
         if (ok1) atomicMax(o + 32, fx_key(cur1, false, rbase + (at1 & 3) + 8 * (at1 >> 2)));
         cur0 = -INFINITY; cur1 = -INFINITY;              // the lane's next row starts a new run
@@ -129,6 +126,13 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   constexpr int SMEM_W = 2 * 3 * 64 * RS * 2, SMEM_T = NWAVE * 32 * TS * 4;
   __shared__ __attribute__((aligned(16))) char smem[SMEM_W > SMEM_T ? SMEM_W : SMEM_T];
   yl_bf16_t (*Ws)[3 * 64 * RS] = reinterpret_cast<yl_bf16_t (*)[3 * 64 * RS]>(smem);
+  __shared__ int seg_s[T / 2];
+  // eval-mode pooling, K = 128: per-column-tile pooled maxima of the workgroup's 256 rows (segmax.hpp, round 6 — the
+  // direct form sends ~2.8 k lane-atomics per column tile and workgroup to the L2: 44 M per cfg-5 launch, 1.0-1.3 us of
+  // every 4.8 us tile by the stamps of tools/exp/r06_fx_stamps.py, and in-order issue keeps MFMAs from hiding them).
+  // K = 64 keeps the direct atomics: two of its 75 KB workgroups share a CU.
+  constexpr int FX_TAB = KD == 128 ? FX_NP * 64 : 1;
+  __shared__ int tab_s[2 * FX_TAB];
   constexpr int FX_STG_LD = 36;
   // per-wave staging tile of the plain-store epilogue — KD = 64 only (node side, training Linear): the KD = 128 kernel
   // sits at 248 registers and spilled with it
@@ -201,43 +205,6 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int row0 = rt * (T / 2) + wave * 32;
   FX_STAMP(0);
-  // (round 6) everything the tile loop needs besides A goes out FIRST — the rows' proposal ids, the first W tile, its
-  // shifts and sign masks: their latency runs under the A prologue instead of after it (stamps: 1.5 us of a cfg-2
-  // workgroup's 23.5 lay between the end of the split and the first MFMA)
-  const int sv_pre = (P.seg != nullptr && row0 + l31 < N) ? P.seg[row0 + l31] : -1;
-  const yl_bf16_t* const wparts[3] = {small ? p1.Wh : p0.Wh, small ? p1.Wm : p0.Wm, small ? p1.Wl : p0.Wl};
-  // W tile pieces: thread tid moves 16-byte piece (tid + T t) of the [3][64][KD] tile; 64 * CPR is a multiple of
-  // T, so the part (hi / mid / lo) of piece t is a compile-time constant
-  constexpr int PER = 64 * CPR / T;                         // pieces per thread and part
-  static_assert((64 * CPR) % T == 0, "part boundary inside a thread's pieces");
-  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
-  auto load_w = [&](int ct, fx_u32x4* rw) {
-#pragma unroll
-    for (int t = 0; t < NW; ++t) {
-      const int part = t / PER;
-      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
-      rw[t] = *reinterpret_cast<const fx_u32x4*>(wparts[part] + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
-    }
-  };
-  auto store_w = [&](int buf, const fx_u32x4* rw) {
-#pragma unroll
-    for (int t = 0; t < NW; ++t) {
-      const int part = t / PER;
-      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
-      *reinterpret_cast<fx_u32x4*>(&Ws[buf][part * 64 * RS + r * RS + wk]) = rw[t];
-    }
-  };
-  fx_u32x4 rw[NW];
-  load_w(ct0, rw);
-  // shifts (and, training mode, the sign-bit masks of the key) of the first tile; later tiles: fetched one tile ahead,
-  // BEFORE that tile's W loads, so that no wait on them ever sits behind younger loads or the epilogue's atomics (vmcnt
-  // retires in order).  (Rounds 2-5 loaded the signs inside the epilogue: an exposed L2 round trip per column tile.)
-  float t0 = P.tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = P.tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
-  unsigned sm0 = 0u, sm1 = 0u;
-  if (P.key64 != nullptr) {
-    sm0 = P.sgn[yl_min(ct0 * 64 + l31, F - 1)] < 0.f ? 0x80000000u : 0u;
-    sm1 = P.sgn[yl_min(ct0 * 64 + 32 + l31, F - 1)] < 0.f ? 0x80000000u : 0u;
-  }
   // ---- this wave's 32 rows of A, split once.  Loaded row by row (a row's 64 floats of the pass = 16 lanes x 16 bytes:
   // whole cache lines per instruction, eight loads in flight) and turned into the MFMA operand order (lane = row, 8
   // consecutive k) through a [32][TK + 4] fp32 tile in LDS — the weights' buffers, not yet in use.  (Reading the operand
@@ -274,8 +241,45 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   FX_STAMP(1);
   const bool pooling = P.seg != nullptr;
   FxRuns runs;
-  unsigned roff[16];                                    // element offset of each of the lane's rows' proposal in the output
-  fx_seg_runs_off(sv_pre, lhi, P.key64 != nullptr ? (unsigned)F : (unsigned)P.ldo, runs, roff);
+  {
+    const int sv = (pooling && row0 + l31 < N) ? P.seg[row0 + l31] : -1;
+    if (lhi == 0) seg_s[wave * 32 + l31] = sv;          // read back by the same wave only, after the barrier below
+    fx_seg_runs(sv, lhi, runs);
+  }
+  const int* segs = seg_s + wave * 32;
+  FxTile tile{};
+  if (KD == 128 && pooling && P.key64 == nullptr) {
+    const int row_lo = rt * (T / 2), row_hi = yl_min(row_lo + T / 2, N);
+    tile = fx_tile(P.seg, row_lo, row_hi, N);
+    for (int e = tid; e < 2 * FX_TAB; e += T) tab_s[e] = 0;   // visible behind the barriers in front of the tile loop
+  }
+  const yl_bf16_t* const wparts[3] = {small ? p1.Wh : p0.Wh, small ? p1.Wm : p0.Wm, small ? p1.Wl : p0.Wl};
+  // W tile pieces: thread tid moves 16-byte piece (tid + T t) of the [3][64][KD] tile; 64 * CPR is a multiple of
+  // T, so the part (hi / mid / lo) of piece t is a compile-time constant
+  constexpr int PER = 64 * CPR / T;                         // pieces per thread and part
+  static_assert((64 * CPR) % T == 0, "part boundary inside a thread's pieces");
+  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
+  auto load_w = [&](int ct, fx_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int part = t / PER;
+      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
+      rw[t] = *reinterpret_cast<const fx_u32x4*>(wparts[part] + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
+    }
+  };
+  auto store_w = [&](int buf, const fx_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int part = t / PER;
+      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
+      *reinterpret_cast<fx_u32x4*>(&Ws[buf][part * 64 * RS + r * RS + wk]) = rw[t];
+    }
+  };
+  fx_u32x4 rw[NW];
+  load_w(ct0, rw);
+  // shifts of the first tile; later tiles: fetched one tile ahead, BEFORE that tile's W loads, so that no wait on
+  // them ever sits behind younger loads or the epilogue's atomics (vmcnt retires in order)
+  float t0 = P.tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = P.tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
   FX_STAMP(2);
   __syncthreads();                                          // every wave is done with its transposition tile
   store_w(0, rw);
@@ -287,16 +291,14 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = t0; acc1[r] = t1; }
-    const unsigned m0 = sm0, m1 = sm1;
     if (j + 1 < ngl) {
       t0 = P.tfold[yl_min(c0 + 64, F - 1)];
       t1 = P.tfold[yl_min(c1 + 64, F - 1)];
-      if (P.key64 != nullptr) {
-        sm0 = P.sgn[yl_min(c0 + 64, F - 1)] < 0.f ? 0x80000000u : 0u;
-        sm1 = P.sgn[yl_min(c1 + 64, F - 1)] < 0.f ? 0x80000000u : 0u;
-      }
       load_w(ct + 1, rw);                              // in flight while the MFMAs below run
     }
+    // the previous column tile's pooled maxima (complete since its closing barrier) go out while this tile's MFMAs run
+    if (KD == 128 && pooling && P.key64 == nullptr && j > 0)
+      fx_tab_drain(&tab_s[(buf ^ 1) * FX_TAB], tile, P.out, (unsigned)P.ldo, ct - 1, F, tid, T);
     const yl_bf16_t* wb = &Ws[buf][l31 * RS + 8 * lhi];
     // B fragments: column block 0 / 1 x hi / mid / lo; the compiler issues the next k step's reads as registers free up
 #pragma unroll
@@ -335,9 +337,14 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
     FX_STAMP(5 + 4 * (j & 3));
     if (pooling && P.key64 != nullptr) {
-      fx_key64(acc0, acc1, P.key64, roff, (unsigned)c0, c0 < F, c1 < F, m0, m1, (unsigned)(row0 + 4 * lhi), runs);
+      fx_key64(acc0, acc1, P.key64, (unsigned)F, segs, lhi, (unsigned)c0, c0 < F, c1 < F,
+               P.sgn[yl_min(c0, F - 1)] < 0.f, P.sgn[yl_min(c1, F - 1)] < 0.f, (unsigned)(row0 + 4 * lhi), runs);
     } else if (pooling) {
-      fx_segmax2_off(acc0, acc1, P.out, roff, (unsigned)c0, c0 < F, c1 < F, runs);
+      if constexpr (KD == 128)
+        fx_segmax2_lds(acc0, acc1, &tab_s[buf * FX_TAB], P.out, (unsigned)P.ldo, segs, tile.seg_base, lhi, (unsigned)c0,
+                       (unsigned)l31, c0 < F, c1 < F, runs);
+      else
+        fx_segmax2(acc0, acc1, P.out, (unsigned)P.ldo, segs, lhi, (unsigned)c0, c0 < F, c1 < F, runs);
     } else {
       // the row base goes through an opaque asm so that the 16 row addresses are recomputed here instead of being
       // kept in 32 registers across the MFMA loop
@@ -410,6 +417,8 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
     __syncthreads();
     FX_STAMP(7 + 4 * (j & 3));
   }
+  if (KD == 128 && pooling && P.key64 == nullptr)
+    fx_tab_drain(&tab_s[((ngl - 1) & 1) * FX_TAB], tile, P.out, (unsigned)P.ldo, ct0 + ngl - 1, F, tid, T);
   FX_STAMP(20);
   FX_STAMP_META();
 }
@@ -572,8 +581,7 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
                             yolat_stream_t stream) {
   if ((K != 64 && K != 128) || F % 64 != 0 || lda % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(wsplit) || !bias)
     return YOLAT_E_UNSUPPORTED;
-  // (the kernel addresses the keys with 32-bit element offsets proposal id x F; ids are < N)
-  if (N >= (1LL << 31) - 256 || (long long)N * F >= (1LL << 32)) return YOLAT_E_UNSUPPORTED;
+  if (N >= (1LL << 31) - 256) return YOLAT_E_UNSUPPORTED;
   uint16_t *wh = wsplit, *wm = wsplit + F * K, *wl = wsplit + 2 * F * K;
   const int rc = yolat_split_bf16x3(W, K, F, K, nullptr, wh, wm, wl, stream);
   if (rc != 0) return rc;

@@ -18,10 +18,6 @@
 // bf16_eval.hip's rows kernel (values >= 0: int order == float order, exact, order-independent).
 // fusion_block_super (P rows, its own weights, plain relu store) is a second problem of the same launch.
 #include "x6.hpp"
-#ifdef YOLAT_FX_STAMPS
-extern __device__ long long fx_stamps_d[4096 * 32];
-#define FX_EPI_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) fx_stamps_d[blockIdx.x * 32 + 25 + (k)] = wall_clock64(); } while (0)
-#endif
 #include "segmax.hpp"
 #include <algorithm>
 #include <map>
@@ -33,6 +29,9 @@ extern __device__ long long fx_stamps_d[4096 * 32];
 // rows kernel, read back through yolat_debug_fx_stamps — where a workgroup's time goes
 __device__ long long fx_stamps_d[4096 * 32];
 #define FX_STAMP(k) do { if (KD == 128 && threadIdx.x == 0 && blockIdx.x < 4096) fx_stamps_d[blockIdx.x * 32 + (k)] = wall_clock64(); } while (0)
+extern "C" int yolat_debug_fx_stamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_stamps_d), sizeof(long long) * (size_t)n);
+}
 #define FX_STAMP_META()                                                                          \
   do {                                                                                           \
     if (KD == 128 && threadIdx.x == 0 && blockIdx.x < 4096) {                                    \
@@ -43,9 +42,6 @@ __device__ long long fx_stamps_d[4096 * 32];
       fx_stamps_d[blockIdx.x * 32 + 23] = (long long)xcc_;                                       \
     }                                                                                            \
   } while (0)
-extern "C" int yolat_debug_fx_stamps(long long* out, int n) {
-  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(fx_stamps_d), sizeof(long long) * (size_t)n);
-}
 #else
 #define FX_STAMP(k) do { } while (0)
 #define FX_STAMP_META() do { } while (0)
@@ -64,27 +60,33 @@ __device__ __forceinline__ unsigned long long fx_key(float z, bool neg, unsigned
 // kernel's MFMA time at two waves per SIMD.  Same key, same tie rule (strict >: the lowest row of equal values wins);
 // differences only where IEEE comparison and the key order differ: -0 / +0 inside one lane's run count as equal (the
 // lower row wins, as in torch_scatter's `>` walk), and a NaN never replaces a number.
-__device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1, unsigned long long* keys,
-                                         const unsigned off[16], unsigned c0, bool ok0, bool ok1, unsigned m0, unsigned m1,
-                                         unsigned rbase, const FxRuns& sr) {
-  float cur0 = -INFINITY, cur1 = -INFINITY;
-  int at0 = 0, at1 = 0;
-#pragma unroll
-  for (int r = 0; r < 16; ++r) {
-    const float x0 = __uint_as_float(__float_as_uint(acc0[r]) ^ m0), x1 = __uint_as_float(__float_as_uint(acc1[r]) ^ m1);
-    const bool b0 = x0 > cur0, b1 = x1 > cur1;
-    cur0 = b0 ? x0 : cur0; at0 = b0 ? r : at0;
-    cur1 = b1 ? x1 : cur1; at1 = b1 ? r : at1;
-    if ((sr.uflush >> r) & 1u) {
-      if ((sr.flush_bits >> r) & 1u) {
-        unsigned long long* o = keys + (off[r] + c0);      // (proposal id x F precomputed per row: no LDS read here)
-        if (ok0) atomicMax(o, fx_key(cur0, false, rbase + (at0 & 3) + 8 * (at0 >> 2)));
-        if (ok1) atomicMax(o + 32, fx_key(cur1, false, rbase + (at1 & 3) + 8 * (at1 >> 2)));
-        cur0 = -INFINITY; cur1 = -INFINITY;              // the lane's next row starts a new run
-        at0 = r + 1; at1 = r + 1;
-      }
+struct FxKeyRun { float cur0, cur1; int at0, at1; };
+__device__ __forceinline__ void fx_key_begin(FxKeyRun& k) { k.cur0 = -INFINITY; k.cur1 = -INFINITY; k.at0 = 0; k.at1 = 0; }
+// one row of the walk (r is a compile-time constant after unrolling); m0 / m1: sign-bit masks of the two columns
+__device__ __forceinline__ void fx_key_row(int r, float v0, float v1, FxKeyRun& k, unsigned long long* keys, unsigned ldk,
+                                           const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, unsigned m0, unsigned m1,
+                                           unsigned rbase, const FxRuns& sr) {
+  const float x0 = __uint_as_float(__float_as_uint(v0) ^ m0), x1 = __uint_as_float(__float_as_uint(v1) ^ m1);
+  const bool b0 = x0 > k.cur0, b1 = x1 > k.cur1;
+  k.cur0 = b0 ? x0 : k.cur0; k.at0 = b0 ? r : k.at0;
+  k.cur1 = b1 ? x1 : k.cur1; k.at1 = b1 ? r : k.at1;
+  if ((sr.uflush >> r) & 1u) {
+    if ((sr.flush_bits >> r) & 1u) {
+      unsigned long long* o = keys + ((unsigned long)(unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldk + c0);
+      if (ok0) atomicMax(o, fx_key(k.cur0, false, rbase + (k.at0 & 3) + 8 * (k.at0 >> 2)));
+      if (ok1) atomicMax(o + 32, fx_key(k.cur1, false, rbase + (k.at1 & 3) + 8 * (k.at1 >> 2)));
+      k.cur0 = -INFINITY; k.cur1 = -INFINITY;            // the lane's next row starts a new run
+      k.at0 = r + 1; k.at1 = r + 1;
     }
   }
+}
+__device__ __forceinline__ void fx_key64(const f32x16& acc0, const f32x16& acc1, unsigned long long* keys, unsigned ldk,
+                                         const int* segs, int lhi, unsigned c0, bool ok0, bool ok1, unsigned m0, unsigned m1,
+                                         unsigned rbase, const FxRuns& sr) {
+  FxKeyRun k;
+  fx_key_begin(k);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) fx_key_row(r, acc0[r], acc1[r], k, keys, ldk, segs, lhi, c0, ok0, ok1, m0, m1, rbase, sr);
 }
 }  // namespace
 
@@ -129,6 +131,7 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   constexpr int SMEM_W = 2 * 3 * 64 * RS * 2, SMEM_T = NWAVE * 32 * TS * 4;
   __shared__ __attribute__((aligned(16))) char smem[SMEM_W > SMEM_T ? SMEM_W : SMEM_T];
   yl_bf16_t (*Ws)[3 * 64 * RS] = reinterpret_cast<yl_bf16_t (*)[3 * 64 * RS]>(smem);
+  __shared__ int seg_s[T / 2];
   constexpr int FX_STG_LD = 36;
   // per-wave staging tile of the plain-store epilogue — KD = 64 only (node side, training Linear): the KD = 128 kernel
   // sits at 248 registers and spilled with it
@@ -201,43 +204,6 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int row0 = rt * (T / 2) + wave * 32;
   FX_STAMP(0);
-  // (round 6) everything the tile loop needs besides A goes out FIRST — the rows' proposal ids, the first W tile, its
-  // shifts and sign masks: their latency runs under the A prologue instead of after it (stamps: 1.5 us of a cfg-2
-  // workgroup's 23.5 lay between the end of the split and the first MFMA)
-  const int sv_pre = (P.seg != nullptr && row0 + l31 < N) ? P.seg[row0 + l31] : -1;
-  const yl_bf16_t* const wparts[3] = {small ? p1.Wh : p0.Wh, small ? p1.Wm : p0.Wm, small ? p1.Wl : p0.Wl};
-  // W tile pieces: thread tid moves 16-byte piece (tid + T t) of the [3][64][KD] tile; 64 * CPR is a multiple of
-  // T, so the part (hi / mid / lo) of piece t is a compile-time constant
-  constexpr int PER = 64 * CPR / T;                         // pieces per thread and part
-  static_assert((64 * CPR) % T == 0, "part boundary inside a thread's pieces");
-  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
-  auto load_w = [&](int ct, fx_u32x4* rw) {
-#pragma unroll
-    for (int t = 0; t < NW; ++t) {
-      const int part = t / PER;
-      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
-      rw[t] = *reinterpret_cast<const fx_u32x4*>(wparts[part] + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
-    }
-  };
-  auto store_w = [&](int buf, const fx_u32x4* rw) {
-#pragma unroll
-    for (int t = 0; t < NW; ++t) {
-      const int part = t / PER;
-      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
-      *reinterpret_cast<fx_u32x4*>(&Ws[buf][part * 64 * RS + r * RS + wk]) = rw[t];
-    }
-  };
-  fx_u32x4 rw[NW];
-  load_w(ct0, rw);
-  // shifts (and, training mode, the sign-bit masks of the key) of the first tile; later tiles: fetched one tile ahead,
-  // BEFORE that tile's W loads, so that no wait on them ever sits behind younger loads or the epilogue's atomics (vmcnt
-  // retires in order).  (Rounds 2-5 loaded the signs inside the epilogue: an exposed L2 round trip per column tile.)
-  float t0 = P.tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = P.tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
-  unsigned sm0 = 0u, sm1 = 0u;
-  if (P.key64 != nullptr) {
-    sm0 = P.sgn[yl_min(ct0 * 64 + l31, F - 1)] < 0.f ? 0x80000000u : 0u;
-    sm1 = P.sgn[yl_min(ct0 * 64 + 32 + l31, F - 1)] < 0.f ? 0x80000000u : 0u;
-  }
   // ---- this wave's 32 rows of A, split once.  Loaded row by row (a row's 64 floats of the pass = 16 lanes x 16 bytes:
   // whole cache lines per instruction, eight loads in flight) and turned into the MFMA operand order (lane = row, 8
   // consecutive k) through a [32][TK + 4] fp32 tile in LDS — the weights' buffers, not yet in use.  (Reading the operand
@@ -274,31 +240,159 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   FX_STAMP(1);
   const bool pooling = P.seg != nullptr;
   FxRuns runs;
-  unsigned roff[16];                                    // element offset of each of the lane's rows' proposal in the output
-  fx_seg_runs_off(sv_pre, lhi, P.key64 != nullptr ? (unsigned)F : (unsigned)P.ldo, runs, roff);
+  {
+    const int sv = (pooling && row0 + l31 < N) ? P.seg[row0 + l31] : -1;
+    if (lhi == 0) seg_s[wave * 32 + l31] = sv;          // read back by the same wave only, after the barrier below
+    fx_seg_runs(sv, lhi, runs);
+  }
+  const int* segs = seg_s + wave * 32;
+  const yl_bf16_t* const wparts[3] = {small ? p1.Wh : p0.Wh, small ? p1.Wm : p0.Wm, small ? p1.Wl : p0.Wl};
+  // W tile pieces: thread tid moves 16-byte piece (tid + T t) of the [3][64][KD] tile; 64 * CPR is a multiple of
+  // T, so the part (hi / mid / lo) of piece t is a compile-time constant
+  constexpr int PER = 64 * CPR / T;                         // pieces per thread and part
+  static_assert((64 * CPR) % T == 0, "part boundary inside a thread's pieces");
+  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
+  auto load_w = [&](int ct, fx_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int part = t / PER;
+      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
+      rw[t] = *reinterpret_cast<const fx_u32x4*>(wparts[part] + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
+    }
+  };
+  auto store_w = [&](int buf, const fx_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const int part = t / PER;
+      const unsigned r = wr0 + (unsigned)(t % PER) * (T / CPR);
+      *reinterpret_cast<fx_u32x4*>(&Ws[buf][part * 64 * RS + r * RS + wk]) = rw[t];
+    }
+  };
+  fx_u32x4 rw[NW];
+  load_w(ct0, rw);
+  // shifts of the first tile; later tiles: fetched one tile ahead, BEFORE that tile's W loads, so that no wait on
+  // them ever sits behind younger loads or the epilogue's atomics (vmcnt retires in order)
+  float t0 = P.tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = P.tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
   FX_STAMP(2);
   __syncthreads();                                          // every wave is done with its transposition tile
   store_w(0, rw);
   __syncthreads();
   FX_STAMP(3);
+  // B fragments: column block 0 / 1 x hi / mid / lo; the compiler issues the next k step's reads as registers free up.
+  // Small terms first.  The empty asm ties both accumulators after every MFMA: it pins the MFMAs' program order
+  // (instruction selection otherwise pairs up MFMAs on the same accumulator) and emits nothing
+#define FX_MFMA(acc, a, b)                                         \
+  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); \
+  asm volatile("" : "+v"(acc0), "+v"(acc1))
+#define FX_MFMA_A(ks)          \
+  FX_MFMA(acc0, Al[ks], bf[0]); \
+  FX_MFMA(acc1, Al[ks], bf[1]); \
+  FX_MFMA(acc0, Ah[ks], bf[4]); \
+  FX_MFMA(acc1, Ah[ks], bf[5]); \
+  FX_MFMA(acc0, Am[ks], bf[2]); \
+  FX_MFMA(acc1, Am[ks], bf[3])
+#define FX_MFMA_B(ks)          \
+  FX_MFMA(acc0, Am[ks], bf[0]); \
+  FX_MFMA(acc1, Am[ks], bf[1]); \
+  FX_MFMA(acc0, Ah[ks], bf[2]); \
+  FX_MFMA(acc1, Ah[ks], bf[3]); \
+  FX_MFMA(acc0, Ah[ks], bf[0]); \
+  FX_MFMA(acc1, Ah[ks], bf[1])
+  if (pooling) {
+    // ---- pooling modes, software-pipelined (round 6).  Stamps of one cfg-2 workgroup (tools/exp/r06_fx_stamps.py): per
+    // column tile 2.0-3.0 us of MFMAs (the matrix pipe's rate at two waves per SIMD), then 1.0-2.0 us of pooling epilogue
+    // (run walk + global atomics, matrix pipe idle), 0.3-0.5 us of W staging / waits and 0.4-0.8 us of barrier — 47 % of a
+    // tile without an MFMA in flight.  A wave issues in order, so its epilogue only hides under MFMAs that FOLLOW it in its
+    // own instruction stream: the finished tile's accumulators move to a second pair (32 v_mov) and their walk is spread,
+    // RPS rows per k step, over the FIRST HALF of the next tile's k loop, between its MFMAs; the atomics are acknowledged
+    // during the second half, so the vmcnt(0) in front of the barrier still costs nothing.  Only the last tile's
+    // epilogue runs in the open.
+    const bool train = P.key64 != nullptr;
+    constexpr int ES = KS / 2, RPS = 16 / ES;          // k steps that carry epilogue rows, rows per step
+    f32x16 acc0, acc1, prv0, prv1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+    // sign masks of the columns (training): nm = the tile about to start (fetched one tile ahead, like the shifts), m = the
+    // tile whose products accumulate, pm = the tile whose walk runs
+    unsigned m0 = 0u, m1 = 0u, pm0 = 0u, pm1 = 0u, nm0 = 0u, nm1 = 0u;
+    if (train) {
+      nm0 = P.sgn[yl_min(ct0 * 64 + l31, F - 1)] < 0.f ? 0x80000000u : 0u;
+      nm1 = P.sgn[yl_min(ct0 * 64 + 32 + l31, F - 1)] < 0.f ? 0x80000000u : 0u;
+    }
+    const unsigned rbase = (unsigned)(row0 + 4 * lhi);
+    for (int j = 0; j < ngl; ++j) {
+      const int ct = ct0 + j, buf = j & 1;
+      const int c0 = ct * 64 + l31, c1 = c0 + 32;
+      const bool prev = j > 0;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) { prv0[r] = acc0[r]; prv1[r] = acc1[r]; acc0[r] = t0; acc1[r] = t1; }
+      pm0 = m0; pm1 = m1; m0 = nm0; m1 = nm1;
+      if (j + 1 < ngl) {
+        t0 = P.tfold[yl_min(c0 + 64, F - 1)];
+        t1 = P.tfold[yl_min(c1 + 64, F - 1)];
+        if (train) {
+          nm0 = P.sgn[yl_min(c0 + 64, F - 1)] < 0.f ? 0x80000000u : 0u;
+          nm1 = P.sgn[yl_min(c1 + 64, F - 1)] < 0.f ? 0x80000000u : 0u;
+        }
+      }
+      float cur0 = 0.f, cur1 = 0.f;
+      FxKeyRun kr;
+      fx_key_begin(kr);
+      const unsigned pc0 = (unsigned)(c0 - 64);
+      const bool pok0 = c0 - 64 < F, pok1 = c1 - 64 < F;
+      // rows [r_lo, r_lo + n) of the previous tile's walk
+      auto epi_rows = [&](int r_lo, int n) {
+#pragma unroll
+        for (int i = 0; i < n; ++i) {
+          const int r = r_lo + i;
+          if (train) fx_key_row(r, prv0[r], prv1[r], kr, P.key64, (unsigned)F, segs, lhi, pc0, pok0, pok1, pm0, pm1, rbase, runs);
+          else fx_segmax_row(r, prv0[r], prv1[r], cur0, cur1, P.out, (unsigned)P.ldo, segs, lhi, pc0, pok0, pok1, runs);
+        }
+      };
+      const yl_bf16_t* wb = &Ws[buf][l31 * RS + 8 * lhi];
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        fx_bf16x8 bf[6];                               // [0] b0h [1] b1h [2] b0m [3] b1m [4] b0l [5] b1l
+#pragma unroll
+        for (int q = 0; q < 6; ++q) bf[q] = *reinterpret_cast<const fx_bf16x8*>(wb + q * 32 * RS + 16 * ks);
+        // the next tile's W pieces go out when the walk is through: their 24 registers are the ones the previous tile's
+        // accumulators just left (with both live the kernel needs 271); half a tile of MFMAs covers their latency
+        if (ks == ES && j + 1 < ngl) load_w(ct + 1, rw);
+        FX_MFMA_A(ks);
+        if (ks < ES && prev) epi_rows(ks * RPS, RPS / 2);
+        FX_MFMA_B(ks);
+        if (ks < ES && prev) epi_rows(ks * RPS + RPS / 2, RPS / 2);
+      }
+      FX_STAMP(4 + 4 * (j & 3));
+      if (j + 1 < ngl) store_w(buf ^ 1, rw);
+      __builtin_amdgcn_s_waitcnt(0x0F70);              // vmcnt(0): shifts, masks, W pieces, the walk's atomics (half a tile old)
+      FX_STAMP(5 + 4 * (j & 3));
+      FX_STAMP(6 + 4 * (j & 3));
+      __syncthreads();
+      FX_STAMP(7 + 4 * (j & 3));
+    }
+    {   // the last tile's epilogue
+      const unsigned lc0 = (unsigned)((ct0 + ngl - 1) * 64 + l31);
+      const bool lok0 = (int)lc0 < F, lok1 = (int)lc0 + 32 < F;
+      if (train) fx_key64(acc0, acc1, P.key64, (unsigned)F, segs, lhi, lc0, lok0, lok1, m0, m1, rbase, runs);
+      else fx_segmax2(acc0, acc1, P.out, (unsigned)P.ldo, segs, lhi, lc0, lok0, lok1, runs);
+    }
+    FX_STAMP(20);
+    FX_STAMP_META();
+    return;
+  }
   for (int j = 0; j < ngl; ++j) {
     const int ct = ct0 + j, buf = j & 1;
     const int c0 = ct * 64 + l31, c1 = c0 + 32;
     f32x16 acc0, acc1;
 #pragma unroll
     for (int r = 0; r < 16; ++r) { acc0[r] = t0; acc1[r] = t1; }
-    const unsigned m0 = sm0, m1 = sm1;
     if (j + 1 < ngl) {
       t0 = P.tfold[yl_min(c0 + 64, F - 1)];
       t1 = P.tfold[yl_min(c1 + 64, F - 1)];
-      if (P.key64 != nullptr) {
-        sm0 = P.sgn[yl_min(c0 + 64, F - 1)] < 0.f ? 0x80000000u : 0u;
-        sm1 = P.sgn[yl_min(c1 + 64, F - 1)] < 0.f ? 0x80000000u : 0u;
-      }
       load_w(ct + 1, rw);                              // in flight while the MFMAs below run
     }
     const yl_bf16_t* wb = &Ws[buf][l31 * RS + 8 * lhi];
-    // B fragments: column block 0 / 1 x hi / mid / lo; the compiler issues the next k step's reads as registers free up
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       fx_bf16x8 bf[6];                                 // [0] b0h [1] b1h [2] b0m [3] b1m [4] b0l [5] b1l
@@ -306,24 +400,8 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
       for (int q = 0; q < 6; ++q) {
         bf[q] = *reinterpret_cast<const fx_bf16x8*>(wb + q * 32 * RS + 16 * ks);
       }
-      // small terms first.  The empty asm ties both accumulators after every MFMA: it pins the MFMAs' program order
-      // (instruction selection otherwise pairs up MFMAs on the same accumulator) and emits nothing
-#define FX_MFMA(acc, a, b)                                         \
-  acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc, 0, 0, 0); \
-  asm volatile("" : "+v"(acc0), "+v"(acc1))
-      FX_MFMA(acc0, Al[ks], bf[0]);
-      FX_MFMA(acc1, Al[ks], bf[1]);
-      FX_MFMA(acc0, Ah[ks], bf[4]);
-      FX_MFMA(acc1, Ah[ks], bf[5]);
-      FX_MFMA(acc0, Am[ks], bf[2]);
-      FX_MFMA(acc1, Am[ks], bf[3]);
-      FX_MFMA(acc0, Am[ks], bf[0]);
-      FX_MFMA(acc1, Am[ks], bf[1]);
-      FX_MFMA(acc0, Ah[ks], bf[2]);
-      FX_MFMA(acc1, Ah[ks], bf[3]);
-      FX_MFMA(acc0, Ah[ks], bf[0]);
-      FX_MFMA(acc1, Ah[ks], bf[1]);
-#undef FX_MFMA
+      FX_MFMA_A(ks);
+      FX_MFMA_B(ks);
     }
     // next W tile into the other buffer (its readers finished before the last barrier) BEFORE the epilogue: the
     // wait for its loads then never includes the epilogue's atomics / stores
@@ -334,11 +412,7 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
     // of the next tile, where the wait would also cover this tile's atomics (vmcnt retires in order)
     __builtin_amdgcn_s_waitcnt(0x0F70);                // vmcnt(0)
     FX_STAMP(5 + 4 * (j & 3));
-    if (pooling && P.key64 != nullptr) {
-      fx_key64(acc0, acc1, P.key64, roff, (unsigned)c0, c0 < F, c1 < F, m0, m1, (unsigned)(row0 + 4 * lhi), runs);
-    } else if (pooling) {
-      fx_segmax2_off(acc0, acc1, P.out, roff, (unsigned)c0, c0 < F, c1 < F, runs);
-    } else {
+    {
       // the row base goes through an opaque asm so that the 16 row addresses are recomputed here instead of being
       // kept in 32 registers across the MFMA loop
       unsigned rb = (unsigned)(row0 + 4 * lhi);
@@ -412,6 +486,9 @@ __global__ void __launch_bounds__(FxShape<KD>::T, 2) k_fusion_rows_x6(FxProb p0,
   }
   FX_STAMP(20);
   FX_STAMP_META();
+#undef FX_MFMA_A
+#undef FX_MFMA_B
+#undef FX_MFMA
 }
 
 // W [rows, cols] fp32 (optionally scaled per row) -> three bfloat16 matrices hi / mid / lo [rows, cols] with
@@ -572,8 +649,7 @@ int yl_fusion_rows_x6_key64(const float* A, long lda, long N, long K, const floa
                             yolat_stream_t stream) {
   if ((K != 64 && K != 128) || F % 64 != 0 || lda % 4 != 0 || !yl_aligned16(A) || !yl_aligned16(wsplit) || !bias)
     return YOLAT_E_UNSUPPORTED;
-  // (the kernel addresses the keys with 32-bit element offsets proposal id x F; ids are < N)
-  if (N >= (1LL << 31) - 256 || (long long)N * F >= (1LL << 32)) return YOLAT_E_UNSUPPORTED;
+  if (N >= (1LL << 31) - 256) return YOLAT_E_UNSUPPORTED;
   uint16_t *wh = wsplit, *wm = wsplit + F * K, *wl = wsplit + 2 * F * K;
   const int rc = yolat_split_bf16x3(W, K, F, K, nullptr, wh, wm, wl, stream);
   if (rc != 0) return rc;

@@ -3,6 +3,9 @@
 // the fusion block's activations, which are never written to memory.
 #pragma once
 #include "common.hpp"
+#ifndef FX_EPI_STAMP
+#define FX_EPI_STAMP(k) do { } while (0)      // debug builds of fusion_x6.hip define it (tools/exp/r06_fx_stamps.sh)
+#endif
 
 namespace {
 // Run structure of a lane's 16 rows (C/D layout of a 32x32 MFMA tile) from their proposal ids — the same for every
@@ -24,6 +27,47 @@ __device__ __forceinline__ void fx_seg_runs(int segv, int lhi, FxRuns& sr) {
   }
   sr.flush_bits = fb; sr.uflush = uf;
 }
+// The same with the 32-bit element offset of every row's proposal (id x stride) kept in 16 registers: the flush block of
+// the direct-atomics epilogue then needs no LDS read (and no wait for it) — round 6, the fp32 rows kernel has the registers
+// since its training epilogue shrank.
+__device__ __forceinline__ void fx_seg_runs_off(int segv, int lhi, unsigned stride, FxRuns& sr, unsigned off[16]) {
+  int sgs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);
+  unsigned fb = 0, uf = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    off[r] = (unsigned)(sgs[r] < 0 ? 0 : sgs[r]) * stride;
+    const bool fl = sgs[r] >= 0 && (r == 15 || sgs[r] != sgs[r + 1]);
+    fb |= fl ? (1u << r) : 0u;
+    uf |= (__builtin_amdgcn_ballot_w64(fl) != 0ull) ? (1u << r) : 0u;
+  }
+  sr.flush_bits = fb; sr.uflush = uf;
+}
+// Direct-atomics epilogue on those offsets.  The running maximum is an INTEGER max on the float bits: cur >= 0 always (it
+// starts at 0 = the ReLU), so a negative value (sign bit: a negative integer) never wins and non-negative floats order like
+// their bits — one v_max_i32 per element where fmaxf costs three instructions (both operands are canonicalised first).
+// A positive NaN wins (as it does in the integer atomicMax that follows, and in torch's max); fmaxf dropped it.
+__device__ __forceinline__ void fx_segmax2_off(const f32x16& acc0, const f32x16& acc1, float* pool, const unsigned off[16],
+                                               unsigned c0, bool ok0, bool ok1, const FxRuns& sr) {
+  int cur0 = 0, cur1 = 0;
+  FX_EPI_STAMP(0);
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cur0 = yl_max(cur0, __float_as_int(acc0[r]));
+    cur1 = yl_max(cur1, __float_as_int(acc1[r]));
+    if ((sr.uflush >> r) & 1u) {
+      if ((sr.flush_bits >> r) & 1u) {
+        int* o = reinterpret_cast<int*>(pool) + (off[r] + c0);
+        if (ok0 && cur0 > 0) atomicMax(o, cur0);
+        if (ok1 && cur1 > 0) atomicMax(o + 32, cur1);
+        cur0 = 0; cur1 = 0;                              // the lane's next row starts a new run
+      }
+    }
+    if ((r & 3) == 3) FX_EPI_STAMP(1 + (r >> 2));
+  }
+}
+
 // values = relu(acc) (the shift is the accumulator's initial value, the scale is inside the weights).  Both column
 // blocks in one pass: two independent running-max chains (the chain is latency bound) and one test per row.
 __device__ __forceinline__ void fx_segmax2(const f32x16& acc0, const f32x16& acc1, float* pool, unsigned ldpool,
@@ -92,6 +136,49 @@ __device__ __forceinline__ void fx_segmax2_lds(const f32x16& acc0, const f32x16&
           if (ok1 && cur1 > 0.f) atomicMax(o + 32, __float_as_int(cur1));
         }
         cur0 = 0.f; cur1 = 0.f;
+      }
+    }
+  }
+}
+// Round 6: the same with the table offset of every row's proposal (position x 64; >= FX_NP * 64: the proposal is
+// beyond the table) in 16 registers and the running maximum as an integer max on the float bits (see fx_segmax2_off): per
+// element one instruction instead of three, per flush no LDS read of the proposal id and no wait for it.  Stamps of the
+// fp32 kernel (tools/exp/r06_fx_stamps.py) price this walk at ~1 us per column tile and wave — twice the bf16 kernel's
+// 16 MFMAs per tile.
+__device__ __forceinline__ void fx_seg_runs_tab(int segv, int lhi, int seg_base, FxRuns& sr, unsigned toff[16]) {
+  int sgs[16];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sgs[r] = __shfl(segv, (r & 3) + 8 * (r >> 2) + 4 * lhi);
+  unsigned fb = 0, uf = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const unsigned pos = (unsigned)(sgs[r] - seg_base);
+    toff[r] = (sgs[r] >= 0 && pos < (unsigned)FX_NP) ? pos * 64u : 0xFFFFFFFFu;
+    const bool fl = sgs[r] >= 0 && (r == 15 || sgs[r] != sgs[r + 1]);
+    fb |= fl ? (1u << r) : 0u;
+    uf |= (__builtin_amdgcn_ballot_w64(fl) != 0ull) ? (1u << r) : 0u;
+  }
+  sr.flush_bits = fb; sr.uflush = uf;
+}
+__device__ __forceinline__ void fx_segmax2_lds_off(const f32x16& acc0, const f32x16& acc1, int* tab, float* pool,
+                                                   unsigned ldpool, const int* segs, const unsigned toff[16], int lhi,
+                                                   unsigned c0, unsigned cl, bool ok0, bool ok1, const FxRuns& sr) {
+  int cur0 = 0, cur1 = 0;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    cur0 = yl_max(cur0, __float_as_int(acc0[r]));
+    cur1 = yl_max(cur1, __float_as_int(acc1[r]));
+    if ((sr.uflush >> r) & 1u) {
+      if ((sr.flush_bits >> r) & 1u) {
+        if (toff[r] != 0xFFFFFFFFu) {
+          if (ok0 && cur0 > 0) atomicMax(tab + toff[r] + cl, cur0);
+          if (ok1 && cur1 > 0) atomicMax(tab + toff[r] + 32 + cl, cur1);
+        } else {
+          int* o = reinterpret_cast<int*>(pool) + ((unsigned)segs[(r & 3) + 8 * (r >> 2) + 4 * lhi] * ldpool + c0);
+          if (ok0 && cur0 > 0) atomicMax(o, cur0);
+          if (ok1 && cur1 > 0) atomicMax(o + 32, cur1);
+        }
+        cur0 = 0; cur1 = 0;
       }
     }
   }
