@@ -21,7 +21,7 @@ typedef unsigned h8_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 h8_bf16x8 __attribute__((ext_vector_type(8)));
 
 #ifdef YOLAT_H8_STAMPS
-// debug build only (tools/exp/r06_fx_stamps.sh <cfg> h8): wall-clock stamps (100 MHz) of thread 0 of every workgroup
+// debug build only (tools/exp/r06_fx_stamps.sh h8): wall-clock stamps (100 MHz) of thread 0 of every workgroup
 __device__ long long h8_stamps_d[4096 * 32];
 #define H8_STAMP(k) do { if (KD == 128 && threadIdx.x == 0 && blockIdx.x < 4096) h8_stamps_d[blockIdx.x * 32 + (k)] = wall_clock64(); } while (0)
 #define H8_STAMP_META()                                                          \
@@ -48,6 +48,7 @@ struct H8Prob {
   const int* seg;       // != NULL: pooling epilogue into out (pooled matrix); else out[row, col] = relu(.)
   float* out; long ldo;
   int F, tm, groups, ng;
+  int v4;               // pooled rows are 16-byte addressable (out aligned, ldo % 4 == 0): the drain moves 16-byte pieces
 };
 
 template <int KD>
@@ -83,6 +84,7 @@ __global__ void __launch_bounds__(512, 2) k_hfusion_rows8(H8Prob p0, H8Prob p1) 
   float* const out = small ? p1.out : p0.out;
   const long ldo = small ? p1.ldo : p0.ldo;
   const int groups = small ? p1.groups : p0.groups, ng = small ? p1.ng : p0.ng;
+  const int v4 = small ? p1.v4 : p0.v4;
   const int rt = logical / groups, cg = logical % groups;
   const int tn = (F + 63) >> 6;
   const int ct0 = cg * ng;
@@ -92,6 +94,34 @@ __global__ void __launch_bounds__(512, 2) k_hfusion_rows8(H8Prob p0, H8Prob p1) 
   const int wave = tid >> 6, lane = tid & 63, l31 = lane & 31, lhi = lane >> 5;
   const int row0 = rt * 256 + wave * 32;
   H8_STAMP(0);
+  const bool pooling = seg != nullptr;
+  // (round 6) everything the tile loop needs besides A goes out first — the tile's proposal range (four scalar loads), the
+  // rows' proposal ids, the first W tile and its shifts: one round trip under the A loads instead of a chain behind them
+  // (stamps: 3.3 us of a workgroup's 43 between the A loads' issue and the first barrier)
+  FxTile tile{};
+  if (pooling) {
+    const int row_lo = rt * 256, row_hi = yl_min(row_lo + 256, N);
+    tile = fx_tile(seg, row_lo, row_hi, N);
+  }
+  const int sv = (pooling && row0 + l31 < N) ? seg[row0 + l31] : -1;
+  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
+  auto load_w = [&](int ct, h8_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const unsigned r = wr0 + (unsigned)t * (512 / CPR);
+      rw[t] = *reinterpret_cast<const h8_u32x4*>(W + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
+    }
+  };
+  auto store_w = [&](int buf, const h8_u32x4* rw) {
+#pragma unroll
+    for (int t = 0; t < NW; ++t) {
+      const unsigned r = wr0 + (unsigned)t * (512 / CPR);
+      *reinterpret_cast<h8_u32x4*>(&Ws[buf][r * RS + wk]) = rw[t];
+    }
+  };
+  h8_u32x4 rw[NW];
+  load_w(ct0, rw);
+  float t0 = tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
   // ---- this wave's 32 rows of A as MFMA A fragments (lane = row, 8 consecutive k per lane half)
   h8_bf16x8 Afr[KS];
   {
@@ -112,38 +142,12 @@ __global__ void __launch_bounds__(512, 2) k_hfusion_rows8(H8Prob p0, H8Prob p1) 
     }
   }
   H8_STAMP(1);
-  const bool pooling = seg != nullptr;
-  FxTile tile{};
-  if (pooling) {
-    const int row_lo = rt * 256, row_hi = yl_min(row_lo + 256, N);
-    tile = fx_tile(seg, row_lo, row_hi, N);
+  if (pooling)
     for (int e = tid; e < 2 * FX_NP * 64; e += 512) (&tab_s[0][0])[e] = 0;
-  }
   FxRuns runs;
-  {
-    const int sv = (pooling && row0 + l31 < N) ? seg[row0 + l31] : -1;
-    if (lhi == 0) seg_s[wave * 32 + l31] = sv;          // read back by the same wave only, after the barrier below
-    fx_seg_runs(sv, lhi, runs);
-  }
+  if (lhi == 0) seg_s[wave * 32 + l31] = sv;            // read back by the same wave only, after the barrier below
+  fx_seg_runs(sv, lhi, runs);
   const int* segs = seg_s + wave * 32;
-  const unsigned wr0 = (unsigned)tid / CPR, wk = ((unsigned)tid % CPR) * 8;   // row (of the first piece), k offset
-  auto load_w = [&](int ct, h8_u32x4* rw) {
-#pragma unroll
-    for (int t = 0; t < NW; ++t) {
-      const unsigned r = wr0 + (unsigned)t * (512 / CPR);
-      rw[t] = *reinterpret_cast<const h8_u32x4*>(W + (unsigned)yl_min(ct * 64 + (int)r, F - 1) * KD + wk);
-    }
-  };
-  auto store_w = [&](int buf, const h8_u32x4* rw) {
-#pragma unroll
-    for (int t = 0; t < NW; ++t) {
-      const unsigned r = wr0 + (unsigned)t * (512 / CPR);
-      *reinterpret_cast<h8_u32x4*>(&Ws[buf][r * RS + wk]) = rw[t];
-    }
-  };
-  h8_u32x4 rw[NW];
-  load_w(ct0, rw);
-  float t0 = tfold[yl_min(ct0 * 64 + l31, F - 1)], t1 = tfold[yl_min(ct0 * 64 + 32 + l31, F - 1)];
   H8_STAMP(2);
   store_w(0, rw);
   __syncthreads();
@@ -160,7 +164,10 @@ __global__ void __launch_bounds__(512, 2) k_hfusion_rows8(H8Prob p0, H8Prob p1) 
       load_w(ct + 1, rw);                              // in flight while the MFMAs below run
     }
     // the previous column tile's pooled maxima (complete since its closing barrier) go out while this tile's MFMAs run
-    if (pooling && j > 0) fx_tab_drain(tab_s[buf ^ 1], tile, out, (unsigned)ldo, ct - 1, F, tid, 512);
+    if (pooling && j > 0) {
+      if (v4) fx_tab_drain_v4(tab_s[buf ^ 1], tile, out, (unsigned)ldo, ct - 1, tid, 512);
+      else fx_tab_drain(tab_s[buf ^ 1], tile, out, (unsigned)ldo, ct - 1, F, tid, 512);
+    }
     if (j >= 4 && j < 8) H8_STAMP(24 + (j - 4));        // after the drain of tiles 4..7
     const u16* wb = &Ws[buf][l31 * RS + 8 * lhi];
 #pragma unroll
@@ -198,7 +205,10 @@ __global__ void __launch_bounds__(512, 2) k_hfusion_rows8(H8Prob p0, H8Prob p1) 
   }
   H8_STAMP(20);
   H8_STAMP_META();
-  if (pooling) fx_tab_drain(tab_s[(ngl - 1) & 1], tile, out, (unsigned)ldo, ct0 + ngl - 1, F, tid, 512);
+  if (pooling) {
+    if (v4) fx_tab_drain_v4(tab_s[(ngl - 1) & 1], tile, out, (unsigned)ldo, ct0 + ngl - 1, tid, 512);
+    else fx_tab_drain(tab_s[(ngl - 1) & 1], tile, out, (unsigned)ldo, ct0 + ngl - 1, F, tid, 512);
+  }
 }
 
 // A [N, lda] bf16 x Wf [F, D] (folded) with the per-proposal max into pool [*, ld_pool] (columns 0..F), and
@@ -233,6 +243,7 @@ int yl_hfusion_rows8(const uint16_t* A, int64_t lda, int64_t N, int64_t D, const
   H8Prob p0{}, p1{};
   p0.Ah = A; p0.Af = nullptr; p0.lda = lda; p0.N = (int)N; p0.W = Wf; p0.tfold = tf; p0.seg = seg; p0.out = pool;
   p0.ldo = ld_pool; p0.F = (int)F;
+  p0.v4 = (ld_pool % 4 == 0 && yl_aligned16(pool)) ? 1 : 0;
   split(N, p0.tm, p0.groups, p0.ng, false);
   p1.Ah = nullptr; p1.Af = As; p1.lda = lda_s; p1.N = (int)P; p1.W = Wfs; p1.tfold = tfs; p1.seg = nullptr; p1.out = sup_out;
   p1.ldo = ld_sup; p1.F = (int)F;

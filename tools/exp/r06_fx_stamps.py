@@ -20,8 +20,11 @@ from yolat_vectorgraphicsrecognition_amd._lib import lib  # noqa: E402
 
 def main():
     cfg = sys.argv[1] if len(sys.argv) > 1 else "2"
+    h8 = len(sys.argv) > 2 and sys.argv[2] == "h8"      # the bf16 kernel (fusion_h8.hip, -DYOLAT_H8_STAMPS): tiles 4..7
     data, slices, optkw, _ = yv.config(cfg)
     model = gu.fill_state_(yv.SparseCADGCN(yv.Opt(**optkw)), 0).cuda().eval()
+    if h8:
+        model.set_eval_precision("bf16")
     bench.to_device(data)
 
     def one():
@@ -34,7 +37,7 @@ def main():
     n = 4096 * 32
     buf = (ctypes.c_longlong * n)()
     zero = (ctypes.c_longlong * n)()
-    fn = lib.yolat_debug_fx_stamps
+    fn = lib.yolat_debug_h8_stamps if h8 else lib.yolat_debug_fx_stamps
     fn.argtypes = [ctypes.c_void_p, ctypes.c_int]
     rc = fn(buf, n)
     assert rc == 0, rc
@@ -58,14 +61,19 @@ def main():
         print("   runs + W0 issue (1->2)    : median %.2f us" % us(np.median(s[:, 2] - s[:, 1])))
         print("   barrier + W0 -> LDS (2->3): median %.2f us" % us(np.median(s[:, 3] - s[:, 2])))
         for j in range(int(min(4, ngl.max()))):
-            m = ngl > j
-            prev = s[m, 3] if j == 0 else s[m, 7 + 4 * (j - 1)]
+            m = ngl > (j + 4 if h8 else j)
+            if not m.any():
+                continue
+            prev = (s[m, 28] if h8 else s[m, 3]) if j == 0 else s[m, 7 + 4 * (j - 1)]
+            if h8:
+                print("   tile %d: drain %.2f |" % (j + 4, us(np.median(s[m, 24 + j] - prev))), end="")
+                prev = s[m, 24 + j]
             print("   tile %d: MFMAs %.2f | store_w + vmcnt(0) %.2f | epilogue %.2f | barrier %.2f us   (median over %d)" % (
                 j, us(np.median(s[m, 4 + 4 * j] - prev)), us(np.median(s[m, 5 + 4 * j] - s[m, 4 + 4 * j])),
                 us(np.median(s[m, 6 + 4 * j] - s[m, 5 + 4 * j])), us(np.median(s[m, 7 + 4 * j] - s[m, 6 + 4 * j])), m.sum()))
         print("   whole workgroup (0->end)  : median %.2f  max %.2f us;  end after launch begin: median %.2f  max %.2f us" % (
             us(np.median(s[:, 20] - s[:, 0])), us((s[:, 20] - s[:, 0]).max()), us(np.median(s[:, 20] - t0)), us((s[:, 20] - t0).max())))
-        if s[:, 25].max() > 0:
+        if not h8 and s[:, 25].max() > 0:
             e = s[:, 25:30]
             print("   last tile's run walk (wave 0): rows 0-3 %.2f | 4-7 %.2f | 8-11 %.2f | 12-15 %.2f us (median)" % tuple(
                 us(np.median(e[:, i + 1] - e[:, i])) for i in range(4)))
