@@ -273,6 +273,17 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2(const float* __restrict__ 
 // ------------------------------------------------------------------------------------------------
 // NG = 16-node groups per tile: 1 (<= 16 nodes, the dense-graph case) or 4 (<= 64 nodes: graphs with ~1 edge per
 // node — the Floorplans shape — would otherwise fill a 64-edge pass to a third).
+#ifdef YOLAT_EDGE_STAMPS
+// debug build only (tools/exp/r06_edge_stamps.sh): wall-clock stamps (100 MHz) of thread 0 of every node-tile workgroup
+__device__ long long edge_stamps_d[2][4096 * 16];
+__device__ int edge_stamps_launch_d;
+#define EDGE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) edge_stamps_d[nx.Wp != nullptr ? 0 : 1][blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
+extern "C" int yolat_debug_edge_stamps(long long* out, int n) {
+  return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(edge_stamps_d), sizeof(long long) * (size_t)n);
+}
+#else
+#define EDGE_STAMP(k) do { } while (0)
+#endif
 template <int NG>
 __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restrict__ UV, long ld_uv,
                                                            const int* __restrict__ src,
@@ -334,6 +345,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   }
   const int n0 = blockIdx.x * npt;
   const int nn = yl_min(npt, N - n0);                 // nodes of this tile
+  EDGE_STAMP(0);
   if (tid <= 16 * NG) rp[tid] = row_ptr[yl_min(n0 + tid, n0 + nn)];
   const int q = tid & 15, rb = tid >> 4;              // gather role: columns 4q..4q+3 of rows rb + 16t
   const int col = wn * 32 + l31;                      // MFMA role: output column of this lane
@@ -342,21 +354,25 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   // finishes with at the very end: both shorten the workgroup's chain of dependent global round trips, which is what
   // a small graph's launch time consists of (715 workgroups, all resident at once, at E = 40 k)
   const int e0g = row_ptr[n0], e1g = row_ptr[n0 + nn];
-  int di0[4], si0[4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int e = yl_min(e0g + rb + 16 * t, E - 1);
-    di0[t] = dst[e]; si0[t] = src[e];
-  }
-  float4 fo[NG];
-#pragma unroll
-  for (int j = 0; j < NG; ++j)
-    fo[j] = *reinterpret_cast<const float4*>(f_out + (long)yl_min(n0 + rb + 16 * j, N - 1) * ld_fo + 4 * q);
+  // (round 6, after the stamps of tools/exp/r06_edge_stamps.py: 3.0-3.7 us of a 9.5-13.8 us workgroup passed before the
+  // first barrier) the loads that depend on nothing — the layer-2 weight tile, the f_out rows, and below the next layer's
+  // B fragments — go out BEFORE the edge ids, which have to wait for the tile's edge range: their round trip runs under the
+  // row_ptr -> ids chain instead of behind it (vmcnt retires in order)
   float rw2[4][4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int i = tid + t * 256;
     W2.template load4<false>(i >> 4, 4 * (i & 15), rw2[t]);
+  }
+  float4 fo[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j)
+    fo[j] = *reinterpret_cast<const float4*>(f_out + (long)yl_min(n0 + rb + 16 * j, N - 1) * ld_fo + 4 * q);
+  int di0[4], si0[4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int e = yl_min(e0g + rb + 16 * t, E - 1);
+    di0[t] = dst[e]; si0[t] = src[e];
   }
   float4 wc[4];
 #pragma unroll
@@ -380,7 +396,9 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       for (int ks = 0; ks < 16; ++ks) bf0[ks] = nx.Wp[(wave * 16 + ks) * 64 + lane];
     }
   }
+  EDGE_STAMP(1);
   __syncthreads();
+  EDGE_STAMP(2);
   const int e0 = e0g, e1 = e1g;
   int my_b[NG], my_e[NG];                             // aggregation role: nodes rb + 16 j, columns 4q..
   float4 sum[NG];
@@ -420,7 +438,9 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       hrow[2] = one(u[t].z, v[t].z, wc[2], bb.z, sc.z, sh.z);
       hrow[3] = one(u[t].w, v[t].w, wc[3], bb.w, sc.w, sh.w);
     }
+    if (c0 == e0) EDGE_STAMP(3);
     __syncthreads();
+    if (c0 == e0) EDGE_STAMP(4);
     f32x16 acc2;
 #pragma unroll
     for (int r = 0; r < 16; ++r) acc2[r] = 0.f;
@@ -430,6 +450,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       const float bv = W2s[(wn * 32 + l31) * LDH + kk + lhi];
       acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc2, 0, 0, 0);
     }
+    if (c0 == e0) EDGE_STAMP(5);
     __syncthreads();                      // every wave is done reading Hs as the layer-1 tile
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -437,6 +458,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       Hs[row * LDH + col] = fmaxf(fmaf(acc2[r] + bias2, sc2, sh2), 0.f);
     }
     __syncthreads();
+    if (c0 == e0) EDGE_STAMP(6);
 #pragma unroll
     for (int j = 0; j < NG; ++j) {
       if (rb + 16 * j < nn) {             // rows of node rb + 16 j inside this pass, ascending edge order
@@ -448,7 +470,22 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
         }
       }
     }
+    if (c0 == e0) EDGE_STAMP(7);
     __syncthreads();
+  }
+  EDGE_STAMP(8);
+  // (round 6) the second and third column tile's B fragments of the next layer's node side go out HERE, together, under the
+  // f_out epilogue — they used to be fetched one tile ahead under sixteen small MFMAs (0.15 us of cover for a 1 us round
+  // trip, twice: 3.8 us for the tail by the stamps of tools/exp/r06_edge_stamps.py); the gather registers are free now
+  float bf1[16], bf2[16];
+  if constexpr (NG == 1) {
+    if (nx.Wp != nullptr) {
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) {
+        bf1[ks] = nx.Wp[((wave + 4) * 16 + ks) * 64 + lane];
+        bf2[ks] = nx.Wp[((wave + 8) * 16 + ks) * 64 + lane];
+      }
+    }
   }
 #pragma unroll
   for (int j = 0; j < NG; ++j) {
@@ -464,6 +501,7 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       fo[j] = d;
     }
   }
+  EDGE_STAMP(9);
   // ---- node side of the NEXT layer for this tile's nodes (EdgeNext, common.hpp): [nn <= 16, 64] x [192, 64]^T
   if constexpr (NG == 1) {
     if (nx.Wp != nullptr) {
@@ -474,16 +512,10 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       frow[0] = fz.x; frow[1] = fz.y; frow[2] = fz.z; frow[3] = fz.w;
       __syncthreads();
       const int fr = lane & 15, fk = lane >> 4;
-      float bfa[16], bfb[16];
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) bfa[ks] = bf0[ks];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int ct = wave + 4 * t;                   // 12 column tiles of 16: UV' 0..7, root' 8..11
-        if (t < 2) {
-#pragma unroll
-          for (int ks = 0; ks < 16; ++ks) bfb[ks] = nx.Wp[((ct + 4) * 16 + ks) * 64 + lane];
-        }
+        const float* bfa = t == 0 ? bf0 : t == 1 ? bf1 : bf2;
         const int col = ct * 16 + fr;
         const float bias = nx.bias[col];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -499,11 +531,13 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
             else nx.root[(long)(n0 + row) * nx.ld_root + (col - 128)] = v;
           }
         }
-#pragma unroll
-        for (int ks = 0; ks < 16; ++ks) bfa[ks] = bfb[ks];
       }
     }
   }
+  EDGE_STAMP(10);
+#ifdef YOLAT_EDGE_STAMPS
+  if (threadIdx.x == 0 && blockIdx.x < 4096) edge_stamps_d[nx.Wp != nullptr ? 0 : 1][blockIdx.x * 16 + 11] = (long long)((e1g - e0g + 63) / 64);
+#endif
 }
 
 // ------------------------------------------------------------------------------------------------
