@@ -274,9 +274,11 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2(const float* __restrict__ 
 // NG = 16-node groups per tile: 1 (<= 16 nodes, the dense-graph case) or 4 (<= 64 nodes: graphs with ~1 edge per
 // node — the Floorplans shape — would otherwise fill a 64-edge pass to a third).
 #ifdef YOLAT_EDGE_STAMPS
-// debug build only (tools/exp/r06_edge_stamps.sh): wall-clock stamps (100 MHz) of thread 0 of every node-tile workgroup
+// debug build only (tools/exp/r06_edge_stamps.sh): wall-clock stamps (100 MHz) of thread 0 of every node-tile workgroup.
+// The stamped build is for the STRUCTURE of a workgroup's time; a stamp is a scalar memory read + a wait + a store, and the
+// build that carries them schedules differently (round 6: two load re-orderings that cut the stamped workgroup from 13.4 to
+// 9.2 us left the product build's launch where it was, by rocprof) — changes are judged by A/B of product builds.
 __device__ long long edge_stamps_d[2][4096 * 16];
-__device__ int edge_stamps_launch_d;
 #define EDGE_STAMP(k) do { if (threadIdx.x == 0 && blockIdx.x < 4096) edge_stamps_d[nx.Wp != nullptr ? 0 : 1][blockIdx.x * 16 + (k)] = wall_clock64(); } while (0)
 extern "C" int yolat_debug_edge_stamps(long long* out, int n) {
   return (int)hipMemcpyFromSymbol(out, HIP_SYMBOL(edge_stamps_d), sizeof(long long) * (size_t)n);
@@ -354,25 +356,21 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
   // finishes with at the very end: both shorten the workgroup's chain of dependent global round trips, which is what
   // a small graph's launch time consists of (715 workgroups, all resident at once, at E = 40 k)
   const int e0g = row_ptr[n0], e1g = row_ptr[n0 + nn];
-  // (round 6, after the stamps of tools/exp/r06_edge_stamps.py: 3.0-3.7 us of a 9.5-13.8 us workgroup passed before the
-  // first barrier) the loads that depend on nothing — the layer-2 weight tile, the f_out rows, and below the next layer's
-  // B fragments — go out BEFORE the edge ids, which have to wait for the tile's edge range: their round trip runs under the
-  // row_ptr -> ids chain instead of behind it (vmcnt retires in order)
-  float rw2[4][4];
-#pragma unroll
-  for (int t = 0; t < 4; ++t) {
-    const int i = tid + t * 256;
-    W2.template load4<false>(i >> 4, 4 * (i & 15), rw2[t]);
-  }
-  float4 fo[NG];
-#pragma unroll
-  for (int j = 0; j < NG; ++j)
-    fo[j] = *reinterpret_cast<const float4*>(f_out + (long)yl_min(n0 + rb + 16 * j, N - 1) * ld_fo + 4 * q);
   int di0[4], si0[4];
 #pragma unroll
   for (int t = 0; t < 4; ++t) {
     const int e = yl_min(e0g + rb + 16 * t, E - 1);
     di0[t] = dst[e]; si0[t] = src[e];
+  }
+  float4 fo[NG];
+#pragma unroll
+  for (int j = 0; j < NG; ++j)
+    fo[j] = *reinterpret_cast<const float4*>(f_out + (long)yl_min(n0 + rb + 16 * j, N - 1) * ld_fo + 4 * q);
+  float rw2[4][4];
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int i = tid + t * 256;
+    W2.template load4<false>(i >> 4, 4 * (i & 15), rw2[t]);
   }
   float4 wc[4];
 #pragma unroll
@@ -474,19 +472,6 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
     __syncthreads();
   }
   EDGE_STAMP(8);
-  // (round 6) the second and third column tile's B fragments of the next layer's node side go out HERE, together, under the
-  // f_out epilogue — they used to be fetched one tile ahead under sixteen small MFMAs (0.15 us of cover for a 1 us round
-  // trip, twice: 3.8 us for the tail by the stamps of tools/exp/r06_edge_stamps.py); the gather registers are free now
-  float bf1[16], bf2[16];
-  if constexpr (NG == 1) {
-    if (nx.Wp != nullptr) {
-#pragma unroll
-      for (int ks = 0; ks < 16; ++ks) {
-        bf1[ks] = nx.Wp[((wave + 4) * 16 + ks) * 64 + lane];
-        bf2[ks] = nx.Wp[((wave + 8) * 16 + ks) * 64 + lane];
-      }
-    }
-  }
 #pragma unroll
   for (int j = 0; j < NG; ++j) {
     const int deg = my_e[j] - my_b[j];
@@ -512,10 +497,16 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
       frow[0] = fz.x; frow[1] = fz.y; frow[2] = fz.z; frow[3] = fz.w;
       __syncthreads();
       const int fr = lane & 15, fk = lane >> 4;
+      float bfa[16], bfb[16];
+#pragma unroll
+      for (int ks = 0; ks < 16; ++ks) bfa[ks] = bf0[ks];
 #pragma unroll
       for (int t = 0; t < 3; ++t) {
         const int ct = wave + 4 * t;                   // 12 column tiles of 16: UV' 0..7, root' 8..11
-        const float* bfa = t == 0 ? bf0 : t == 1 ? bf1 : bf2;
+        if (t < 2) {
+#pragma unroll
+          for (int ks = 0; ks < 16; ++ks) bfb[ks] = nx.Wp[((ct + 4) * 16 + ks) * 64 + lane];
+        }
         const int col = ct * 16 + fr;
         const float bias = nx.bias[col];
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
@@ -531,6 +522,8 @@ __global__ void __launch_bounds__(256) k_edge_uv_mlp2_mean(const float* __restri
             else nx.root[(long)(n0 + row) * nx.ld_root + (col - 128)] = v;
           }
         }
+#pragma unroll
+        for (int ks = 0; ks < 16; ++ks) bfa[ks] = bfb[ks];
       }
     }
   }
