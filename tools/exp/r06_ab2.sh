@@ -1,4 +1,5 @@
 # A/B of two builds of the library on one box (round 6): the tree's build against tools/exp/libyolat_hip_prev.so
+# ("prev" = another commit of the library: bash tools/exp/r06_build_prev.sh <commit>)
 # usage: bash tools/exp/r06_ab2.sh "5:bf16 2:bf16" [train cfgs, e.g. "3:fp32 5:fp32"]
 CASES=${1:-"5:bf16 2:bf16 1:bf16 2:fp32 5:fp32"}
 TRAIN=${2:-""}
