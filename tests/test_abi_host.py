@@ -36,6 +36,14 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, name), "libyolat_hip.so does not export %s" % name
 
 
+def test_product_library_carries_no_debug_stamps():
+    """The wall-clock stamps of tools/exp/r06_*_stamps.* exist only in debug builds (-DYOLAT_{FX,H8,EDGE}_STAMPS): the
+    product library must not export their read-back entry points (a build with the stamps compiled in times differently)."""
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    for name in ("yolat_debug_fx_stamps", "yolat_debug_h8_stamps", "yolat_debug_edge_stamps"):
+        assert not hasattr(lib, name), "%s is exported: the library was built with debug stamps" % name
+
+
 def test_ctypes_signatures_match_header():
     decls = _header_decls()
     assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
